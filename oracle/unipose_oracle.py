@@ -1,0 +1,343 @@
+"""CPU oracle for the UniPose / UniPose-LSTM forward+backward hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``unipose_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` use it, and only as the checker / baseline.
+
+It is a functional restatement (plain ``torch.nn.functional`` calls on CPU
+tensors, driven by a flat ``state_dict``) of the network the reference builds
+out of ``nn.Module`` objects.  Each function cites the reference lines it
+follows (paths relative to /root/reference).
+
+Parity pin: ``tools/make_goldens.py`` imports the genuine reference ``model/``
+package (possible only in the development container) and stores its outputs
+under ``tests/golden/``; ``tests/test_oracle_golden.py`` checks this file
+against those vectors.  The arithmetic itself lives in PyTorch (un-pinned in
+the reference; 2.10.0 here): conv2d / batch_norm / max_pool2d / interpolate.
+"""
+from __future__ import annotations
+
+import zlib
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+SD = Dict[str, torch.Tensor]
+
+BN_EPS = 1e-5       # nn.BatchNorm2d default; the reference never overrides it
+BN_MOMENTUM = 0.1
+
+
+# --------------------------------------------------------------------------
+# building blocks
+# --------------------------------------------------------------------------
+def _bn(sd: SD, p: str, x, train: bool):
+    """nn.BatchNorm2d as used at every bnX site (resnet.py:11,14,16,62)."""
+    if train:
+        nbt = sd.get(p + ".num_batches_tracked")
+        if nbt is not None:
+            nbt += 1
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
+                        sd[p + ".weight"], sd[p + ".bias"],
+                        training=train, momentum=BN_MOMENTUM, eps=BN_EPS)
+
+
+def bottleneck(sd: SD, p: str, x, stride: int, dil: int, train: bool):
+    """Bottleneck.forward, resnet.py:22-42 (ctor :8-20)."""
+    y = F.relu(_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"]), train))
+    y = F.conv2d(y, sd[p + ".conv2.weight"], stride=stride, padding=dil, dilation=dil)
+    y = F.relu(_bn(sd, p + ".bn2", y, train))
+    y = _bn(sd, p + ".bn3", F.conv2d(y, sd[p + ".conv3.weight"]), train)
+    if (p + ".downsample.0.weight") in sd:
+        x = F.conv2d(x, sd[p + ".downsample.0.weight"], stride=stride)
+        x = _bn(sd, p + ".downsample.1", x, train)
+    return F.relu(y + x)
+
+
+# (blocks, stride of first block, per-block dilation) for output_stride 16:
+# resnet.py:49-53 (strides [1,2,2,1], dilations [1,1,1,2]), :67-70, MG unit :94-111
+_LAYERS_OS16 = (
+    ("layer1", 3, 1, (1, 1, 1)),
+    ("layer2", 4, 2, (1, 1, 1, 1)),
+    ("layer3", 23, 2, (1,) * 23),
+    ("layer4", 3, 1, (2, 4, 8)),
+)
+
+
+def backbone(sd: SD, x, train: bool, taps: Optional[dict] = None, prefix="backbone"):
+    """ResNet.forward, resnet.py:113-124."""
+    x = F.conv2d(x, sd[prefix + ".conv1.weight"], stride=2, padding=3)
+    x = F.relu(_bn(sd, prefix + ".bn1", x, train))
+    x = F.max_pool2d(x, 3, 2, 1)
+    if taps is not None:
+        taps["stem"] = x
+    low = None
+    for name, n, stride, dils in _LAYERS_OS16:
+        for i in range(n):
+            x = bottleneck(sd, f"{prefix}.{name}.{i}", x, stride if i == 0 else 1, dils[i], train)
+        if name == "layer1":
+            low = x
+        if taps is not None:
+            taps[name] = x
+    return x, low
+
+
+def _atrous(sd: SD, p: str, x, dil: int, k: int, train: bool):
+    """_AtrousModule.forward, wasp.py:16-20."""
+    pad = 0 if k == 1 else dil
+    y = F.conv2d(x, sd[p + ".atrous_conv.weight"], padding=pad, dilation=dil)
+    return F.relu(_bn(sd, p + ".bn", y, train))
+
+
+def wasp(sd: SD, x, train: bool, drop_masks: Optional[dict] = None,
+         video: bool = False, taps: Optional[dict] = None, p_drop: float = 0.5):
+    """wasp.forward, wasp.py:66-90 (video variant waspVideo.py:56-59: GAP branch has no BN)."""
+    x1 = _atrous(sd, "wasp.aspp1", x, 24, 1, train)
+    x2 = _atrous(sd, "wasp.aspp2", x1, 18, 3, train)
+    x3 = _atrous(sd, "wasp.aspp3", x2, 12, 3, train)
+    x4 = _atrous(sd, "wasp.aspp4", x3, 6, 3, train)
+    if taps is not None:
+        taps.update(x1=x1, x2=x2, x3=x3, x4=x4)
+    w2 = sd["wasp.conv2.weight"]
+    xs = [F.conv2d(F.conv2d(t, w2), w2) for t in (x1, x2, x3, x4)]   # wasp.py:72-80
+    g = F.adaptive_avg_pool2d(x, 1)
+    g = F.conv2d(g, sd["wasp.global_avg_pool.1.weight"])
+    if not video:
+        g = _bn(sd, "wasp.global_avg_pool.2", g, train)
+    g = F.relu(g)
+    g = F.interpolate(g, size=x4.shape[2:], mode="bilinear", align_corners=True)
+    y = torch.cat(xs + [g], dim=1)
+    y = F.relu(_bn(sd, "wasp.bn1", F.conv2d(y, sd["wasp.conv1.weight"]), train))
+    return _dropout(y, p_drop, train, drop_masks, "wasp")
+
+
+def _dropout(x, p: float, train: bool, masks: Optional[dict], key: str):
+    """nn.Dropout with an injectable keep-mask (masks[key] in {0,1}); masks=None, p>0
+    and train=True falls back to torch's RNG like the reference does."""
+    if not train or p == 0.0:
+        return x
+    if masks is not None and key in masks:
+        return x * masks[key] / (1.0 - p)
+    return F.dropout(x, p, True)
+
+
+def decoder(sd: SD, x, low, train: bool, drop_masks: Optional[dict] = None,
+            taps: Optional[dict] = None, p_drop=(0.5, 0.1)):
+    """Decoder.forward, decoder.py:38-56."""
+    low = F.relu(_bn(sd, "decoder.bn1", F.conv2d(low, sd["decoder.conv1.weight"]), train))
+    low = F.max_pool2d(low, 3, 2, 1)
+    x = F.interpolate(x, size=low.shape[2:], mode="bilinear", align_corners=True)
+    x = torch.cat((x, low), dim=1)
+    x = F.conv2d(x, sd["decoder.last_conv.0.weight"], padding=1)
+    x = F.relu(_bn(sd, "decoder.last_conv.1", x, train))
+    x = _dropout(x, p_drop[0], train, drop_masks, "dec0")
+    x = F.conv2d(x, sd["decoder.last_conv.4.weight"], padding=1)
+    x = F.relu(_bn(sd, "decoder.last_conv.5", x, train))
+    x = _dropout(x, p_drop[1], train, drop_masks, "dec1")
+    if taps is not None:
+        taps["dec_pre"] = x
+    return F.conv2d(x, sd["decoder.last_conv.8.weight"], sd["decoder.last_conv.8.bias"])
+
+
+def unipose_forward(sd: SD, x, train: bool = False, stride: int = 8,
+                    drop_masks: Optional[dict] = None, taps: Optional[dict] = None,
+                    p_drop=(0.5, 0.5, 0.1)):
+    """unipose.forward, model/unipose.py:27-38."""
+    if train and x.shape[0] == 1:
+        raise ValueError("Expected more than 1 value per channel when training")  # wasp.py:51-54
+    f, low = backbone(sd, x, train, taps)
+    f = wasp(sd, f, train, drop_masks, False, taps, p_drop[0])
+    if taps is not None:
+        taps["wasp"] = f
+    y = decoder(sd, f, low, train, drop_masks, taps, p_drop[1:])
+    if stride != 8:
+        y = F.interpolate(y, size=x.shape[2:], mode="bilinear", align_corners=True)
+    return y
+
+
+# --------------------------------------------------------------------------
+# UniPose-LSTM
+# --------------------------------------------------------------------------
+def lstm0_cell(sd: SD, z):
+    """LSTM_0.forward, model/uniposeLSTM.py:16-24 (cell = tanh(g*i), no forget gate)."""
+    def c(n):
+        return F.conv2d(z, sd[f"lstm_0.conv_{n}_lstm.weight"], sd[f"lstm_0.conv_{n}_lstm.bias"], padding=1)
+    g, i, o = torch.tanh(c("g")), torch.sigmoid(c("i")), torch.sigmoid(c("o"))
+    cell = torch.tanh(g * i)
+    return cell, o * cell
+
+
+def lstm_cell(sd: SD, z, h, c_prev):
+    """LSTM.forward, model/uniposeLSTM.py:40-64."""
+    def s(n):
+        return (F.conv2d(z, sd[f"lstm.conv_{n}x_lstm.weight"], sd[f"lstm.conv_{n}x_lstm.bias"], padding=1)
+                + F.conv2d(h, sd[f"lstm.conv_{n}h_lstm.weight"], sd[f"lstm.conv_{n}h_lstm.bias"], padding=1))
+    g, o, i, f = torch.tanh(s("g")), torch.sigmoid(s("o")), torch.sigmoid(s("i")), torch.sigmoid(s("f"))
+    cell = f * c_prev + i * g
+    return cell, o * torch.tanh(cell)
+
+
+def lstm_head(sd: SD, hide):
+    """conv1..conv5 with ReLU after each, model/uniposeLSTM.py:120-124."""
+    y = hide
+    for n, pad in (("conv1", 5), ("conv2", 5), ("conv3", 5), ("conv4", 0), ("conv5", 0)):
+        y = F.relu(F.conv2d(y, sd[n + ".weight"], sd[n + ".bias"], padding=pad))
+    return y
+
+
+def unipose_lstm_forward(sd: SD, frames, centermap, it: int, prev_hide, prev_cell,
+                         train: bool = False, drop_masks: Optional[dict] = None):
+    """uniposeLSTM.unipose.forward, model/uniposeLSTM.py:98-147, with the state generalised
+    from the hard-wired batch 1 (:99-104) to (B,15,H/8,W/8).  `previous` is unused there."""
+    x = frames[:, it]
+    f, low = backbone(sd, x, train)
+    f = wasp(sd, f, train, drop_masks, video=True)
+    y = decoder(sd, f, low, train, drop_masks)
+    c = F.avg_pool2d(centermap[:, it], 9, 8, 1)
+    z = torch.cat((y, c), dim=1)
+    if it == 0:
+        cell, hide = lstm0_cell(sd, z)
+    else:
+        if prev_hide.dim() == 3:
+            prev_hide, prev_cell = prev_hide[None], prev_cell[None]
+        cell, hide = lstm_cell(sd, z, prev_hide, prev_cell)
+    return lstm_head(sd, hide), cell, hide
+
+
+# --------------------------------------------------------------------------
+# heat-map argmax (numpy, like the reference)
+# --------------------------------------------------------------------------
+def get_max_preds(hm: np.ndarray):
+    """utils/evaluate.py:32-54: first-max flat argmax per (n, joint); x = idx % W,
+    y = floor(idx / W); both zeroed where max <= 0."""
+    b, j, h, w = hm.shape
+    flat = hm.reshape(b, j, -1)
+    idx = flat.argmax(2)
+    mx = flat.max(2)
+    preds = np.stack((idx % w, idx // w), axis=2).astype(np.float32)
+    preds *= (mx > 0.0)[:, :, None].astype(np.float32)
+    return preds, mx[:, :, None]
+
+
+def get_kpts(maps: np.ndarray, img_h: float = 368.0, img_w: float = 368.0):
+    """utils/utils.py:94-106: per joint (channel 0 skipped), [x, y] ints in image pixels."""
+    out = []
+    for m in maps[0][1:]:
+        r, c = np.unravel_index(m.argmax(), m.shape)
+        out.append([int(c * img_w / m.shape[1]), int(r * img_h / m.shape[0])])
+    return out
+
+
+# --------------------------------------------------------------------------
+# deterministic synthetic weights (same values here and on the GPU box)
+# --------------------------------------------------------------------------
+def _gen(name: str, seed: int):
+    g = torch.Generator()
+    g.manual_seed((zlib.crc32(name.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+    return g
+
+
+def _conv_w(name, shape, seed, gain=1.0):
+    fan_in = shape[1] * shape[2] * shape[3]
+    return torch.randn(shape, generator=_gen(name, seed)) * (gain * (2.0 / fan_in) ** 0.5)
+
+
+def _bn_entries(sd, p, c, seed):
+    sd[p + ".weight"] = 0.5 + torch.rand(c, generator=_gen(p + ".weight", seed))
+    sd[p + ".bias"] = 0.1 * torch.randn(c, generator=_gen(p + ".bias", seed))
+    sd[p + ".running_mean"] = 0.1 * torch.randn(c, generator=_gen(p + ".rm", seed))
+    sd[p + ".running_var"] = 0.5 + torch.rand(c, generator=_gen(p + ".rv", seed))
+    sd[p + ".num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+
+
+def synth_state_dict(num_classes: int, seed: int = 0, lstm: bool = False) -> SD:
+    """Every key of the reference state_dict (687 for K=14), He-scaled conv
+    weights and non-trivial BN affine/running statistics, derived from (name, seed)."""
+    sd: SD = {}
+
+    def conv(name, co, ci, k, bias=False, gain=1.0):
+        sd[name + ".weight"] = _conv_w(name, (co, ci, k, k), seed, gain)
+        if bias:
+            sd[name + ".bias"] = 0.05 * torch.randn(co, generator=_gen(name + ".bias", seed))
+
+    conv("backbone.conv1", 64, 3, 7)
+    _bn_entries(sd, "backbone.bn1", 64, seed)
+    inpl = 64
+    for name, n, _, _ in _LAYERS_OS16:
+        planes = {"layer1": 64, "layer2": 128, "layer3": 256, "layer4": 512}[name]
+        for i in range(n):
+            p = f"backbone.{name}.{i}"
+            conv(p + ".conv1", planes, inpl if i == 0 else planes * 4, 1)
+            _bn_entries(sd, p + ".bn1", planes, seed)
+            conv(p + ".conv2", planes, planes, 3)
+            _bn_entries(sd, p + ".bn2", planes, seed)
+            conv(p + ".conv3", planes * 4, planes, 1, gain=0.5)
+            _bn_entries(sd, p + ".bn3", planes * 4, seed)
+            if i == 0:
+                conv(p + ".downsample.0", planes * 4, inpl, 1)
+                _bn_entries(sd, p + ".downsample.1", planes * 4, seed)
+        inpl = planes * 4
+    conv("wasp.aspp1.atrous_conv", 256, 2048, 1)
+    _bn_entries(sd, "wasp.aspp1.bn", 256, seed)
+    for i in (2, 3, 4):
+        conv(f"wasp.aspp{i}.atrous_conv", 256, 256, 3)
+        _bn_entries(sd, f"wasp.aspp{i}.bn", 256, seed)
+    conv("wasp.global_avg_pool.1", 256, 2048, 1)
+    if not lstm:
+        _bn_entries(sd, "wasp.global_avg_pool.2", 256, seed)
+    conv("wasp.conv1", 256, 1280, 1)
+    conv("wasp.conv2", 256, 256, 1, gain=0.7)
+    _bn_entries(sd, "wasp.bn1", 256, seed)
+    conv("decoder.conv1", 48, 256, 1)
+    _bn_entries(sd, "decoder.bn1", 48, seed)
+    conv("decoder.conv2", 256, 2048, 1)          # defined, never used (decoder.py:20-21,43-45)
+    _bn_entries(sd, "decoder.bn2", 256, seed)
+    conv("decoder.last_conv.0", 256, 304, 3)
+    _bn_entries(sd, "decoder.last_conv.1", 256, seed)
+    conv("decoder.last_conv.4", 256, 256, 3)
+    _bn_entries(sd, "decoder.last_conv.5", 256, seed)
+    conv("decoder.last_conv.8", num_classes + 1, 256, 1, bias=True)
+    if lstm:
+        c = num_classes + 2
+        for n in "gio":
+            conv(f"lstm_0.conv_{n}_lstm", c, c, 3, bias=True)
+        for n in "giof":
+            conv(f"lstm.conv_{n}x_lstm", c, c, 3, bias=True)
+            conv(f"lstm.conv_{n}h_lstm", c, c, 3, bias=True)
+        conv("conv1", 128, c, 11, bias=True)
+        conv("conv2", 128, 128, 11, bias=True)
+        conv("conv3", 128, 128, 11, bias=True)
+        conv("conv4", 128, 128, 1, bias=True)
+        conv("conv5", num_classes + 1, 128, 1, bias=True)
+    # state_dict ordering of the reference interleaves differently; order is irrelevant to
+    # load_state_dict, which matches by key.
+    return sd
+
+
+def synth_input(shape, seed: int, kind: str = "randn"):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    if kind == "randn":
+        return torch.randn(shape, generator=g)
+    return torch.rand(shape, generator=g)
+
+
+def clone_sd(sd: SD, requires_grad: bool = False) -> SD:
+    out = {}
+    for k, v in sd.items():
+        t = v.clone()
+        if requires_grad and t.is_floating_point() and "running_" not in k:
+            t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+def max_rel(a, b) -> float:
+    """max|a-b| / max|b| — SURVEY §8c: relative-to-max, not elementwise."""
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    d = (a - b).abs().max().item()
+    s = b.abs().max().item()
+    return d / s if s > 0 else d

@@ -1,0 +1,170 @@
+"""Generate tests/golden/*.npz by running the GENUINE reference model.
+
+Runs ONLY in the development container (needs /root/reference); the fixtures it writes are
+data (inputs are re-derived from seeds, outputs are stored) and travel with the repo, the
+reference never does.  Usage:  python tools/make_goldens.py
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.path.insert(1, ROOT)
+
+import model.modules.backbone.resnet as R  # noqa: E402  (reference)
+
+R.model_zoo.load_url = lambda *a, **k: {}   # ctor downloads ImageNet weights (resnet.py:142); no network
+torch.Tensor.cuda = lambda self, *a, **k: self  # LSTM forward calls .cuda() (model/uniposeLSTM.py:99-104)
+
+from model.unipose import unipose as RefUniPose  # noqa: E402
+from model.uniposeLSTM import unipose as RefUniPoseLSTM  # noqa: E402
+from oracle import unipose_oracle as O  # noqa: E402
+
+SUB = 4   # stride used to sub-sample large gradient tensors (tests index the same way)
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.manual_seed(0)
+
+
+def save(name, **arrs):
+    np.savez_compressed(os.path.join(OUT, name), **{k: np.asarray(v) for k, v in arrs.items()})
+    print("wrote", name, {k: np.asarray(v).shape for k, v in arrs.items()})
+
+
+def ref_image_model(K, seed):
+    m = RefUniPose("LSP", num_classes=K)
+    sd = O.synth_state_dict(K, seed)
+    missing = set(m.state_dict()) ^ set(sd)
+    assert not missing, missing
+    m.load_state_dict(sd)
+    return m
+
+
+def g1_eval_full():
+    """G1: eval forward, K=14, B=2, 368x368."""
+    m = ref_image_model(14, 1).eval()
+    x = O.synth_input((2, 3, 368, 368), 11)
+    with torch.no_grad():
+        y = m(x)
+    flat = y.reshape(2, 15, -1)
+    save("g1_eval_368.npz", out=y.numpy(), argmax=flat.argmax(2).numpy().astype(np.int32),
+         meta=np.array([14, 1, 11]))
+
+
+def g2_taps():
+    """G2: intermediate taps at 160x160 (hooks on the reference modules)."""
+    m = ref_image_model(16, 2).eval()
+    x = O.synth_input((2, 3, 160, 160), 12)
+    taps = {}
+
+    def hook(name):
+        def f(_m, _i, o):
+            taps[name] = (o[0] if isinstance(o, tuple) else o).detach().numpy()
+        return f
+    m.backbone.maxpool.register_forward_hook(hook("stem"))
+    for n in ("layer1", "layer2", "layer3", "layer4"):
+        getattr(m.backbone, n).register_forward_hook(hook(n))
+    for n in ("aspp1", "aspp2", "aspp3", "aspp4"):
+        getattr(m.wasp, n).register_forward_hook(hook("x" + n[-1]))
+    m.wasp.register_forward_hook(hook("wasp"))
+    m.decoder.last_conv[7].register_forward_hook(hook("dec_pre"))
+    with torch.no_grad():
+        y = m(x)
+        y_full = torch.nn.functional.interpolate(y, size=(160, 160), mode="bilinear", align_corners=True)
+    # keep the fixture small: store sub-sampled taps (every 4th channel) + checksums
+    small = {k: v[:, ::4] for k, v in taps.items()}
+    sums = {k + "_abs_sum": np.abs(v).sum(dtype=np.float64) for k, v in taps.items()}
+    save("g2_taps_160.npz", out=y.numpy(), out_stride1=y_full.numpy()[:, ::4, ::2, ::2], **small, **sums,
+         meta=np.array([16, 2, 12]))
+
+
+def g4_train():
+    """G4: train-mode fwd+bwd, B=2, dropouts p=0, 128x128: loss, grads, BN running stats."""
+    K = 16
+    m = ref_image_model(K, 3).train()
+    m.wasp.dropout.p = 0.0
+    m.decoder.last_conv[3].p = 0.0
+    m.decoder.last_conv[7].p = 0.0
+    x = O.synth_input((2, 3, 128, 128), 13)
+    t = O.synth_input((2, K + 1, 16, 16), 14, "rand")
+    y = m(x)
+    loss = torch.nn.MSELoss()(y, t)
+    loss.backward()
+    sd = m.state_dict()
+    g = dict(m.named_parameters())
+    keys = ["backbone.conv1.weight", "backbone.layer1.0.conv2.weight", "backbone.layer2.0.downsample.0.weight",
+            "backbone.layer3.5.bn2.weight", "backbone.layer3.5.bn2.bias", "backbone.layer4.2.conv2.weight",
+            "wasp.conv2.weight", "wasp.aspp2.atrous_conv.weight", "wasp.global_avg_pool.1.weight",
+            "decoder.conv1.weight", "decoder.last_conv.0.weight", "decoder.last_conv.8.weight",
+            "decoder.last_conv.8.bias"]
+    arrs = {"grad/" + k: g[k].grad.numpy() for k in keys}
+    for k in list(arrs):                       # keep the fixture small: sub-sample big tensors
+        if arrs[k].size > 100_000:
+            arrs[k] = arrs[k][::SUB, ::SUB]
+    arrs["grad_norms"] = np.array([g[k].grad.double().norm().item() if g[k].grad is not None else -1.0
+                                   for k in sorted(g)])
+    for k in ("backbone.bn1", "backbone.layer3.5.bn2", "wasp.bn1", "wasp.global_avg_pool.2", "decoder.last_conv.5"):
+        arrs["rm/" + k] = sd[k + ".running_mean"].numpy()
+        arrs["rv/" + k] = sd[k + ".running_var"].numpy()
+    none_grad = [k for k in sorted(g) if g[k].grad is None]
+    print("params without grad:", none_grad)
+    save("g4_train_128.npz", out=y.detach().numpy(), loss=np.array(loss.item()), **arrs,
+         meta=np.array([K, 3, 13, 14]))
+    # train-mode B=1 must raise
+    try:
+        m(x[:1])
+        raise SystemExit("expected failure for train-mode batch 1")
+    except ValueError as e:
+        print("B=1 train raises:", str(e)[:60])
+
+
+def g5_lstm():
+    """G5: UniPose-LSTM, K=13, T=5, B=1, eval, 368x368 frames (state shapes are hard-wired to 46x46)."""
+    K = 13
+    m = RefUniPoseLSTM(num_classes=K)
+    sd = O.synth_state_dict(K, 4, lstm=True)
+    assert not (set(m.state_dict()) ^ set(sd)), set(m.state_dict()) ^ set(sd)
+    m.load_state_dict(sd)
+    m.eval()
+    T = 5
+    x = O.synth_input((1, T, 3, 368, 368), 15)
+    cm = O.synth_input((1, T, 1, 368, 368), 16, "rand")
+    heat = torch.zeros(K + 1, 46, 46)
+    cell = torch.zeros(15, 46, 46)
+    hide = torch.zeros(15, 46, 46)
+    res = {}
+    with torch.no_grad():
+        for j in range(T):                      # uniposeLSTM.py:124-128 call pattern
+            heat, cell, hide = m(x, cm, j, heat, hide, cell)
+            res[f"heat{j}"], res[f"cell{j}"], res[f"hide{j}"] = heat.numpy(), cell.numpy(), hide.numpy()
+    save("g5_lstm_368.npz", **res, meta=np.array([K, 4, 15, 16]))
+
+
+def g6_argmax():
+    """G6: reference get_max_preds (utils/evaluate.py loaded by path; numpy only) on edge cases."""
+    spec = importlib.util.spec_from_file_location("ref_evaluate", os.path.join(REF, "utils", "evaluate.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    rng = np.random.default_rng(5)
+    hm = rng.standard_normal((3, 15, 46, 46)).astype(np.float32)
+    hm[0, 0] = -1.0                              # all negative & all equal -> idx 0, masked
+    hm[0, 1] = 0.0                               # all zero -> masked
+    hm[0, 2] = -5.0; hm[0, 2, 45, 45] = 3.0      # max at last index
+    hm[0, 3] = 1.0                               # all ties -> first
+    hm[0, 4] = 0.0; hm[0, 4, 10, 7] = 2.0; hm[0, 4, 30, 3] = 2.0   # duplicate max -> first
+    hm[1, 5, 0, 0] = 100.0
+    hm[2, 6] = -np.abs(hm[2, 6])                 # negative everywhere, unique max
+    preds, maxvals = ev.get_max_preds(hm)
+    save("g6_argmax.npz", hm=hm, preds=preds, maxvals=maxvals)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6"]
+    fns = dict(g1=g1_eval_full, g2=g2_taps, g4=g4_train, g5=g5_lstm, g6=g6_argmax)
+    for w in which:
+        fns[w]()
