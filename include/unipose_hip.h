@@ -1,0 +1,165 @@
+/*
+ * unipose_hip.h — C ABI of libunipose_hip.so: hand-written gfx950 (MI355X, CDNA4) kernels for the
+ * UniPose / UniPose-LSTM forward+backward hot path.
+ *
+ * The reference (bmartacho/UniPose) has NO native / FFI layer: its arithmetic is PyTorch ATen ops
+ * reached from Python nn.Modules.  Each entry point below therefore cites the
+ * reference call site(s) whose ATen op it replaces (paths relative to the reference tree).  The
+ * Python binding a maintainer adds is the ctypes table in unipose_amd/_C.py.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (fp32 unless stated), borrowed for the call, never freed;
+ *   - activations are NHWC ("pixel-major"): element (n,h,w,c) of a tensor with pixel stride `ld`
+ *     lives at ((n*H + h)*W + w)*ld + c; ld >= C lets a producer write into a channel slice of a
+ *     wider buffer (this is how torch.cat is eliminated: wasp.py:84, decoder.py:51);
+ *   - channel counts seen by the convolution kernels are padded to a multiple of 4 (`Cp`), pad
+ *     channels hold zeros; pixel strides and base pointers are multiples of 4 floats (16 B);
+ *   - `stream` is a hipStream_t (as void*); all work is enqueued asynchronously on it;
+ *   - return value: 0 on success, negative up_status on failure; up_last_error() gives the text.
+ *     No C++ exception crosses this boundary.  No host-side global state except the error string.
+ */
+#ifndef UNIPOSE_HIP_H
+#define UNIPOSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    UP_OK = 0,
+    UP_ERR_INVALID = -1,     /* bad argument (shape, alignment, null pointer) */
+    UP_ERR_UNSUPPORTED = -2, /* configuration this library does not implement */
+    UP_ERR_LAUNCH = -3,      /* HIP launch / runtime error */
+    UP_ERR_WORKSPACE = -4    /* caller-provided workspace too small */
+} up_status;
+
+const char* up_last_error(void);
+int up_abi_version(void);
+
+/* Geometry of one 2-D convolution (nn.Conv2d as used at resnet.py:10-16,61,80-84,104-109;
+ * wasp.py:9,52,59-60; decoder.py:17,22,26,30; model/uniposeLSTM.py:12-14,30-38,85-89). */
+typedef struct {
+    int32_t N, H, W;      /* input batch / height / width                                   */
+    int32_t C, Cp;        /* real input channels, padded input channels (Cp%4==0, Cp>=C)    */
+    int32_t ldx;          /* input pixel stride in floats (>= Cp, %4==0)                     */
+    int32_t K;            /* output channels                                                 */
+    int32_t R, S;         /* kernel height / width                                           */
+    int32_t stride, pad, dil;
+    int32_t P, Q;         /* output height / width                                           */
+    int32_t ldy;          /* output pixel stride in floats (>= K)                            */
+    int32_t Kp;           /* padded output channels for the dgrad weight image (Kp%4==0)     */
+} up_conv_desc;
+
+/* Fused epilogue of the forward convolution (all optional, applied in this order):
+ *   v = acc;  if(scale) v = v*scale[k] + shift[k];   (folded eval-mode BatchNorm, K7)
+ *   if(bias) v += bias[k];  if(residual) v += residual[pixel*ldr + k];  if(relu) v = max(v,0)
+ * `stats` != NULL asks for per-(row-tile, channel) Welford partials {count, mean, M2} of the RAW
+ * accumulator (train-mode BatchNorm statistics, K7); it excludes scale/bias/residual/relu. */
+typedef struct {
+    const float* scale;
+    const float* shift;
+    const float* bias;
+    const float* residual;
+    int32_t ldr;
+    int32_t relu;
+    float* stats;         /* [up_conv_stats_tiles(desc)][K][3] or NULL */
+} up_conv_epilogue;
+
+/* Re-lay an OIHW fp32 weight (PyTorch layout) for the implicit-GEMM kernels:
+ *   w_fwd  [K][R*S][Cp]  (forward, B operand rows = output channel, k-contiguous)
+ *   w_dgrad[C ][R*S][Kp] (data-gradient: rows = input channel)           — either may be NULL. */
+int up_pack_weights(const up_conv_desc* d, const float* w_oihw, float* w_fwd, float* w_dgrad, void* stream);
+
+/* Forward convolution, implicit GEMM on v_mfma_f32_32x32x2_f32 (replaces aten::convolution, K1-K6,K17). */
+int up_conv2d_fwd(const up_conv_desc* d, const float* x, const float* w_fwd, float* y,
+                  const up_conv_epilogue* ep, void* stream);
+int up_conv_stats_tiles(const up_conv_desc* d);   /* row tiles the forward kernel will use */
+
+/* Data gradient: dx[N,H,W,ldx(:Cp)] from dy[N,P,Q,ldy(:K)] (replaces convolution_backward, input half).
+ * Writes all Cp channels of every input pixel (pad channels get 0). */
+int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const float* w_dgrad, float* dx, void* stream);
+
+/* Weight gradient into PyTorch OIHW layout (replaces convolution_backward, weight half); `dbias`
+ * (K floats) may be NULL.  Split-K partial slabs live in the caller-provided workspace. */
+size_t up_conv2d_bwd_weight_workspace(const up_conv_desc* d);
+int up_conv2d_bwd_weight(const up_conv_desc* d, const float* x, const float* dy, float* dw_oihw,
+                         float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- BatchNorm (nn.BatchNorm2d, K7; every bnX site, e.g. resnet.py:11,14,16; wasp.py:11,53,61) ---- */
+/* eval: scale = g/sqrt(rv+eps), shift = b - rm*scale */
+int up_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                      const float* running_var, float eps, int C, float* scale, float* shift, void* stream);
+/* train: merge the conv epilogue partials -> batch mean / invstd, update running stats in place
+ * (momentum, unbiased variance), emit scale/shift for up_bn_apply and mean/invstd for backward. */
+int up_bn_finalize(const float* stats, int tiles, int C, float eps, float momentum,
+                   float* running_mean, float* running_var,
+                   const float* gamma, const float* beta,
+                   float* mean, float* invstd, float* scale, float* shift, void* stream);
+/* z = relu?(y*scale[c] + shift[c] (+ residual)) */
+int up_bn_apply(const float* y, int ldy, const float* scale, const float* shift,
+                const float* residual, int ldr, int relu, float* z, int ldz,
+                int64_t rows, int C, void* stream);
+/* backward of z = relu?(bn(y) (+res)):  g = dz * (z>0 if relu);  dgamma = sum g*xhat, dbeta = sum g,
+ * dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M)  (train)   or   gamma*invstd*g (eval: use_batch_stats=0);
+ * dres (optional) = g. */
+int up_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+              const float* gamma, const float* mean, const float* invstd, int relu, int use_batch_stats,
+              float* dy, int lddy, float* dres, int lddres, float* dgamma, float* dbeta,
+              float* workspace, size_t workspace_bytes, int64_t rows, int C, void* stream);
+size_t up_bn_bwd_workspace(int64_t rows, int C);
+
+/* ---- pointwise / data movement ---- */
+int up_relu_bwd(const float* dz, const float* z, float* dx, int64_t n, void* stream);              /* K8 */
+int up_copy2d(const float* src, int lds, float* dst, int ldd, int64_t rows, int C, void* stream);   /* K13 */
+int up_add2d(const float* a, int lda, const float* b, int ldb, float* dst, int ldd, int64_t rows, int C, void* stream);
+int up_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int ldy, void* stream);   /* boundary */
+int up_nhwc_to_nchw(const float* x, int ldx, float* y, int N, int C, int H, int W, void* stream);
+/* nn.MaxPool2d(3,2,1) (resnet.py:65, decoder.py:33): idx (uint8, 0..8 = window tap of the first max). */
+int up_maxpool3s2_fwd(const float* x, int ldx, float* y, int ldy, uint8_t* idx,
+                      int N, int H, int W, int C, int P, int Q, void* stream);
+int up_maxpool3s2_bwd(const float* dy, int lddy, const uint8_t* idx, float* dx, int lddx,
+                      int N, int H, int W, int C, int P, int Q, void* stream);
+/* F.interpolate(mode='bilinear', align_corners=True) (wasp.py:83, decoder.py:49, model/unipose.py:32) */
+int up_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int P, int Q, void* stream);
+int up_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int H, int W, int C, int P, int Q, void* stream);
+/* nn.AdaptiveAvgPool2d(1) (wasp.py:51) */
+int up_gap_fwd(const float* x, int ldx, float* y, int N, int HW, int C, void* stream);
+int up_gap_bwd(const float* dy, float* dx, int lddx, int N, int HW, int C, void* stream);
+/* nn.AvgPool2d(9,8,1) on the 1-channel centre map (model/uniposeLSTM.py:75,114); NCHW(1ch) in,
+ * writes channel `coff` of an NHWC buffer with pixel stride ldy */
+int up_avgpool9s8_fwd(const float* x, float* y, int ldy, int coff, int N, int H, int W, int P, int Q, void* stream);
+/* nn.Dropout (wasp.py:63, decoder.py:25,29): keep-mask from a counter hash of (seed, element index)
+ * or, when ext_mask != NULL, from the caller (float 0/1) — the injectable-RNG hook used for parity. */
+int up_dropout_fwd(const float* x, float* y, uint8_t* mask, const float* ext_mask, int64_t n,
+                   float p, uint64_t seed, void* stream);
+int up_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, void* stream);
+/* nn.MSELoss() mean reduction (unipose.py:70,117): loss[0] = mean((y-t)^2); bwd: dy = 2(y-t)/n * dloss[0] */
+int up_mse_fwd(const float* y, const float* t, float* loss, float* workspace, int64_t n, void* stream);
+int up_mse_bwd(const float* y, const float* t, const float* dloss, float* dy, int64_t n, void* stream);
+size_t up_mse_workspace(int64_t n);
+
+/* ---- ConvLSTM gate math (model/uniposeLSTM.py:16-24, 40-64).  `gates` is the fused gate
+ * pre-activation tensor [rows][ldg] laid out g|i|o(|f), each Cg wide, produced by ONE convolution
+ * over cat(x,h) with the gate weights stacked along K. ---- */
+int up_lstm0_fwd(const float* gates, int ldg, float* cell, float* hide, int ldo, int64_t rows, int Cg, void* stream);
+int up_lstm0_bwd(const float* gates, int ldg, const float* dcell, const float* dhide, int ldo,
+                 float* dgates, int64_t rows, int Cg, void* stream);
+int up_lstm_fwd(const float* gates, int ldg, const float* cprev, int ldc, float* cell, float* hide, int ldo,
+                int64_t rows, int Cg, void* stream);
+int up_lstm_bwd(const float* gates, int ldg, const float* cprev, int ldc, const float* cell,
+                const float* dcell, const float* dhide, int ldo,
+                float* dgates, float* dcprev, int64_t rows, int Cg, void* stream);
+
+/* ---- heat-map argmax (utils/evaluate.py:32-54 get_max_preds; utils/utils.py:94-106) ----
+ * hm: NCHW fp32 (B,J,H,W) as returned by the model.  One wavefront per (b,j): first-max flat index
+ * (lowest index wins ties), preds = (idx % W, idx / W) zeroed where max <= 0.  idx may be NULL. */
+int up_heatmap_argmax(const float* hm, int B, int J, int H, int W,
+                      int32_t* idx, float* preds_xy, float* maxvals, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNIPOSE_HIP_H */

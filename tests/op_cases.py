@@ -1,0 +1,276 @@
+"""Per-operator parity cases shared by the CPU-emulation tests and the GPU tests.  The checker is plain
+torch fp32 on CPU (the ops the reference itself calls: F.conv2d, F.batch_norm, ...)."""
+import torch
+import torch.nn.functional as F
+
+from unipose_amd import ops
+
+
+def nhwc(x, dev, pad_to=None):
+    """NCHW cpu tensor -> NHWC (channel-padded to a multiple of 4) on dev."""
+    n, c, h, w = x.shape
+    cp = pad_to or ops.rup4(c)
+    y = torch.zeros(n, h, w, cp)
+    y[..., :c] = x.permute(0, 2, 3, 1)
+    return y.to(dev)
+
+
+def nchw(y, c):
+    return y.detach().cpu()[..., :c].permute(0, 3, 1, 2).contiguous()
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    s = b.abs().max().item()
+    return (a - b).abs().max().item() / (s if s > 0 else 1.0)
+
+
+def g(seed):
+    gen = torch.Generator()
+    gen.manual_seed(seed)
+    return gen
+
+
+def conv_case(dev, n, c, h, w, k, r, stride, pad, dil, bias=False, relu=False, seed=0, tol=2e-5):
+    x = torch.randn(n, c, h, w, generator=g(seed))
+    wt = torch.randn(k, c, r, r, generator=g(seed + 1)) * (2.0 / (c * r * r)) ** 0.5
+    b = torch.randn(k, generator=g(seed + 2)) if bias else None
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=pad, dilation=dil)
+    if relu:
+        yr = F.relu(yr)
+    dy = torch.randn(yr.shape, generator=g(seed + 3))
+    yr.backward(dy)
+
+    xd = nhwc(x, dev).requires_grad_(True)
+    wd = wt.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True) if bias else None
+    y = ops.ConvBias.apply(xd, wd, bd, ops.ConvCfg(stride, pad, dil), relu)
+    assert y.shape == (n, yr.shape[2], yr.shape[3], ops.rup4(k))
+    y.backward(nhwc(dy, dev))
+    errs = {
+        "y": rel(nchw(y, k), yr.detach()),
+        "dx": rel(nchw(xd.grad, c), xr.grad),
+        "dw": rel(wd.grad.cpu(), wr.grad),
+    }
+    if bias:
+        errs["db"] = rel(bd.grad.cpu(), br.grad)
+    if ops.rup4(k) != k:
+        assert float(y.detach()[..., k:].abs().max()) == 0.0
+    bad = {k_: v for k_, v in errs.items() if not v < tol}
+    assert not bad, (bad, errs)
+    return errs
+
+
+def conv_bn_case(dev, n, c, h, w, k, r, stride, pad, dil, relu=True, residual=False, train=True, seed=0, tol=5e-5):
+    x = torch.randn(n, c, h, w, generator=g(seed)) + 0.3
+    conv = torch.nn.Conv2d(c, k, r, stride=stride, padding=pad, dilation=dil, bias=False)
+    bn = torch.nn.BatchNorm2d(k)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g(seed + 1)) * (2.0 / (c * r * r)) ** 0.5)
+        bn.weight.copy_(0.5 + torch.rand(k, generator=g(seed + 2)))
+        bn.bias.copy_(0.2 * torch.randn(k, generator=g(seed + 3)))
+        bn.running_mean.copy_(0.1 * torch.randn(k, generator=g(seed + 4)))
+        bn.running_var.copy_(0.5 + torch.rand(k, generator=g(seed + 5)))
+    import copy
+    conv_d, bn_d = copy.deepcopy(conv).to(dev), copy.deepcopy(bn).to(dev)
+    conv.train(train), bn.train(train), conv_d.train(train), bn_d.train(train)
+    xr = x.clone().requires_grad_(True)
+    yr = bn(conv(xr))
+    res = torch.randn(yr.shape, generator=g(seed + 6)) if residual else None
+    rr = res.clone().requires_grad_(True) if residual else None
+    if residual:
+        yr = yr + rr
+    if relu:
+        yr = F.relu(yr)
+    dy = torch.randn(yr.shape, generator=g(seed + 7))
+    yr.backward(dy)
+
+    xd = nhwc(x, dev).requires_grad_(True)
+    rd = nhwc(res, dev).requires_grad_(True) if residual else None
+    y = ops.conv_bn_act(xd, conv_d, bn_d, relu=relu, residual=rd)
+    y.backward(nhwc(dy, dev))
+    errs = {
+        "y": rel(nchw(y, k), yr.detach()),
+        "dx": rel(nchw(xd.grad, c), xr.grad),
+        "dw": rel(conv_d.weight.grad.cpu(), conv.weight.grad),
+        "dgamma": rel(bn_d.weight.grad.cpu(), bn.weight.grad),
+        "dbeta": rel(bn_d.bias.grad.cpu(), bn.bias.grad),
+        "rm": rel(bn_d.running_mean.cpu(), bn.running_mean),
+        "rv": rel(bn_d.running_var.cpu(), bn.running_var),
+    }
+    if residual:
+        errs["dres"] = rel(nchw(rd.grad, k), rr.grad)
+    assert int(bn_d.num_batches_tracked) == int(bn.num_batches_tracked)
+    bad = {k_: v for k_, v in errs.items() if not v < tol}
+    assert not bad, (bad, errs)
+    # inference fast path (BN folded into the conv epilogue) against eval-mode torch
+    conv.eval(), bn.eval(), conv_d.eval(), bn_d.eval()
+    with torch.no_grad():
+        ye = bn(conv(x))
+        if residual:
+            ye = ye + res
+        if relu:
+            ye = F.relu(ye)
+        yf = ops.conv_bn_act(nhwc(x, dev), conv_d, bn_d, relu=relu, residual=nhwc(res, dev) if residual else None)
+    e = rel(nchw(yf, k), ye)
+    assert e < tol, ("eval fused", e)
+    return errs
+
+
+def layout_case(dev):
+    x = torch.randn(2, 3, 5, 7, generator=g(1))
+    xd = x.to(dev).requires_grad_(True)
+    y = ops.ToNHWC.apply(xd)
+    assert y.shape == (2, 5, 7, 4)
+    assert rel(nchw(y, 3), x) == 0 and float(y.detach()[..., 3].abs().max()) == 0
+    z = ops.ToNCHW.apply(y, 3)
+    assert torch.equal(z.detach().cpu(), x)
+    dz = torch.randn(z.shape, generator=g(2))
+    z.backward(dz.to(dev))
+    assert torch.equal(xd.grad.cpu(), dz)
+
+
+def maxpool_case(dev, n=2, c=8, h=9, w=10):
+    x = torch.randn(n, c, h, w, generator=g(3))
+    x[0, 0, :3, :3] = 1.5          # ties: first max in window-scan order must win
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    dy = torch.randn(yr.shape, generator=g(4))
+    yr.backward(dy)
+    xd = nhwc(x, dev).requires_grad_(True)
+    y = ops.MaxPool3s2.apply(xd)
+    y.backward(nhwc(dy, dev))
+    assert torch.equal(nchw(y, c), yr.detach())
+    assert rel(nchw(xd.grad, c), xr.grad) < 1e-6
+
+
+def bilinear_case(dev, n, c, h, w, p, q, tol=1e-5):
+    x = torch.randn(n, c, h, w, generator=g(5))
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, size=(p, q), mode="bilinear", align_corners=True)
+    dy = torch.randn(yr.shape, generator=g(6))
+    yr.backward(dy)
+    xd = nhwc(x, dev).requires_grad_(True)
+    y = ops.Bilinear.apply(xd, p, q)
+    y.backward(nhwc(dy, dev))
+    assert rel(nchw(y, c), yr.detach()) < tol
+    assert rel(nchw(xd.grad, c), xr.grad) < tol
+
+
+def gap_case(dev, n=3, c=72, h=5, w=7):
+    x = torch.randn(n, c, h, w, generator=g(7))
+    xr = x.clone().requires_grad_(True)
+    yr = F.adaptive_avg_pool2d(xr, 1)
+    dy = torch.randn(yr.shape, generator=g(8))
+    yr.backward(dy)
+    xd = nhwc(x, dev).requires_grad_(True)
+    y = ops.GlobalAvgPool.apply(xd)
+    y.backward(nhwc(dy, dev))
+    assert rel(nchw(y, c), yr.detach()) < 1e-5
+    assert rel(nchw(xd.grad, c), xr.grad) < 1e-6
+
+
+def concat_case(dev):
+    a = torch.randn(2, 8, 4, 5, generator=g(9))
+    b = torch.randn(2, 12, 4, 5, generator=g(10))
+    ad, bd = nhwc(a, dev).requires_grad_(True), nhwc(b, dev).requires_grad_(True)
+    y = ops.ConcatC.apply(0, ad, bd)
+    assert torch.equal(nchw(y, 20), torch.cat((a, b), 1))
+    dy = torch.randn(2, 20, 4, 5, generator=g(11))
+    y.backward(nhwc(dy, dev))
+    assert torch.equal(nchw(ad.grad, 8), dy[:, :8]) and torch.equal(nchw(bd.grad, 12), dy[:, 8:])
+
+
+def dropout_case(dev):
+    x = torch.randn(2, 6, 6, 16, generator=g(12)).to(dev).requires_grad_(True)
+    m = (torch.rand(2, 6, 6, 16, generator=g(13)) > 0.5).float().to(dev)
+    y = ops.Dropout.apply(x, 0.5, 1, m)
+    assert torch.equal(y.detach().cpu(), (x.detach() * m / 0.5).cpu())
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad.cpu(), (m / 0.5).cpu())
+    big = torch.ones(64, 8, 8, 64).to(dev)
+    y1 = ops.Dropout.apply(big, 0.3, 7, None)
+    y2 = ops.Dropout.apply(big, 0.3, 7, None)
+    y3 = ops.Dropout.apply(big, 0.3, 8, None)
+    keep = float((y1 != 0).float().mean())
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    assert abs(keep - 0.7) < 0.01, keep
+    assert abs(float(y1.max()) - 1 / 0.7) < 1e-6
+
+
+def mse_case(dev):
+    y = torch.randn(2, 17, 9, 9, generator=g(14))
+    t = torch.rand(2, 17, 9, 9, generator=g(15))
+    yr = y.clone().requires_grad_(True)
+    lr = F.mse_loss(yr, t)
+    (lr * 3.0).backward()
+    yd = y.to(dev).requires_grad_(True)
+    l = ops.mse_loss(yd, t.to(dev))
+    (l * 3.0).backward()
+    assert abs(float(l) - float(lr)) < 1e-6 * abs(float(lr))
+    assert rel(yd.grad.cpu(), yr.grad) < 1e-6
+
+
+def avgpool_case(dev, h=40, w=48):
+    c = torch.rand(2, 1, h, w, generator=g(16))
+    ref = F.avg_pool2d(c, 9, 8, 1)
+    p, q = ref.shape[2:]
+    buf = torch.zeros(2, p, q, 16).to(dev)
+    ops.avgpool9s8_into(c.to(dev), buf, 14)
+    assert rel(buf.cpu()[..., 14], ref[:, 0]) < 1e-6
+    assert float(buf[..., :14].abs().max()) == 0 and float(buf[..., 15].abs().max()) == 0
+
+
+def lstm_case(dev):
+    cg, n, h, w = 15, 2, 5, 6
+    G0 = torch.randn(n, h, w, 48, generator=g(17))
+    G = torch.randn(n, h, w, 60, generator=g(18))
+    cp = torch.randn(n, h, w, 16, generator=g(19))
+    dcell = torch.randn(n, h, w, 16, generator=g(20))
+    dhide = torch.randn(n, h, w, 16, generator=g(21))
+    # reference math (model/uniposeLSTM.py:17-22, 41-62) with torch autograd
+    a = G0.clone().requires_grad_(True)
+    gg, ii, oo = torch.tanh(a[..., :cg]), torch.sigmoid(a[..., cg:2 * cg]), torch.sigmoid(a[..., 2 * cg:3 * cg])
+    cell = torch.tanh(gg * ii)
+    hide = oo * cell
+    (cell * dcell[..., :cg]).sum().backward(retain_graph=True)
+    (hide * dhide[..., :cg]).sum().backward()
+    ad = G0.to(dev).requires_grad_(True)
+    c_, h_ = ops.LSTM0Gates.apply(ad, cg)
+    ((c_ * dcell.to(dev)).sum() + (h_ * dhide.to(dev)).sum()).backward()
+    assert rel(c_.detach().cpu()[..., :cg], cell.detach()) < 1e-5 and rel(h_.detach().cpu()[..., :cg], hide.detach()) < 1e-5
+    assert rel(ad.grad.cpu()[..., :45], a.grad[..., :45]) < 1e-5
+    b = G.clone().requires_grad_(True)
+    cpr = cp.clone().requires_grad_(True)
+    gg, ii = torch.tanh(b[..., :cg]), torch.sigmoid(b[..., cg:2 * cg])
+    oo, ff = torch.sigmoid(b[..., 2 * cg:3 * cg]), torch.sigmoid(b[..., 3 * cg:4 * cg])
+    cell = ff * cpr[..., :cg] + ii * gg
+    hide = oo * torch.tanh(cell)
+    ((cell * dcell[..., :cg]).sum() + (hide * dhide[..., :cg]).sum()).backward()
+    bd = G.to(dev).requires_grad_(True)
+    cpd = cp.to(dev).requires_grad_(True)
+    c_, h_ = ops.LSTMGates.apply(bd, cpd, cg)
+    ((c_ * dcell.to(dev)).sum() + (h_ * dhide.to(dev)).sum()).backward()
+    assert rel(c_.detach().cpu()[..., :cg], cell.detach()) < 1e-5 and rel(h_.detach().cpu()[..., :cg], hide.detach()) < 1e-5
+    assert rel(bd.grad.cpu(), b.grad) < 1e-5
+    assert rel(cpd.grad.cpu()[..., :cg], cpr.grad[..., :cg]) < 1e-5
+
+
+def argmax_case(dev, golden_dir):
+    import os
+    import numpy as np
+    gd = np.load(os.path.join(golden_dir, "g6_argmax.npz"))
+    preds, mx, idx = ops.heatmap_argmax(torch.from_numpy(gd["hm"]).to(dev))
+    assert np.array_equal(preds.cpu().numpy(), gd["preds"])          # bit-exact vs the reference's numpy
+    assert np.array_equal(mx.cpu().numpy(), gd["maxvals"])
+    flat = gd["hm"].reshape(3, 15, -1)
+    assert np.array_equal(idx.cpu().numpy(), flat.argmax(2).astype(np.int32))
+    hm = torch.from_numpy(gd["hm"][:1]).to(dev)
+    kp = ops.get_kpts(hm)
+    ref = []
+    for m in gd["hm"][0][1:]:
+        r, c = np.unravel_index(m.argmax(), m.shape)
+        ref.append([int(c * 368.0 / 46), int(r * 368.0 / 46)])
+    assert kp == ref

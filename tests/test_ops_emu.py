@@ -1,0 +1,82 @@
+"""Kernel index/tiling/fragment logic on a GPU-less box: the HIP sources compiled against the fiber
+emulator (tests/emu) and driven through the real host code (unipose_amd.ops) with tiny shapes."""
+import pytest
+import torch
+
+import op_cases as oc
+
+
+@pytest.mark.parametrize("cfg", [
+    # n, c,  h,  w,  k, r, stride, pad, dil, bias, relu
+    (2, 16, 6, 5, 32, 1, 1, 0, 1, False, False),      # 1x1 (K1)
+    (1, 32, 9, 8, 16, 3, 1, 1, 1, False, False),      # 3x3 (K3)
+    (2, 16, 9, 9, 24, 3, 2, 1, 1, False, False),      # 3x3 stride 2 (K4), K=24 -> n-tile tail
+    (1, 16, 7, 7, 16, 3, 1, 4, 4, False, False),      # dilated, dil > H/2 (K5: taps wholly in padding)
+    (2, 32, 8, 8, 20, 1, 2, 0, 1, False, False),      # 1x1 stride 2 downsample (K2)
+    (1, 3, 20, 18, 8, 7, 2, 3, 1, False, False),      # stem 7x7 s2, Cin=3 (K6, unaligned K slices)
+    (1, 15, 6, 6, 14, 3, 1, 1, 1, True, True),        # LSTM-like: odd channels, bias, relu
+    (1, 15, 12, 12, 8, 11, 1, 5, 1, True, True),      # 11x11 (K17)
+])
+def test_conv_fwd_bwd(emu_backend, cfg):
+    n, c, h, w, k, r, s, p, d, bias, relu = cfg
+    oc.conv_case(emu_backend, n, c, h, w, k, r, s, p, d, bias=bias, relu=relu)
+
+
+def test_conv_multi_tile(emu_backend):
+    # M = 2*13*11 = 286 rows -> several 64-row tiles with a ragged tail; K = 80 -> 2 n-tiles of 64
+    oc.conv_case(emu_backend, 2, 16, 13, 11, 80, 3, 1, 1, 1)
+
+
+@pytest.mark.parametrize("cfg", [
+    # n, c, h, w, k, r, stride, pad, dil, relu, residual, train
+    (2, 16, 6, 6, 32, 1, 1, 0, 1, True, False, True),
+    (2, 16, 7, 7, 16, 3, 1, 2, 2, True, True, True),
+    (3, 8, 9, 9, 72, 3, 2, 1, 1, False, False, True),
+    (2, 16, 5, 5, 16, 1, 1, 0, 1, True, True, False),     # eval statistics, with grad (freeze_bn path)
+])
+def test_conv_bn_act(emu_backend, cfg):
+    n, c, h, w, k, r, s, p, d, relu, res, train = cfg
+    oc.conv_bn_case(emu_backend, n, c, h, w, k, r, s, p, d, relu=relu, residual=res, train=train)
+
+
+def test_layout(emu_backend):
+    oc.layout_case(emu_backend)
+
+
+def test_maxpool(emu_backend):
+    oc.maxpool_case(emu_backend)
+    oc.maxpool_case(emu_backend, 1, 4, 8, 8)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 5, 6, 10, 12), (1, 4, 1, 1, 7, 7), (1, 4, 4, 4, 32, 32), (1, 4, 6, 6, 6, 6)])
+def test_bilinear(emu_backend, shape):
+    oc.bilinear_case(emu_backend, *shape)
+
+
+def test_gap(emu_backend):
+    oc.gap_case(emu_backend)
+
+
+def test_concat(emu_backend):
+    oc.concat_case(emu_backend)
+
+
+def test_dropout(emu_backend):
+    oc.dropout_case(emu_backend)
+
+
+def test_mse(emu_backend):
+    oc.mse_case(emu_backend)
+
+
+def test_avgpool(emu_backend):
+    oc.avgpool_case(emu_backend)
+    oc.avgpool_case(emu_backend, 37, 41)
+
+
+def test_lstm_gates(emu_backend):
+    oc.lstm_case(emu_backend)
+
+
+def test_argmax(emu_backend, golden_dir):
+    oc.argmax_case(emu_backend, golden_dir)

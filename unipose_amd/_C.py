@@ -1,0 +1,109 @@
+"""ctypes binding of libunipose_hip.so (the C ABI declared in include/unipose_hip.h).
+
+The product path has exactly one backend: the HIP library built in-tree by
+``unipose_amd.build.build_library()`` (``__graft_entry__.build()``).  If it is missing the import
+of any op fails loudly — there is no PyTorch / CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libunipose_hip.so")
+
+c_f32p = C.c_void_p       # device pointers travel as integers (tensor.data_ptr())
+c_stream = C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    """up_conv_desc"""
+    _fields_ = [(n, C.c_int32) for n in
+                ("N", "H", "W", "C", "Cp", "ldx", "K", "R", "S", "stride", "pad", "dil", "P", "Q", "ldy", "Kp")]
+
+
+class ConvEpilogue(C.Structure):
+    """up_conv_epilogue"""
+    _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
+                ("ldr", C.c_int32), ("relu", C.c_int32), ("stats", C.c_void_p)]
+
+
+_i, _i64, _f, _u64, _sz, _p = C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_size_t, C.c_void_p
+_D, _E = C.POINTER(ConvDesc), C.POINTER(ConvEpilogue)
+
+# name -> (restype, argtypes); mirrors include/unipose_hip.h one to one
+SIGNATURES = {
+    "up_last_error": (C.c_char_p, []),
+    "up_abi_version": (_i, []),
+    "up_pack_weights": (_i, [_D, _p, _p, _p, _p]),
+    "up_conv2d_fwd": (_i, [_D, _p, _p, _p, _E, _p]),
+    "up_conv_stats_tiles": (_i, [_D]),
+    "up_conv2d_bwd_data": (_i, [_D, _p, _p, _p, _p]),
+    "up_conv2d_bwd_weight_workspace": (_sz, [_D]),
+    "up_conv2d_bwd_weight": (_i, [_D, _p, _p, _p, _p, _p, _sz, _p]),
+    "up_bn_eval_coeffs": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
+    "up_bn_finalize": (_i, [_p, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "up_bn_apply": (_i, [_p, _i, _p, _p, _p, _i, _i, _p, _i, _i64, _i, _p]),
+    "up_bn_bwd": (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _sz, _i64, _i, _p]),
+    "up_bn_bwd_workspace": (_sz, [_i64, _i]),
+    "up_relu_bwd": (_i, [_p, _p, _p, _i64, _p]),
+    "up_copy2d": (_i, [_p, _i, _p, _i, _i64, _i, _p]),
+    "up_add2d": (_i, [_p, _i, _p, _i, _p, _i, _i64, _i, _p]),
+    "up_nchw_to_nhwc": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "up_nhwc_to_nchw": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
+    "up_maxpool3s2_fwd": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "up_maxpool3s2_bwd": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "up_bilinear_fwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "up_bilinear_bwd": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "up_gap_fwd": (_i, [_p, _i, _p, _i, _i, _i, _p]),
+    "up_gap_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "up_avgpool9s8_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "up_dropout_fwd": (_i, [_p, _p, _p, _p, _i64, _f, _u64, _p]),
+    "up_dropout_bwd": (_i, [_p, _p, _p, _i64, _f, _p]),
+    "up_mse_fwd": (_i, [_p, _p, _p, _p, _i64, _p]),
+    "up_mse_bwd": (_i, [_p, _p, _p, _p, _i64, _p]),
+    "up_mse_workspace": (_sz, [_i64]),
+    "up_lstm0_fwd": (_i, [_p, _i, _p, _p, _i, _i64, _i, _p]),
+    "up_lstm0_bwd": (_i, [_p, _i, _p, _p, _i, _p, _i64, _i, _p]),
+    "up_lstm_fwd": (_i, [_p, _i, _p, _i, _p, _p, _i, _i64, _i, _p]),
+    "up_lstm_bwd": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _i64, _i, _p]),
+    "up_heatmap_argmax": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p]),
+}
+
+_lib = None
+# Set ONLY by tests/conftest.py when it points the binding at the CPU emulation build of the same
+# kernel sources (tests/emu).  The product never sets it: ops then refuse non-CUDA tensors.
+_ALLOW_HOST_POINTERS = False
+
+
+class UniPoseHipError(RuntimeError):
+    pass
+
+
+def load(path: str | None = None):
+    """dlopen the library and attach the prototypes.  Raises if it is missing (no fallback)."""
+    global _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise UniPoseHipError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  unipose_amd has no non-HIP fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)        # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def lib():
+    return _lib if _lib is not None else load()
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = lib().up_last_error().decode(errors="replace")
+        if status == -2:
+            raise NotImplementedError(f"{what}: {msg}")
+        raise UniPoseHipError(f"{what}: status {status}: {msg}")

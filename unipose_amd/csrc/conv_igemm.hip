@@ -1,0 +1,785 @@
+// Implicit-GEMM convolution for gfx950 on the exact-fp32 matrix instruction
+// v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD, bitwise an fmaf chain).
+//
+//   forward / data-gradient ("TN" GEMM, both operands k-contiguous in HBM):
+//       Y[m][n] = sum_k A[m][k] * B[n][k]
+//       m = output pixel (n_img,p,q), k = (tap, channel), A = on-the-fly im2col gather of the
+//       NHWC activation (16-B loads along channels), B = re-laid weights [n][tap][channel].
+//       The data gradient is the same kernel with source/destination roles swapped and the
+//       divisibility test of a strided convolution folded into the gather predicate.
+//   weight-gradient ("NT" GEMM, both operands m-contiguous), split-K over pixels:
+//       dW[co][tap*Cp+ci] = sum_m dY[m][co] * X[src(m,tap)][ci]
+//
+// Tiling: 256 threads = 4 wavefronts (2x2), block tile BMxBN (128/64), BK=16, wave tile
+// (BM/2)x(BN/2) built from 32x32 MFMA tiles.  One LDS buffer + register prefetch of the next
+// K-slice (global loads stay in flight under the MFMAs); 3-4 blocks per CU hide the two barriers
+// per slice (MI355X_MICROARCH: one f32 MFMA chain per wave already saturates the pipe).
+// LDS rows are 20 dwords (16 + 4 pad): the ds_read_b128 fragment reads are conflict-free because
+// 20/4 = 5 is odd (16 lanes of a b128 group hit 16 distinct 16-B slots).
+// Within each group of 8 k the two half-waves take k = {0..3} / {4..7}: any k permutation is
+// legal as long as A and B use the same one, and it turns 4 ds_read_b32 into one ds_read_b128.
+#include "up_common.h"
+
+namespace up {
+
+constexpr int BK = 16;
+constexpr int LDS_LD = 20;
+
+struct IgemmArgs {
+    const float* x;
+    const float* w;
+    float* y;
+    int M, Ng, Ktot, Cp, Creal;
+    int H, W, P, Q;  // source H,W; destination P,Q
+    int ldx, ldy;
+    int S;
+    int mul, off0, tapstep, div;  // src = (dst*mul + off0 + r*tapstep) / div
+    int ntn;                      // number of n tiles
+    int nwg;
+    FastDiv fPQ, fQ, fCp, fS, fNtn;
+    const float* scale;
+    const float* shift;
+    const float* bias;
+    const float* residual;
+    int ldr;
+    int relu;
+    float* stats;
+};
+
+__device__ __forceinline__ void wf_merge(float& n1, float& m1, float& s1, float n2, float m2, float s2) {
+    if (n2 == 0.f) return;
+    if (n1 == 0.f) {
+        n1 = n2;
+        m1 = m2;
+        s1 = s2;
+        return;
+    }
+    float n = n1 + n2;
+    float d = m2 - m1;
+    m1 = m1 + d * (n2 / n);
+    s1 = s1 + s2 + d * d * (n1 * n2 / n);
+    n1 = n;
+}
+
+// XCD-aware bijective remap: hardware block b runs on XCD b%8; give every XCD a contiguous run of
+// logical tiles so the n-tiles sharing one A row-panel hit the same L2.
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+    int q = nwg >> 3, r = nwg & 7;
+    int xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int BM, int BN, bool ALIGNED>
+__global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
+    float* As = smem;
+    float* Bs = smem + BM * LDS_LD;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int logical = xcd_remap(blockIdx.x, a.nwg);
+    const int mt = fdiv(logical, a.fNtn);
+    const int nt = logical - mt * a.ntn;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int lrow = tid >> 2;  // 0..63
+    const int kq = tid & 3;     // which float4 of the 16-wide k slice
+
+    // per-thread gather bases for its TM rows
+    int hb[TM], wb[TM], ib[TM];
+    bool mv[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int m = m0 + i * 64 + lrow;
+        mv[i] = m < a.M;
+        int mm = mv[i] ? m : 0;
+        int img = fdiv(mm, a.fPQ);
+        int rem = mm - img * (a.P * a.Q);
+        int p = fdiv(rem, a.fQ);
+        int q = rem - p * a.Q;
+        hb[i] = p * a.mul + a.off0;
+        wb[i] = q * a.mul + a.off0;
+        ib[i] = img * a.H * a.W;
+    }
+    const float* wrow[TN];
+    bool nv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int n = n0 + j * 64 + lrow;
+        nv[j] = n < a.Ng;
+        wrow[j] = a.w + (size_t)(nv[j] ? n : 0) * a.Ktot + kq * 4;
+    }
+
+    float4 ra[TM], rb[TN];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // aligned path: the 16-wide slice never straddles a tap; (tap, ci0) advance as scalars
+    int tap_c = 0, ci0_c = 0;
+
+    auto gload = [&](int kt) {
+        int tap, ci;
+        bool kvalid = true;
+        if (ALIGNED) {
+            tap = tap_c;
+            ci = ci0_c + kq * 4;
+        } else {
+            int k = kt * BK + kq * 4;
+            kvalid = k < a.Ktot;
+            int kk = kvalid ? k : 0;
+            tap = fdiv(kk, a.fCp);
+            ci = kk - tap * a.Cp;
+        }
+        int r = fdiv(tap, a.fS);
+        int s = tap - r * a.S;
+        int dh = r * a.tapstep, dw = s * a.tapstep;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            int h = hb[i] + dh, w = wb[i] + dw;
+            bool ok = mv[i] && kvalid && h >= 0 && w >= 0;
+            if (a.div == 2) {
+                ok = ok && !((h | w) & 1);
+                h >>= 1;
+                w >>= 1;
+            } else if (a.div > 2) {
+                int hq = h / a.div, wq = w / a.div;
+                ok = ok && hq * a.div == h && wq * a.div == w;
+                h = hq;
+                w = wq;
+            }
+            ok = ok && h < a.H && w < a.W;
+            float4 v = zero4;
+            if (ok) {
+                v = *reinterpret_cast<const float4*>(a.x + (size_t)(ib[i] + h * a.W + w) * a.ldx + ci);
+                if (a.Creal != a.Cp) {
+                    if (ci + 1 >= a.Creal) v.y = 0.f;
+                    if (ci + 2 >= a.Creal) v.z = 0.f;
+                    if (ci + 3 >= a.Creal) v.w = 0.f;
+                    if (ci >= a.Creal) v.x = 0.f;
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            rb[j] = (nv[j] && kvalid) ? *reinterpret_cast<const float4*>(wrow[j] + (size_t)kt * BK) : zero4;
+        }
+        if (ALIGNED) {
+            ci0_c += BK;
+            if (ci0_c >= a.Cp) {
+                ci0_c = 0;
+                tap_c += 1;
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) *reinterpret_cast<float4*>(&As[(i * 64 + lrow) * LDS_LD + kq * 4]) = ra[i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) *reinterpret_cast<float4*>(&Bs[(j * 64 + lrow) * LDS_LD + kq * 4]) = rb[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (a.Ktot + BK - 1) / BK;
+    gload(0);
+    lstore();
+    __syncthreads();
+
+    const float* Ard = As + (wm * (BM / 2) + l31) * LDS_LD + lh * 4;
+    const float* Brd = Bs + (wn * (BN / 2) + l31) * LDS_LD + lh * 4;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload(kt + 1);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(Ard + i * 32 * LDS_LD + g * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(Brd + j * 32 * LDS_LD + g * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+        if (more) {
+            lstore();
+            __syncthreads();
+        }
+    }
+
+    // ---------------- epilogue ----------------
+    // C/D map of the 32x32 MFMA: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int mrow0 = m0 + wm * (BM / 2) + 4 * lh;
+    const int ncol0 = n0 + wn * (BN / 2) + l31;
+
+    if (a.stats) {
+        float sc[TN], sm[TN], s2[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float cnt = 0.f, sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (m < a.M) {
+                        cnt += 1.f;
+                        sum += acc[i][j][r];
+                    }
+                }
+            float mean = cnt > 0.f ? sum / cnt : 0.f;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (m < a.M) {
+                        float d = acc[i][j][r] - mean;
+                        q += d * d;
+                    }
+                }
+            float c2 = __shfl_xor(cnt, 32), m2 = __shfl_xor(mean, 32), q2 = __shfl_xor(q, 32);
+            if (lh) {  // both halves must merge in the same order to agree bitwise
+                float tc = c2, tm = m2, tq = q2;
+                wf_merge(tc, tm, tq, cnt, mean, q);
+                cnt = tc;
+                mean = tm;
+                q = tq;
+            } else {
+                wf_merge(cnt, mean, q, c2, m2, q2);
+            }
+            sc[j] = cnt;
+            sm[j] = mean;
+            s2[j] = q;
+        }
+        // smem is free: the K loop ended with a barrier after the last LDS read
+        if (wm == 1 && lh == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float* d = smem + ((wn * TN + j) * 32 + l31) * 3;
+                d[0] = sc[j];
+                d[1] = sm[j];
+                d[2] = s2[j];
+            }
+        }
+        __syncthreads();
+        if (wm == 0 && lh == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float* s = smem + ((wn * TN + j) * 32 + l31) * 3;
+                wf_merge(sc[j], sm[j], s2[j], s[0], s[1], s[2]);
+                int n = ncol0 + j * 32;
+                if (n < a.Ng) {
+                    float* o = a.stats + ((size_t)mt * a.Ng + n) * 3;
+                    o[0] = sc[j];
+                    o[1] = sm[j];
+                    o[2] = s2[j];
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = ncol0 + j * 32;
+        if (n >= a.Ng) continue;
+        const float sc = a.scale ? a.scale[n] : 1.f;
+        float sh = a.scale ? a.shift[n] : 0.f;
+        if (a.bias) sh += a.bias[n];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (m < a.M) {
+                    float v = acc[i][j][r] * sc + sh;
+                    if (a.residual) v += a.residual[(size_t)m * a.ldr + n];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    a.y[(size_t)m * a.ldy + n] = v;
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* x;
+    const float* dy;
+    float* slab;
+    int M, K, Ncols, Cp, Creal;
+    int H, W, P, Q;
+    int ldx, ldy;
+    int S;
+    int stride, pad, dil;
+    int rows_per_split;
+    int ntn;
+    FastDiv fPQ, fQ, fCp, fS, fNtn;
+};
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int A4 = BM / 4, B4 = BN / 4;        // float4 per k row
+    constexpr int PA = BK * A4 / 256, PB = BK * B4 / 256;  // load passes (1 or 2)
+    constexpr int KA = 256 / A4, KB = 256 / B4;    // k rows covered per pass
+    __shared__ __attribute__((aligned(16))) float smem[BK * (BM + BN)];
+    float* As = smem;
+    float* Bs = smem + BK * BM;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int tile = blockIdx.x;
+    const int mt = fdiv(tile, a.fNtn);
+    const int nt = tile - mt * a.ntn;
+    const int co0 = mt * BM, col0 = nt * BN;
+    const int mbeg = blockIdx.y * a.rows_per_split;
+    const int mend = min(a.M, mbeg + a.rows_per_split);
+
+    // A (dY): thread -> (k row within pass, 4 output channels)
+    const int a_c4 = tid % A4, a_kr = tid / A4;
+    const int a_co = co0 + a_c4 * 4;
+    // B (X gather): thread -> (k row within pass, 4 columns = one tap, 4 channels)
+    const int b_c4 = tid % B4, b_kr = tid / B4;
+    const int b_col = col0 + b_c4 * 4;
+    const bool b_cv = b_col < a.Ncols;
+    const int b_tap = fdiv(b_cv ? b_col : 0, a.fCp);
+    const int b_ci = (b_cv ? b_col : 0) - b_tap * a.Cp;
+    const int b_r = fdiv(b_tap, a.fS);
+    const int b_dh = b_r * a.dil - a.pad, b_dw = (b_tap - b_r * a.S) * a.dil - a.pad;
+
+    float4 ra[PA], rb[PB];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto gload = [&](int kbase) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            int m = kbase + p * KA + a_kr;
+            float4 v = zero4;
+            if (m < mend && a_co < a.K) {
+                v = *reinterpret_cast<const float4*>(a.dy + (size_t)m * a.ldy + a_co);
+                if (a_co + 1 >= a.K) v.y = 0.f;
+                if (a_co + 2 >= a.K) v.z = 0.f;
+                if (a_co + 3 >= a.K) v.w = 0.f;
+            }
+            ra[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            int m = kbase + p * KB + b_kr;
+            float4 v = zero4;
+            if (m < mend && b_cv) {
+                int img = fdiv(m, a.fPQ);
+                int rem = m - img * (a.P * a.Q);
+                int pp = fdiv(rem, a.fQ);
+                int qq = rem - pp * a.Q;
+                int h = pp * a.stride + b_dh, w = qq * a.stride + b_dw;
+                if (h >= 0 && w >= 0 && h < a.H && w < a.W) {
+                    v = *reinterpret_cast<const float4*>(a.x + (size_t)((img * a.H + h) * a.W + w) * a.ldx + b_ci);
+                    if (a.Creal != a.Cp) {
+                        if (b_ci + 1 >= a.Creal) v.y = 0.f;
+                        if (b_ci + 2 >= a.Creal) v.z = 0.f;
+                        if (b_ci + 3 >= a.Creal) v.w = 0.f;
+                        if (b_ci >= a.Creal) v.x = 0.f;
+                    }
+                }
+            }
+            rb[p] = v;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) *reinterpret_cast<float4*>(&As[(p * KA + a_kr) * BM + a_c4 * 4]) = ra[p];
+#pragma unroll
+        for (int p = 0; p < PB; ++p) *reinterpret_cast<float4*>(&Bs[(p * KB + b_kr) * BN + b_c4 * 4]) = rb[p];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (mbeg < mend) {
+        gload(mbeg);
+        lstore();
+    }
+    __syncthreads();
+    const float* Ard = As + lh * BM + wm * (BM / 2) + l31;
+    const float* Brd = Bs + lh * BN + wn * (BN / 2) + l31;
+    for (int kb = mbeg; kb < mend; kb += BK) {
+        const bool more = kb + BK < mend;
+        if (more) gload(kb + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = Ard[2 * kk * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Brd[2 * kk * BN + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            lstore();
+            __syncthreads();
+        }
+    }
+
+    float* out = a.slab + (size_t)blockIdx.y * a.K * a.Ncols;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        int col = col0 + wn * (BN / 2) + j * 32 + l31;
+        if (col >= a.Ncols) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int co = co0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < a.K) out[(size_t)co * a.Ncols + col] = acc[i][j][r];
+            }
+    }
+}
+
+// sum the split-K slabs and scatter into PyTorch OIHW
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* slab, float* dw, int splits, int K, int C,
+                                                          int Cp, int taps, long long total /* K*taps*Cp */) {
+    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    int ci = (int)(e % Cp);
+    long long t = e / Cp;
+    int tap = (int)(t % taps);
+    int co = (int)(t / taps);
+    if (ci >= C) return;
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += slab[(size_t)sp * total + e];
+    dw[((size_t)co * C + ci) * taps + tap] = s;
+}
+
+__global__ void __launch_bounds__(256) pack_fwd_kernel(const float* w, float* o, int K, int C, int Cp, int taps,
+                                                       long long total) {
+    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    int ci = (int)(e % Cp);
+    long long t = e / Cp;
+    int tap = (int)(t % taps);
+    int k = (int)(t / taps);
+    o[e] = ci < C ? w[((size_t)k * C + ci) * taps + tap] : 0.f;
+}
+
+__global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* w, float* o, int K, int Kp, int C, int taps,
+                                                         long long total) {
+    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    int k = (int)(e % Kp);
+    long long t = e / Kp;
+    int tap = (int)(t % taps);
+    int c = (int)(t / taps);
+    o[e] = k < K ? w[((size_t)k * C + c) * taps + tap] : 0.f;
+}
+
+// column sums of a [rows][ld] matrix (bias gradient): partial per block, atomically combined
+__global__ void __launch_bounds__(256) colsum_kernel(const float* x, int ld, long long rows, int C, float* out,
+                                                     int rows_per_block) {
+    // blockDim = 256 = 4 row-lanes x 64 columns
+    __shared__ float red[256];
+    int c = blockIdx.y * 64 + (threadIdx.x & 63);
+    int rl = threadIdx.x >> 6;
+    long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float s = 0.f;
+    if (c < C)
+        for (long long r = r0 + rl; r < r1; r += 4) s += x[r * ld + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        s = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+        atomicAdd(out + c, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int check_desc(const up_conv_desc* d) {
+    UP_REQUIRE(d, UP_ERR_INVALID, "conv desc is null");
+    UP_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0 && d->R > 0 && d->S > 0, UP_ERR_INVALID,
+               "conv desc: non-positive dimension");
+    UP_REQUIRE(d->Cp % 4 == 0 && d->Cp >= d->C && d->ldx % 4 == 0 && d->ldx >= d->Cp, UP_ERR_INVALID,
+               "conv desc: Cp=%d ldx=%d must be multiples of 4 with ldx >= Cp >= C=%d", d->Cp, d->ldx, d->C);
+    UP_REQUIRE(d->ldy >= d->K, UP_ERR_INVALID, "conv desc: ldy=%d < K=%d", d->ldy, d->K);
+    UP_REQUIRE(d->stride >= 1 && d->dil >= 1 && d->pad >= 0, UP_ERR_INVALID, "conv desc: bad stride/dil/pad");
+    int P = (d->H + 2 * d->pad - d->dil * (d->R - 1) - 1) / d->stride + 1;
+    int Q = (d->W + 2 * d->pad - d->dil * (d->S - 1) - 1) / d->stride + 1;
+    UP_REQUIRE(P == d->P && Q == d->Q, UP_ERR_INVALID, "conv desc: P,Q=(%d,%d) but geometry gives (%d,%d)", d->P,
+               d->Q, P, Q);
+    UP_REQUIRE((int64_t)d->N * d->H * d->W < (1ll << 31) && (int64_t)d->N * d->P * d->Q < (1ll << 31),
+               UP_ERR_UNSUPPORTED, "conv: more than 2^31 pixels");
+    return UP_OK;
+}
+
+struct TileChoice {
+    int bm, bn;
+};
+static TileChoice choose_tile(int64_t M, int Ng) {
+    const int cands[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
+    for (auto& c : cands) {
+        if (Ng <= 64 && c[1] == 128) continue;
+        int64_t wgs = (int64_t)cdiv(M, c[0]) * cdiv(Ng, c[1]);
+        if (wgs >= 1000) return {c[0], c[1]};
+    }
+    return {64, 64};
+}
+
+template <int BM, int BN>
+static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
+    int ntm = cdiv(a.M, BM);
+    a.ntn = cdiv(a.Ng, BN);
+    a.nwg = ntm * a.ntn;
+    a.fNtn = make_fastdiv(a.ntn);
+    if (aligned)
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, true>), dim3(a.nwg), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, false>), dim3(a.nwg), dim3(256), 0, st, a);
+}
+
+static void run_igemm(IgemmArgs& a, TileChoice t, hipStream_t st) {
+    bool aligned = (a.Cp % BK) == 0;
+    if (t.bm == 128 && t.bn == 128)
+        launch_igemm<128, 128>(a, aligned, st);
+    else if (t.bm == 64 && t.bn == 128)
+        launch_igemm<64, 128>(a, aligned, st);
+    else if (t.bm == 128 && t.bn == 64)
+        launch_igemm<128, 64>(a, aligned, st);
+    else
+        launch_igemm<64, 64>(a, aligned, st);
+}
+
+}  // namespace up
+
+using namespace up;
+
+extern "C" int up_conv_stats_tiles(const up_conv_desc* d) {
+    if (!d) return UP_ERR_INVALID;
+    int64_t M = (int64_t)d->N * d->P * d->Q;
+    return cdiv(M, choose_tile(M, d->K).bm);
+}
+
+extern "C" int up_pack_weights(const up_conv_desc* d, const float* w, float* w_fwd, float* w_dgrad, void* stream) {
+    if (int e = check_desc(d)) return e;
+    UP_REQUIRE(w, UP_ERR_INVALID, "pack_weights: null weight");
+    int taps = d->R * d->S;
+    if (w_fwd) {
+        long long total = (long long)d->K * taps * d->Cp;
+        hipLaunchKernelGGL(pack_fwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w, w_fwd, d->K,
+                           d->C, d->Cp, taps, total);
+    }
+    if (w_dgrad) {
+        UP_REQUIRE(d->Kp % 4 == 0 && d->Kp >= d->K, UP_ERR_INVALID, "pack_weights: Kp=%d invalid for K=%d", d->Kp,
+                   d->K);
+        long long total = (long long)d->C * taps * d->Kp;
+        hipLaunchKernelGGL(pack_dgrad_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w, w_dgrad,
+                           d->K, d->Kp, d->C, taps, total);
+    }
+    return check_launch("pack_weights");
+}
+
+extern "C" int up_conv2d_fwd(const up_conv_desc* d, const float* x, const float* w_fwd, float* y,
+                             const up_conv_epilogue* ep, void* stream) {
+    if (int e = check_desc(d)) return e;
+    UP_REQUIRE(x && w_fwd && y, UP_ERR_INVALID, "conv2d_fwd: null pointer");
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.w = w_fwd;
+    a.y = y;
+    a.M = d->N * d->P * d->Q;
+    a.Ng = d->K;
+    a.Cp = d->Cp;
+    a.Creal = d->C;
+    a.Ktot = d->R * d->S * d->Cp;
+    a.H = d->H;
+    a.W = d->W;
+    a.P = d->P;
+    a.Q = d->Q;
+    a.ldx = d->ldx;
+    a.ldy = d->ldy;
+    a.S = d->S;
+    a.mul = d->stride;
+    a.off0 = -d->pad;
+    a.tapstep = d->dil;
+    a.div = 1;
+    a.fPQ = make_fastdiv(d->P * d->Q);
+    a.fQ = make_fastdiv(d->Q);
+    a.fCp = make_fastdiv(d->Cp);
+    a.fS = make_fastdiv(d->S);
+    if (ep) {
+        UP_REQUIRE(!ep->scale || ep->shift, UP_ERR_INVALID, "conv2d_fwd: scale without shift");
+        UP_REQUIRE(!ep->residual || ep->ldr >= d->K, UP_ERR_INVALID, "conv2d_fwd: residual stride < K");
+        UP_REQUIRE(!ep->stats || !(ep->scale || ep->bias || ep->residual || ep->relu), UP_ERR_INVALID,
+                   "conv2d_fwd: stats are taken on the raw accumulator; no other epilogue allowed");
+        a.scale = ep->scale;
+        a.shift = ep->shift;
+        a.bias = ep->bias;
+        a.residual = ep->residual;
+        a.ldr = ep->ldr;
+        a.relu = ep->relu;
+        a.stats = ep->stats;
+    }
+    run_igemm(a, choose_tile(a.M, a.Ng), as_stream(stream));
+    return check_launch("conv2d_fwd");
+}
+
+extern "C" int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
+                                  void* stream) {
+    if (int e = check_desc(d)) return e;
+    UP_REQUIRE(dy && w_dgrad && dx, UP_ERR_INVALID, "conv2d_bwd_data: null pointer");
+    UP_REQUIRE(d->Kp % 4 == 0 && d->Kp >= d->K && d->ldy % 4 == 0 && d->ldy >= d->Kp, UP_ERR_INVALID,
+               "conv2d_bwd_data: need Kp%%4==0, ldy%%4==0, ldy>=Kp (Kp=%d ldy=%d K=%d)", d->Kp, d->ldy, d->K);
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = dy;
+    a.w = w_dgrad;
+    a.y = dx;
+    a.M = d->N * d->H * d->W;
+    a.Ng = d->C;
+    a.Cp = d->Kp;
+    a.Creal = d->K;
+    a.Ktot = d->R * d->S * d->Kp;
+    a.H = d->P;
+    a.W = d->Q;  // source = dy
+    a.P = d->H;
+    a.Q = d->W;  // destination = dx
+    a.ldx = d->ldy;
+    a.ldy = d->ldx;
+    a.S = d->S;
+    a.mul = 1;
+    a.off0 = d->pad;
+    a.tapstep = -d->dil;
+    a.div = d->stride;
+    a.fPQ = make_fastdiv(d->H * d->W);
+    a.fQ = make_fastdiv(d->W);
+    a.fCp = make_fastdiv(d->Kp);
+    a.fS = make_fastdiv(d->S);
+    run_igemm(a, choose_tile(a.M, a.Ng), as_stream(stream));
+    return check_launch("conv2d_bwd_data");
+}
+
+namespace up {
+struct WgradPlan {
+    int bm, bn, ntm, ntn, splits, rows_per_split;
+};
+static WgradPlan plan_wgrad(const up_conv_desc* d) {
+    WgradPlan p;
+    int ncols = d->R * d->S * d->Cp;
+    p.bm = d->K <= 64 ? 64 : 128;
+    p.bn = ncols <= 64 ? 64 : 128;
+    p.ntm = cdiv(d->K, p.bm);
+    p.ntn = cdiv(ncols, p.bn);
+    int64_t M = (int64_t)d->N * d->P * d->Q;
+    int tiles = p.ntm * p.ntn;
+    int want = cdiv(1024, tiles);
+    int64_t max_splits = (M + 255) / 256;  // at least 256 pixel rows per split
+    if (max_splits < 1) max_splits = 1;
+    int splits = (int)(want < max_splits ? want : max_splits);
+    if (splits < 1) splits = 1;
+    int64_t rps = (M + splits - 1) / splits;
+    rps = (rps + BK - 1) / BK * BK;
+    p.rows_per_split = (int)rps;
+    p.splits = (int)((M + rps - 1) / rps);
+    return p;
+}
+}  // namespace up
+
+extern "C" size_t up_conv2d_bwd_weight_workspace(const up_conv_desc* d) {
+    if (!d || check_desc(d)) return 0;
+    WgradPlan p = plan_wgrad(d);
+    return (size_t)p.splits * d->K * d->R * d->S * d->Cp * sizeof(float);
+}
+
+extern "C" int up_conv2d_bwd_weight(const up_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (int e = check_desc(d)) return e;
+    UP_REQUIRE(x && dy && dw && workspace, UP_ERR_INVALID, "conv2d_bwd_weight: null pointer");
+    UP_REQUIRE(d->ldy % 4 == 0, UP_ERR_INVALID, "conv2d_bwd_weight: ldy=%d must be a multiple of 4", d->ldy);
+    WgradPlan p = plan_wgrad(d);
+    size_t need = (size_t)p.splits * d->K * d->R * d->S * d->Cp * sizeof(float);
+    UP_REQUIRE(workspace_bytes >= need, UP_ERR_WORKSPACE, "conv2d_bwd_weight: workspace %zu < %zu", workspace_bytes,
+               need);
+    hipStream_t st = as_stream(stream);
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x;
+    a.dy = dy;
+    a.slab = (float*)workspace;
+    a.M = d->N * d->P * d->Q;
+    a.K = d->K;
+    a.Cp = d->Cp;
+    a.Creal = d->C;
+    a.Ncols = d->R * d->S * d->Cp;
+    a.H = d->H;
+    a.W = d->W;
+    a.P = d->P;
+    a.Q = d->Q;
+    a.ldx = d->ldx;
+    a.ldy = d->ldy;
+    a.S = d->S;
+    a.stride = d->stride;
+    a.pad = d->pad;
+    a.dil = d->dil;
+    a.rows_per_split = p.rows_per_split;
+    a.ntn = p.ntn;
+    a.fPQ = make_fastdiv(d->P * d->Q);
+    a.fQ = make_fastdiv(d->Q);
+    a.fCp = make_fastdiv(d->Cp);
+    a.fS = make_fastdiv(d->S);
+    a.fNtn = make_fastdiv(p.ntn);
+    dim3 grid(p.ntm * p.ntn, p.splits);
+    if (p.bm == 128 && p.bn == 128)
+        hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, st, a);
+    else if (p.bm == 128 && p.bn == 64)
+        hipLaunchKernelGGL((wgrad_kernel<128, 64>), grid, dim3(256), 0, st, a);
+    else if (p.bm == 64 && p.bn == 128)
+        hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, dim3(256), 0, st, a);
+    long long total = (long long)d->K * a.Ncols;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)workspace, dw,
+                       p.splits, d->K, d->C, d->Cp, d->R * d->S, total);
+    if (dbias) {
+        if (hipMemsetAsync(dbias, 0, sizeof(float) * d->K, st) != hipSuccess) return check_launch("dbias memset");
+        int rpb = 1024;
+        dim3 g(cdiv(a.M, rpb), cdiv(d->K, 64));
+        hipLaunchKernelGGL(colsum_kernel, g, dim3(256), 0, st, dy, d->ldy, (long long)a.M, d->K, dbias, rpb);
+    }
+    return check_launch("conv2d_bwd_weight");
+}

@@ -1,0 +1,392 @@
+// BatchNorm (train statistics merge, apply, backward), ReLU backward, dropout, MSE.
+// All of these are HBM-bound streaming kernels: 16-byte accesses along the channel axis of the
+// NHWC tensors, grid-stride loops capped at a few blocks per CU, wave-level shuffles + LDS for
+// the per-channel reductions.
+#include "up_common.h"
+
+#include <stdarg.h>
+
+namespace up {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return UP_ERR_LAUNCH;
+    }
+    return UP_OK;
+}
+
+static inline int grid_for(int64_t work_items, int per_block = 256, int cap = 4096) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+__device__ __forceinline__ void wf_merge3(float& n1, float& m1, float& s1, float n2, float m2, float s2) {
+    if (n2 == 0.f) return;
+    if (n1 == 0.f) {
+        n1 = n2;
+        m1 = m2;
+        s1 = s2;
+        return;
+    }
+    float n = n1 + n2;
+    float d = m2 - m1;
+    m1 = m1 + d * (n2 / n);
+    s1 = s1 + s2 + d * d * (n1 * n2 / n);
+    n1 = n;
+}
+
+__global__ void __launch_bounds__(256) bn_eval_coeffs_kernel(const float* g, const float* b, const float* rm,
+                                                             const float* rv, float eps, int C, float* scale,
+                                                             float* shift) {
+    int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float is = 1.0f / sqrtf(rv[c] + eps);
+    float sc = g[c] * is;
+    scale[c] = sc;
+    shift[c] = b[c] - rm[c] * sc;
+}
+
+// one wavefront per channel: lanes stride over the row-tile partials, then a shuffle tree
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* stats, int tiles, int C, float eps, float mom,
+                                                          float* rm, float* rv, const float* gamma,
+                                                          const float* beta, float* mean_o, float* invstd_o,
+                                                          float* scale, float* shift) {
+    int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (c >= C) return;  // whole wave exits together
+    float n = 0.f, m = 0.f, q = 0.f;
+    for (int t = lane; t < tiles; t += 64) {
+        const float* s = stats + ((size_t)t * C + c) * 3;
+        wf_merge3(n, m, q, s[0], s[1], s[2]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        float n2 = __shfl_down(n, off), m2 = __shfl_down(m, off), q2 = __shfl_down(q, off);
+        wf_merge3(n, m, q, n2, m2, q2);
+    }
+    if (lane == 0) {
+        float var = q / n;
+        float is = 1.0f / sqrtf(var + eps);
+        mean_o[c] = m;
+        invstd_o[c] = is;
+        float sc = gamma[c] * is;
+        scale[c] = sc;
+        shift[c] = beta[c] - m * sc;
+        if (rm) {
+            float unb = n > 1.f ? q / (n - 1.f) : var;
+            rm[c] = (1.f - mom) * rm[c] + mom * m;
+            rv[c] = (1.f - mom) * rv[c] + mom * unb;
+        }
+    }
+}
+
+struct Apply2D {
+    int64_t rows;
+    int C4;
+    FastDiv fC4;
+};
+
+__global__ void __launch_bounds__(256) bn_apply_kernel(const float* y, int ldy, const float* scale,
+                                                       const float* shift, const float* res, int ldr, int relu,
+                                                       float* z, int ldz, int64_t total, int C4, FastDiv fC4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        uint32_t row = fdiv((uint32_t)i, fC4);
+        int c = ((int)i - (int)row * C4) * 4;
+        float4 v = *reinterpret_cast<const float4*>(y + (size_t)row * ldy + c);
+        float4 s = *reinterpret_cast<const float4*>(scale + c);
+        float4 h = *reinterpret_cast<const float4*>(shift + c);
+        v.x = v.x * s.x + h.x;
+        v.y = v.y * s.y + h.y;
+        v.z = v.z * s.z + h.z;
+        v.w = v.w * s.w + h.w;
+        if (res) {
+            float4 r = *reinterpret_cast<const float4*>(res + (size_t)row * ldr + c);
+            v.x += r.x;
+            v.y += r.y;
+            v.z += r.z;
+            v.w += r.w;
+        }
+        if (relu) {
+            v.x = fmaxf(v.x, 0.f);
+            v.y = fmaxf(v.y, 0.f);
+            v.z = fmaxf(v.z, 0.f);
+            v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(z + (size_t)row * ldz + c) = v;
+    }
+}
+
+// ---- BN backward -------------------------------------------------------------------------
+// pass 1: partial[chunk][c] = {sum g, sum g*xhat},   g = dz * (z > 0 if relu)
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* dz, int lddz, const float* z, int ldz,
+                                                            const float* y, int ldy, const float* mean,
+                                                            const float* invstd, int relu, float* partial,
+                                                            int64_t rows, int C, int rows_per_chunk) {
+    __shared__ float red[2][256];
+    int c = blockIdx.y * 64 + (threadIdx.x & 63);
+    int rl = threadIdx.x >> 6;
+    int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk;
+    int64_t r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+        float mu = mean[c], is = invstd[c];
+        for (int64_t r = r0 + rl; r < r1; r += 4) {
+            float g = dz[r * lddz + c];
+            if (relu && !(z[r * ldz + c] > 0.f)) g = 0.f;
+            s1 += g;
+            s2 += g * (y[r * ldy + c] - mu) * is;
+        }
+    }
+    red[0][threadIdx.x] = s1;
+    red[1][threadIdx.x] = s2;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        int t = threadIdx.x;
+        float a = red[0][t] + red[0][t + 64] + red[0][t + 128] + red[0][t + 192];
+        float b = red[1][t] + red[1][t + 64] + red[1][t + 128] + red[1][t + 192];
+        float* o = partial + ((size_t)blockIdx.x * C + c) * 2;
+        o[0] = a;
+        o[1] = b;
+    }
+}
+// pass 2: one wave per channel sums the chunk partials
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* partial, int chunks, int C, float* dgamma,
+                                                              float* dbeta) {
+    int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int t = lane; t < chunks; t += 64) {
+        a += partial[((size_t)t * C + c) * 2];
+        b += partial[((size_t)t * C + c) * 2 + 1];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        a += __shfl_down(a, off);
+        b += __shfl_down(b, off);
+    }
+    if (lane == 0) {
+        dbeta[c] = a;
+        dgamma[c] = b;
+    }
+}
+// pass 3: dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M);  dres = g
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* dz, int lddz, const float* z, int ldz,
+                                                           const float* y, int ldy, const float* gamma,
+                                                           const float* mean, const float* invstd,
+                                                           const float* dgamma, const float* dbeta, int relu,
+                                                           int use_batch, float inv_m, float* dy, int lddy,
+                                                           float* dres, int lddres, int64_t total, int C4,
+                                                           FastDiv fC4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        uint32_t row = fdiv((uint32_t)i, fC4);
+        int c = ((int)i - (int)row * C4) * 4;
+        float4 g4 = *reinterpret_cast<const float4*>(dz + (size_t)row * lddz + c);
+        float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        if (relu) {
+            float4 z4 = *reinterpret_cast<const float4*>(z + (size_t)row * ldz + c);
+            if (!(z4.x > 0.f)) g[0] = 0.f;
+            if (!(z4.y > 0.f)) g[1] = 0.f;
+            if (!(z4.z > 0.f)) g[2] = 0.f;
+            if (!(z4.w > 0.f)) g[3] = 0.f;
+        }
+        if (dres) *reinterpret_cast<float4*>(dres + (size_t)row * lddres + c) = make_float4(g[0], g[1], g[2], g[3]);
+        float4 y4 = *reinterpret_cast<const float4*>(y + (size_t)row * ldy + c);
+        float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float is = invstd[c + e];
+            float k = gamma[c + e] * is;
+            if (use_batch) {
+                float xh = (yv[e] - mean[c + e]) * is;
+                o[e] = k * (g[e] - dbeta[c + e] * inv_m - xh * dgamma[c + e] * inv_m);
+            } else {
+                o[e] = k * g[e];
+            }
+        }
+        *reinterpret_cast<float4*>(dy + (size_t)row * lddy + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ void __launch_bounds__(256) relu_bwd_kernel(const float* dz, const float* z, float* dx, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dx[i] = z[i] > 0.f ? dz[i] : 0.f;
+}
+
+// ---- dropout -----------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mix_hash(uint64_t seed, uint64_t idx) {
+    uint64_t v = seed ^ (idx * 0x9E3779B97F4A7C15ull);
+    v ^= v >> 30;
+    v *= 0xBF58476D1CE4E5B9ull;
+    v ^= v >> 27;
+    v *= 0x94D049BB133111EBull;
+    v ^= v >> 31;
+    return (uint32_t)(v >> 40);  // 24 random bits
+}
+__global__ void __launch_bounds__(256) dropout_fwd_kernel(const float* x, float* y, uint8_t* mask,
+                                                          const float* ext, int64_t n, float p, float inv_keep,
+                                                          uint64_t seed) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        bool keep;
+        if (ext)
+            keep = ext[i] != 0.f;
+        else
+            keep = (float)mix_hash(seed, (uint64_t)i) * (1.0f / 16777216.0f) >= p;
+        mask[i] = keep ? 1 : 0;
+        y[i] = keep ? x[i] * inv_keep : 0.f;
+    }
+}
+__global__ void __launch_bounds__(256) dropout_bwd_kernel(const float* dy, const uint8_t* mask, float* dx, int64_t n,
+                                                          float inv_keep) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dx[i] = mask[i] ? dy[i] * inv_keep : 0.f;
+}
+
+// ---- MSE ---------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+__global__ void __launch_bounds__(256) mse_partial_kernel(const float* y, const float* t, float* ws, int64_t n) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float d = y[i] - t[i];
+        s += d * d;
+    }
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) ws[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) mse_final_kernel(const float* ws, int parts, float inv_n, float* loss) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < parts; i += 256) s += ws[i];
+    s = block_sum_256(s, red);
+    if (threadIdx.x == 0) loss[0] = s * inv_n;
+}
+__global__ void __launch_bounds__(256) mse_bwd_kernel(const float* y, const float* t, const float* dloss, float* dy,
+                                                      int64_t n, float two_inv_n) {
+    float k = two_inv_n * dloss[0];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dy[i] = (y[i] - t[i]) * k;
+}
+
+constexpr int MSE_PARTS = 512;
+constexpr int BNB_ROWS = 512;
+
+}  // namespace up
+
+using namespace up;
+
+extern "C" const char* up_last_error(void) { return g_err; }
+extern "C" int up_abi_version(void) { return 1; }
+
+extern "C" int up_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                 int C, float* scale, float* shift, void* stream) {
+    UP_REQUIRE(gamma && beta && rm && rv && scale && shift && C > 0, UP_ERR_INVALID, "bn_eval_coeffs: bad argument");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(stream), gamma, beta, rm,
+                       rv, eps, C, scale, shift);
+    return check_launch("bn_eval_coeffs");
+}
+
+extern "C" int up_bn_finalize(const float* stats, int tiles, int C, float eps, float momentum, float* rm, float* rv,
+                              const float* gamma, const float* beta, float* mean, float* invstd, float* scale,
+                              float* shift, void* stream) {
+    UP_REQUIRE(stats && gamma && beta && mean && invstd && scale && shift && tiles > 0 && C > 0, UP_ERR_INVALID,
+               "bn_finalize: bad argument");
+    UP_REQUIRE((rm == nullptr) == (rv == nullptr), UP_ERR_INVALID, "bn_finalize: running stats must come in pairs");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, as_stream(stream), stats, tiles, C, eps,
+                       momentum, rm, rv, gamma, beta, mean, invstd, scale, shift);
+    return check_launch("bn_finalize");
+}
+
+extern "C" int up_bn_apply(const float* y, int ldy, const float* scale, const float* shift, const float* res,
+                           int ldr, int relu, float* z, int ldz, int64_t rows, int C, void* stream) {
+    UP_REQUIRE(y && scale && shift && z && rows > 0 && C > 0, UP_ERR_INVALID, "bn_apply: bad argument");
+    UP_REQUIRE(C % 4 == 0 && ldy % 4 == 0 && ldz % 4 == 0 && (!res || ldr % 4 == 0), UP_ERR_INVALID,
+               "bn_apply: C and strides must be multiples of 4");
+    UP_REQUIRE(rows * (C / 4) < (1ll << 31), UP_ERR_UNSUPPORTED, "bn_apply: tensor too large");
+    int64_t total = rows * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), y, ldy, scale, shift,
+                       res, ldr, relu, z, ldz, total, C / 4, make_fastdiv(C / 4));
+    return check_launch("bn_apply");
+}
+
+extern "C" size_t up_bn_bwd_workspace(int64_t rows, int C) {
+    return (size_t)cdiv(rows, BNB_ROWS) * C * 2 * sizeof(float);
+}
+
+extern "C" int up_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+                         const float* gamma, const float* mean, const float* invstd, int relu, int use_batch_stats,
+                         float* dy, int lddy, float* dres, int lddres, float* dgamma, float* dbeta,
+                         float* workspace, size_t workspace_bytes, int64_t rows, int C, void* stream) {
+    UP_REQUIRE(dz && y && gamma && mean && invstd && dy && dgamma && dbeta && workspace, UP_ERR_INVALID,
+               "bn_bwd: null pointer");
+    UP_REQUIRE(!relu || z, UP_ERR_INVALID, "bn_bwd: relu needs the forward output z");
+    UP_REQUIRE(C % 4 == 0 && lddz % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && (!relu || ldz % 4 == 0) &&
+                   (!dres || lddres % 4 == 0),
+               UP_ERR_INVALID, "bn_bwd: C and strides must be multiples of 4");
+    UP_REQUIRE(rows * (C / 4) < (1ll << 31), UP_ERR_UNSUPPORTED, "bn_bwd: tensor too large");
+    UP_REQUIRE(workspace_bytes >= up_bn_bwd_workspace(rows, C), UP_ERR_WORKSPACE, "bn_bwd: workspace too small");
+    hipStream_t st = as_stream(stream);
+    int chunks = cdiv(rows, BNB_ROWS);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(chunks, cdiv(C, 64)), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy,
+                       mean, invstd, relu, workspace, rows, C, BNB_ROWS);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, (const float*)workspace, chunks, C,
+                       dgamma, dbeta);
+    int64_t total = rows * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, gamma,
+                       mean, invstd, (const float*)dgamma, (const float*)dbeta, relu, use_batch_stats,
+                       1.0f / (float)rows, dy, lddy, dres, lddres, total, C / 4, make_fastdiv(C / 4));
+    return check_launch("bn_bwd");
+}
+
+extern "C" int up_relu_bwd(const float* dz, const float* z, float* dx, int64_t n, void* stream) {
+    UP_REQUIRE(dz && z && dx && n > 0, UP_ERR_INVALID, "relu_bwd: bad argument");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), dz, z, dx, n);
+    return check_launch("relu_bwd");
+}
+
+extern "C" int up_dropout_fwd(const float* x, float* y, uint8_t* mask, const float* ext_mask, int64_t n, float p,
+                              uint64_t seed, void* stream) {
+    UP_REQUIRE(x && y && mask && n > 0 && p >= 0.f && p < 1.f, UP_ERR_INVALID, "dropout_fwd: bad argument");
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, y, mask, ext_mask,
+                       n, p, 1.0f / (1.0f - p), seed);
+    return check_launch("dropout_fwd");
+}
+extern "C" int up_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, void* stream) {
+    UP_REQUIRE(dy && mask && dx && n > 0 && p >= 0.f && p < 1.f, UP_ERR_INVALID, "dropout_bwd: bad argument");
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), dy, mask, dx, n,
+                       1.0f / (1.0f - p));
+    return check_launch("dropout_bwd");
+}
+
+extern "C" size_t up_mse_workspace(int64_t) { return MSE_PARTS * sizeof(float); }
+extern "C" int up_mse_fwd(const float* y, const float* t, float* loss, float* ws, int64_t n, void* stream) {
+    UP_REQUIRE(y && t && loss && ws && n > 0, UP_ERR_INVALID, "mse_fwd: bad argument");
+    int parts = grid_for(n, 256, MSE_PARTS);
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(parts), dim3(256), 0, as_stream(stream), y, t, ws, n);
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const float*)ws, parts,
+                       1.0f / (float)n, loss);
+    return check_launch("mse_fwd");
+}
+extern "C" int up_mse_bwd(const float* y, const float* t, const float* dloss, float* dy, int64_t n, void* stream) {
+    UP_REQUIRE(y && t && dloss && dy && n > 0, UP_ERR_INVALID, "mse_bwd: bad argument");
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), y, t, dloss, dy, n,
+                       2.0f / (float)n);
+    return check_launch("mse_bwd");
+}

@@ -1,0 +1,530 @@
+// Layout conversion at the NCHW boundary, max-pool 3/2/1, bilinear (align_corners) resampling,
+// global average pool, AvgPool(9,8,1) of the centre map, strided copies (concat/slice), ConvLSTM
+// gate math and the wave-reduced heat-map argmax.  All HBM-bound: 16-byte channel-vector accesses on
+// NHWC tensors, one thread per (pixel, 4 channels).
+#include "up_common.h"
+
+namespace up {
+
+static inline int grid_cap(int64_t work_items, int cap = 8192) {
+    int64_t g = (work_items + 255) / 256;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+#define UP_GRID_STRIDE(i, total) \
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (total); i += (int64_t)gridDim.x * 256)
+
+// ---- layout ------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* x, float* y, int C, int HW, int ld,
+                                                           int64_t npix) {
+    UP_GRID_STRIDE(i, npix) {
+        int64_t n = i / HW;
+        int hw = (int)(i - n * HW);
+        const float* src = x + n * C * HW + hw;
+        float* dst = y + i * ld;
+        for (int c = 0; c < ld; ++c) dst[c] = c < C ? src[(int64_t)c * HW] : 0.f;
+    }
+}
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float* x, int ld, float* y, int C, int HW,
+                                                           int64_t npix) {
+    UP_GRID_STRIDE(i, npix) {
+        int64_t n = i / HW;
+        int hw = (int)(i - n * HW);
+        const float* src = x + i * ld;
+        float* dst = y + n * C * HW + hw;
+        for (int c = 0; c < C; ++c) dst[(int64_t)c * HW] = src[c];
+    }
+}
+
+// ---- 2-D strided copy / add ----------------------------------------------------------------
+__global__ void __launch_bounds__(256) copy2d_v4_kernel(const float* s, int lds, float* d, int ldd, int64_t total,
+                                                        int C4, FastDiv fC4) {
+    UP_GRID_STRIDE(i, total) {
+        uint32_t row = fdiv((uint32_t)i, fC4);
+        int c = ((int)i - (int)row * C4) * 4;
+        *reinterpret_cast<float4*>(d + (size_t)row * ldd + c) = *reinterpret_cast<const float4*>(s + (size_t)row * lds + c);
+    }
+}
+__global__ void __launch_bounds__(256) copy2d_s_kernel(const float* s, int lds, float* d, int ldd, int64_t total,
+                                                       int C, FastDiv fC) {
+    UP_GRID_STRIDE(i, total) {
+        uint32_t row = fdiv((uint32_t)i, fC);
+        int c = (int)i - (int)row * C;
+        d[(size_t)row * ldd + c] = s[(size_t)row * lds + c];
+    }
+}
+__global__ void __launch_bounds__(256) add2d_kernel(const float* a, int lda, const float* b, int ldb, float* d,
+                                                    int ldd, int64_t total, int C, FastDiv fC) {
+    UP_GRID_STRIDE(i, total) {
+        uint32_t row = fdiv((uint32_t)i, fC);
+        int c = (int)i - (int)row * C;
+        d[(size_t)row * ldd + c] = a[(size_t)row * lda + c] + b[(size_t)row * ldb + c];
+    }
+}
+
+// ---- max-pool 3x3 / stride 2 / pad 1 --------------------------------------------------------
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* x, int ldx, float* y, int ldy, uint8_t* idx,
+                                                          int H, int W, int C4, int P, int Q, int64_t total,
+                                                          FastDiv fC4, FastDiv fQ, FastDiv fP) {
+    UP_GRID_STRIDE(i, total) {
+        uint32_t pix = fdiv((uint32_t)i, fC4);
+        int c = ((int)i - (int)pix * C4) * 4;
+        uint32_t t = fdiv(pix, fQ);
+        int q = (int)pix - (int)t * Q;
+        uint32_t n = fdiv(t, fP);
+        int p = (int)t - (int)n * P;
+        float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {0, 0, 0, 0};
+        bool first = true;
+        for (int r = 0; r < 3; ++r) {
+            int h = 2 * p - 1 + r;
+            if (h < 0 || h >= H) continue;
+            for (int s = 0; s < 3; ++s) {
+                int w = 2 * q - 1 + s;
+                if (w < 0 || w >= W) continue;
+                float4 v4 = *reinterpret_cast<const float4*>(x + ((size_t)(n * H + h) * W + w) * ldx + c);
+                float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (first || v[e] > best[e] || v[e] != v[e]) {
+                        best[e] = v[e];
+                        bi[e] = r * 3 + s;
+                    }
+                first = false;
+            }
+        }
+        *reinterpret_cast<float4*>(y + (size_t)pix * ldy + c) = make_float4(best[0], best[1], best[2], best[3]);
+        uint8_t* ip = idx + (size_t)pix * (C4 * 4) + c;
+        ip[0] = (uint8_t)bi[0];
+        ip[1] = (uint8_t)bi[1];
+        ip[2] = (uint8_t)bi[2];
+        ip[3] = (uint8_t)bi[3];
+    }
+}
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* dy, int lddy, const uint8_t* idx, float* dx,
+                                                          int lddx, int H, int W, int C4, int P, int Q,
+                                                          int64_t total, FastDiv fC4, FastDiv fW, FastDiv fH) {
+    UP_GRID_STRIDE(i, total) {
+        uint32_t pix = fdiv((uint32_t)i, fC4);
+        int c = ((int)i - (int)pix * C4) * 4;
+        uint32_t t = fdiv(pix, fW);
+        int w = (int)pix - (int)t * W;
+        uint32_t n = fdiv(t, fH);
+        int h = (int)t - (int)n * H;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 3; ++r) {
+            int tp = h + 1 - r;
+            if (tp < 0 || (tp & 1) || (tp >> 1) >= P) continue;
+            int p = tp >> 1;
+            for (int s = 0; s < 3; ++s) {
+                int tq = w + 1 - s;
+                if (tq < 0 || (tq & 1) || (tq >> 1) >= Q) continue;
+                int q = tq >> 1;
+                size_t op = (size_t)(n * P + p) * Q + q;
+                const uint8_t* ip = idx + op * (C4 * 4) + c;
+                float4 g = *reinterpret_cast<const float4*>(dy + op * lddy + c);
+                int code = r * 3 + s;
+                if (ip[0] == code) acc[0] += g.x;
+                if (ip[1] == code) acc[1] += g.y;
+                if (ip[2] == code) acc[2] += g.z;
+                if (ip[3] == code) acc[3] += g.w;
+            }
+        }
+        *reinterpret_cast<float4*>(dx + (size_t)pix * lddx + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+// ---- bilinear, align_corners=True ----------------------------------------------------------
+__global__ void __launch_bounds__(256) bilinear_fwd_kernel(const float* x, int ldx, float* y, int ldy, int H, int W,
+                                                           int C4, int P, int Q, float sh, float sw, int64_t total,
+                                                           FastDiv fC4, FastDiv fQ, FastDiv fP) {
+    UP_GRID_STRIDE(i, total) {
+        uint32_t pix = fdiv((uint32_t)i, fC4);
+        int c = ((int)i - (int)pix * C4) * 4;
+        uint32_t t = fdiv(pix, fQ);
+        int q = (int)pix - (int)t * Q;
+        uint32_t n = fdiv(t, fP);
+        int p = (int)t - (int)n * P;
+        float fh = sh * p, fw = sw * q;
+        int h0 = (int)fh, w0 = (int)fw;
+        int h1 = h0 < H - 1 ? h0 + 1 : h0, w1 = w0 < W - 1 ? w0 + 1 : w0;
+        float lh1 = fh - h0, lw1 = fw - w0, lh0 = 1.f - lh1, lw0 = 1.f - lw1;
+        const float* b = x + (size_t)n * H * W * ldx + c;
+        float4 a00 = *reinterpret_cast<const float4*>(b + (size_t)(h0 * W + w0) * ldx);
+        float4 a01 = *reinterpret_cast<const float4*>(b + (size_t)(h0 * W + w1) * ldx);
+        float4 a10 = *reinterpret_cast<const float4*>(b + (size_t)(h1 * W + w0) * ldx);
+        float4 a11 = *reinterpret_cast<const float4*>(b + (size_t)(h1 * W + w1) * ldx);
+        float4 o;
+        o.x = lh0 * (lw0 * a00.x + lw1 * a01.x) + lh1 * (lw0 * a10.x + lw1 * a11.x);
+        o.y = lh0 * (lw0 * a00.y + lw1 * a01.y) + lh1 * (lw0 * a10.y + lw1 * a11.y);
+        o.z = lh0 * (lw0 * a00.z + lw1 * a01.z) + lh1 * (lw0 * a10.z + lw1 * a11.z);
+        o.w = lh0 * (lw0 * a00.w + lw1 * a01.w) + lh1 * (lw0 * a10.w + lw1 * a11.w);
+        *reinterpret_cast<float4*>(y + (size_t)pix * ldy + c) = o;
+    }
+}
+// weight with which output coordinate o (of `out` samples, scale s) reads input sample `in_i`
+__device__ __forceinline__ float bil_weight(int o, int in_i, int in_n, float s) {
+    float f = s * o;
+    int i0 = (int)f;
+    int i1 = i0 < in_n - 1 ? i0 + 1 : i0;
+    float l1 = f - i0;
+    float w = 0.f;
+    if (i0 == in_i) w += 1.f - l1;
+    if (i1 == in_i) w += l1;
+    return w;
+}
+__global__ void __launch_bounds__(256) bilinear_bwd_kernel(const float* dy, int lddy, float* dx, int lddx, int H,
+                                                           int W, int C4, int P, int Q, float sh, float sw,
+                                                           int64_t total, FastDiv fC4, FastDiv fW, FastDiv fH) {
+    UP_GRID_STRIDE(i, total) {
+        uint32_t pix = fdiv((uint32_t)i, fC4);
+        int c = ((int)i - (int)pix * C4) * 4;
+        uint32_t t = fdiv(pix, fW);
+        int w = (int)pix - (int)t * W;
+        uint32_t n = fdiv(t, fH);
+        int h = (int)t - (int)n * H;
+        int p_lo = 0, p_hi = P - 1, q_lo = 0, q_hi = Q - 1;
+        if (sh > 0.f) {
+            p_lo = max(0, (int)floorf((h - 1) / sh) - 1);
+            p_hi = min(P - 1, (int)ceilf((h + 1) / sh) + 1);
+        }
+        if (sw > 0.f) {
+            q_lo = max(0, (int)floorf((w - 1) / sw) - 1);
+            q_hi = min(Q - 1, (int)ceilf((w + 1) / sw) + 1);
+        }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int p = p_lo; p <= p_hi; ++p) {
+            float wh = bil_weight(p, h, H, sh);
+            if (wh == 0.f) continue;
+            for (int q = q_lo; q <= q_hi; ++q) {
+                float ww = bil_weight(q, w, W, sw);
+                if (ww == 0.f) continue;
+                float4 g = *reinterpret_cast<const float4*>(dy + ((size_t)(n * P + p) * Q + q) * lddy + c);
+                float k = wh * ww;
+                acc[0] += k * g.x;
+                acc[1] += k * g.y;
+                acc[2] += k * g.z;
+                acc[3] += k * g.w;
+            }
+        }
+        *reinterpret_cast<float4*>(dx + (size_t)pix * lddx + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+}
+
+// ---- global average pool ---------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gap_fwd_kernel(const float* x, int ldx, float* y, int HW, int C) {
+    __shared__ float red[256];
+    int n = blockIdx.x;
+    int c = blockIdx.y * 64 + (threadIdx.x & 63);
+    int rl = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < C)
+        for (int r = rl; r < HW; r += 4) s += x[((size_t)n * HW + r) * ldx + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        int t = threadIdx.x;
+        y[(size_t)n * C + c] = (red[t] + red[t + 64] + red[t + 128] + red[t + 192]) / (float)HW;
+    }
+}
+__global__ void __launch_bounds__(256) gap_bwd_kernel(const float* dy, float* dx, int lddx, int HW, int C4,
+                                                      float inv, int64_t total, FastDiv fC4, FastDiv fHW) {
+    UP_GRID_STRIDE(i, total) {
+        uint32_t pix = fdiv((uint32_t)i, fC4);
+        int c = ((int)i - (int)pix * C4) * 4;
+        uint32_t n = fdiv(pix, fHW);
+        float4 g = *reinterpret_cast<const float4*>(dy + (size_t)n * (C4 * 4) + c);
+        *reinterpret_cast<float4*>(dx + (size_t)pix * lddx + c) = make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
+    }
+}
+
+// ---- AvgPool2d(9, 8, 1), count_include_pad -----------------------------------------------------
+__global__ void __launch_bounds__(256) avgpool9s8_kernel(const float* x, float* y, int ldy, int coff, int H, int W,
+                                                         int P, int Q, int64_t total) {
+    UP_GRID_STRIDE(i, total) {
+        int q = (int)(i % Q);
+        int64_t t = i / Q;
+        int p = (int)(t % P);
+        int64_t n = t / P;
+        int hs = p * 8 - 1, ws = q * 8 - 1;
+        int he = min(hs + 9, H + 1), we = min(ws + 9, W + 1);
+        float div = (float)((he - hs) * (we - ws));
+        hs = max(hs, 0);
+        ws = max(ws, 0);
+        he = min(he, H);
+        we = min(we, W);
+        float s = 0.f;
+        for (int h = hs; h < he; ++h)
+            for (int w = ws; w < we; ++w) s += x[(n * H + h) * W + w];
+        y[i * ldy + coff] = s / div;
+    }
+}
+
+// ---- ConvLSTM gates -------------------------------------------------------------------------
+__device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+__global__ void __launch_bounds__(256) lstm0_fwd_kernel(const float* G, int ldg, float* cell, float* hide, int ldo,
+                                                        int64_t total, int Cg) {
+    UP_GRID_STRIDE(i, total) {
+        int64_t r = i / Cg;
+        int c = (int)(i - r * Cg);
+        const float* g = G + r * ldg;
+        float gg = tanhf(g[c]), ii = sigm(g[Cg + c]), oo = sigm(g[2 * Cg + c]);
+        float cl = tanhf(gg * ii);
+        cell[r * ldo + c] = cl;
+        hide[r * ldo + c] = oo * cl;
+    }
+}
+__global__ void __launch_bounds__(256) lstm0_bwd_kernel(const float* G, int ldg, const float* dcell,
+                                                        const float* dhide, int ldo, float* dG, int64_t total,
+                                                        int Cg) {
+    UP_GRID_STRIDE(i, total) {
+        int64_t r = i / Cg;
+        int c = (int)(i - r * Cg);
+        const float* g = G + r * ldg;
+        float gg = tanhf(g[c]), ii = sigm(g[Cg + c]), oo = sigm(g[2 * Cg + c]);
+        float cl = tanhf(gg * ii);
+        float dh = dhide[r * ldo + c];
+        float dc = dcell[r * ldo + c] + dh * oo;
+        float dgi = dc * (1.f - cl * cl);
+        float* o = dG + r * ldg;
+        o[c] = dgi * ii * (1.f - gg * gg);
+        o[Cg + c] = dgi * gg * ii * (1.f - ii);
+        o[2 * Cg + c] = dh * cl * oo * (1.f - oo);
+    }
+}
+__global__ void __launch_bounds__(256) lstm_fwd_kernel(const float* G, int ldg, const float* cprev, int ldc,
+                                                       float* cell, float* hide, int ldo, int64_t total, int Cg) {
+    UP_GRID_STRIDE(i, total) {
+        int64_t r = i / Cg;
+        int c = (int)(i - r * Cg);
+        const float* g = G + r * ldg;
+        float gg = tanhf(g[c]), ii = sigm(g[Cg + c]), oo = sigm(g[2 * Cg + c]), ff = sigm(g[3 * Cg + c]);
+        float cl = ff * cprev[r * ldc + c] + ii * gg;
+        cell[r * ldo + c] = cl;
+        hide[r * ldo + c] = oo * tanhf(cl);
+    }
+}
+__global__ void __launch_bounds__(256) lstm_bwd_kernel(const float* G, int ldg, const float* cprev, int ldc,
+                                                       const float* cell, const float* dcell, const float* dhide,
+                                                       int ldo, float* dG, float* dcprev, int64_t total, int Cg) {
+    UP_GRID_STRIDE(i, total) {
+        int64_t r = i / Cg;
+        int c = (int)(i - r * Cg);
+        const float* g = G + r * ldg;
+        float gg = tanhf(g[c]), ii = sigm(g[Cg + c]), oo = sigm(g[2 * Cg + c]), ff = sigm(g[3 * Cg + c]);
+        float tc = tanhf(cell[r * ldo + c]);
+        float dh = dhide[r * ldo + c];
+        float dc = dcell[r * ldo + c] + dh * oo * (1.f - tc * tc);
+        float* o = dG + r * ldg;
+        o[c] = dc * ii * (1.f - gg * gg);
+        o[Cg + c] = dc * gg * ii * (1.f - ii);
+        o[2 * Cg + c] = dh * tc * oo * (1.f - oo);
+        o[3 * Cg + c] = dc * cprev[r * ldc + c] * ff * (1.f - ff);
+        dcprev[r * ldo + c] = dc * ff;
+    }
+}
+
+// ---- heat-map argmax: one wavefront per (b, j) map ------------------------------------------------
+__device__ __forceinline__ bool am_better(float v, int i, float bv, int bi) {
+    bool vn = v != v, bn = bv != bv;
+    if (vn != bn) return vn;        // NaN beats a number (np.argmax semantics)
+    if (vn) return i < bi;          // both NaN: first one
+    if (v != bv) return v > bv;
+    return i < bi;                  // ties: lowest flat index
+}
+__global__ void __launch_bounds__(256) argmax_kernel(const float* hm, int maps, int HW, int W, int32_t* idx,
+                                                     float* preds, float* maxvals) {
+    int map = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int lane = threadIdx.x & 63;
+    if (map >= maps) return;
+    const float* p = hm + (size_t)map * HW;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = lane; i < HW; i += 64) {
+        float v = p[i];
+        if (am_better(v, i, bv, bi)) {
+            bv = v;
+            bi = i;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        float ov = __shfl_down(bv, off);
+        int oi = __shfl_down(bi, off);
+        if (am_better(ov, oi, bv, bi)) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    if (lane == 0) {
+        if (idx) idx[map] = bi;
+        float keep = bv > 0.f ? 1.f : 0.f;
+        preds[map * 2] = (float)(bi % W) * keep;
+        preds[map * 2 + 1] = (float)(bi / W) * keep;
+        maxvals[map] = bv;
+    }
+}
+
+}  // namespace up
+
+using namespace up;
+
+#define UP_LAUNCH_1D(kernel, total, st, ...) \
+    hipLaunchKernelGGL(kernel, dim3(grid_cap(total)), dim3(256), 0, st, __VA_ARGS__)
+
+extern "C" int up_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int ldy, void* stream) {
+    UP_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && ldy >= C, UP_ERR_INVALID, "nchw_to_nhwc: bad argument");
+    int64_t npix = (int64_t)N * H * W;
+    UP_LAUNCH_1D(nchw_to_nhwc_kernel, npix, as_stream(stream), x, y, C, H * W, ldy, npix);
+    return check_launch("nchw_to_nhwc");
+}
+extern "C" int up_nhwc_to_nchw(const float* x, int ldx, float* y, int N, int C, int H, int W, void* stream) {
+    UP_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && ldx >= C, UP_ERR_INVALID, "nhwc_to_nchw: bad argument");
+    int64_t npix = (int64_t)N * H * W;
+    UP_LAUNCH_1D(nhwc_to_nchw_kernel, npix, as_stream(stream), x, ldx, y, C, H * W, npix);
+    return check_launch("nhwc_to_nchw");
+}
+
+extern "C" int up_copy2d(const float* s, int lds, float* d, int ldd, int64_t rows, int C, void* stream) {
+    UP_REQUIRE(s && d && rows > 0 && C > 0 && lds >= C && ldd >= C, UP_ERR_INVALID, "copy2d: bad argument");
+    UP_REQUIRE(rows * C < (1ll << 31), UP_ERR_UNSUPPORTED, "copy2d: tensor too large");
+    bool v4 = C % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && ((uintptr_t)s % 16 == 0) && ((uintptr_t)d % 16 == 0);
+    if (v4) {
+        int64_t total = rows * (C / 4);
+        UP_LAUNCH_1D(copy2d_v4_kernel, total, as_stream(stream), s, lds, d, ldd, total, C / 4, make_fastdiv(C / 4));
+    } else {
+        int64_t total = rows * C;
+        UP_LAUNCH_1D(copy2d_s_kernel, total, as_stream(stream), s, lds, d, ldd, total, C, make_fastdiv(C));
+    }
+    return check_launch("copy2d");
+}
+extern "C" int up_add2d(const float* a, int lda, const float* b, int ldb, float* d, int ldd, int64_t rows, int C,
+                        void* stream) {
+    UP_REQUIRE(a && b && d && rows > 0 && C > 0, UP_ERR_INVALID, "add2d: bad argument");
+    UP_REQUIRE(rows * C < (1ll << 31), UP_ERR_UNSUPPORTED, "add2d: tensor too large");
+    int64_t total = rows * C;
+    UP_LAUNCH_1D(add2d_kernel, total, as_stream(stream), a, lda, b, ldb, d, ldd, total, C, make_fastdiv(C));
+    return check_launch("add2d");
+}
+
+static int pool_args_ok(int N, int H, int W, int C, int P, int Q, int lda, int ldb) {
+    UP_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && P > 0 && Q > 0, UP_ERR_INVALID, "spatial op: bad dimension");
+    UP_REQUIRE(C % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0 && lda >= C && ldb >= C, UP_ERR_INVALID,
+               "spatial op: C and strides must be multiples of 4");
+    UP_REQUIRE((int64_t)N * H * W * (C / 4) < (1ll << 31) && (int64_t)N * P * Q * (C / 4) < (1ll << 31),
+               UP_ERR_UNSUPPORTED, "spatial op: tensor too large");
+    return UP_OK;
+}
+
+extern "C" int up_maxpool3s2_fwd(const float* x, int ldx, float* y, int ldy, uint8_t* idx, int N, int H, int W, int C,
+                                 int P, int Q, void* stream) {
+    if (int e = pool_args_ok(N, H, W, C, P, Q, ldx, ldy)) return e;
+    UP_REQUIRE(x && y && idx, UP_ERR_INVALID, "maxpool_fwd: null pointer");
+    UP_REQUIRE(P == (H - 1) / 2 + 1 && Q == (W - 1) / 2 + 1, UP_ERR_INVALID, "maxpool_fwd: P,Q mismatch");
+    int64_t total = (int64_t)N * P * Q * (C / 4);
+    UP_LAUNCH_1D(maxpool_fwd_kernel, total, as_stream(stream), x, ldx, y, ldy, idx, H, W, C / 4, P, Q, total,
+                 make_fastdiv(C / 4), make_fastdiv(Q), make_fastdiv(P));
+    return check_launch("maxpool_fwd");
+}
+extern "C" int up_maxpool3s2_bwd(const float* dy, int lddy, const uint8_t* idx, float* dx, int lddx, int N, int H,
+                                 int W, int C, int P, int Q, void* stream) {
+    if (int e = pool_args_ok(N, H, W, C, P, Q, lddx, lddy)) return e;
+    UP_REQUIRE(dy && idx && dx, UP_ERR_INVALID, "maxpool_bwd: null pointer");
+    int64_t total = (int64_t)N * H * W * (C / 4);
+    UP_LAUNCH_1D(maxpool_bwd_kernel, total, as_stream(stream), dy, lddy, idx, dx, lddx, H, W, C / 4, P, Q, total,
+                 make_fastdiv(C / 4), make_fastdiv(W), make_fastdiv(H));
+    return check_launch("maxpool_bwd");
+}
+
+static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+extern "C" int up_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int P, int Q,
+                               void* stream) {
+    if (int e = pool_args_ok(N, H, W, C, P, Q, ldx, ldy)) return e;
+    UP_REQUIRE(x && y, UP_ERR_INVALID, "bilinear_fwd: null pointer");
+    int64_t total = (int64_t)N * P * Q * (C / 4);
+    UP_LAUNCH_1D(bilinear_fwd_kernel, total, as_stream(stream), x, ldx, y, ldy, H, W, C / 4, P, Q, ac_scale(H, P),
+                 ac_scale(W, Q), total, make_fastdiv(C / 4), make_fastdiv(Q), make_fastdiv(P));
+    return check_launch("bilinear_fwd");
+}
+extern "C" int up_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int H, int W, int C, int P,
+                               int Q, void* stream) {
+    if (int e = pool_args_ok(N, H, W, C, P, Q, lddx, lddy)) return e;
+    UP_REQUIRE(dy && dx, UP_ERR_INVALID, "bilinear_bwd: null pointer");
+    int64_t total = (int64_t)N * H * W * (C / 4);
+    UP_LAUNCH_1D(bilinear_bwd_kernel, total, as_stream(stream), dy, lddy, dx, lddx, H, W, C / 4, P, Q, ac_scale(H, P),
+                 ac_scale(W, Q), total, make_fastdiv(C / 4), make_fastdiv(W), make_fastdiv(H));
+    return check_launch("bilinear_bwd");
+}
+
+extern "C" int up_gap_fwd(const float* x, int ldx, float* y, int N, int HW, int C, void* stream) {
+    UP_REQUIRE(x && y && N > 0 && HW > 0 && C > 0 && ldx >= C, UP_ERR_INVALID, "gap_fwd: bad argument");
+    hipLaunchKernelGGL(gap_fwd_kernel, dim3(N, cdiv(C, 64)), dim3(256), 0, as_stream(stream), x, ldx, y, HW, C);
+    return check_launch("gap_fwd");
+}
+extern "C" int up_gap_bwd(const float* dy, float* dx, int lddx, int N, int HW, int C, void* stream) {
+    UP_REQUIRE(dy && dx && N > 0 && HW > 0 && C > 0 && C % 4 == 0 && lddx % 4 == 0 && lddx >= C, UP_ERR_INVALID,
+               "gap_bwd: bad argument");
+    int64_t total = (int64_t)N * HW * (C / 4);
+    UP_REQUIRE(total < (1ll << 31), UP_ERR_UNSUPPORTED, "gap_bwd: tensor too large");
+    UP_LAUNCH_1D(gap_bwd_kernel, total, as_stream(stream), dy, dx, lddx, HW, C / 4, 1.0f / (float)HW, total,
+                 make_fastdiv(C / 4), make_fastdiv(HW));
+    return check_launch("gap_bwd");
+}
+
+extern "C" int up_avgpool9s8_fwd(const float* x, float* y, int ldy, int coff, int N, int H, int W, int P, int Q,
+                                 void* stream) {
+    UP_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && coff >= 0 && coff < ldy, UP_ERR_INVALID, "avgpool: bad argument");
+    UP_REQUIRE(P == (H + 2 - 9) / 8 + 1 && Q == (W + 2 - 9) / 8 + 1, UP_ERR_INVALID, "avgpool: P,Q mismatch");
+    int64_t total = (int64_t)N * P * Q;
+    UP_LAUNCH_1D(avgpool9s8_kernel, total, as_stream(stream), x, y, ldy, coff, H, W, P, Q, total);
+    return check_launch("avgpool9s8");
+}
+
+extern "C" int up_lstm0_fwd(const float* gates, int ldg, float* cell, float* hide, int ldo, int64_t rows, int Cg,
+                            void* stream) {
+    UP_REQUIRE(gates && cell && hide && rows > 0 && Cg > 0 && ldg >= 3 * Cg && ldo >= Cg, UP_ERR_INVALID,
+               "lstm0_fwd: bad argument");
+    int64_t total = rows * Cg;
+    UP_LAUNCH_1D(lstm0_fwd_kernel, total, as_stream(stream), gates, ldg, cell, hide, ldo, total, Cg);
+    return check_launch("lstm0_fwd");
+}
+extern "C" int up_lstm0_bwd(const float* gates, int ldg, const float* dcell, const float* dhide, int ldo,
+                            float* dgates, int64_t rows, int Cg, void* stream) {
+    UP_REQUIRE(gates && dcell && dhide && dgates && rows > 0 && Cg > 0 && ldg >= 3 * Cg && ldo >= Cg, UP_ERR_INVALID,
+               "lstm0_bwd: bad argument");
+    int64_t total = rows * Cg;
+    UP_LAUNCH_1D(lstm0_bwd_kernel, total, as_stream(stream), gates, ldg, dcell, dhide, ldo, dgates, total, Cg);
+    return check_launch("lstm0_bwd");
+}
+extern "C" int up_lstm_fwd(const float* gates, int ldg, const float* cprev, int ldc, float* cell, float* hide, int ldo,
+                           int64_t rows, int Cg, void* stream) {
+    UP_REQUIRE(gates && cprev && cell && hide && rows > 0 && Cg > 0 && ldg >= 4 * Cg && ldo >= Cg && ldc >= Cg,
+               UP_ERR_INVALID, "lstm_fwd: bad argument");
+    int64_t total = rows * Cg;
+    UP_LAUNCH_1D(lstm_fwd_kernel, total, as_stream(stream), gates, ldg, cprev, ldc, cell, hide, ldo, total, Cg);
+    return check_launch("lstm_fwd");
+}
+extern "C" int up_lstm_bwd(const float* gates, int ldg, const float* cprev, int ldc, const float* cell,
+                           const float* dcell, const float* dhide, int ldo, float* dgates, float* dcprev,
+                           int64_t rows, int Cg, void* stream) {
+    UP_REQUIRE(gates && cprev && cell && dcell && dhide && dgates && dcprev && rows > 0 && Cg > 0 && ldg >= 4 * Cg &&
+                   ldo >= Cg && ldc >= Cg,
+               UP_ERR_INVALID, "lstm_bwd: bad argument");
+    int64_t total = rows * Cg;
+    UP_LAUNCH_1D(lstm_bwd_kernel, total, as_stream(stream), gates, ldg, cprev, ldc, cell, dcell, dhide, ldo, dgates,
+                 dcprev, total, Cg);
+    return check_launch("lstm_bwd");
+}
+
+extern "C" int up_heatmap_argmax(const float* hm, int B, int J, int H, int W, int32_t* idx, float* preds_xy,
+                                 float* maxvals, void* stream) {
+    UP_REQUIRE(hm && preds_xy && maxvals && B > 0 && J > 0 && H > 0 && W > 0, UP_ERR_INVALID,
+               "heatmap_argmax: bad argument");
+    int maps = B * J;
+    hipLaunchKernelGGL(argmax_kernel, dim3(cdiv(maps, 4)), dim3(256), 0, as_stream(stream), hm, maps, H * W, W, idx,
+                       preds_xy, maxvals);
+    return check_launch("heatmap_argmax");
+}

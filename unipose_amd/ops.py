@@ -1,0 +1,658 @@
+"""Host-side operators: torch tensors in, C-ABI calls out (``_C.lib()``), wired into autograd.
+
+Tensors inside the network are NHWC fp32 ("pixel-major", see include/unipose_hip.h): shape
+(N, H, W, Cp) with Cp a multiple of 4; ``logical`` channel counts smaller than Cp (3, 14, 15, 17 …)
+are carried by the weights' shapes, pad channels hold zeros.  PyTorch owns all memory; kernels borrow
+raw pointers and run on the current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _C
+
+BN_EPS_DEFAULT = 1e-5
+
+
+def rup4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _dev_ok(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda and not _C._ALLOW_HOST_POINTERS:
+            raise _C.UniPoseHipError("unipose_amd kernels need CUDA(HIP) tensors; there is no CPU fallback")
+        if t.dtype != torch.float32 and t.dtype != torch.uint8 and t.dtype != torch.int32:
+            raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _nhwc_ok(t: torch.Tensor):
+    n, h, w, c = t.shape
+    ld = t.stride(2)
+    if t.stride(3) != 1 or t.stride(1) != w * ld or (n > 1 and t.stride(0) != h * w * ld) or ld % 4 or \
+            t.data_ptr() % 16:
+        raise ValueError(f"tensor is not a pixel-contiguous NHWC view: shape {tuple(t.shape)} strides {t.stride()}")
+    return ld
+
+
+def _dense(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+_WS = {}
+
+
+def workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
+    """Stream-ordered scratch (split-K slabs, BN-backward partials); grows monotonically per device."""
+    key = (dev.type, dev.index)
+    t = _WS.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
+        _WS[key] = t
+    return t
+
+
+# --------------------------------------------------------------------------------------------
+# convolution
+# --------------------------------------------------------------------------------------------
+class ConvCfg:
+    __slots__ = ("stride", "pad", "dil")
+
+    def __init__(self, stride=1, pad=0, dil=1):
+        self.stride, self.pad, self.dil = int(stride), int(pad), int(dil)
+
+
+def make_desc(x: torch.Tensor, weight: torch.Tensor, cfg: ConvCfg, ldy: Optional[int] = None) -> _C.ConvDesc:
+    n, h, w, cp = x.shape
+    k, c, r, s = weight.shape
+    if cp < c or cp % 4:
+        raise ValueError(f"input has {cp} physical channels, weight expects {c}")
+    p = (h + 2 * cfg.pad - cfg.dil * (r - 1) - 1) // cfg.stride + 1
+    q = (w + 2 * cfg.pad - cfg.dil * (s - 1) - 1) // cfg.stride + 1
+    d = _C.ConvDesc()
+    d.N, d.H, d.W, d.C, d.Cp, d.ldx = n, h, w, c, rup4(c), _nhwc_ok(x)
+    d.K, d.R, d.S = k, r, s
+    d.stride, d.pad, d.dil = cfg.stride, cfg.pad, cfg.dil
+    d.P, d.Q = p, q
+    d.Kp = rup4(k)
+    d.ldy = ldy if ldy is not None else rup4(k)
+    return d
+
+
+_PACK_CACHE = {}
+
+
+def packed_fwd(weight: torch.Tensor, d: _C.ConvDesc) -> torch.Tensor:
+    """[K][R*S][Cp] image of an OIHW parameter; re-made only when the parameter object changed
+    (identity via weakref + in-place version counter, so optimizer steps and load_state_dict repack)."""
+    key = id(weight)
+    hit = _PACK_CACHE.get(key)
+    n = d.K * d.R * d.S * d.Cp
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2].numel() == n:
+        return hit[2]
+    out = torch.empty(n, dtype=torch.float32, device=weight.device)
+    _C.check(_C.lib().up_pack_weights(C.byref(d), _dense(weight).data_ptr(), out.data_ptr(), None, _stream(weight)),
+             "pack_weights")
+    if len(_PACK_CACHE) > 4096:
+        _PACK_CACHE.clear()
+    if weight.is_leaf:
+        _PACK_CACHE[key] = (weakref.ref(weight), weight._version, out)
+    return out
+
+
+def packed_dgrad(weight: torch.Tensor, d: _C.ConvDesc) -> torch.Tensor:
+    out = torch.empty(d.C * d.R * d.S * d.Kp, dtype=torch.float32, device=weight.device)
+    _C.check(_C.lib().up_pack_weights(C.byref(d), _dense(weight).data_ptr(), None, out.data_ptr(), _stream(weight)),
+             "pack_weights")
+    return out
+
+
+def conv_fwd_raw(x, weight, cfg, *, scale=None, shift=None, bias=None, residual=None, relu=False, stats=False,
+                 out=None):
+    """One launch of the implicit-GEMM kernel.  Returns (y, desc, stats_tensor|None)."""
+    _dev_ok(x, weight, scale, shift, bias, residual)
+    d = make_desc(x, weight, cfg, None if out is None else _nhwc_ok(out))
+    if out is None:
+        alloc = torch.zeros if d.ldy != d.K else torch.empty      # pad channels must read as zeros
+        out = alloc((d.N, d.P, d.Q, d.ldy), dtype=torch.float32, device=x.device)
+    wp = packed_fwd(weight, d)
+    ep = _C.ConvEpilogue()
+    ep.scale, ep.shift, ep.bias = _ptr(scale), _ptr(shift), _ptr(bias)
+    ep.residual = _ptr(residual)
+    ep.ldr = _nhwc_ok(residual) if residual is not None else 0
+    ep.relu = int(relu)
+    st = None
+    if stats:
+        tiles = _C.lib().up_conv_stats_tiles(C.byref(d))
+        st = torch.empty((tiles, d.K, 3), dtype=torch.float32, device=x.device)
+        ep.stats = st.data_ptr()
+    _C.check(_C.lib().up_conv2d_fwd(C.byref(d), x.data_ptr(), wp.data_ptr(), out.data_ptr(), C.byref(ep),
+                                    _stream(x)), "conv2d_fwd")
+    return out, d, st
+
+
+def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev):
+    wd = packed_dgrad(weight, d)
+    n, h, w, cp = x_shape
+    alloc = torch.zeros if cp != d.C else torch.empty
+    dx = alloc((n, h, w, cp), dtype=torch.float32, device=dev)
+    dd = _C.ConvDesc.from_buffer_copy(d)
+    dd.ldx = cp
+    dd.ldy = _nhwc_ok(dy)
+    _C.check(_C.lib().up_conv2d_bwd_data(C.byref(dd), dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), _stream(dy)),
+             "conv2d_bwd_data")
+    return dx
+
+
+def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool):
+    dd = _C.ConvDesc.from_buffer_copy(d)
+    dd.ldx = _nhwc_ok(x)
+    dd.ldy = _nhwc_ok(dy)
+    need = _C.lib().up_conv2d_bwd_weight_workspace(C.byref(dd))
+    ws = workspace(x.device, need)
+    dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)
+    db = torch.empty(weight_shape[0], dtype=torch.float32, device=x.device) if want_bias else None
+    _C.check(_C.lib().up_conv2d_bwd_weight(C.byref(dd), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db),
+                                           ws.data_ptr(), ws.numel(), _stream(x)), "conv2d_bwd_weight")
+    return dw, db
+
+
+class ConvBias(Function):
+    """conv (+bias) (+ReLU) — the LSTM head, gate and final 1x1 convolutions
+    (decoder.py:30, model/uniposeLSTM.py:12-14,30-38,85-89,120-124)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cfg: ConvCfg, relu: bool):
+        y, d, _ = conv_fwd_raw(x, weight, cfg, bias=bias, relu=relu)
+        ctx.d, ctx.relu, ctx.has_bias = d, relu, bias is not None
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dy = _dense(dy)
+        if ctx.relu:
+            g = torch.empty_like(dy)
+            _C.check(_C.lib().up_relu_bwd(dy.data_ptr(), y.data_ptr(), g.data_ptr(), dy.numel(), _stream(dy)),
+                     "relu_bwd")
+            dy = g
+        dx = conv_bwd_data_raw(dy, weight, ctx.d, x.shape, x.device) if ctx.needs_input_grad[0] else None
+        dw, db = conv_bwd_weight_raw(x, dy, weight.shape, ctx.d, ctx.has_bias)
+        return dx, dw, db, None, None
+
+
+class ConvBnAct(Function):
+    """conv -> BatchNorm2d -> (+residual) -> (ReLU): Bottleneck.forward resnet.py:22-42, the stem
+    :113-116, _AtrousModule wasp.py:16-20, wasp.py:86-88, decoder.py:39-41,52.
+
+    train (batch statistics): conv kernel with Welford partials in its epilogue -> finalize ->
+    one apply pass.  eval with grad: same graph with the running statistics."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, rm, rv, cfg: ConvCfg, relu: bool, train: bool, eps: float,
+                momentum: float):
+        L = _C.lib()
+        dev = x.device
+        k = weight.shape[0]
+        if train:
+            y, d, st = conv_fwd_raw(x, weight, cfg, stats=True)
+            rows = d.N * d.P * d.Q
+            if rows <= 1:
+                raise ValueError(f"Expected more than 1 value per channel when training, got input size "
+                                 f"{(d.N, k, d.P, d.Q)}")          # F.batch_norm's check
+            coef = torch.empty((4, k), dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
+            _C.check(L.up_bn_finalize(st.data_ptr(), st.shape[0], k, eps, momentum, _ptr(rm), _ptr(rv),
+                                      gamma.data_ptr(), beta.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                                      coef[2].data_ptr(), coef[3].data_ptr(), _stream(x)), "bn_finalize")
+        else:
+            y, d, _ = conv_fwd_raw(x, weight, cfg)
+            rows = d.N * d.P * d.Q
+            coef = torch.empty((4, k), dtype=torch.float32, device=dev)
+            coef[0].copy_(rm)
+            torch.rsqrt(rv + eps, out=coef[1])
+            _C.check(L.up_bn_eval_coeffs(gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), eps, k,
+                                         coef[2].data_ptr(), coef[3].data_ptr(), _stream(x)), "bn_eval_coeffs")
+        z = torch.empty_like(y)
+        _C.check(L.up_bn_apply(y.data_ptr(), d.ldy, coef[2].data_ptr(), coef[3].data_ptr(), _ptr(residual),
+                               _nhwc_ok(residual) if residual is not None else 0, int(relu), z.data_ptr(), d.ldy,
+                               rows, k, _stream(x)), "bn_apply")
+        ctx.d, ctx.relu, ctx.train, ctx.has_res = d, relu, train, residual is not None
+        ctx.save_for_backward(x, weight, gamma, y, z, coef)
+        return z
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz):
+        x, weight, gamma, y, z, coef = ctx.saved_tensors
+        L, d = _C.lib(), ctx.d
+        dz = _dense(dz)
+        k = weight.shape[0]
+        rows = d.N * d.P * d.Q
+        dy = torch.empty_like(y)
+        dres = torch.empty_like(y) if ctx.has_res else None
+        dgb = torch.empty((2, k), dtype=torch.float32, device=x.device)
+        need = L.up_bn_bwd_workspace(rows, k)
+        ws = workspace(x.device, need)
+        _C.check(L.up_bn_bwd(dz.data_ptr(), d.ldy, z.data_ptr(), d.ldy, y.data_ptr(), d.ldy, gamma.data_ptr(),
+                             coef[0].data_ptr(), coef[1].data_ptr(), int(ctx.relu), int(ctx.train), dy.data_ptr(),
+                             d.ldy, _ptr(dres), d.ldy, dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(),
+                             ws.numel(), rows, k, _stream(x)), "bn_bwd")
+        dx = conv_bwd_data_raw(dy, weight, d, x.shape, x.device) if ctx.needs_input_grad[0] else None
+        dw, _ = conv_bwd_weight_raw(x, dy, weight.shape, d, False)
+        return dx, dw, dgb[0], dgb[1], dres, None, None, None, None, None, None, None
+
+
+def conv_bn_act_eval_fused(x, weight, gamma, beta, rm, rv, cfg, relu, residual=None, eps=BN_EPS_DEFAULT):
+    """Inference fast path: BatchNorm folded into the convolution epilogue, ONE kernel per layer."""
+    k = weight.shape[0]
+    coef = torch.empty((2, k), dtype=torch.float32, device=x.device)
+    _C.check(_C.lib().up_bn_eval_coeffs(gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), eps, k,
+                                        coef[0].data_ptr(), coef[1].data_ptr(), _stream(x)), "bn_eval_coeffs")
+    y, _, _ = conv_fwd_raw(x, weight, cfg, scale=coef[0], shift=coef[1], residual=residual, relu=relu)
+    return y
+
+
+def conv_bn_act(x, conv, bn, relu=True, residual=None):
+    """Dispatch on (bn.training, grad mode) exactly like nn.BatchNorm2d would."""
+    cfg = ConvCfg(conv.stride[0], conv.padding[0], conv.dilation[0])
+    need_grad = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad or bn.weight.requires_grad)
+    train = bn.training
+    if not train and not need_grad:
+        return conv_bn_act_eval_fused(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, cfg, relu,
+                                      residual, bn.eps)
+    if train and bn.track_running_stats:
+        bn.num_batches_tracked.add_(1)
+    mom = 0.1 if bn.momentum is None else bn.momentum
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    return ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, rm, rv, cfg, relu, train, bn.eps, mom)
+
+
+def conv_bias_act(x, conv, relu=False):
+    cfg = ConvCfg(conv.stride[0], conv.padding[0], conv.dilation[0])
+    return ConvBias.apply(x, conv.weight, conv.bias, cfg, relu)
+
+
+# --------------------------------------------------------------------------------------------
+# layout, pooling, resampling, concat, dropout, loss
+# --------------------------------------------------------------------------------------------
+class ToNHWC(Function):
+    @staticmethod
+    def forward(ctx, x):
+        _dev_ok(x)
+        x = _dense(x)
+        n, c, h, w = x.shape
+        y = torch.empty((n, h, w, rup4(c)), dtype=torch.float32, device=x.device)
+        _C.check(_C.lib().up_nchw_to_nhwc(x.data_ptr(), y.data_ptr(), n, c, h, w, rup4(c), _stream(x)), "nchw_to_nhwc")
+        ctx.c = c
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy = _dense(dy)
+        n, h, w, ld = dy.shape
+        dx = torch.empty((n, ctx.c, h, w), dtype=torch.float32, device=dy.device)
+        _C.check(_C.lib().up_nhwc_to_nchw(dy.data_ptr(), ld, dx.data_ptr(), n, ctx.c, h, w, _stream(dy)), "nhwc_to_nchw")
+        return dx
+
+
+class ToNCHW(Function):
+    @staticmethod
+    def forward(ctx, x, c: int):
+        _dev_ok(x)
+        n, h, w, _ = x.shape
+        ld = _nhwc_ok(x)
+        y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+        _C.check(_C.lib().up_nhwc_to_nchw(x.data_ptr(), ld, y.data_ptr(), n, c, h, w, _stream(x)), "nhwc_to_nchw")
+        ctx.ld = x.shape[3]
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy = _dense(dy)
+        n, c, h, w = dy.shape
+        dx = torch.empty((n, h, w, ctx.ld), dtype=torch.float32, device=dy.device)
+        _C.check(_C.lib().up_nchw_to_nhwc(dy.data_ptr(), dx.data_ptr(), n, c, h, w, ctx.ld, _stream(dy)), "nchw_to_nhwc")
+        return dx, None
+
+
+class MaxPool3s2(Function):
+    """nn.MaxPool2d(3, 2, 1): resnet.py:65,117; decoder.py:33,47."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _dev_ok(x)
+        n, h, w, c = x.shape
+        p, q = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = torch.empty((n, p, q, c), dtype=torch.float32, device=x.device)
+        idx = torch.empty((n, p, q, c), dtype=torch.uint8, device=x.device)
+        _C.check(_C.lib().up_maxpool3s2_fwd(x.data_ptr(), _nhwc_ok(x), y.data_ptr(), c, idx.data_ptr(), n, h, w, c,
+                                            p, q, _stream(x)), "maxpool_fwd")
+        ctx.save_for_backward(idx)
+        ctx.hw = (h, w)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        dy = _dense(dy)
+        n, p, q, c = dy.shape
+        h, w = ctx.hw
+        dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device)
+        _C.check(_C.lib().up_maxpool3s2_bwd(dy.data_ptr(), c, idx.data_ptr(), dx.data_ptr(), c, n, h, w, c, p, q,
+                                            _stream(dy)), "maxpool_bwd")
+        return dx
+
+
+class Bilinear(Function):
+    """F.interpolate(mode='bilinear', align_corners=True): wasp.py:83, decoder.py:49, model/unipose.py:32."""
+
+    @staticmethod
+    def forward(ctx, x, p: int, q: int):
+        _dev_ok(x)
+        n, h, w, c = x.shape
+        y = torch.empty((n, p, q, c), dtype=torch.float32, device=x.device)
+        _C.check(_C.lib().up_bilinear_fwd(x.data_ptr(), _nhwc_ok(x), y.data_ptr(), c, n, h, w, c, p, q, _stream(x)),
+                 "bilinear_fwd")
+        ctx.hw = (h, w)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy = _dense(dy)
+        n, p, q, c = dy.shape
+        h, w = ctx.hw
+        dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device)
+        _C.check(_C.lib().up_bilinear_bwd(dy.data_ptr(), c, dx.data_ptr(), c, n, h, w, c, p, q, _stream(dy)),
+                 "bilinear_bwd")
+        return dx, None, None
+
+
+class GlobalAvgPool(Function):
+    """nn.AdaptiveAvgPool2d((1,1)): wasp.py:51 -> (N,1,1,C)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _dev_ok(x)
+        n, h, w, c = x.shape
+        y = torch.empty((n, 1, 1, c), dtype=torch.float32, device=x.device)
+        _C.check(_C.lib().up_gap_fwd(x.data_ptr(), _nhwc_ok(x), y.data_ptr(), n, h * w, c, _stream(x)), "gap_fwd")
+        ctx.hw = (h, w)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy = _dense(dy)
+        n, _, _, c = dy.shape
+        h, w = ctx.hw
+        dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device)
+        _C.check(_C.lib().up_gap_bwd(dy.data_ptr(), dx.data_ptr(), c, n, h * w, c, _stream(dy)), "gap_bwd")
+        return dx
+
+
+class ConcatC(Function):
+    """torch.cat(dim=1) of NCHW == channel concat of NHWC (wasp.py:84, decoder.py:51,
+    model/uniposeLSTM.py:116): strided copies into slices of one buffer; backward slices."""
+
+    @staticmethod
+    def forward(ctx, ld_out: int, *xs):
+        _dev_ok(*xs)
+        n, h, w, _ = xs[0].shape
+        widths = [t.shape[3] for t in xs]
+        tot = sum(widths)
+        alloc = torch.zeros if ld_out > tot else torch.empty
+        y = alloc((n, h, w, max(ld_out, tot)), dtype=torch.float32, device=xs[0].device)
+        off = 0
+        for t, c in zip(xs, widths):
+            _C.check(_C.lib().up_copy2d(t.data_ptr(), _nhwc_ok(t), y.data_ptr() + 4 * off, y.shape[3], n * h * w, c,
+                                        _stream(t)), "copy2d")
+            off += c
+        ctx.widths = widths
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy = _dense(dy)
+        n, h, w, ld = dy.shape
+        outs, off = [], 0
+        for i, c in enumerate(ctx.widths):
+            if ctx.needs_input_grad[i + 1]:
+                g = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device)
+                _C.check(_C.lib().up_copy2d(dy.data_ptr() + 4 * off, ld, g.data_ptr(), c, n * h * w, c, _stream(dy)),
+                         "copy2d")
+                outs.append(g)
+            else:
+                outs.append(None)
+            off += c
+        return (None, *outs)
+
+
+def narrow_c(x, c: int):
+    """First c channels of an NHWC tensor as a dense tensor (used to drop pad channels)."""
+    return SliceC.apply(x, c)
+
+
+class SliceC(Function):
+    @staticmethod
+    def forward(ctx, x, c: int):
+        _dev_ok(x)
+        n, h, w, ld = x.shape
+        y = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+        _C.check(_C.lib().up_copy2d(x.data_ptr(), _nhwc_ok(x), y.data_ptr(), c, n * h * w, c, _stream(x)), "copy2d")
+        ctx.ld = ld
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        dy = _dense(dy)
+        n, h, w, c = dy.shape
+        dx = torch.zeros((n, h, w, ctx.ld), dtype=torch.float32, device=dy.device)
+        _C.check(_C.lib().up_copy2d(dy.data_ptr(), c, dx.data_ptr(), ctx.ld, n * h * w, c, _stream(dy)), "copy2d")
+        return dx, None
+
+
+class Dropout(Function):
+    """nn.Dropout (wasp.py:63,90; decoder.py:25,29).  `ext_mask` (float 0/1, same shape) injects the
+    keep decisions for parity tests; otherwise a counter hash of (seed, element index) is used."""
+
+    @staticmethod
+    def forward(ctx, x, p: float, seed: int, ext_mask):
+        _dev_ok(x, ext_mask)
+        x = _dense(x)
+        y = torch.empty_like(x)
+        mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        _C.check(_C.lib().up_dropout_fwd(x.data_ptr(), y.data_ptr(), mask.data_ptr(), _ptr(ext_mask), x.numel(),
+                                         float(p), int(seed) & (2 ** 64 - 1), _stream(x)), "dropout_fwd")
+        ctx.p = float(p)
+        ctx.save_for_backward(mask)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dy = _dense(dy)
+        dx = torch.empty_like(dy)
+        _C.check(_C.lib().up_dropout_bwd(dy.data_ptr(), mask.data_ptr(), dx.data_ptr(), dy.numel(), ctx.p,
+                                         _stream(dy)), "dropout_bwd")
+        return dx, None, None, None
+
+
+_DROPOUT_STATE = {"seed": 0x5EED, "calls": 0, "ext": None}
+
+
+def set_dropout_masks(masks):
+    """Test hook: list of float (0/1) NHWC masks consumed in call order (None restores the hash RNG)."""
+    _DROPOUT_STATE["ext"] = list(masks) if masks is not None else None
+
+
+def dropout(x, module):
+    if not module.training or module.p == 0.0:
+        return x
+    if module.p >= 1.0:
+        raise NotImplementedError("dropout p >= 1")
+    ext = None
+    if _DROPOUT_STATE["ext"]:
+        ext = _DROPOUT_STATE["ext"].pop(0)
+    _DROPOUT_STATE["calls"] += 1
+    seed = _DROPOUT_STATE["seed"] * 1000003 + _DROPOUT_STATE["calls"]
+    return Dropout.apply(x, module.p, seed, ext)
+
+
+def manual_seed(seed: int):
+    _DROPOUT_STATE["seed"], _DROPOUT_STATE["calls"] = int(seed), 0
+
+
+class MSELoss(Function):
+    """nn.MSELoss() (mean) as used at unipose.py:70,117."""
+
+    @staticmethod
+    def forward(ctx, y, t):
+        _dev_ok(y, t)
+        y, t = _dense(y), _dense(t)
+        if y.shape != t.shape:
+            raise ValueError(f"mse: shape mismatch {tuple(y.shape)} vs {tuple(t.shape)}")
+        loss = torch.empty(1, dtype=torch.float32, device=y.device)
+        ws = torch.empty(_C.lib().up_mse_workspace(y.numel()) // 4, dtype=torch.float32, device=y.device)
+        _C.check(_C.lib().up_mse_fwd(y.data_ptr(), t.data_ptr(), loss.data_ptr(), ws.data_ptr(), y.numel(),
+                                     _stream(y)), "mse_fwd")
+        ctx.save_for_backward(y, t)
+        return loss.reshape(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dl):
+        y, t = ctx.saved_tensors
+        dl = dl.reshape(1).contiguous()
+        dy = torch.empty_like(y)
+        _C.check(_C.lib().up_mse_bwd(y.data_ptr(), t.data_ptr(), dl.data_ptr(), dy.data_ptr(), y.numel(),
+                                     _stream(y)), "mse_bwd")
+        return dy, None
+
+
+def mse_loss(y, t):
+    return MSELoss.apply(y, t)
+
+
+def avgpool9s8_into(center_nchw, out_nhwc, coff: int):
+    """nn.AvgPool2d(9, 8, 1) of the (N,1,H,W) centre map into channel `coff` of an NHWC buffer
+    (model/uniposeLSTM.py:114).  No gradient: the centre map is an input."""
+    _dev_ok(center_nchw, out_nhwc)
+    c = _dense(center_nchw)
+    n, one, h, w = c.shape
+    assert one == 1
+    _, p, q, ld = out_nhwc.shape
+    _C.check(_C.lib().up_avgpool9s8_fwd(c.data_ptr(), out_nhwc.data_ptr(), ld, coff, n, h, w, p, q, _stream(c)),
+             "avgpool9s8")
+
+
+# --------------------------------------------------------------------------------------------
+# ConvLSTM gate math
+# --------------------------------------------------------------------------------------------
+class LSTM0Gates(Function):
+    """model/uniposeLSTM.py:17-22 given the stacked gate pre-activations g|i|o."""
+
+    @staticmethod
+    def forward(ctx, gates, cg: int):
+        _dev_ok(gates)
+        n, h, w, ldg = gates.shape
+        ldo = rup4(cg)
+        alloc = torch.zeros if ldo != cg else torch.empty
+        cell = alloc((n, h, w, ldo), dtype=torch.float32, device=gates.device)
+        hide = alloc((n, h, w, ldo), dtype=torch.float32, device=gates.device)
+        _C.check(_C.lib().up_lstm0_fwd(gates.data_ptr(), ldg, cell.data_ptr(), hide.data_ptr(), ldo, n * h * w, cg,
+                                       _stream(gates)), "lstm0_fwd")
+        ctx.cg = cg
+        ctx.save_for_backward(gates)
+        return cell, hide
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dcell, dhide):
+        (gates,) = ctx.saved_tensors
+        n, h, w, ldg = gates.shape
+        dcell, dhide = _dense(dcell), _dense(dhide)
+        dg = torch.zeros_like(gates)
+        _C.check(_C.lib().up_lstm0_bwd(gates.data_ptr(), ldg, dcell.data_ptr(), dhide.data_ptr(), dcell.shape[3],
+                                       dg.data_ptr(), n * h * w, ctx.cg, _stream(gates)), "lstm0_bwd")
+        return dg, None
+
+
+class LSTMGates(Function):
+    """model/uniposeLSTM.py:41-62 given the stacked gate pre-activations g|i|o|f and the previous cell."""
+
+    @staticmethod
+    def forward(ctx, gates, cprev, cg: int):
+        _dev_ok(gates, cprev)
+        n, h, w, ldg = gates.shape
+        ldo = rup4(cg)
+        alloc = torch.zeros if ldo != cg else torch.empty
+        cell = alloc((n, h, w, ldo), dtype=torch.float32, device=gates.device)
+        hide = alloc((n, h, w, ldo), dtype=torch.float32, device=gates.device)
+        _C.check(_C.lib().up_lstm_fwd(gates.data_ptr(), ldg, cprev.data_ptr(), _nhwc_ok(cprev), cell.data_ptr(),
+                                      hide.data_ptr(), ldo, n * h * w, cg, _stream(gates)), "lstm_fwd")
+        ctx.cg = cg
+        ctx.save_for_backward(gates, cprev, cell)
+        return cell, hide
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dcell, dhide):
+        gates, cprev, cell = ctx.saved_tensors
+        n, h, w, ldg = gates.shape
+        dcell, dhide = _dense(dcell), _dense(dhide)
+        dg = torch.zeros_like(gates)
+        dcp = torch.zeros_like(cell)
+        _C.check(_C.lib().up_lstm_bwd(gates.data_ptr(), ldg, cprev.data_ptr(), _nhwc_ok(cprev), cell.data_ptr(),
+                                      dcell.data_ptr(), dhide.data_ptr(), cell.shape[3], dg.data_ptr(),
+                                      dcp.data_ptr(), n * h * w, ctx.cg, _stream(gates)), "lstm_bwd")
+        return dg, dcp, None
+
+
+# --------------------------------------------------------------------------------------------
+# heat-map argmax
+# --------------------------------------------------------------------------------------------
+def heatmap_argmax(hm: torch.Tensor):
+    """get_max_preds (utils/evaluate.py:32-54) on the device: returns (preds (B,J,2) float32,
+    maxvals (B,J,1) float32, idx (B,J) int32)."""
+    _dev_ok(hm)
+    hm = _dense(hm.detach())
+    b, j, h, w = hm.shape
+    idx = torch.empty((b, j), dtype=torch.int32, device=hm.device)
+    preds = torch.empty((b, j, 2), dtype=torch.float32, device=hm.device)
+    mx = torch.empty((b, j, 1), dtype=torch.float32, device=hm.device)
+    _C.check(_C.lib().up_heatmap_argmax(hm.data_ptr(), b, j, h, w, idx.data_ptr(), preds.data_ptr(), mx.data_ptr(),
+                                        _stream(hm)), "heatmap_argmax")
+    return preds, mx, idx
+
+
+def get_kpts(maps: torch.Tensor, img_h: float = 368.0, img_w: float = 368.0):
+    """utils/utils.py:94-106 on top of the device argmax: [[x, y], ...] for joints 1.. of sample 0."""
+    _, _, idx = heatmap_argmax(maps[:1])
+    h, w = maps.shape[2], maps.shape[3]
+    flat = idx[0].tolist()[1:]
+    return [[int((i % w) * img_w / w), int((i // w) * img_h / h)] for i in flat]
