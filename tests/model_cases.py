@@ -1,0 +1,175 @@
+"""Whole-network parity cases shared by the emulation (CPU) and GPU test files.  Checker = the CPU
+oracle (oracle/unipose_oracle.py, pinned to the reference by tests/test_oracle_golden.py)."""
+import torch
+
+from oracle import unipose_oracle as O
+
+
+def build_image_model(K, wseed, dev):
+    from model.unipose import unipose
+    m = unipose("LSP", num_classes=K)
+    sd = O.synth_state_dict(K, wseed)
+    m.load_state_dict(sd)
+    return m.to(dev), sd
+
+
+def eval_case(dev, K=14, B=2, size=64, wseed=1, xseed=5, tol=1e-3, stride=8):
+    m, sd = build_image_model(K, wseed, dev)
+    m.eval()
+    m.stride = stride
+    x = O.synth_input((B, 3, size, size), xseed)
+    with torch.no_grad():
+        y = m(x.to(dev))
+        yr = O.unipose_forward(sd, x, stride=stride)
+    assert y.shape == yr.shape
+    e = O.max_rel(y.cpu(), yr)
+    assert e < tol, e
+    return e
+
+
+def _sd64(sd, requires_grad):
+    out = {}
+    for k, v in sd.items():
+        t = v.double() if v.is_floating_point() else v.clone()
+        if requires_grad and t.is_floating_point() and "running_" not in k:
+            t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+def yardstick(ours, ref32, ref64, slack=10.0, floor=2e-5):
+    """Train-mode BatchNorm over a handful of samples is ill-conditioned: two fp32 evaluations of the
+    reference graph (1 vs 8 threads, fp32 vs fp64) already differ by 1e-3..1e-2 at these test sizes.
+    So the bar is 'as close to the exact (fp64) result as the fp32 reference implementation is':
+    err(ours, fp64) <= slack * err(ref fp32, fp64) (+ a floor for well-conditioned tensors)."""
+    e_ref = O.max_rel(ref32, ref64)
+    e_our = O.max_rel(ours, ref64)
+    return e_our <= slack * e_ref + floor, e_our, e_ref
+
+
+def train_case(dev, K=16, B=2, size=32, wseed=3, dropout_masks=False):
+    """fwd + MSE + bwd in train mode; dropouts disabled (p=0) or injected; compares loss, output, every
+    parameter gradient and all BN running statistics against the oracle (see `yardstick`)."""
+    from unipose_amd import ops
+    m, sd = build_image_model(K, wseed, dev)
+    m.train()
+    x = O.synth_input((B, 3, size, size), 13)
+    t = O.synth_input((B, K + 1, size // 8, size // 8), 14, "rand")
+    sd32 = O.clone_sd(sd, requires_grad=True)
+    sd64 = _sd64(sd, True)
+    m32 = m64 = None
+    if dropout_masks:
+        h16, h8 = size // 16, size // 8
+        g = torch.Generator().manual_seed(99)
+        mk = [(torch.rand(B, 256, s, s, generator=g) > p).float() for s, p in ((h16, 0.5), (h8, 0.5), (h8, 0.1))]
+        m32 = dict(wasp=mk[0], dec0=mk[1], dec1=mk[2])
+        m64 = {k: v.double() for k, v in m32.items()}
+        ops.set_dropout_masks([k.permute(0, 2, 3, 1).contiguous().to(dev) for k in mk])
+        pdrop = (0.5, 0.5, 0.1)
+    else:
+        m.wasp.dropout.p = 0.0
+        m.decoder.last_conv[3].p = 0.0
+        m.decoder.last_conv[7].p = 0.0
+        pdrop = (0.0, 0.0, 0.0)
+    try:
+        y = m(x.to(dev))
+        loss = ops.mse_loss(y, t.to(dev))
+        loss.backward()
+    finally:
+        ops.set_dropout_masks(None)
+    y32 = O.unipose_forward(sd32, x, train=True, drop_masks=m32, p_drop=pdrop)
+    l32 = torch.nn.functional.mse_loss(y32, t)
+    l32.backward()
+    y64 = O.unipose_forward(sd64, x.double(), train=True, drop_masks=m64, p_drop=pdrop)
+    l64 = torch.nn.functional.mse_loss(y64, t.double())
+    l64.backward()
+    ok, eo, er = yardstick(y.detach().cpu(), y32.detach(), y64.detach())
+    assert ok, ("output", eo, er)
+    ok, eo, er = yardstick(loss.detach().cpu(), l32.detach(), l64.detach())
+    assert ok, ("loss", eo, er)
+    worst = {}
+    for name, p in m.named_parameters():
+        g64 = sd64[name].grad
+        if g64 is None:
+            assert p.grad is None, name                      # decoder.conv2 / bn2
+            continue
+        ok, eo, er = yardstick(p.grad.cpu(), sd32[name].grad, g64, floor=1e-4)
+        if not ok:
+            worst[name] = (eo, er)
+    assert not worst, worst
+    msd = m.state_dict()
+    for k, v in sd64.items():
+        if "running_" in k:
+            ok, eo, er = yardstick(msd[k].cpu(), sd32[k], v)
+            assert ok, (k, eo, er)
+        if k.endswith("num_batches_tracked") and not k.startswith("decoder.bn2"):
+            assert int(msd[k]) == int(v) == 1, k
+
+
+def lstm_case(dev, K=13, B=1, size=32, T=3, wseed=4, tol=1e-3, train=False):
+    """T-frame unroll with the reference driver's call pattern (uniposeLSTM.py:116-133).  eval: strict
+    tolerance per frame.  train: summed MSE, ONE backward through all frames (BPTT), fp64 yardstick."""
+    from model.uniposeLSTM import unipose_lstm
+    from unipose_amd import ops
+    m = unipose_lstm(num_classes=K)
+    sd = O.synth_state_dict(K, wseed, lstm=True)
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    m.train(train)
+    if train:
+        m.wasp.dropout.p = 0.0
+        m.decoder.last_conv[3].p = 0.0
+        m.decoder.last_conv[7].p = 0.0
+    hs = size // 8
+    x = O.synth_input((B, T, 3, size, size), 15)
+    cm = O.synth_input((B, T, 1, size, size), 16, "rand")
+    tg = O.synth_input((B, T, K + 1, hs, hs), 17, "rand")
+    heat = torch.zeros(K + 1, hs, hs).to(dev)
+    cell = torch.zeros(K + 2, hs, hs).to(dev)
+    hide = torch.zeros(K + 2, hs, hs).to(dev)
+
+    def run_oracle(sdx, dt):
+        h = torch.zeros(K + 2, hs, hs, dtype=dt)
+        c = torch.zeros(K + 2, hs, hs, dtype=dt)
+        if B > 1:
+            h, c = h.expand(B, -1, -1, -1), c.expand(B, -1, -1, -1)
+        outs, tot = [], 0.0
+        for j in range(T):
+            ht, c, h = O.unipose_lstm_forward(sdx, x.to(dt), cm.to(dt), j, h, c, train=train,
+                                              drop_masks=None)
+            outs.append((ht, c, h))
+            tot = tot + torch.nn.functional.mse_loss(ht, tg[:, j].to(dt))
+        return outs, tot
+
+    sd32 = O.clone_sd(sd, requires_grad=train)
+    with (torch.enable_grad() if train else torch.no_grad()):
+        o32, l32 = run_oracle(sd32, torch.float32)
+        if train:
+            sd64 = _sd64(sd, True)
+            o64, l64 = run_oracle(sd64, torch.float64)
+        loss = 0.0
+        for j in range(T):                                   # uniposeLSTM.py:124-128 call pattern
+            heat, cell, hide = m(x.to(dev), cm.to(dev), j, heat, hide, cell)
+            assert heat.shape == (B, K + 1, hs, hs) and cell.shape == (B, K + 2, hs, hs)
+            for got, i in ((heat, 0), (cell, 1), (hide, 2)):
+                if train:
+                    ok, eo, er = yardstick(got.detach().cpu(), o32[j][i].detach(), o64[j][i].detach())
+                    assert ok, (j, i, eo, er)
+                else:
+                    assert O.max_rel(got.cpu(), o32[j][i]) < tol, (j, i)
+            if train:
+                loss = loss + ops.mse_loss(heat, tg[:, j].to(dev))
+    if train:
+        loss.backward()
+        l32.backward()
+        l64.backward()
+        worst = {}
+        for name, p in m.named_parameters():
+            g64 = sd64[name].grad
+            if g64 is None:
+                assert p.grad is None, name
+                continue
+            ok, eo, er = yardstick(p.grad.cpu(), sd32[name].grad, g64, floor=1e-4)
+            if not ok:
+                worst[name] = (eo, er)
+        assert not worst, worst

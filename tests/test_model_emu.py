@@ -1,0 +1,23 @@
+"""Whole-network parity on a GPU-less box: drop-in modules -> host ops -> HIP kernel sources running on
+the fiber emulator, against the CPU oracle.  Tiny inputs (the emulator is ~1e5x slower than the GPU)."""
+import model_cases as mc
+
+
+def test_eval_forward_emu(emu_backend):
+    assert mc.eval_case(emu_backend, size=64) < 1e-4
+
+
+def test_eval_forward_stride1_emu(emu_backend):
+    mc.eval_case(emu_backend, size=32, B=1, stride=1)
+
+
+def test_train_dropout_masks_emu(emu_backend):
+    mc.train_case(emu_backend, size=32, dropout_masks=True)
+
+
+def test_lstm_eval_emu(emu_backend):
+    mc.lstm_case(emu_backend, size=32, T=3, B=1)
+
+
+def test_lstm_train_bptt_emu(emu_backend):
+    mc.lstm_case(emu_backend, size=32, T=2, B=2, train=True)

@@ -1,0 +1,88 @@
+"""``unipose`` (alias ``unipose_lstm``) — drop-in for the reference's video model
+(model/uniposeLSTM.py:67-147): ResNet-101 + WASP(video) + decoder trunk per frame, ConvLSTM state,
+five-convolution head.  The state is generalised from the reference's hard-wired batch 1
+(:99-104) to (B, 15, H/8, W/8); B=1 reproduces the reference numerics."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .modules import LSTM, LSTM_0, build_backbone, build_decoder, build_wasp
+
+
+class _AddCenter(torch.autograd.Function):
+    """cat(heat, AvgPool2d(9,8,1)(centermap)) (model/uniposeLSTM.py:114-116): the heat tensor already has
+    a spare pad channel, so the pooled centre map is written in place of it."""
+
+    @staticmethod
+    def forward(ctx, heat_nhwc, center_nchw, k):
+        z = heat_nhwc.clone()
+        ops.avgpool9s8_into(center_nchw, z, k)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        return dz, None, None     # channels >= k are ignored upstream (the producer masks them)
+
+
+class unipose(nn.Module):
+    def __init__(self, backbone="resnet", output_stride=16, num_classes=21, sync_bn=True, freeze_bn=False, stride=8):
+        super().__init__()
+        self.stride = stride
+        self.num_classes = num_classes
+        self.BatchNorm = nn.BatchNorm2d
+        self.backbone = build_backbone(backbone, output_stride, self.BatchNorm)
+        self.wasp = build_wasp(backbone, output_stride, self.BatchNorm, video=True)
+        self.decoder = build_decoder("Penn_Action", num_classes, backbone, self.BatchNorm)
+        c = num_classes + 2                     # joints + background + centre map (15 for Penn Action)
+        if (num_classes + 1) % 4 == 0:
+            raise NotImplementedError("num_classes+1 must leave a pad channel for the centre map")
+        self.lstm_0 = LSTM_0(c, c, 3, 1)
+        self.lstm = LSTM(c, c, 3, 1)
+        self.conv1 = nn.Conv2d(c, 128, kernel_size=11, padding=5)
+        self.conv2 = nn.Conv2d(128, 128, kernel_size=11, padding=5)
+        self.conv3 = nn.Conv2d(128, 128, kernel_size=11, padding=5)
+        self.conv4 = nn.Conv2d(128, 128, kernel_size=1, padding=0)
+        self.conv5 = nn.Conv2d(128, num_classes + 1, kernel_size=1, padding=0)
+        self.pool_center = nn.AvgPool2d(kernel_size=9, stride=8, padding=1)
+        if freeze_bn:
+            self.freeze_bn()
+
+    def _state(self, t, like, b):
+        """(C,h,w) zeros from the first call, or the (B,C,h,w) tensor returned by the previous one."""
+        if t.dim() == 3:
+            t = t.unsqueeze(0).expand(b, -1, -1, -1)
+        return ops.ToNHWC.apply(t.to(like.device))
+
+    def forward(self, input, centermap, iter, previous, previousHide, previousCell):
+        b = input.shape[0]
+        x = ops.ToNHWC.apply(input[:, iter])
+        x, low = self.backbone(x)
+        x = self.wasp(x)
+        x = self.decoder(x, low)                                   # (B,h,w,16), 14 real channels
+        z = _AddCenter.apply(x, centermap[:, iter], self.num_classes + 1)
+        if iter == 0:
+            cell, hide = self.lstm_0(z)
+        else:
+            cell, hide = self.lstm(z, self._state(previousHide, x, b), self._state(previousCell, x, b))
+        h = hide
+        for conv in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5):
+            h = ops.conv_bias_act(h, conv, relu=True)
+        c = self.num_classes + 2
+        return ops.ToNCHW.apply(h, self.num_classes + 1), ops.ToNCHW.apply(cell, c), ops.ToNCHW.apply(hide, c)
+
+    def freeze_bn(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+
+    def get_1x_lr_params(self):
+        for m in self.backbone.modules():
+            if isinstance(m, (nn.Conv2d, nn.BatchNorm2d)):
+                for p in m.parameters(recurse=False):
+                    if p.requires_grad:
+                        yield p
+
+
+unipose_lstm = unipose
