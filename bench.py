@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""images/sec, forward+backward(+Adam), UniPose ResNet-101 on synthetic 368x368 batches (BASELINE.json
+configs[1]: K=16, batch 32/GPU, fp32) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU (RCCL via torch.distributed "nccl"); the batch is sharded (weak scaling: 32
+images per GPU), weights are replicated, gradients are all-reduced once per step (unipose_amd/dist.py).
+A step = zero_grad -> forward -> MSE -> backward -> gradient all-reduce -> Adam, exactly the loop of
+the reference's Trainer.training (unipose.py:100-131) with synthetic inputs already resident in HBM.
+Rank 0 prints ONE JSON line.  `roofline` is measured live: every MFMA convolution launch inside the
+timed region is bracketed by hipEvents on its stream (up_profile_begin/end in the C ABI).
+`cpu_baseline` times the CPU oracle (a torch-CPU restatement of the reference graph, pinned to the
+reference by tests/golden) on this box's host cores on a bounded sample; baseline only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+FLOP_PER_IMAGE_FWD_BWD = 187.7e9    # 3 x 31.279 GMAC x 2 at 368x368, K=16
+
+
+def cpu_baseline(num_classes, size, batch, steps):
+    """Reference graph (oracle restatement) fwd+MSE+bwd on the host cores; images/sec."""
+    from oracle import unipose_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = O.clone_sd(O.synth_state_dict(num_classes, 0), requires_grad=True)
+    x = O.synth_input((batch, 3, size, size), 1)
+    t = O.synth_input((batch, num_classes + 1, size // 8, size // 8), 2, "rand")
+
+    def one():
+        for v in sd.values():
+            v.grad = None
+        y = O.unipose_forward(sd, x, train=True)
+        torch.nn.functional.mse_loss(y, t).backward()
+
+    one()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{steps} train steps (fwd+MSE+bwd, no optimizer) of batch {batch} at {size}x{size}, "
+                      f"torch {torch.__version__} CPU, after 1 warm-up step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--size", type=int, default=368)
+    ap.add_argument("--num-classes", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-launch hipEvent timing")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from model.unipose import unipose
+    from unipose_amd import _C, ops
+    from unipose_amd.dist import GradAllReducer, shard_seed
+
+    K, B, S = args.num_classes, args.batch, args.size
+    torch.manual_seed(0)
+    model = unipose("MPII", num_classes=K).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)        # unipose.py:72 (no weight decay)
+    g = torch.Generator(device="cpu").manual_seed(shard_seed(0, rank))
+    x = torch.randn(B, 3, S, S, generator=g).to(dev)
+    t = torch.rand(B, K + 1, S // 8, S // 8, generator=g).to(dev)
+    ops.manual_seed(shard_seed(0, rank))
+    reducer = GradAllReducer(model) if world > 1 else None
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = ops.mse_loss(model(x), t)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    profile = (not args.no_profile) and rank == 0
+    if profile:
+        _C.lib().up_profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    loss_val = float(loss.detach())
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    roofline = None
+    if profile:
+        nv = _C.lib().up_profile_variants()
+        arr = (ctypes.c_double * (nv * 3))()
+        _C.check(_C.lib().up_profile_end(arr, nv), "profile_end")
+        rows = []
+        for i in range(nv):
+            n, ms, fl = arr[i * 3], arr[i * 3 + 1], arr[i * 3 + 2]
+            if n:
+                rows.append({"kernel": _C.lib().up_profile_variant_name(i).decode(), "launches": int(n),
+                             "avg_ms": ms / n, "total_ms": ms, "tflops": fl / ms / 1e9})
+        rows.sort(key=lambda r: -r["total_ms"])
+        if rows:
+            top = rows[0]
+            tot_ms = sum(r["total_ms"] for r in rows)
+            tot_fl = sum(r["tflops"] * r["total_ms"] for r in rows)
+            roofline = {"bound": "mfma", "kernel": top["kernel"], "achieved": round(top["tflops"], 2),
+                        "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(top["tflops"] / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                        "avg_launch_ms": round(top["avg_ms"], 4), "launches": top["launches"],
+                        "all_mfma_kernels": {"achieved": round(tot_fl / tot_ms, 2),
+                                             "frac": round(tot_fl / tot_ms / F32_MFMA_PEAK_TFLOPS, 4),
+                                             "ms_per_step": round(tot_ms / args.steps, 3)},
+                        "by_kernel": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}
+                                      for r in rows]}
+
+    if rank == 0:
+        ips = world * B * args.steps / dt
+        out = {
+            "metric": "images/sec fwd+bwd, UniPose ResNet-101 368x368",
+            "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"UniPose ResNet-101 (K={K}) train step: fwd + MSE + bwd + Adam, synthetic "
+                                   f"{S}x{S}, batch {B}/GPU (BASELINE.json configs[1]; configs[2] for N>1)",
+                       "global_batch": world * B, "per_gpu_batch": B, "input": [3, S, S],
+                       "parallelism": f"dp{world}", "optimizer": "Adam(lr=1e-4)", "arithmetic": "fp32 MFMA 32x32x2"},
+            "step_tflops_per_gpu": round(ips / world * FLOP_PER_IMAGE_FWD_BWD * (S / 368.0) ** 2 / 1e12, 2),
+            "loss": loss_val,
+        }
+        if roofline:
+            out["roofline"] = roofline
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(K, S, args.cpu_batch, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -159,6 +159,14 @@ int up_lstm_bwd(const float* gates, int ldg, const float* cprev, int ldc, const 
 int up_heatmap_argmax(const float* hm, int B, int J, int H, int W,
                       int32_t* idx, float* preds_xy, float* maxvals, void* stream);
 
+/* ---- measurement hooks (bench.py roofline leg; no reference counterpart) ----
+ * Between begin/end every MFMA convolution launch is bracketed by two hipEvents on its stream;
+ * end() returns per kernel variant {launches, total ms, total algorithmic FLOP}. */
+int up_profile_variants(void);
+const char* up_profile_variant_name(int i);
+int up_profile_begin(void);
+int up_profile_end(double* out, int variants);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,77 @@
+"""N>1 path on CPU: world_size 2, gloo backend — the gradient exchange used by bench.py --gpus N."""
+import os
+import socket
+
+import numpy as np
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(8, 16)
+        self.unused = torch.nn.Linear(4, 4)       # never receives a gradient (like decoder.conv2/bn2)
+        self.b = torch.nn.Linear(16, 3)
+
+    def forward(self, x):
+        return self.b(torch.relu(self.a(x)))
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unipose_amd.dist import GradAllReducer, shard_seed
+    torch.manual_seed(100 + rank)                  # different initial weights: must be overwritten by rank 0's
+    net = _Net()
+    red = GradAllReducer(net, bucket_bytes=256)    # tiny buckets -> several of them
+    w0 = [p.detach().numpy().copy() for p in net.parameters()]
+    outs = []
+    for step in range(3):                          # step 0 = unbucketed path, 1-2 = hooks + buckets
+        g = torch.Generator().manual_seed(shard_seed(7, rank) + 10 * step)
+        x = torch.randn(5, 8, generator=g)
+        net.zero_grad(set_to_none=True)
+        net(x).square().mean().backward()
+        local = [None if p.grad is None else p.grad.numpy().copy() for p in net.parameters()]
+        red.finish()
+        outs.append((local, [None if p.grad is None else p.grad.numpy().copy() for p in net.parameters()]))
+    q.put((rank, w0, outs, red.payload_bytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, w_a, out_a, bytes_a), (_, w_b, out_b, _) = res
+    for x, y in zip(w_a, w_b):
+        assert np.array_equal(x, y)                # weights replicated from rank 0
+    for step in range(3):
+        la, ra = out_a[step]
+        lb, rb = out_b[step]
+        for i in range(len(la)):
+            if la[i] is None:
+                assert ra[i] is None and rb[i] is None
+                continue
+            want = (la[i] + lb[i]) / 2
+            assert np.allclose(ra[i], want, atol=1e-7) and np.allclose(rb[i], want, atol=1e-7), (step, i)
+    n_live = sum(p.numel() for n, p in _Net().named_parameters() if not n.startswith("unused"))
+    assert bytes_a == 4 * n_live                   # the unused parameters are not in the exchange

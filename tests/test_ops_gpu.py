@@ -1,0 +1,118 @@
+"""Per-operator parity on a real MI355X at the reference network's own layer shapes,
+through the C ABI (ctypes -> libunipose_hip.so).  Checker: plain torch fp32 on the CPU."""
+import pytest
+import torch
+
+import op_cases as oc
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+# n, c, h, w, k, r, stride, pad, dil, bias, relu           (one row per distinct conv flavour of T1)
+CONVS = [
+    (2, 1024, 23, 23, 256, 1, 1, 0, 1, False, False),      # layer3 1x1 reduce            (K1)
+    (2, 256, 23, 23, 1024, 1, 1, 0, 1, False, False),      # layer3 1x1 expand            (K1)
+    (2, 256, 23, 23, 256, 3, 1, 1, 1, False, False),       # layer3 3x3                   (K3)
+    (2, 512, 23, 23, 512, 3, 1, 2, 2, False, False),       # layer4 dilated d2            (K5)
+    (2, 512, 23, 23, 512, 3, 1, 8, 8, False, False),       # layer4 dilated d8            (K5)
+    (2, 256, 23, 23, 256, 3, 1, 18, 18, False, False),     # WASP d18: 77% of taps in padding (K5)
+    (2, 256, 23, 23, 256, 3, 1, 12, 12, False, False),     # WASP d12
+    (2, 256, 23, 23, 256, 3, 1, 6, 6, False, False),       # WASP d6
+    (1, 256, 46, 46, 256, 3, 1, 24, 24, False, False),     # WASP at 736 input: dil 24 on 46x46 (K5)
+    (2, 3, 368, 368, 64, 7, 2, 3, 1, False, False),        # stem 7x7 s2                  (K6)
+    (2, 128, 92, 92, 128, 3, 2, 1, 1, False, False),       # layer2.0 3x3 s2              (K4)
+    (2, 256, 92, 92, 512, 1, 2, 0, 1, False, False),       # layer2.0 downsample 1x1 s2   (K2)
+    (2, 64, 92, 92, 64, 3, 1, 1, 1, False, False),         # layer1 3x3
+    (2, 304, 46, 46, 256, 3, 1, 1, 1, False, False),       # decoder 3x3 304->256
+    (2, 256, 46, 46, 17, 1, 1, 0, 1, True, False),         # decoder head 1x1 + bias, K=17
+    (2, 256, 92, 92, 48, 1, 1, 0, 1, False, False),        # decoder low-level 1x1 -> 48
+    (2, 2048, 1, 1, 256, 1, 1, 0, 1, False, True),         # WASP GAP branch (M = batch)
+    (1, 15, 46, 46, 128, 11, 1, 5, 1, True, True),         # LSTM head 11x11 15->128      (K17)
+    (1, 128, 46, 46, 128, 11, 1, 5, 1, True, True),        # LSTM head 11x11 128->128     (K17)
+    (2, 32, 46, 46, 60, 3, 1, 1, 1, True, False),          # fused ConvLSTM gates over cat(x,h)
+    (2, 128, 46, 46, 14, 1, 1, 0, 1, True, True),          # LSTM head conv5
+]
+
+
+@pytest.mark.parametrize("cfg", CONVS, ids=lambda c: "c%d_%dx%d_k%d_r%d_s%d_d%d" % (c[1], c[2], c[3], c[4], c[5], c[6], c[8]))
+def test_conv_fwd_bwd(cfg):
+    n, c, h, w, k, r, s, p, d, bias, relu = cfg
+    oc.conv_case(DEV, n, c, h, w, k, r, s, p, d, bias=bias, relu=relu, tol=5e-5)
+
+
+CONV_BN = [
+    # n, c, h, w, k, r, stride, pad, dil, relu, residual, train
+    (2, 64, 92, 92, 256, 1, 1, 0, 1, True, True, True),     # layer1 expand + residual + relu
+    (2, 512, 46, 46, 128, 1, 1, 0, 1, True, False, True),
+    (2, 256, 23, 23, 256, 3, 1, 1, 1, True, False, True),
+    (2, 256, 23, 23, 256, 3, 1, 12, 12, True, False, True),  # _AtrousModule
+    (2, 512, 46, 46, 1024, 1, 2, 0, 1, False, False, True),  # downsample: no relu
+    (2, 3, 184, 184, 64, 7, 2, 3, 1, True, False, True),     # stem
+    (4, 2048, 1, 1, 256, 1, 1, 0, 1, True, False, True),     # GAP branch BN over batch only
+    (2, 1280, 23, 23, 256, 1, 1, 0, 1, True, False, True),   # WASP fuse conv1
+    (2, 256, 23, 23, 1024, 1, 1, 0, 1, True, True, False),   # eval statistics with grad
+]
+
+
+@pytest.mark.parametrize("cfg", CONV_BN, ids=lambda c: "c%d_%dx%d_k%d_r%d_s%d_d%d_%s" % (c[1], c[2], c[3], c[4], c[5], c[6], c[8], "train" if c[11] else "eval"))
+def test_conv_bn_act(cfg):
+    n, c, h, w, k, r, s, p, d, relu, res, train = cfg
+    oc.conv_bn_case(DEV, n, c, h, w, k, r, s, p, d, relu=relu, residual=res, train=train, tol=1e-4)
+
+
+def test_layout():
+    oc.layout_case(DEV)
+
+
+def test_maxpool():
+    oc.maxpool_case(DEV, 2, 64, 184, 184)        # stem pool
+    oc.maxpool_case(DEV, 2, 48, 92, 92)          # decoder pool
+    oc.maxpool_case(DEV, 1, 8, 9, 10)
+
+
+@pytest.mark.parametrize("shape", [(2, 256, 23, 23, 46, 46), (2, 256, 1, 1, 23, 23), (1, 20, 46, 46, 368, 368),
+                                   (1, 256, 46, 46, 92, 92)])
+def test_bilinear(shape):
+    oc.bilinear_case(DEV, *shape)
+
+
+def test_gap():
+    oc.gap_case(DEV, 2, 2048, 23, 23)
+
+
+def test_concat():
+    oc.concat_case(DEV)
+
+
+def test_dropout():
+    oc.dropout_case(DEV)
+
+
+def test_mse():
+    oc.mse_case(DEV)
+
+
+def test_avgpool():
+    oc.avgpool_case(DEV, 368, 368)
+    oc.avgpool_case(DEV, 37, 41)
+
+
+def test_lstm_gates():
+    oc.lstm_case(DEV)
+
+
+def test_argmax(golden_dir):
+    oc.argmax_case(DEV, golden_dir)
+
+
+def test_argmax_full_size_properties():
+    """B=32 x 17 maps of 92x92 (BASELINE config 5 output size): bit-exact vs torch's first-max argmax."""
+    from unipose_amd import ops
+    g = torch.Generator().manual_seed(3)
+    hm = torch.randn(32, 17, 92, 92, generator=g)
+    hm[3, 4] = hm[3, 4].round()                      # plenty of ties
+    preds, mx, idx = ops.heatmap_argmax(hm.to(DEV))
+    flat = hm.reshape(32, 17, -1)
+    ref = flat.numpy().argmax(2)
+    assert (idx.cpu().numpy() == ref).all()
+    assert torch.equal(mx.cpu()[..., 0], flat.max(2).values)

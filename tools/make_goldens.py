@@ -13,8 +13,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
+# /root/repo/model is a regular package (import-path shim) and would shadow the reference's
+# namespace package `model`: import the reference FIRST with the repo root off sys.path.
+sys.path[:] = [p for p in sys.path if os.path.abspath(p or ".") != ROOT]
 sys.path.insert(0, REF)
-sys.path.insert(1, ROOT)
 
 import model.modules.backbone.resnet as R  # noqa: E402  (reference)
 
@@ -23,6 +25,9 @@ torch.Tensor.cuda = lambda self, *a, **k: self  # LSTM forward calls .cuda() (mo
 
 from model.unipose import unipose as RefUniPose  # noqa: E402
 from model.uniposeLSTM import unipose as RefUniPoseLSTM  # noqa: E402
+
+assert RefUniPose.__module__ == "model.unipose" and "/root/reference" in sys.modules["model.unipose"].__file__
+sys.path.insert(1, ROOT)
 from oracle import unipose_oracle as O  # noqa: E402
 
 SUB = 4   # stride used to sub-sample large gradient tensors (tests index the same way)
@@ -163,8 +168,20 @@ def g6_argmax():
     save("g6_argmax.npz", hm=hm, preds=preds, maxvals=maxvals)
 
 
+def g0_keys():
+    """G0: the reference's state_dict contract (names, shapes, dtypes, order) for both models."""
+    import json
+    out = {}
+    for name, m in (("unipose_K14", RefUniPose("LSP", num_classes=14)), ("unipose_lstm_K13", RefUniPoseLSTM(num_classes=13))):
+        out[name] = [[k, list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in m.state_dict().items()]
+        out[name + "_params"] = [k for k, _ in m.named_parameters()]
+    with open(os.path.join(OUT, "g0_state_dict_keys.json"), "w") as f:
+        json.dump(out, f)
+    print("wrote g0_state_dict_keys.json", {k: len(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6"]
-    fns = dict(g1=g1_eval_full, g2=g2_taps, g4=g4_train, g5=g5_lstm, g6=g6_argmax)
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g4", "g5", "g6"]
+    fns = dict(g0=g0_keys, g1=g1_eval_full, g2=g2_taps, g4=g4_train, g5=g5_lstm, g6=g6_argmax)
     for w in which:
         fns[w]()

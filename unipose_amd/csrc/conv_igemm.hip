@@ -20,7 +20,51 @@
 // legal as long as A and B use the same one, and it turns 4 ds_read_b32 into one ds_read_b128.
 #include "up_common.h"
 
+#include <vector>
+
 namespace up {
+
+// ---- optional per-launch timing of the MFMA kernels (bench.py roofline leg) -------------------
+// up_profile_begin() arms it; every igemm/wgrad launch is then bracketed by two hipEvents on the
+// launch stream; up_profile_end() synchronises and returns, per kernel variant, {launches, total ms,
+// total algorithmic flops}.  Off by default: no events, no overhead.
+constexpr int PROF_VARIANTS = 12;
+static const char* const kVariantNames[PROF_VARIANTS] = {
+    "igemm_kernel<128,128,aligned>", "igemm_kernel<128,128,generic>", "igemm_kernel<64,128,aligned>",
+    "igemm_kernel<64,128,generic>",  "igemm_kernel<128,64,aligned>",  "igemm_kernel<128,64,generic>",
+    "igemm_kernel<64,64,aligned>",   "igemm_kernel<64,64,generic>",   "wgrad_kernel<128,128>",
+    "wgrad_kernel<128,64>",          "wgrad_kernel<64,128>",          "wgrad_kernel<64,64>"};
+#ifndef UP_EMU
+struct ProfRec {
+    hipEvent_t a, b;
+    int variant;
+    double flops;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+struct ProfScope {
+    ProfRec r;
+    hipStream_t st;
+    bool on;
+    ProfScope(int variant, double flops, hipStream_t s) : st(s), on(g_prof_on) {
+        if (!on) return;
+        r.variant = variant;
+        r.flops = flops;
+        (void)hipEventCreate(&r.a);
+        (void)hipEventCreate(&r.b);
+        (void)hipEventRecord(r.a, st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, st);
+        g_prof.push_back(r);
+    }
+};
+#else
+struct ProfScope {
+    ProfScope(int, double, hipStream_t) {}
+};
+#endif
 
 constexpr int BK = 16;
 constexpr int LDS_LD = 20;
@@ -30,6 +74,7 @@ struct IgemmArgs {
     const float* w;
     float* y;
     int M, Ng, Ktot, Cp, Creal;
+    long long Ktot_real;  // taps * real channels: the algorithmic reduction length (profiling only)
     int H, W, P, Q;  // source H,W; destination P,Q
     int ldx, ldy;
     int S;
@@ -566,6 +611,8 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     a.ntn = cdiv(a.Ng, BN);
     a.nwg = ntm * a.ntn;
     a.fNtn = make_fastdiv(a.ntn);
+    const int vbase = (BM == 128 && BN == 128) ? 0 : (BM == 64 && BN == 128) ? 2 : (BM == 128 && BN == 64) ? 4 : 6;
+    ProfScope prof(vbase + (aligned ? 0 : 1), 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st);
     if (aligned)
         hipLaunchKernelGGL((igemm_kernel<BM, BN, true>), dim3(a.nwg), dim3(256), 0, st, a);
     else
@@ -627,6 +674,7 @@ extern "C" int up_conv2d_fwd(const up_conv_desc* d, const float* x, const float*
     a.Cp = d->Cp;
     a.Creal = d->C;
     a.Ktot = d->R * d->S * d->Cp;
+    a.Ktot_real = (long long)d->R * d->S * d->C;
     a.H = d->H;
     a.W = d->W;
     a.P = d->P;
@@ -675,6 +723,7 @@ extern "C" int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const 
     a.Cp = d->Kp;
     a.Creal = d->K;
     a.Ktot = d->R * d->S * d->Kp;
+    a.Ktot_real = (long long)d->R * d->S * d->K;
     a.H = d->P;
     a.W = d->Q;  // source = dy
     a.P = d->H;
@@ -764,14 +813,18 @@ extern "C" int up_conv2d_bwd_weight(const up_conv_desc* d, const float* x, const
     a.fS = make_fastdiv(d->S);
     a.fNtn = make_fastdiv(p.ntn);
     dim3 grid(p.ntm * p.ntn, p.splits);
-    if (p.bm == 128 && p.bn == 128)
-        hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, st, a);
-    else if (p.bm == 128 && p.bn == 64)
-        hipLaunchKernelGGL((wgrad_kernel<128, 64>), grid, dim3(256), 0, st, a);
-    else if (p.bm == 64 && p.bn == 128)
-        hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, dim3(256), 0, st, a);
+    {
+        const int v = (p.bm == 128 && p.bn == 128) ? 8 : (p.bm == 128 && p.bn == 64) ? 9 : (p.bm == 64 && p.bn == 128) ? 10 : 11;
+        ProfScope prof(v, 2.0 * (double)a.M * (double)d->K * (double)d->R * d->S * d->C, st);
+        if (p.bm == 128 && p.bn == 128)
+            hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, st, a);
+        else if (p.bm == 128 && p.bn == 64)
+            hipLaunchKernelGGL((wgrad_kernel<128, 64>), grid, dim3(256), 0, st, a);
+        else if (p.bm == 64 && p.bn == 128)
+            hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, dim3(256), 0, st, a);
+    }
     long long total = (long long)d->K * a.Ncols;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)workspace, dw,
                        p.splits, d->K, d->C, d->Cp, d->R * d->S, total);
@@ -782,4 +835,34 @@ extern "C" int up_conv2d_bwd_weight(const up_conv_desc* d, const float* x, const
         hipLaunchKernelGGL(colsum_kernel, g, dim3(256), 0, st, dy, d->ldy, (long long)a.M, d->K, dbias, rpb);
     }
     return check_launch("conv2d_bwd_weight");
+}
+
+// ---- profiling control (see ProfScope above) ----------------------------------------------------
+extern "C" int up_profile_variants(void) { return PROF_VARIANTS; }
+extern "C" const char* up_profile_variant_name(int i) { return (i >= 0 && i < PROF_VARIANTS) ? kVariantNames[i] : ""; }
+extern "C" int up_profile_begin(void) {
+#ifndef UP_EMU
+    g_prof.clear();
+    g_prof_on = true;
+#endif
+    return UP_OK;
+}
+extern "C" int up_profile_end(double* out /* [variants][3] = launches, ms, flops */, int variants) {
+    UP_REQUIRE(out && variants == PROF_VARIANTS, UP_ERR_INVALID, "profile_end: expected %d variants", PROF_VARIANTS);
+    for (int i = 0; i < variants * 3; ++i) out[i] = 0.0;
+#ifndef UP_EMU
+    g_prof_on = false;
+    for (auto& r : g_prof) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(r.b);
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        out[r.variant * 3 + 0] += 1.0;
+        out[r.variant * 3 + 1] += ms;
+        out[r.variant * 3 + 2] += r.flops;
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof.clear();
+#endif
+    return UP_OK;
 }
