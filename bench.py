@@ -32,10 +32,17 @@ F32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f3
 FLOP_PER_IMAGE_FWD_BWD = 187.7e9    # 3 x 31.279 GMAC x 2 at 368x368, K=16
 
 
-def cpu_baseline(num_classes, size, batch, steps):
+T_START = time.perf_counter()
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(num_classes, size, batch, steps, threads):
     """Reference graph (oracle restatement) fwd+MSE+bwd on the host cores; images/sec."""
     from oracle import unipose_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     sd = O.clone_sd(O.synth_state_dict(num_classes, 0), requires_grad=True)
     x = O.synth_input((batch, 3, size, size), 1)
     t = O.synth_input((batch, num_classes + 1, size // 8, size // 8), 2, "rand")
@@ -47,6 +54,7 @@ def cpu_baseline(num_classes, size, batch, steps):
         torch.nn.functional.mse_loss(y, t).backward()
 
     one()
+    log("cpu baseline warm-up step done")
     t0 = time.perf_counter()
     for _ in range(steps):
         one()
@@ -69,6 +77,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch hipEvent timing")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-threads", type=int, default=min(os.cpu_count() or 1, 64),
+                    help="host threads for the CPU baseline (default: min(cores, 64); more oversubscribes oneDNN)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,8 +123,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    log(f"model on {dev}, {sum(p.numel() for p in model.parameters())} parameters; warm-up")
+    for i in range(args.warmup):
         step()
+        torch.cuda.synchronize(dev)
+        log(f"warm-up step {i} done")
     fence()
     profile = (not args.no_profile) and rank == 0
     if profile:
@@ -124,6 +137,7 @@ def main():
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    log(f"timed region: {args.steps} steps in {dt:.3f}s")
     loss_val = float(loss.detach())
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -173,7 +187,8 @@ def main():
         if roofline:
             out["roofline"] = roofline
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(K, S, args.cpu_batch, args.cpu_steps)
+            log("cpu baseline (oracle on host cores)")
+            out["cpu_baseline"] = cpu_baseline(K, S, args.cpu_batch, args.cpu_steps, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

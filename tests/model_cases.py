@@ -71,16 +71,26 @@ def train_case(dev, K=16, B=2, size=32, wseed=3, dropout_masks=False):
         m.decoder.last_conv[3].p = 0.0
         m.decoder.last_conv[7].p = 0.0
         pdrop = (0.0, 0.0, 0.0)
+    trace = []
+    ops.set_relu_trace(trace)
     try:
         y = m(x.to(dev))
         loss = ops.mse_loss(y, t.to(dev))
         loss.backward()
     finally:
         ops.set_dropout_masks(None)
-    y32 = O.unipose_forward(sd32, x, train=True, drop_masks=m32, p_drop=pdrop)
+        ops.set_relu_trace(None)
+    trace = [z.cpu() for z in trace]
+    # forward values: plain oracle;  gradients: oracle differentiating with OUR ReLU sign patterns
+    with torch.no_grad():
+        y_plain = O.unipose_forward(O.clone_sd(sd), x, train=True, drop_masks=m32, p_drop=pdrop)
+    assert O.max_rel(y.detach().cpu(), y_plain) < 1e-3
+    with O.relu_masks_from(trace):
+        y32 = O.unipose_forward(sd32, x, train=True, drop_masks=m32, p_drop=pdrop)
     l32 = torch.nn.functional.mse_loss(y32, t)
     l32.backward()
-    y64 = O.unipose_forward(sd64, x.double(), train=True, drop_masks=m64, p_drop=pdrop)
+    with O.relu_masks_from(trace):
+        y64 = O.unipose_forward(sd64, x.double(), train=True, drop_masks=m64, p_drop=pdrop)
     l64 = torch.nn.functional.mse_loss(y64, t.double())
     l64.backward()
     ok, eo, er = yardstick(y.detach().cpu(), y32.detach(), y64.detach())
@@ -143,13 +153,29 @@ def lstm_case(dev, K=13, B=1, size=32, T=3, wseed=4, tol=1e-3, train=False):
 
     sd32 = O.clone_sd(sd, requires_grad=train)
     with (torch.enable_grad() if train else torch.no_grad()):
-        o32, l32 = run_oracle(sd32, torch.float32)
-        if train:
-            sd64 = _sd64(sd, True)
-            o64, l64 = run_oracle(sd64, torch.float64)
         loss = 0.0
-        for j in range(T):                                   # uniposeLSTM.py:124-128 call pattern
-            heat, cell, hide = m(x.to(dev), cm.to(dev), j, heat, hide, cell)
+        ours = []
+        trace = []
+        ops.set_relu_trace(trace if train else None)
+        try:
+            for j in range(T):                               # uniposeLSTM.py:124-128 call pattern
+                heat, cell, hide = m(x.to(dev), cm.to(dev), j, heat, hide, cell)
+                ours.append((heat, cell, hide))
+                if train:
+                    loss = loss + ops.mse_loss(heat, tg[:, j].to(dev))
+        finally:
+            ops.set_relu_trace(None)
+        if train:                                            # same ReLU sign patterns on both sides
+            trace = [z.cpu() for z in trace]
+            with O.relu_masks_from(trace):
+                o32, l32 = run_oracle(sd32, torch.float32)
+            sd64 = _sd64(sd, True)
+            with O.relu_masks_from(trace):
+                o64, l64 = run_oracle(sd64, torch.float64)
+        else:
+            o32, l32 = run_oracle(sd32, torch.float32)
+        for j in range(T):
+            heat, cell, hide = ours[j]
             assert heat.shape == (B, K + 1, hs, hs) and cell.shape == (B, K + 2, hs, hs)
             for got, i in ((heat, 0), (cell, 1), (hide, 2)):
                 if train:
@@ -157,8 +183,6 @@ def lstm_case(dev, K=13, B=1, size=32, T=3, wseed=4, tol=1e-3, train=False):
                     assert ok, (j, i, eo, er)
                 else:
                     assert O.max_rel(got.cpu(), o32[j][i]) < tol, (j, i)
-            if train:
-                loss = loss + ops.mse_loss(heat, tg[:, j].to(dev))
     if train:
         loss.backward()
         l32.backward()

@@ -74,9 +74,7 @@ def test_g5_lstm_368_vs_reference_golden(golden_dir):
 
 
 def test_g4_train_128_vs_reference_golden(golden_dir):
-    """Reference train step at 128x128, B=2, dropouts off: loss / output / gradients / running stats.
-    fp32 round-off through 113 small-batch BatchNorms is ~1e-3 here (see model_cases.yardstick), so the
-    golden is compared with that measured conditioning as tolerance."""
+    """Reference train step at 128x128, B=2, dropouts off: loss / output / gradients / running stats."""
     from unipose_amd import ops
     g = np.load(os.path.join(golden_dir, "g4_train_128.npz"))
     K, wseed, xseed, tseed = (int(v) for v in g["meta"])
@@ -89,16 +87,28 @@ def test_g4_train_128_vs_reference_golden(golden_dir):
     y = m(x)
     loss = ops.mse_loss(y, t)
     loss.backward()
-    assert O.max_rel(y.detach().cpu(), g["out"]) < 2e-2
-    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-2 * abs(float(g["loss"]))
+    assert O.max_rel(y.detach().cpu(), g["out"]) < TOL
+    assert abs(float(loss.detach()) - float(g["loss"])) < TOL * abs(float(g["loss"]))
     sd = m.state_dict()
+    p = dict(m.named_parameters())
     for k in g.files:
         if k.startswith("rm/"):
-            assert O.max_rel(sd[k[3:] + ".running_mean"].cpu(), g[k]) < 2e-2, k
+            assert O.max_rel(sd[k[3:] + ".running_mean"].cpu(), g[k]) < TOL, k
         elif k.startswith("rv/"):
-            assert O.max_rel(sd[k[3:] + ".running_var"].cpu(), g[k]) < 2e-2, k
-    p = dict(m.named_parameters())
-    assert O.max_rel(p["decoder.last_conv.8.bias"].grad.cpu(), g["grad/decoder.last_conv.8.bias"]) < 5e-2
+            assert O.max_rel(sd[k[3:] + ".running_var"].cpu(), g[k]) < TOL, k
+        elif k.startswith("grad/"):
+            gr, ref = p[k[5:]].grad.cpu(), g[k]
+            if tuple(gr.shape) != ref.shape:
+                gr = gr[::4, ::4]                                              # tools/make_goldens.py SUB
+            # relative L2: a ReLU whose pre-activation sits within fp32 round-off of 0 may flip between two
+            # implementations and moves single gradient entries by percents (see oracle.relu_masks_from);
+            # the flip-free, tight comparison is test_train_step_vs_oracle_yardstick below
+            ref = torch.from_numpy(ref).double()
+            l2 = float((gr.double() - ref).norm() / ref.norm())
+            assert l2 < 0.15, (k, l2)
+    names = sorted(n for n, q in m.named_parameters())
+    norms = np.array([p[n].grad.double().norm().item() if p[n].grad is not None else -1.0 for n in names])
+    assert np.allclose(norms, g["grad_norms"], rtol=0.1, atol=1e-9)
     assert [n for n, q in m.named_parameters() if q.grad is None] == \
         ["decoder.conv2.weight", "decoder.bn2.weight", "decoder.bn2.bias"]
 

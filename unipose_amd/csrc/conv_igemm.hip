@@ -10,12 +10,13 @@
 //   weight-gradient ("NT" GEMM, both operands m-contiguous), split-K over pixels:
 //       dW[co][tap*Cp+ci] = sum_m dY[m][co] * X[src(m,tap)][ci]
 //
-// Tiling: 256 threads = 4 wavefronts (2x2), block tile BMxBN (128/64), BK=16, wave tile
+// Tiling: 256 threads = 4 wavefronts (2x2), block tile BMxBN (128/64), BK=32, wave tile
 // (BM/2)x(BN/2) built from 32x32 MFMA tiles.  One LDS buffer + register prefetch of the next
 // K-slice (global loads stay in flight under the MFMAs); 3-4 blocks per CU hide the two barriers
 // per slice (MI355X_MICROARCH: one f32 MFMA chain per wave already saturates the pipe).
-// LDS rows are 20 dwords (16 + 4 pad): the ds_read_b128 fragment reads are conflict-free because
-// 20/4 = 5 is odd (16 lanes of a b128 group hit 16 distinct 16-B slots).
+// LDS rows are 36 dwords (32 + 4 pad): the ds_read_b128 fragment reads are conflict-free because
+// 36/4 = 9 is odd (16 lanes of a b128 group hit 16 distinct 16-B slots).  A K-slice of 32 floats is one
+// full 128-B line per gathered pixel row.  Pad channels (>= C) must hold zeros (finite), see the header.
 // Within each group of 8 k the two half-waves take k = {0..3} / {4..7}: any k permutation is
 // legal as long as A and B use the same one, and it turns 4 ds_read_b32 into one ds_read_b128.
 #include "up_common.h"
@@ -66,8 +67,8 @@ struct ProfScope {
 };
 #endif
 
-constexpr int BK = 16;
-constexpr int LDS_LD = 20;
+constexpr int BK = 32;
+constexpr int LDS_LD = 36;   // 32 + 4 pad dwords: 36/4 = 9 is odd -> conflict-free ds_read_b128
 
 struct IgemmArgs {
     const float* x;
@@ -78,7 +79,8 @@ struct IgemmArgs {
     int H, W, P, Q;  // source H,W; destination P,Q
     int ldx, ldy;
     int S;
-    int mul, off0, tapstep, div;  // src = (dst*mul + off0 + r*tapstep) / div
+    int mul, off0, tapstep;       // src = (dst*mul + off0 + r*tapstep) >> divshift (if divisible)
+    int divshift, divmask;        // 0,0 (forward, stride-1 dgrad) or 1,1 (dgrad of a stride-2 conv)
     int ntn;                      // number of n tiles
     int nwg;
     FastDiv fPQ, fQ, fCp, fS, fNtn;
@@ -106,6 +108,12 @@ __device__ __forceinline__ void wf_merge(float& n1, float& m1, float& s1, float 
     n1 = n;
 }
 
+// component-wise select: a `cond ? float4_a : float4_b` on the aggregates becomes an ADDRESS select and forces
+// the prefetch registers into scratch memory.
+__device__ __forceinline__ float4 keep_or_zero(bool k, float4 v) {
+    return make_float4(k ? v.x : 0.f, k ? v.y : 0.f, k ? v.z : 0.f, k ? v.w : 0.f);
+}
+
 // XCD-aware bijective remap: hardware block b runs on XCD b%8; give every XCD a contiguous run of
 // logical tiles so the n-tiles sharing one A row-panel hit the same L2.
 __device__ __forceinline__ int xcd_remap(int b, int nwg) {
@@ -115,8 +123,9 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 }
 
 template <int BM, int BN, bool ALIGNED>
-__global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
-    constexpr int TM = BM / 64, TN = BN / 64;
+__global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_kernel(IgemmArgs a) {
+    constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave along m / n
+    constexpr int PA = BM / 32, PB = BN / 32;   // staging passes: 32 rows x 8 float4 per pass
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
     float* As = smem;
     float* Bs = smem + BM * LDS_LD;
@@ -131,17 +140,16 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
     const int nt = logical - mt * a.ntn;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    const int lrow = tid >> 2;  // 0..63
-    const int kq = tid & 3;     // which float4 of the 16-wide k slice
+    const int lrow = tid >> 3;  // 0..31
+    const int kq = tid & 7;     // which float4 of the 32-wide k slice
 
-    // per-thread gather bases for its TM rows
-    int hb[TM], wb[TM], ib[TM];
-    bool mv[TM];
+    // per-thread gather bases for its PA rows.  Rows beyond M only need a SAFE address (their results
+    // are never stored); taps that fall into the zero padding are zeroed by a select at LDS-store time.
+    int hb[PA], wb[PA], ib[PA];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        int m = m0 + i * 64 + lrow;
-        mv[i] = m < a.M;
-        int mm = mv[i] ? m : 0;
+    for (int i = 0; i < PA; ++i) {
+        int m = m0 + i * 32 + lrow;
+        int mm = m < a.M ? m : a.M - 1;
         int img = fdiv(mm, a.fPQ);
         int rem = mm - img * (a.P * a.Q);
         int p = fdiv(rem, a.fQ);
@@ -150,21 +158,21 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
         wb[i] = q * a.mul + a.off0;
         ib[i] = img * a.H * a.W;
     }
-    const float* wrow[TN];
-    bool nv[TN];
+    const float* wrow[PB];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        int n = n0 + j * 64 + lrow;
-        nv[j] = n < a.Ng;
-        wrow[j] = a.w + (size_t)(nv[j] ? n : 0) * a.Ktot + kq * 4;
+    for (int j = 0; j < PB; ++j) {
+        int n = n0 + j * 32 + lrow;
+        wrow[j] = a.w + (size_t)(n < a.Ng ? n : a.Ng - 1) * a.Ktot + kq * 4;   // rows >= Ng: never stored
     }
 
-    float4 ra[TM], rb[TN];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 ra[PA], rb[PB];
+    unsigned okmask = 0;   // bit i: ra[i] is real data (else structural zero); bit 31: k slice valid
 
-    // aligned path: the 16-wide slice never straddles a tap; (tap, ci0) advance as scalars
+    // aligned path: the 32-wide slice never straddles a tap; (tap, ci0) advance as scalars
     int tap_c = 0, ci0_c = 0;
 
+    // Branch-free prefetch: every load is issued unconditionally from a clamped (always valid) address so
+    // that all of them are in flight together under the MFMAs of the current slice; no wait until lstore().
     auto gload = [&](int kt) {
         int tap, ci;
         bool kvalid = true;
@@ -181,37 +189,24 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
         int r = fdiv(tap, a.fS);
         int s = tap - r * a.S;
         int dh = r * a.tapstep, dw = s * a.tapstep;
+        unsigned msk = kvalid ? 0x80000000u : 0u;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+        for (int i = 0; i < PA; ++i) {
             int h = hb[i] + dh, w = wb[i] + dw;
-            bool ok = mv[i] && kvalid && h >= 0 && w >= 0;
-            if (a.div == 2) {
-                ok = ok && !((h | w) & 1);
-                h >>= 1;
-                w >>= 1;
-            } else if (a.div > 2) {
-                int hq = h / a.div, wq = w / a.div;
-                ok = ok && hq * a.div == h && wq * a.div == w;
-                h = hq;
-                w = wq;
-            }
+            bool ok = kvalid && h >= 0 && w >= 0;
+            // data gradient of a stride-2 convolution: only even source offsets hit a real dy sample
+            ok = ok && !((h | w) & a.divmask);
+            h >>= a.divshift;
+            w >>= a.divshift;
             ok = ok && h < a.H && w < a.W;
-            float4 v = zero4;
-            if (ok) {
-                v = *reinterpret_cast<const float4*>(a.x + (size_t)(ib[i] + h * a.W + w) * a.ldx + ci);
-                if (a.Creal != a.Cp) {
-                    if (ci + 1 >= a.Creal) v.y = 0.f;
-                    if (ci + 2 >= a.Creal) v.z = 0.f;
-                    if (ci + 3 >= a.Creal) v.w = 0.f;
-                    if (ci >= a.Creal) v.x = 0.f;
-                }
-            }
-            ra[i] = v;
+            size_t off = ok ? (size_t)(ib[i] + h * a.W + w) * a.ldx + ci : (size_t)0;
+            ra[i] = *reinterpret_cast<const float4*>(a.x + off);
+            msk |= ok ? (1u << i) : 0u;
         }
+        const size_t koff = kvalid ? (size_t)kt * BK : (size_t)0;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            rb[j] = (nv[j] && kvalid) ? *reinterpret_cast<const float4*>(wrow[j] + (size_t)kt * BK) : zero4;
-        }
+        for (int j = 0; j < PB; ++j) rb[j] = *reinterpret_cast<const float4*>(wrow[j] + koff);
+        okmask = msk;
         if (ALIGNED) {
             ci0_c += BK;
             if (ci0_c >= a.Cp) {
@@ -222,9 +217,12 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
     };
     auto lstore = [&]() {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) *reinterpret_cast<float4*>(&As[(i * 64 + lrow) * LDS_LD + kq * 4]) = ra[i];
+        for (int i = 0; i < PA; ++i)
+            *reinterpret_cast<float4*>(&As[(i * 32 + lrow) * LDS_LD + kq * 4]) = keep_or_zero((okmask >> i) & 1u, ra[i]);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) *reinterpret_cast<float4*>(&Bs[(j * 64 + lrow) * LDS_LD + kq * 4]) = rb[j];
+        for (int j = 0; j < PB; ++j)
+            *reinterpret_cast<float4*>(&Bs[(j * 32 + lrow) * LDS_LD + kq * 4]) =
+                ALIGNED ? rb[j] : keep_or_zero(okmask >> 31, rb[j]);
     };
 
     f32x16 acc[TM][TN];
@@ -247,7 +245,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(IgemmArgs a) {
         const bool more = kt + 1 < nk;
         if (more) gload(kt + 1);
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < BK / 8; ++g) {
             float4 af[TM], bf[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(Ard + i * 32 * LDS_LD + g * 8);
@@ -383,11 +381,11 @@ struct WgradArgs {
 };
 
 template <int BM, int BN>
-__global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
+__global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) wgrad_kernel(WgradArgs a) {
     constexpr int TM = BM / 64, TN = BN / 64;
-    constexpr int A4 = BM / 4, B4 = BN / 4;        // float4 per k row
-    constexpr int PA = BK * A4 / 256, PB = BK * B4 / 256;  // load passes (1 or 2)
-    constexpr int KA = 256 / A4, KB = 256 / B4;    // k rows covered per pass
+    constexpr int A4 = BM / 4, B4 = BN / 4;                // float4 per k row
+    constexpr int PA = BK * A4 / 256, PB = BK * B4 / 256;  // staging passes
+    constexpr int KA = 256 / A4, KB = 256 / B4;            // k rows covered per pass
     __shared__ __attribute__((aligned(16))) float smem[BK * (BM + BN)];
     float* As = smem;
     float* Bs = smem + BK * BM;
@@ -404,62 +402,54 @@ __global__ void __launch_bounds__(256) wgrad_kernel(WgradArgs a) {
     const int mbeg = blockIdx.y * a.rows_per_split;
     const int mend = min(a.M, mbeg + a.rows_per_split);
 
-    // A (dY): thread -> (k row within pass, 4 output channels)
+    // A (dY): thread -> (k row within pass, 4 output channels).  Channels >= K are never stored: they only
+    // need a valid address.
     const int a_c4 = tid % A4, a_kr = tid / A4;
-    const int a_co = co0 + a_c4 * 4;
-    // B (X gather): thread -> (k row within pass, 4 columns = one tap, 4 channels)
+    const int a_co = (co0 + a_c4 * 4 < a.ldy) ? co0 + a_c4 * 4 : 0;
+    // B (X gather): thread -> (k row within pass, 4 columns = one tap, 4 channels); columns >= Ncols likewise
     const int b_c4 = tid % B4, b_kr = tid / B4;
-    const int b_col = col0 + b_c4 * 4;
-    const bool b_cv = b_col < a.Ncols;
-    const int b_tap = fdiv(b_cv ? b_col : 0, a.fCp);
-    const int b_ci = (b_cv ? b_col : 0) - b_tap * a.Cp;
+    const int b_col = (col0 + b_c4 * 4 < a.Ncols) ? col0 + b_c4 * 4 : 0;
+    const int b_tap = fdiv(b_col, a.fCp);
+    const int b_ci = b_col - b_tap * a.Cp;
     const int b_r = fdiv(b_tap, a.fS);
     const int b_dh = b_r * a.dil - a.pad, b_dw = (b_tap - b_r * a.S) * a.dil - a.pad;
 
     float4 ra[PA], rb[PB];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned okmask = 0;   // bits 0..PA-1: dY row inside [mbeg,mend); bits 8..8+PB-1: tap inside the image
 
+    // branch-free prefetch (see igemm_kernel): clamped addresses, structural zeros selected at lstore()
     auto gload = [&](int kbase) {
+        unsigned msk = 0;
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
             int m = kbase + p * KA + a_kr;
-            float4 v = zero4;
-            if (m < mend && a_co < a.K) {
-                v = *reinterpret_cast<const float4*>(a.dy + (size_t)m * a.ldy + a_co);
-                if (a_co + 1 >= a.K) v.y = 0.f;
-                if (a_co + 2 >= a.K) v.z = 0.f;
-                if (a_co + 3 >= a.K) v.w = 0.f;
-            }
-            ra[p] = v;
+            bool ok = m < mend;
+            ra[p] = *reinterpret_cast<const float4*>(a.dy + (size_t)(ok ? m : mbeg) * a.ldy + a_co);
+            msk |= ok ? (1u << p) : 0u;
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
             int m = kbase + p * KB + b_kr;
-            float4 v = zero4;
-            if (m < mend && b_cv) {
-                int img = fdiv(m, a.fPQ);
-                int rem = m - img * (a.P * a.Q);
-                int pp = fdiv(rem, a.fQ);
-                int qq = rem - pp * a.Q;
-                int h = pp * a.stride + b_dh, w = qq * a.stride + b_dw;
-                if (h >= 0 && w >= 0 && h < a.H && w < a.W) {
-                    v = *reinterpret_cast<const float4*>(a.x + (size_t)((img * a.H + h) * a.W + w) * a.ldx + b_ci);
-                    if (a.Creal != a.Cp) {
-                        if (b_ci + 1 >= a.Creal) v.y = 0.f;
-                        if (b_ci + 2 >= a.Creal) v.z = 0.f;
-                        if (b_ci + 3 >= a.Creal) v.w = 0.f;
-                        if (b_ci >= a.Creal) v.x = 0.f;
-                    }
-                }
-            }
-            rb[p] = v;
+            int mm = m < mend ? m : mbeg;
+            int img = fdiv(mm, a.fPQ);
+            int rem = mm - img * (a.P * a.Q);
+            int pp = fdiv(rem, a.fQ);
+            int qq = rem - pp * a.Q;
+            int h = pp * a.stride + b_dh, w = qq * a.stride + b_dw;
+            bool ok = h >= 0 && w >= 0 && h < a.H && w < a.W;
+            size_t off = ok ? (size_t)((img * a.H + h) * a.W + w) * a.ldx + b_ci : (size_t)0;
+            rb[p] = *reinterpret_cast<const float4*>(a.x + off);
+            msk |= ok ? (1u << (8 + p)) : 0u;
         }
+        okmask = msk;
     };
     auto lstore = [&]() {
 #pragma unroll
-        for (int p = 0; p < PA; ++p) *reinterpret_cast<float4*>(&As[(p * KA + a_kr) * BM + a_c4 * 4]) = ra[p];
+        for (int p = 0; p < PA; ++p)
+            *reinterpret_cast<float4*>(&As[(p * KA + a_kr) * BM + a_c4 * 4]) = keep_or_zero((okmask >> p) & 1u, ra[p]);
 #pragma unroll
-        for (int p = 0; p < PB; ++p) *reinterpret_cast<float4*>(&Bs[(p * KB + b_kr) * BN + b_c4 * 4]) = rb[p];
+        for (int p = 0; p < PB; ++p)
+            *reinterpret_cast<float4*>(&Bs[(p * KB + b_kr) * BN + b_c4 * 4]) = keep_or_zero((okmask >> (8 + p)) & 1u, rb[p]);
     };
 
     f32x16 acc[TM][TN];
@@ -685,7 +675,8 @@ extern "C" int up_conv2d_fwd(const up_conv_desc* d, const float* x, const float*
     a.mul = d->stride;
     a.off0 = -d->pad;
     a.tapstep = d->dil;
-    a.div = 1;
+    a.divshift = 0;
+    a.divmask = 0;
     a.fPQ = make_fastdiv(d->P * d->Q);
     a.fQ = make_fastdiv(d->Q);
     a.fCp = make_fastdiv(d->Cp);
@@ -711,6 +702,7 @@ extern "C" int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const 
                                   void* stream) {
     if (int e = check_desc(d)) return e;
     UP_REQUIRE(dy && w_dgrad && dx, UP_ERR_INVALID, "conv2d_bwd_data: null pointer");
+    UP_REQUIRE(d->stride <= 2, UP_ERR_UNSUPPORTED, "conv2d_bwd_data: stride %d (only 1 and 2 are implemented)", d->stride);
     UP_REQUIRE(d->Kp % 4 == 0 && d->Kp >= d->K && d->ldy % 4 == 0 && d->ldy >= d->Kp, UP_ERR_INVALID,
                "conv2d_bwd_data: need Kp%%4==0, ldy%%4==0, ldy>=Kp (Kp=%d ldy=%d K=%d)", d->Kp, d->ldy, d->K);
     IgemmArgs a;
@@ -734,7 +726,8 @@ extern "C" int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const 
     a.mul = 1;
     a.off0 = d->pad;
     a.tapstep = -d->dil;
-    a.div = d->stride;
+    a.divshift = d->stride == 2 ? 1 : 0;
+    a.divmask = d->stride == 2 ? 1 : 0;
     a.fPQ = make_fastdiv(d->H * d->W);
     a.fQ = make_fastdiv(d->W);
     a.fCp = make_fastdiv(d->Kp);

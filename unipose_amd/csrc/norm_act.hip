@@ -128,35 +128,75 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* y, int ldy, 
 
 // ---- BN backward -------------------------------------------------------------------------
 // pass 1: partial[chunk][c] = {sum g, sum g*xhat},   g = dz * (z > 0 if relu)
+// 256 threads = 16 row lanes x 16 channel quads (64 channels): every access is a 16-byte load of 4
+// consecutive channels, rows strided by 16 and unrolled x2 so 6 loads are in flight per thread.
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* dz, int lddz, const float* z, int ldz,
                                                             const float* y, int ldy, const float* mean,
                                                             const float* invstd, int relu, float* partial,
                                                             int64_t rows, int C, int rows_per_chunk) {
-    __shared__ float red[2][256];
-    int c = blockIdx.y * 64 + (threadIdx.x & 63);
-    int rl = threadIdx.x >> 6;
-    int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk;
-    int64_t r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
-    float s1 = 0.f, s2 = 0.f;
+    __shared__ float red[16][64][2];
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + cq * 4;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk;
+    const int64_t r1 = r0 + rows_per_chunk < rows ? r0 + rows_per_chunk : rows;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
-        float mu = mean[c], is = invstd[c];
-        for (int64_t r = r0 + rl; r < r1; r += 4) {
-            float g = dz[r * lddz + c];
-            if (relu && !(z[r * ldz + c] > 0.f)) g = 0.f;
-            s1 += g;
-            s2 += g * (y[r * ldy + c] - mu) * is;
+        const float4 mu = *reinterpret_cast<const float4*>(mean + c);
+        auto acc = [&](float4 g, float4 zz, float4 yy) {
+            if (relu) {
+                g.x = zz.x > 0.f ? g.x : 0.f;
+                g.y = zz.y > 0.f ? g.y : 0.f;
+                g.z = zz.z > 0.f ? g.z : 0.f;
+                g.w = zz.w > 0.f ? g.w : 0.f;
+            }
+            s1[0] += g.x;
+            s1[1] += g.y;
+            s1[2] += g.z;
+            s1[3] += g.w;
+            s2[0] += g.x * (yy.x - mu.x);
+            s2[1] += g.y * (yy.y - mu.y);
+            s2[2] += g.z * (yy.z - mu.z);
+            s2[3] += g.w * (yy.w - mu.w);
+        };
+        int64_t r = r0 + rl;
+        for (; r + 16 < r1; r += 32) {
+            float4 ga = *reinterpret_cast<const float4*>(dz + r * lddz + c);
+            float4 gb = *reinterpret_cast<const float4*>(dz + (r + 16) * lddz + c);
+            float4 ya = *reinterpret_cast<const float4*>(y + r * ldy + c);
+            float4 yb = *reinterpret_cast<const float4*>(y + (r + 16) * ldy + c);
+            float4 za = ga, zb = gb;
+            if (relu) {
+                za = *reinterpret_cast<const float4*>(z + r * ldz + c);
+                zb = *reinterpret_cast<const float4*>(z + (r + 16) * ldz + c);
+            }
+            acc(ga, za, ya);
+            acc(gb, zb, yb);
         }
+        for (; r < r1; r += 16) {
+            float4 ga = *reinterpret_cast<const float4*>(dz + r * lddz + c);
+            float4 ya = *reinterpret_cast<const float4*>(y + r * ldy + c);
+            float4 za = relu ? *reinterpret_cast<const float4*>(z + r * ldz + c) : ga;
+            acc(ga, za, ya);
+        }
+        const float4 is = *reinterpret_cast<const float4*>(invstd + c);
+        s2[0] *= is.x;
+        s2[1] *= is.y;
+        s2[2] *= is.z;
+        s2[3] *= is.w;
     }
-    red[0][threadIdx.x] = s1;
-    red[1][threadIdx.x] = s2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[rl][cq * 4 + e][0] = s1[e];
+        red[rl][cq * 4 + e][1] = s2[e];
+    }
     __syncthreads();
-    if (rl == 0 && c < C) {
-        int t = threadIdx.x;
-        float a = red[0][t] + red[0][t + 64] + red[0][t + 128] + red[0][t + 192];
-        float b = red[1][t] + red[1][t + 64] + red[1][t + 128] + red[1][t + 192];
-        float* o = partial + ((size_t)blockIdx.x * C + c) * 2;
-        o[0] = a;
-        o[1] = b;
+    if (threadIdx.x < 128) {
+        const int ch = threadIdx.x >> 1, which = threadIdx.x & 1;
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][ch][which];
+        const int cc = blockIdx.y * 64 + ch;
+        if (cc < C) partial[((size_t)blockIdx.x * C + cc) * 2 + which] = t;
     }
 }
 // pass 2: one wave per channel sums the chunk partials
@@ -204,13 +244,18 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* dz, int 
         float4 y4 = *reinterpret_cast<const float4*>(y + (size_t)row * ldy + c);
         float yv[4] = {y4.x, y4.y, y4.z, y4.w};
         float o[4];
+        const float4 is4 = *reinterpret_cast<const float4*>(invstd + c), ga4 = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 mu4 = *reinterpret_cast<const float4*>(mean + c);
+        const float4 dg4 = *reinterpret_cast<const float4*>(dgamma + c), db4 = *reinterpret_cast<const float4*>(dbeta + c);
+        const float isv[4] = {is4.x, is4.y, is4.z, is4.w}, gav[4] = {ga4.x, ga4.y, ga4.z, ga4.w};
+        const float muv[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, dgv[4] = {dg4.x, dg4.y, dg4.z, dg4.w};
+        const float dbv[4] = {db4.x, db4.y, db4.z, db4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float is = invstd[c + e];
-            float k = gamma[c + e] * is;
+            float k = gav[e] * isv[e];
             if (use_batch) {
-                float xh = (yv[e] - mean[c + e]) * is;
-                o[e] = k * (g[e] - dbeta[c + e] * inv_m - xh * dgamma[c + e] * inv_m);
+                float xh = (yv[e] - muv[e]) * isv[e];
+                o[e] = k * (g[e] - dbv[e] * inv_m - xh * dgv[e] * inv_m);
             } else {
                 o[e] = k * g[e];
             }

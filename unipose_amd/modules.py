@@ -212,7 +212,7 @@ class Decoder(nn.Module):
         low = ops.conv_bn_act(low, self.conv1, self.bn1, relu=True)
         low = ops.MaxPool3s2.apply(low)
         x = ops.Bilinear.apply(x, low.shape[1], low.shape[2])
-        y = ops.ConcatC.apply(0, x, low)
+        y = ops.ConcatC.apply(320, x, low)      # 256 + 48 = 304 real channels, zero-padded to a multiple of 32
         y = ops.dropout(ops.conv_bn_act(y, lc[0], lc[1], relu=True), lc[3])
         y = ops.dropout(ops.conv_bn_act(y, lc[4], lc[5], relu=True), lc[7])
         return ops.conv_bias_act(y, lc[8])

@@ -86,7 +86,9 @@ def make_desc(x: torch.Tensor, weight: torch.Tensor, cfg: ConvCfg, ldy: Optional
     p = (h + 2 * cfg.pad - cfg.dil * (r - 1) - 1) // cfg.stride + 1
     q = (w + 2 * cfg.pad - cfg.dil * (s - 1) - 1) // cfg.stride + 1
     d = _C.ConvDesc()
-    d.N, d.H, d.W, d.C, d.Cp, d.ldx = n, h, w, c, rup4(c), _nhwc_ok(x)
+    # Cp = physical channels of the input (pad channels are zeros and meet zero weights): lets a producer
+    # pad e.g. the 304-channel decoder concat to 320 so that 32-wide K slices never straddle a filter tap
+    d.N, d.H, d.W, d.C, d.Cp, d.ldx = n, h, w, c, cp, _nhwc_ok(x)
     d.K, d.R, d.S = k, r, s
     d.stride, d.pad, d.dil = cfg.stride, cfg.pad, cfg.dil
     d.P, d.Q = p, q
@@ -173,6 +175,16 @@ def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool):
     return dw, db
 
 
+_RELU_TRACE = None
+
+
+def set_relu_trace(lst):
+    """Test hook: while a list is installed, every fused ReLU appends its output tensor (NHWC) to it, in
+    call order — the oracle replays those sign patterns for flip-free gradient comparisons."""
+    global _RELU_TRACE
+    _RELU_TRACE = lst
+
+
 class ConvBias(Function):
     """conv (+bias) (+ReLU) — the LSTM head, gate and final 1x1 convolutions
     (decoder.py:30, model/uniposeLSTM.py:12-14,30-38,85-89,120-124)."""
@@ -180,6 +192,8 @@ class ConvBias(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, cfg: ConvCfg, relu: bool):
         y, d, _ = conv_fwd_raw(x, weight, cfg, bias=bias, relu=relu)
+        if relu and _RELU_TRACE is not None:
+            _RELU_TRACE.append(y.detach())
         ctx.d, ctx.relu, ctx.has_bias = d, relu, bias is not None
         ctx.save_for_backward(x, weight, y if relu else None)
         return y
@@ -234,6 +248,8 @@ class ConvBnAct(Function):
         _C.check(L.up_bn_apply(y.data_ptr(), d.ldy, coef[2].data_ptr(), coef[3].data_ptr(), _ptr(residual),
                                _nhwc_ok(residual) if residual is not None else 0, int(relu), z.data_ptr(), d.ldy,
                                rows, k, _stream(x)), "bn_apply")
+        if relu and _RELU_TRACE is not None:
+            _RELU_TRACE.append(z.detach())
         ctx.d, ctx.relu, ctx.train, ctx.has_res = d, relu, train, residual is not None
         ctx.save_for_backward(x, weight, gamma, y, z, coef)
         return z
