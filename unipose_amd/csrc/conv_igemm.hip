@@ -21,6 +21,8 @@
 // legal as long as A and B use the same one, and it turns 4 ds_read_b32 into one ds_read_b128.
 #include "up_common.h"
 
+#include <stdlib.h>
+
 #include <vector>
 
 namespace up {
@@ -40,6 +42,7 @@ struct ProfRec {
     hipEvent_t a, b;
     int variant;
     double flops;
+    int M, N, K, grid;   // GEMM view of the launch + workgroups (for the per-launch CSV)
 };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
@@ -47,10 +50,15 @@ struct ProfScope {
     ProfRec r;
     hipStream_t st;
     bool on;
-    ProfScope(int variant, double flops, hipStream_t s) : st(s), on(g_prof_on) {
+    ProfScope(int variant, double flops, hipStream_t s, int M = 0, int N = 0, int K = 0, int grid = 0)
+        : st(s), on(g_prof_on) {
         if (!on) return;
         r.variant = variant;
         r.flops = flops;
+        r.M = M;
+        r.N = N;
+        r.K = K;
+        r.grid = grid;
         (void)hipEventCreate(&r.a);
         (void)hipEventCreate(&r.b);
         (void)hipEventRecord(r.a, st);
@@ -63,7 +71,7 @@ struct ProfScope {
 };
 #else
 struct ProfScope {
-    ProfScope(int, double, hipStream_t) {}
+    ProfScope(int, double, hipStream_t, int = 0, int = 0, int = 0, int = 0) {}
 };
 #endif
 
@@ -78,7 +86,7 @@ struct IgemmArgs {
     long long Ktot_real;  // taps * real channels: the algorithmic reduction length (profiling only)
     int H, W, P, Q;  // source H,W; destination P,Q
     int ldx, ldy;
-    int S;
+    int S, taps;
     int mul, off0, tapstep;       // src = (dst*mul + off0 + r*tapstep) >> divshift (if divisible)
     int divshift, divmask;        // 0,0 (forward, stride-1 dgrad) or 1,1 (dgrad of a stride-2 conv)
     int ntn;                      // number of n tiles
@@ -122,8 +130,17 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN, bool ALIGNED>
+// DBG is 0 in the library; tools/gpu/igemm_probe.hip instantiates ablations (bit 0: no global prefetch in
+// the loop, bit 1: no LDS refill + its barrier, bit 2: fragments from registers instead of LDS, bit 3: no
+// barrier at all, bit 4: pin the load/MFMA interleave, bit 5: sample shader clocks) to attribute the
+// MFMA-pipe idle time.
+// MODE 0: generic (K slices may straddle taps / ragged K: stem, 15-channel LSTM convolutions)
+// MODE 1: aligned (Cp % 32 == 0), per-slice bounds arithmetic (strided data gradient, > 32 taps)
+// MODE 2: aligned + precomputed per-row offset and per-row tap-validity bit mask: one add + one bit test
+//         per gathered row and K slice (the address arithmetic of MODE 1 was ~20 % of the kernel time)
+template <int BM, int BN, int MODE, int DBG = 0>
 __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_kernel(IgemmArgs a) {
+    constexpr bool ALIGNED = MODE >= 1, FAST = MODE == 2;
     constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave along m / n
     constexpr int PA = BM / 32, PB = BN / 32;   // staging passes: 32 rows x 8 float4 per pass
     __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
@@ -135,6 +152,11 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
 
+    long long dbg_c0 = 0, dbg_w0 = 0;
+    if ((DBG & 32) && threadIdx.x == 0) {
+        dbg_c0 = clock64();
+        dbg_w0 = wall_clock64();
+    }
     const int logical = xcd_remap(blockIdx.x, a.nwg);
     const int mt = fdiv(logical, a.fNtn);
     const int nt = logical - mt * a.ntn;
@@ -145,7 +167,9 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
 
     // per-thread gather bases for its PA rows.  Rows beyond M only need a SAFE address (their results
     // are never stored); taps that fall into the zero padding are zeroed by a select at LDS-store time.
-    int hb[PA], wb[PA], ib[PA];
+    int hb[PA], wb[PA], ib[PA];      // MODE 0/1: image row/col of tap (0,0) and image base (pixels)
+    int roff[PA];                    // MODE 2: element offset of tap (0,0) (may be negative)
+    unsigned tmask[PA];              // MODE 2: bit t set <=> tap t of this row reads a real pixel
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
         int m = m0 + i * 32 + lrow;
@@ -157,6 +181,19 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
         hb[i] = p * a.mul + a.off0;
         wb[i] = q * a.mul + a.off0;
         ib[i] = img * a.H * a.W;
+        if (FAST) {
+            roff[i] = (ib[i] + hb[i] * a.W + wb[i]) * a.ldx;
+            unsigned mk = 0;
+            for (int t = 0, r = 0, sx = 0; t < a.taps; ++t) {
+                int h = hb[i] + r * a.tapstep, w = wb[i] + sx * a.tapstep;
+                mk |= (h >= 0 && w >= 0 && h < a.H && w < a.W) ? (1u << t) : 0u;
+                if (++sx == a.S) {
+                    sx = 0;
+                    ++r;
+                }
+            }
+            tmask[i] = mk;
+        }
     }
     const float* wrow[PB];
 #pragma unroll
@@ -171,42 +208,33 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     // aligned path: the 32-wide slice never straddles a tap; (tap, ci0) advance as scalars
     int tap_c = 0, ci0_c = 0;
 
-    // Branch-free prefetch: every load is issued unconditionally from a clamped (always valid) address so
-    // that all of them are in flight together under the MFMAs of the current slice; no wait until lstore().
-    auto gload = [&](int kt) {
-        int tap, ci;
-        bool kvalid = true;
+    // Branch-free prefetch: every load is issued unconditionally from a clamped (always valid) address; no
+    // wait until lstore().  gprep() does the (mostly scalar) per-slice bookkeeping, gissue(part) issues the
+    // loads of one quarter of the slice so that the K loop can spread them between its MFMA groups: issuing
+    // all of them back-to-back stalls the wave on the texture-address queue while its MFMAs could run.
+    int g_tap = 0, g_ci = 0, g_dh = 0, g_dw = 0, g_delta = 0;
+    bool g_kvalid = true;
+    size_t g_koff = 0;
+    unsigned g_msk = 0;
+    auto gprep = [&](int kt) {
+        g_kvalid = true;
         if (ALIGNED) {
-            tap = tap_c;
-            ci = ci0_c + kq * 4;
+            g_tap = tap_c;
+            g_ci = ci0_c + kq * 4;
         } else {
             int k = kt * BK + kq * 4;
-            kvalid = k < a.Ktot;
-            int kk = kvalid ? k : 0;
-            tap = fdiv(kk, a.fCp);
-            ci = kk - tap * a.Cp;
+            g_kvalid = k < a.Ktot;
+            int kk = g_kvalid ? k : 0;
+            g_tap = fdiv(kk, a.fCp);
+            g_ci = kk - g_tap * a.Cp;
         }
-        int r = fdiv(tap, a.fS);
-        int s = tap - r * a.S;
-        int dh = r * a.tapstep, dw = s * a.tapstep;
-        unsigned msk = kvalid ? 0x80000000u : 0u;
-#pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            int h = hb[i] + dh, w = wb[i] + dw;
-            bool ok = kvalid && h >= 0 && w >= 0;
-            // data gradient of a stride-2 convolution: only even source offsets hit a real dy sample
-            ok = ok && !((h | w) & a.divmask);
-            h >>= a.divshift;
-            w >>= a.divshift;
-            ok = ok && h < a.H && w < a.W;
-            size_t off = ok ? (size_t)(ib[i] + h * a.W + w) * a.ldx + ci : (size_t)0;
-            ra[i] = *reinterpret_cast<const float4*>(a.x + off);
-            msk |= ok ? (1u << i) : 0u;
-        }
-        const size_t koff = kvalid ? (size_t)kt * BK : (size_t)0;
-#pragma unroll
-        for (int j = 0; j < PB; ++j) rb[j] = *reinterpret_cast<const float4*>(wrow[j] + koff);
-        okmask = msk;
+        int r = fdiv(g_tap, a.fS);
+        int s = g_tap - r * a.S;
+        g_dh = r * a.tapstep;
+        g_dw = s * a.tapstep;
+        g_delta = (g_dh * a.W + g_dw) * a.ldx + g_ci;
+        g_msk = g_kvalid ? 0x80000000u : 0u;
+        g_koff = g_kvalid ? (size_t)kt * BK : (size_t)0;
         if (ALIGNED) {
             ci0_c += BK;
             if (ci0_c >= a.Cp) {
@@ -214,6 +242,41 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
                 tap_c += 1;
             }
         }
+    };
+    auto gloadA = [&](int i) {
+        if (FAST) {
+            const bool ok = (tmask[i] >> g_tap) & 1u;
+            const int off = ok ? roff[i] + g_delta : 0;
+            ra[i] = *reinterpret_cast<const float4*>(a.x + off);
+            g_msk |= ok ? (1u << i) : 0u;
+        } else {
+            int h = hb[i] + g_dh, w = wb[i] + g_dw;
+            bool ok = g_kvalid && h >= 0 && w >= 0;
+            // data gradient of a stride-2 convolution: only even source offsets hit a real dy sample
+            ok = ok && !((h | w) & a.divmask);
+            h >>= a.divshift;
+            w >>= a.divshift;
+            ok = ok && h < a.H && w < a.W;
+            size_t off = ok ? (size_t)(ib[i] + h * a.W + w) * a.ldx + g_ci : (size_t)0;
+            ra[i] = *reinterpret_cast<const float4*>(a.x + off);
+            g_msk |= ok ? (1u << i) : 0u;
+        }
+    };
+    auto gloadB = [&](int j) { rb[j] = *reinterpret_cast<const float4*>(wrow[j] + g_koff); };
+    // quarter `part` (0..3) of the slice: PA/4 (or all in part < PA) A rows and likewise B rows
+    auto gissue = [&](int part) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            if ((PA >= 4 ? i * 4 / PA : i) == part) gloadA(i);
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+            if ((PB >= 4 ? j * 4 / PB : j) == part) gloadB(j);
+        if (part == 3) okmask = g_msk;
+    };
+    auto gload = [&](int kt) {
+        gprep(kt);
+#pragma unroll
+        for (int part = 0; part < 4; ++part) gissue(part);
     };
     auto lstore = [&]() {
 #pragma unroll
@@ -243,31 +306,48 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
 
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
-        if (more) gload(kt + 1);
+        if (more && !(DBG & 1)) gprep(kt + 1);
+        // fragments of k-group g+1 are read from LDS while the MFMAs of group g run (static double buffer)
+        float4 af[2][TM], bf[2][TN];
+        auto frag = [&](int g, int b) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[b][i] = (DBG & 4) ? make_float4(lane, kt, g, i)
+                                     : *reinterpret_cast<const float4*>(Ard + i * 32 * LDS_LD + g * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[b][j] = (DBG & 4) ? make_float4(g, lane, j, kt)
+                                     : *reinterpret_cast<const float4*>(Brd + j * 32 * LDS_LD + g * 8);
+        };
+        frag(0, 0);
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
-            float4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(Ard + i * 32 * LDS_LD + g * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(Brd + j * 32 * LDS_LD + g * 8);
+            const int b = g & 1;
+            if (g + 1 < BK / 8) frag(g + 1, b ^ 1);
+            if (more && !(DBG & 1)) gissue(g);     // a quarter of the next slice's global loads per MFMA group
+            if (DBG & 16) __builtin_amdgcn_sched_barrier(0);   // pinning the order measured 4-9 % slower
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[b][i].x, bf[b][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[b][i].y, bf[b][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[b][i].z, bf[b][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[b][i].w, bf[b][j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        __syncthreads();
-        if (more) {
+        if (!(DBG & 8)) __syncthreads();
+        if (more && !(DBG & 2)) {
             lstore();
             __syncthreads();
         }
     }
 
+    if ((DBG & 32) && threadIdx.x == 0 && (blockIdx.x % 97) == 0) {   // shader clocks vs 100 MHz wall ticks
+        long long* o = reinterpret_cast<long long*>(const_cast<float*>(a.bias)) + 2 * (blockIdx.x / 97);
+        o[0] = clock64() - dbg_c0;
+        o[1] = wall_clock64() - dbg_w0;
+    }
     // ---------------- epilogue ----------------
     // C/D map of the 32x32 MFMA: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int mrow0 = m0 + wm * (BM / 2) + 4 * lh;
@@ -602,11 +682,17 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     a.nwg = ntm * a.ntn;
     a.fNtn = make_fastdiv(a.ntn);
     const int vbase = (BM == 128 && BN == 128) ? 0 : (BM == 64 && BN == 128) ? 2 : (BM == 128 && BN == 64) ? 4 : 6;
-    ProfScope prof(vbase + (aligned ? 0 : 1), 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st);
-    if (aligned)
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, true>), dim3(a.nwg), dim3(256), 0, st, a);
+    ProfScope prof(vbase + (aligned ? 0 : 1), 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st, a.M, a.Ng,
+                   a.Ktot, a.nwg);
+    // MODE 2 needs <= 32 taps (bit mask), no stride division and 32-bit element offsets
+    const bool fast = aligned && a.taps <= 32 && a.divshift == 0 &&
+                      (long long)a.H * a.W * a.ldx * ((long long)a.M / (a.P * a.Q) + 1) < (1ll << 31);
+    if (fast)
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, 2>), dim3(a.nwg), dim3(256), 0, st, a);
+    else if (aligned)
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, 1>), dim3(a.nwg), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, false>), dim3(a.nwg), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, 0>), dim3(a.nwg), dim3(256), 0, st, a);
 }
 
 static void run_igemm(IgemmArgs& a, TileChoice t, hipStream_t st) {
@@ -650,11 +736,9 @@ extern "C" int up_pack_weights(const up_conv_desc* d, const float* w, float* w_f
     return check_launch("pack_weights");
 }
 
-extern "C" int up_conv2d_fwd(const up_conv_desc* d, const float* x, const float* w_fwd, float* y,
-                             const up_conv_epilogue* ep, void* stream) {
-    if (int e = check_desc(d)) return e;
-    UP_REQUIRE(x && w_fwd && y, UP_ERR_INVALID, "conv2d_fwd: null pointer");
-    IgemmArgs a;
+namespace up {
+static int fill_fwd_args(IgemmArgs& a, const up_conv_desc* d, const float* x, const float* w_fwd, float* y,
+                         const up_conv_epilogue* ep) {
     memset(&a, 0, sizeof(a));
     a.x = x;
     a.w = w_fwd;
@@ -672,6 +756,7 @@ extern "C" int up_conv2d_fwd(const up_conv_desc* d, const float* x, const float*
     a.ldx = d->ldx;
     a.ldy = d->ldy;
     a.S = d->S;
+    a.taps = d->R * d->S;
     a.mul = d->stride;
     a.off0 = -d->pad;
     a.tapstep = d->dil;
@@ -694,6 +779,16 @@ extern "C" int up_conv2d_fwd(const up_conv_desc* d, const float* x, const float*
         a.relu = ep->relu;
         a.stats = ep->stats;
     }
+    return UP_OK;
+}
+}  // namespace up
+
+extern "C" int up_conv2d_fwd(const up_conv_desc* d, const float* x, const float* w_fwd, float* y,
+                             const up_conv_epilogue* ep, void* stream) {
+    if (int e = check_desc(d)) return e;
+    UP_REQUIRE(x && w_fwd && y, UP_ERR_INVALID, "conv2d_fwd: null pointer");
+    IgemmArgs a;
+    if (int e = fill_fwd_args(a, d, x, w_fwd, y, ep)) return e;
     run_igemm(a, choose_tile(a.M, a.Ng), as_stream(stream));
     return check_launch("conv2d_fwd");
 }
@@ -723,6 +818,7 @@ extern "C" int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const 
     a.ldx = d->ldy;
     a.ldy = d->ldx;
     a.S = d->S;
+    a.taps = d->R * d->S;
     a.mul = 1;
     a.off0 = d->pad;
     a.tapstep = -d->dil;
@@ -808,7 +904,8 @@ extern "C" int up_conv2d_bwd_weight(const up_conv_desc* d, const float* x, const
     dim3 grid(p.ntm * p.ntn, p.splits);
     {
         const int v = (p.bm == 128 && p.bn == 128) ? 8 : (p.bm == 128 && p.bn == 64) ? 9 : (p.bm == 64 && p.bn == 128) ? 10 : 11;
-        ProfScope prof(v, 2.0 * (double)a.M * (double)d->K * (double)d->R * d->S * d->C, st);
+        ProfScope prof(v, 2.0 * (double)a.M * (double)d->K * (double)d->R * d->S * d->C, st, d->K, a.Ncols, a.M,
+                       (int)(grid.x * grid.y));
         if (p.bm == 128 && p.bn == 128)
             hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, st, a);
         else if (p.bm == 128 && p.bn == 64)
@@ -845,6 +942,11 @@ extern "C" int up_profile_end(double* out /* [variants][3] = launches, ms, flops
     for (int i = 0; i < variants * 3; ++i) out[i] = 0.0;
 #ifndef UP_EMU
     g_prof_on = false;
+    FILE* csv = nullptr;
+    if (const char* path = getenv("UP_PROFILE_CSV")) {   // optional per-launch dump for offline analysis
+        csv = fopen(path, "w");
+        if (csv) fprintf(csv, "kernel,M,N,K,workgroups,ms,tflops\n");
+    }
     for (auto& r : g_prof) {
         float ms = 0.f;
         (void)hipEventSynchronize(r.b);
@@ -852,10 +954,14 @@ extern "C" int up_profile_end(double* out /* [variants][3] = launches, ms, flops
         out[r.variant * 3 + 0] += 1.0;
         out[r.variant * 3 + 1] += ms;
         out[r.variant * 3 + 2] += r.flops;
+        if (csv)
+            fprintf(csv, "\"%s\",%d,%d,%d,%d,%.5f,%.2f\n", kVariantNames[r.variant], r.M, r.N, r.K, r.grid, ms,
+                    r.flops / ms / 1e9);
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
     }
     g_prof.clear();
+    if (csv) fclose(csv);
 #endif
     return UP_OK;
 }
