@@ -201,6 +201,8 @@ inline T shfl(T v, int src) {
 #define hipLaunchKernelGGL(k, g, b, sh, strm, ...) ::emu::launch((g), (b), [&]() { k(__VA_ARGS__); })
 
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline long long clock64() { return 0; }
+static inline long long wall_clock64() { return 0; }
 static inline void __syncthreads() { ::emu::bar_wait(::emu::st().block_bar, ::emu::st().live); }
 static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 template <class T>
