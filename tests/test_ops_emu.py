@@ -16,6 +16,7 @@ import op_cases as oc
     (1, 3, 20, 18, 8, 7, 2, 3, 1, False, False),      # stem 7x7 s2, Cin=3 (K6, unaligned K slices)
     (1, 15, 6, 6, 14, 3, 1, 1, 1, True, True),        # LSTM-like: odd channels, bias, relu
     (1, 15, 12, 12, 8, 11, 1, 5, 1, True, True),      # 11x11 (K17)
+    (2, 32, 5, 5, 14, 1, 1, 0, 1, True, False),       # K=14: data gradient with a ragged (16 < 32) K slice
 ])
 def test_conv_fwd_bwd(emu_backend, cfg):
     n, c, h, w, k, r, s, p, d, bias, relu = cfg

@@ -199,7 +199,9 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
         int n = n0 + j * 32 + lrow;
-        wrow[j] = a.w + (size_t)(n < a.Ng ? n : a.Ng - 1) * a.Ktot + kq * 4;   // rows >= Ng: never stored
+        // rows >= Ng are never stored: clamp.  The kq*4 column offset is folded in only when every K slice is
+        // full (ALIGNED); the generic path adds it per slice so that a ragged last slice stays inside the row.
+        wrow[j] = a.w + (size_t)(n < a.Ng ? n : a.Ng - 1) * a.Ktot + (ALIGNED ? kq * 4 : 0);
     }
 
     float4 ra[PA], rb[PB];
@@ -234,7 +236,7 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
         g_dw = s * a.tapstep;
         g_delta = (g_dh * a.W + g_dw) * a.ldx + g_ci;
         g_msk = g_kvalid ? 0x80000000u : 0u;
-        g_koff = g_kvalid ? (size_t)kt * BK : (size_t)0;
+        g_koff = ALIGNED ? (size_t)kt * BK : (g_kvalid ? (size_t)(kt * BK + kq * 4) : (size_t)0);
         if (ALIGNED) {
             ci0_c += BK;
             if (ci0_c >= a.Cp) {

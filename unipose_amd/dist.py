@@ -65,6 +65,9 @@ class GradAllReducer:
     def _hook(self, p):
         bi, pi = self._where[p]
         b = self.buckets[bi]
+        if p.grad.is_cuda:
+            from . import ops
+            ops.wgrad_fence(p.grad.device)      # weight gradients are produced on a side stream
         b.views[pi].copy_(p.grad)
         b.pending -= 1
         if b.pending == 0:
@@ -76,6 +79,9 @@ class GradAllReducer:
             return
         if self.buckets is None:
             grads = [p.grad for p in self.params if p.grad is not None]
+            if grads and grads[0].is_cuda:
+                from . import ops
+                ops.wgrad_fence(grads[0].device)
             flat = torch.cat([g.reshape(-1) for g in grads])
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             flat.div_(self.world)

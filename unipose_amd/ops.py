@@ -58,9 +58,9 @@ def _dense(t: torch.Tensor) -> torch.Tensor:
 _WS = {}
 
 
-def workspace(dev: torch.device, nbytes: int) -> torch.Tensor:
-    """Stream-ordered scratch (split-K slabs, BN-backward partials); grows monotonically per device."""
-    key = (dev.type, dev.index)
+def workspace(dev: torch.device, nbytes: int, tag: str = "main") -> torch.Tensor:
+    """Stream-ordered scratch (split-K slabs, BN-backward partials); grows monotonically per (device, stream tag)."""
+    key = (dev.type, dev.index, tag)
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev)
@@ -100,29 +100,33 @@ def make_desc(x: torch.Tensor, weight: torch.Tensor, cfg: ConvCfg, ldy: Optional
 _PACK_CACHE = {}
 
 
-def packed_fwd(weight: torch.Tensor, d: _C.ConvDesc) -> torch.Tensor:
-    """[K][R*S][Cp] image of an OIHW parameter; re-made only when the parameter object changed
-    (identity via weakref + in-place version counter, so optimizer steps and load_state_dict repack)."""
+def _packed(weight: torch.Tensor, d: _C.ConvDesc):
+    """(forward image [K][R*S][Cp], data-gradient image [C][R*S][Kp]) of an OIHW parameter, made by ONE
+    up_pack_weights call and cached per parameter object + in-place version counter (optimizer steps and
+    load_state_dict bump the version, so stale images are never used)."""
     key = id(weight)
     hit = _PACK_CACHE.get(key)
-    n = d.K * d.R * d.S * d.Cp
-    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2].numel() == n:
-        return hit[2]
-    out = torch.empty(n, dtype=torch.float32, device=weight.device)
-    _C.check(_C.lib().up_pack_weights(C.byref(d), _dense(weight).data_ptr(), out.data_ptr(), None, _stream(weight)),
-             "pack_weights")
+    nf, nd = d.K * d.R * d.S * d.Cp, d.C * d.R * d.S * d.Kp
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2].numel() == nf and \
+            hit[3].numel() == nd:
+        return hit[2], hit[3]
+    wf = torch.empty(nf, dtype=torch.float32, device=weight.device)
+    wd = torch.empty(nd, dtype=torch.float32, device=weight.device)
+    _C.check(_C.lib().up_pack_weights(C.byref(d), _dense(weight).data_ptr(), wf.data_ptr(), wd.data_ptr(),
+                                      _stream(weight)), "pack_weights")
     if len(_PACK_CACHE) > 4096:
         _PACK_CACHE.clear()
     if weight.is_leaf:
-        _PACK_CACHE[key] = (weakref.ref(weight), weight._version, out)
-    return out
+        _PACK_CACHE[key] = (weakref.ref(weight), weight._version, wf, wd)
+    return wf, wd
+
+
+def packed_fwd(weight: torch.Tensor, d: _C.ConvDesc) -> torch.Tensor:
+    return _packed(weight, d)[0]
 
 
 def packed_dgrad(weight: torch.Tensor, d: _C.ConvDesc) -> torch.Tensor:
-    out = torch.empty(d.C * d.R * d.S * d.Kp, dtype=torch.float32, device=weight.device)
-    _C.check(_C.lib().up_pack_weights(C.byref(d), _dense(weight).data_ptr(), None, out.data_ptr(), _stream(weight)),
-             "pack_weights")
-    return out
+    return _packed(weight, d)[1]
 
 
 def conv_fwd_raw(x, weight, cfg, *, scale=None, shift=None, bias=None, residual=None, relu=False, stats=False,
@@ -162,16 +166,77 @@ def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev):
     return dx
 
 
-def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool):
+def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws_tag: str = "main"):
     dd = _C.ConvDesc.from_buffer_copy(d)
     dd.ldx = _nhwc_ok(x)
     dd.ldy = _nhwc_ok(dy)
     need = _C.lib().up_conv2d_bwd_weight_workspace(C.byref(dd))
-    ws = workspace(x.device, need)
+    ws = workspace(x.device, need, ws_tag)
     dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)
     db = torch.empty(weight_shape[0], dtype=torch.float32, device=x.device) if want_bias else None
     _C.check(_C.lib().up_conv2d_bwd_weight(C.byref(dd), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db),
                                            ws.data_ptr(), ws.numel(), _stream(x)), "conv2d_bwd_weight")
+    return dw, db
+
+
+# ---- weight gradients on a side stream ------------------------------------------------------------
+# dW of a layer has no consumer until the optimizer (or the gradient all-reduce) runs, while dX is on the
+# critical path of backward.  The wgrad kernels therefore go to a second HIP stream: their workgroups fill
+# the CUs left idle by the tail of the data-gradient kernels and overlap the HBM-bound BatchNorm-backward
+# passes of the following layers.  Ordering: side waits for main before each launch (dy, x ready); main
+# waits for side (a) at the end of the backward pass (engine callback), (b) before a weight that was already
+# seen in this pass returns a second gradient (autograd will ADD the two on the main stream), (c) whenever
+# `wgrad_fence()` is called (the data-parallel reducer does before it reads a gradient).
+ASYNC_WGRAD = True
+_SIDE = {}
+_PASS = {"seen": set(), "cb": False}
+
+
+def _side_stream(dev):
+    st = _SIDE.get(dev.index)
+    if st is None:
+        st = torch.cuda.Stream(device=dev)
+        _SIDE[dev.index] = st
+    return st
+
+
+def wgrad_fence(dev=None):
+    """Make the current stream wait for every weight gradient issued so far."""
+    for idx, st in _SIDE.items():
+        if dev is None or dev.index == idx:
+            torch.cuda.current_stream(st.device).wait_stream(st)
+
+
+def _end_of_backward():
+    wgrad_fence()
+    _PASS["seen"].clear()
+    _PASS["cb"] = False
+
+
+def conv_bwd_weight(x, dy, weight, d, want_bias):
+    if not (ASYNC_WGRAD and dy.is_cuda and weight.is_leaf):
+        # non-leaf weights (the stacked ConvLSTM gate weights) feed torch ops on the main stream right away
+        return conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias)
+    dev = dy.device
+    main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+    if not _PASS["cb"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+            _PASS["cb"] = True
+        except RuntimeError:          # not inside an autograd backward pass: stay synchronous
+            return conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        dw, db = conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias, ws_tag="side")
+    for t in (x, dy):
+        t.record_stream(side)
+    for t in (dw, db):
+        if t is not None:
+            t.record_stream(main)
+    key = id(weight)
+    if key in _PASS["seen"] or weight.grad is not None:
+        main.wait_stream(side)        # autograd is about to accumulate into an earlier, possibly in-flight dW
+    _PASS["seen"].add(key)
     return dw, db
 
 
@@ -209,7 +274,7 @@ class ConvBias(Function):
                      "relu_bwd")
             dy = g
         dx = conv_bwd_data_raw(dy, weight, ctx.d, x.shape, x.device) if ctx.needs_input_grad[0] else None
-        dw, db = conv_bwd_weight_raw(x, dy, weight.shape, ctx.d, ctx.has_bias)
+        dw, db = conv_bwd_weight(x, dy, weight, ctx.d, ctx.has_bias)
         return dx, dw, db, None, None
 
 
@@ -272,7 +337,7 @@ class ConvBnAct(Function):
                              d.ldy, _ptr(dres), d.ldy, dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(),
                              ws.numel(), rows, k, _stream(x)), "bn_bwd")
         dx = conv_bwd_data_raw(dy, weight, d, x.shape, x.device) if ctx.needs_input_grad[0] else None
-        dw, _ = conv_bwd_weight_raw(x, dy, weight.shape, d, False)
+        dw, _ = conv_bwd_weight(x, dy, weight, d, False)
         return dx, dw, dgb[0], dgb[1], dres, None, None, None, None, None, None, None
 
 
