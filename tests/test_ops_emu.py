@@ -17,6 +17,8 @@ import op_cases as oc
     (1, 15, 6, 6, 14, 3, 1, 1, 1, True, True),        # LSTM-like: odd channels, bias, relu
     (1, 15, 12, 12, 8, 11, 1, 5, 1, True, True),      # 11x11 (K17)
     (2, 32, 5, 5, 14, 1, 1, 0, 1, True, False),       # K=14: data gradient with a ragged (16 < 32) K slice
+    (1, 128, 5, 5, 32, 3, 1, 1, 1, False, False),     # reduction 1152 >= 1024: double-buffered LDS loop
+    (1, 128, 6, 6, 128, 3, 2, 1, 1, False, False),    # same for the strided data gradient (MODE 1)
 ])
 def test_conv_fwd_bwd(emu_backend, cfg):
     n, c, h, w, k, r, s, p, d, bias, relu = cfg

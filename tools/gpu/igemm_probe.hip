@@ -8,7 +8,7 @@
 
 using namespace up;
 
-template <int BM, int BN, int DBG>
+template <int BM, int BN, int DBG, int KT = 32>
 static float run(IgemmArgs a, int iters) {
     a.ntn = cdiv(a.Ng, BN);
     a.nwg = cdiv(a.M, BM) * a.ntn;
@@ -16,9 +16,9 @@ static float run(IgemmArgs a, int iters) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, DBG>), dim3(a.nwg), dim3(256), 0, 0, a);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, DBG, KT>), dim3(a.nwg), dim3(256), 0, 0, a);
     hipEventRecord(e0, 0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, DBG>), dim3(a.nwg), dim3(256), 0, 0, a);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, DBG, KT>), dim3(a.nwg), dim3(256), 0, 0, a);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms;
@@ -46,7 +46,9 @@ static void sweep(const char* name, up_conv_desc d) {
     t[2] = run<BM, BN, 3>(a, 20);
     t[3] = run<BM, BN, 7>(a, 20);
     t[4] = run<BM, BN, 15>(a, 20);
-    t[5] = run<BM, BN, 16>(a, 20);
+    t[3] = run<BM, BN, 64>(a, 20);
+    t[4] = run<BM, BN, 64, 64>(a, 20);
+    t[5] = run<BM, BN, 0, 64>(a, 20);
     {   // effective shader clock while the kernel runs: full vs no-gload
         long long* dbg;
         hipMalloc(&dbg, 1 << 16);
@@ -76,7 +78,7 @@ static void sweep(const char* name, up_conv_desc d) {
         }
         hipFree(dbg);
     }
-    const char* lab[6] = {"full", "no-gload", "no-gload,no-lstore", "+no-lds-read", "+no-barrier(MFMA only)", "full, pinned interleave"};
+    const char* lab[6] = {"full", "no-gload", "no-gload,no-lstore", "double-buffered LDS (K32)", "double-buffered LDS (K64)", "full, K slice 64"};
     printf("%s  tile %dx%d  M=%d N=%d K=%d  WGs=%d\n", name, BM, BN, a.M, a.Ng, a.Ktot, cdiv(a.M, BM) * cdiv(a.Ng, BN));
     for (int i = 0; i < 6; ++i) printf("   %-28s %8.4f ms  %7.1f TFLOP/s\n", lab[i], t[i], fl / t[i] / 1e9);
     hipFree(x);

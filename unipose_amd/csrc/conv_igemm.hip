@@ -75,8 +75,7 @@ struct ProfScope {
 };
 #endif
 
-constexpr int BK = 32;
-constexpr int LDS_LD = 36;   // 32 + 4 pad dwords: 36/4 = 9 is odd -> conflict-free ds_read_b128
+constexpr int BK = 32;   // K slice of the weight-gradient kernel (the conv/dgrad kernel takes it as a template parameter)
 
 struct IgemmArgs {
     const float* x;
@@ -138,12 +137,20 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 // MODE 1: aligned (Cp % 32 == 0), per-slice bounds arithmetic (strided data gradient, > 32 taps)
 // MODE 2: aligned + precomputed per-row offset and per-row tap-validity bit mask: one add + one bit test
 //         per gathered row and K slice (the address arithmetic of MODE 1 was ~20 % of the kernel time)
-template <int BM, int BN, int MODE, int DBG = 0>
+template <int BM, int BN, int MODE, int DBG = 0, int KT = 32>
 __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_kernel(IgemmArgs a) {
     constexpr bool ALIGNED = MODE >= 1, FAST = MODE == 2;
     constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave along m / n
-    constexpr int PA = BM / 32, PB = BN / 32;   // staging passes: 32 rows x 8 float4 per pass
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_LD];
+    constexpr int Q4 = KT / 4;                   // float4 per K slice row
+    constexpr int RPP = 256 / Q4;                // rows staged per pass (32 at KT=32, 16 at KT=64)
+    constexpr int PA = BM / RPP, PB = BN / RPP;  // staging passes
+    constexpr int LDS_LD = KT + 4;               // (KT+4)/4 odd -> conflict-free ds_read_b128
+    constexpr int BK = KT;
+    static_assert(PA <= 8 && PB <= 8, "okmask holds 8 row bits");
+    constexpr bool DB = (DBG & 64) == 0;         // two LDS buffers, ONE barrier per slice, refill interleaved
+                                                 // (probe bit 6 selects the older single-buffer loop)
+    constexpr int BUF = (BM + BN) * LDS_LD;
+    __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * BUF];
     float* As = smem;
     float* Bs = smem + BM * LDS_LD;
 
@@ -162,8 +169,8 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     const int nt = logical - mt * a.ntn;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    const int lrow = tid >> 3;  // 0..31
-    const int kq = tid & 7;     // which float4 of the 32-wide k slice
+    const int lrow = tid / Q4;  // row within a staging pass
+    const int kq = tid % Q4;    // which float4 of the K slice
 
     // per-thread gather bases for its PA rows.  Rows beyond M only need a SAFE address (their results
     // are never stored); taps that fall into the zero padding are zeroed by a select at LDS-store time.
@@ -172,7 +179,7 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     unsigned tmask[PA];              // MODE 2: bit t set <=> tap t of this row reads a real pixel
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        int m = m0 + i * 32 + lrow;
+        int m = m0 + i * RPP + lrow;
         int mm = m < a.M ? m : a.M - 1;
         int img = fdiv(mm, a.fPQ);
         int rem = mm - img * (a.P * a.Q);
@@ -198,7 +205,7 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     const float* wrow[PB];
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
-        int n = n0 + j * 32 + lrow;
+        int n = n0 + j * RPP + lrow;
         // rows >= Ng are never stored: clamp.  The kq*4 column offset is folded in only when every K slice is
         // full (ALIGNED); the generic path adds it per slice so that a ragged last slice stays inside the row.
         wrow[j] = a.w + (size_t)(n < a.Ng ? n : a.Ng - 1) * a.Ktot + (ALIGNED ? kq * 4 : 0);
@@ -280,13 +287,14 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
 #pragma unroll
         for (int part = 0; part < 4; ++part) gissue(part);
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int buf = 0) {
 #pragma unroll
         for (int i = 0; i < PA; ++i)
-            *reinterpret_cast<float4*>(&As[(i * 32 + lrow) * LDS_LD + kq * 4]) = keep_or_zero((okmask >> i) & 1u, ra[i]);
+            *reinterpret_cast<float4*>(&As[buf * BUF + (i * RPP + lrow) * LDS_LD + kq * 4]) =
+                keep_or_zero((okmask >> i) & 1u, ra[i]);
 #pragma unroll
         for (int j = 0; j < PB; ++j)
-            *reinterpret_cast<float4*>(&Bs[(j * 32 + lrow) * LDS_LD + kq * 4]) =
+            *reinterpret_cast<float4*>(&Bs[buf * BUF + (j * RPP + lrow) * LDS_LD + kq * 4]) =
                 ALIGNED ? rb[j] : keep_or_zero(okmask >> 31, rb[j]);
     };
 
@@ -306,6 +314,52 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     const float* Ard = As + (wm * (BM / 2) + l31) * LDS_LD + lh * 4;
     const float* Brd = Bs + (wn * (BN / 2) + l31) * LDS_LD + lh * 4;
 
+    auto mfma_group = [&](const float4(&af)[TM], const float4(&bf)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+            }
+    };
+    constexpr int G = BK / 8;   // MFMA groups (8 k each) per slice
+
+    if (DB) {
+        // slice kt is in LDS buffer kt&1; slice kt+1 sits in the staging registers (loaded during slice kt-1)
+        // and is written to the OTHER buffer in the middle of this slice's MFMAs; the registers are then
+        // refilled with slice kt+2.  One barrier per slice, nothing between the MFMAs but LDS/VMEM issue.
+        if (nk > 1) gload(1);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
+            float4 af[2][TM], bf[2][TN];
+            auto frag = [&](int g, int b) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[b][i] = *reinterpret_cast<const float4*>(Ard + cur * BUF + i * 32 * LDS_LD + g * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bf[b][j] = *reinterpret_cast<const float4*>(Brd + cur * BUF + j * 32 * LDS_LD + g * 8);
+            };
+            frag(0, 0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int b = g & 1;
+                if (g + 1 < G) frag(g + 1, b ^ 1);
+                if (g == G / 2 - 1 && has1) lstore(cur ^ 1);
+                if (g >= G / 2 && has2) {
+                    if (g == G / 2) gprep(kt + 2);
+#pragma unroll
+                    for (int q = 0; q < 8 / G; ++q) gissue((g - G / 2) * (8 / G) + q);
+                }
+                mfma_group(af[b], bf[b]);
+            }
+            __syncthreads();
+        }
+    } else {
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
         if (more && !(DBG & 1)) gprep(kt + 1);
@@ -323,26 +377,19 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
         };
         frag(0, 0);
 #pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
+        for (int g = 0; g < G; ++g) {
             const int b = g & 1;
-            if (g + 1 < BK / 8) frag(g + 1, b ^ 1);
-            if (more && !(DBG & 1)) gissue(g);     // a quarter of the next slice's global loads per MFMA group
+            if (g + 1 < G) frag(g + 1, b ^ 1);
+            if (more && !(DBG & 1) && g % (BK / 32) == 0) gissue(g / (BK / 32));   // a quarter of the next slice's loads
             if (DBG & 16) __builtin_amdgcn_sched_barrier(0);   // pinning the order measured 4-9 % slower
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[b][i].x, bf[b][j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[b][i].y, bf[b][j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[b][i].z, bf[b][j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[b][i].w, bf[b][j].w, acc[i][j], 0, 0, 0);
-                }
+            mfma_group(af[b], bf[b]);
         }
         if (!(DBG & 8)) __syncthreads();
         if (more && !(DBG & 2)) {
             lstore();
             __syncthreads();
         }
+    }
     }
 
     if ((DBG & 32) && threadIdx.x == 0 && (blockIdx.x % 97) == 0) {   // shader clocks vs 100 MHz wall ticks
@@ -689,12 +736,17 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     // MODE 2 needs <= 32 taps (bit mask), no stride division and 32-bit element offsets
     const bool fast = aligned && a.taps <= 32 && a.divshift == 0 &&
                       (long long)a.H * a.W * a.ldx * ((long long)a.M / (a.P * a.Q) + 1) < (1ll << 31);
-    if (fast)
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, 2>), dim3(a.nwg), dim3(256), 0, st, a);
+    // double-buffered LDS (one barrier per slice) pays for long reductions; short ones (1x1 convs with few input
+    // channels) are epilogue-bound and prefer the smaller footprint / higher occupancy of the single-buffer loop
+    const bool db = a.Ktot >= 1024;
+    if (fast && db)
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, 0>), dim3(a.nwg), dim3(256), 0, st, a);
+    else if (fast)
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, 64>), dim3(a.nwg), dim3(256), 0, st, a);
     else if (aligned)
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, 1>), dim3(a.nwg), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, 1, 64>), dim3(a.nwg), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, 0>), dim3(a.nwg), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, 0, 64>), dim3(a.nwg), dim3(256), 0, st, a);
 }
 
 static void run_igemm(IgemmArgs& a, TileChoice t, hipStream_t st) {
