@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--num-classes", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch hipEvent timing")
+    ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "bf16"],
+                    help="arithmetic of the forward/data-gradient convolutions: exact fp32 MFMA (default, the parity "
+                         "configuration), split-bf16 fp32-equivalent, or plain bf16 operands")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=min(os.cpu_count() or 1, 64),
@@ -106,6 +109,7 @@ def main():
     x = torch.randn(B, 3, S, S, generator=g).to(dev)
     t = torch.rand(B, K + 1, S // 8, S // 8, generator=g).to(dev)
     ops.manual_seed(shard_seed(0, rank))
+    ops.set_conv_math(args.math)
     reducer = GradAllReducer(model) if world > 1 else None
 
     def step():
@@ -176,11 +180,16 @@ def main():
             "metric": "images/sec fwd+bwd, UniPose ResNet-101 368x368",
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": {"f32": "f32", "bf16x3": "f32 (split-bf16 MFMA, fp32-equivalent)", "bf16": "bf16"}[args.math],
+            "data": "synthetic",
             "config": {"workload": f"UniPose ResNet-101 (K={K}) train step: fwd + MSE + bwd + Adam, synthetic "
                                    f"{S}x{S}, batch {B}/GPU (BASELINE.json configs[1]; configs[2] for N>1)",
                        "global_batch": world * B, "per_gpu_batch": B, "input": [3, S, S],
-                       "parallelism": f"dp{world}", "optimizer": "Adam(lr=1e-4)", "arithmetic": "fp32 MFMA 32x32x2"},
+                       "parallelism": f"dp{world}", "optimizer": "Adam(lr=1e-4)",
+                       "arithmetic": {"f32": "fp32 MFMA 32x32x2 everywhere",
+                                      "bf16x3": "fwd/dgrad: 3x bf16 MFMA 32x32x16 on (hi,lo) split operands; wgrad: fp32 MFMA",
+                                      "bf16": "fwd/dgrad: bf16 MFMA 32x32x16; wgrad: fp32 MFMA"}[args.math]},
             "step_tflops_per_gpu": round(ips / world * FLOP_PER_IMAGE_FWD_BWD * (S / 368.0) ** 2 / 1e12, 2),
             "loss": loss_val,
         }

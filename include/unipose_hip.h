@@ -82,6 +82,20 @@ int up_conv_stats_tiles(const up_conv_desc* d);   /* row tiles the forward kerne
  * Writes all Cp channels of every input pixel (pad channels get 0). */
 int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const float* w_dgrad, float* dx, void* stream);
 
+/* bf16-operand variants of the forward / data-gradient convolution (v_mfma_f32_32x32x16_bf16, fp32 accumulate,
+ * fp32 activations in HBM).  math = UP_MATH_BF16X3: every operand is carried as hi = bf16(x), lo = bf16(x - hi)
+ * and a*b ~= ah*bh + ah*bl + al*bh (fp32-equivalent, relative error 2^-16 per product);  UP_MATH_BF16: plain bf16
+ * operands (BASELINE config 5 arithmetic).  Weights come as bf16 planes made by up_pack_weights_bf16 in the
+ * [rows][R*S][padded channels] order of up_pack_weights.  Requires the padded reduction channel count (Cp forward,
+ * Kp backward) to be a multiple of 64; otherwise UP_ERR_UNSUPPORTED (use the fp32 entry points). */
+typedef enum { UP_MATH_F32 = 0, UP_MATH_BF16X3 = 1, UP_MATH_BF16 = 2 } up_math;
+int up_pack_weights_bf16(const up_conv_desc* d, const float* w_oihw, uint16_t* fwd_hi, uint16_t* fwd_lo,
+                         uint16_t* dgrad_hi, uint16_t* dgrad_lo, void* stream);
+int up_conv2d_fwd_bf16(const up_conv_desc* d, const float* x, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
+                       const up_conv_epilogue* ep, int math, void* stream);
+int up_conv2d_bwd_data_bf16(const up_conv_desc* d, const float* dy, const uint16_t* w_hi, const uint16_t* w_lo,
+                            float* dx, int math, void* stream);
+
 /* Weight gradient into PyTorch OIHW layout (replaces convolution_backward, weight half); `dbias`
  * (K floats) may be NULL.  Split-K partial slabs live in the caller-provided workspace. */
 size_t up_conv2d_bwd_weight_workspace(const up_conv_desc* d);

@@ -201,6 +201,7 @@ inline T shfl(T v, int src) {
 #define hipLaunchKernelGGL(k, g, b, sh, strm, ...) ::emu::launch((g), (b), [&]() { k(__VA_ARGS__); })
 
 static inline void __builtin_amdgcn_sched_barrier(int) {}
+static inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 static inline long long clock64() { return 0; }
 static inline long long wall_clock64() { return 0; }
 static inline void __syncthreads() { ::emu::bar_wait(::emu::st().block_bar, ::emu::st().live); }
@@ -223,6 +224,51 @@ static inline float atomicAdd(float* p, float v) {
         memcpy(&nw, &s, 4);
     } while (!__atomic_compare_exchange_n(ip, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
     return f;
+}
+// ---- bf16 (round-to-nearest-even like v_cvt_pk_bf16_f32) and v_mfma_f32_32x32x16_bf16 ----
+struct bf16x8 {
+    uint16_t v[8];
+};
+static inline uint16_t emu_f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float emu_bf2f(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+static inline uint32_t pack_bf16x2(float lo_elem, float hi_elem) {
+    return (uint32_t)emu_f2bf(lo_elem) | ((uint32_t)emu_f2bf(hi_elem) << 16);
+}
+static inline float __uint_as_float(uint32_t u) {
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// A: lane l holds A[i = l&31][k = 8*(l>>5) + e], B: lane l holds B[k = 8*(l>>5) + e][j = l&31], e = 0..7
+static inline f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c, int, int, int) {
+    static thread_local uint16_t xa[4][64][8], xb[4][64][8];
+    ::emu::Wave& w = ::emu::wave();
+    int l = ::emu::lane();
+    int wid = ::emu::st().cur->lin >> 6;
+    memcpy(xa[wid][l], a.v, 16);
+    memcpy(xb[wid][l], b.v, 16);
+    ::emu::bar_wait(w.bar, 64);
+    const int j = l & 31, hi = l >> 5;
+    for (int r = 0; r < 16; ++r) {
+        int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int h = 0; h < 2; ++h)
+            for (int e = 0; e < 8; ++e) acc = fmaf(emu_bf2f(xa[wid][h * 32 + i][e]), emu_bf2f(xb[wid][h * 32 + j][e]), acc);
+        c[r] = acc;
+    }
+    ::emu::bar_wait(w.bar, 64);
+    return c;
 }
 static inline f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, f32x16 c, int, int, int) {
     ::emu::Wave& w = ::emu::wave();

@@ -191,3 +191,28 @@ def test_full_size_step_properties():
     assert O.max_rel(parts.cpu(), y.cpu()) < 1e-6
     _, _, idx = ops.heatmap_argmax(y)
     assert torch.equal(idx.cpu().long(), y.cpu().reshape(B, K + 1, -1).argmax(2))
+
+
+@pytest.mark.parametrize("math,tol", [("bf16x3", 1e-3), ("bf16", 6e-2)])
+def test_eval_golden_bf16_operand_modes(golden_dir, math, tol):
+    """G1 again with the bf16-MFMA convolution kernels: split-bf16 must meet the fp32 bar (1e-3, bit-exact argmax);
+    plain bf16 gets its own tolerance (~2.5e-2) and only reports argmax agreement."""
+    from unipose_amd import ops
+    g = np.load(os.path.join(golden_dir, "g1_eval_368.npz"))
+    K, wseed, xseed = (int(v) for v in g["meta"])
+    m, _ = mc.build_image_model(K, wseed, DEV)
+    m.eval()
+    x = O.synth_input((2, 3, 368, 368), xseed).to(DEV)
+    ops.set_conv_math(math)
+    try:
+        with torch.no_grad():
+            y = m(x)
+    finally:
+        ops.set_conv_math("f32")
+    e = O.max_rel(y.cpu(), g["out"])
+    _, _, idx = ops.heatmap_argmax(y)
+    agree = float((idx.cpu().numpy() == g["argmax"]).mean())
+    print(f"math={math}: max_rel {e:.3e}, argmax agreement {agree:.3f}")
+    assert e < tol, e
+    if math == "bf16x3":
+        assert agree == 1.0

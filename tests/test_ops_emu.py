@@ -83,3 +83,24 @@ def test_lstm_gates(emu_backend):
 
 def test_argmax(emu_backend, golden_dir):
     oc.argmax_case(emu_backend, golden_dir)
+
+
+@pytest.mark.parametrize("math,tol", [("bf16x3", 2e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("cfg", [
+    (2, 64, 6, 5, 32, 1, 1, 0, 1),        # 1x1
+    (1, 64, 7, 7, 72, 3, 1, 1, 1),        # 3x3, ragged N tile
+    (1, 64, 7, 7, 64, 3, 1, 3, 3),        # dilated, taps in the padding
+    (2, 64, 9, 9, 64, 3, 2, 1, 1),        # stride 2 (data gradient through the parity gather, MODE 1)
+    (1, 128, 5, 5, 64, 1, 1, 0, 1),       # two K slices per tap
+])
+def test_conv_bf16_operand_kernels(emu_backend, cfg, math, tol):
+    """split-bf16 (fp32-equivalent) and plain bf16 MFMA kernels: forward + data gradient (weight gradient stays fp32)."""
+    from unipose_amd import ops
+    n, c, h, w, k, r, s, p, d = cfg
+    ops.set_conv_math(math)
+    try:
+        errs = oc.conv_case(emu_backend, n, c, h, w, k, r, s, p, d, tol=tol)
+    finally:
+        ops.set_conv_math("f32")
+    if math == "bf16":
+        assert errs["y"] > 1e-4       # the bf16 kernel really ran (an fp32 result would sit at 1e-6)

@@ -116,3 +116,32 @@ def test_argmax_full_size_properties():
     ref = flat.numpy().argmax(2)
     assert (idx.cpu().numpy() == ref).all()
     assert torch.equal(mx.cpu()[..., 0], flat.max(2).values)
+
+
+BF16_CONVS = [
+    (2, 1024, 23, 23, 256, 1, 1, 0, 1),
+    (2, 256, 23, 23, 1024, 1, 1, 0, 1),
+    (2, 256, 23, 23, 256, 3, 1, 1, 1),
+    (2, 512, 23, 23, 512, 3, 1, 4, 4),
+    (2, 256, 23, 23, 256, 3, 1, 18, 18),
+    (2, 128, 92, 92, 128, 3, 2, 1, 1),
+    (2, 256, 92, 92, 512, 1, 2, 0, 1),
+    (2, 64, 92, 92, 64, 3, 1, 1, 1),
+    (2, 320, 46, 46, 256, 3, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("math,tol", [("bf16x3", 2e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("cfg", BF16_CONVS, ids=lambda c: "c%d_%dx%d_k%d_r%d_s%d_d%d" % (c[1], c[2], c[3], c[4], c[5], c[6], c[8]))
+def test_conv_bf16_operand_kernels(cfg, math, tol):
+    from unipose_amd import ops
+    n, c, h, w, k, r, s, p, d = cfg
+    ops.set_conv_math(math)
+    try:
+        errs = oc.conv_case(DEV, n, c, h, w, k, r, s, p, d, tol=tol)
+    finally:
+        ops.set_conv_math("f32")
+    if math == "bf16":
+        assert errs["y"] > 1e-4
+    else:
+        assert errs["y"] < 5e-5, errs          # split-bf16 keeps ~16 mantissa bits per operand

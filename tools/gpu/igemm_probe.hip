@@ -13,6 +13,7 @@ static float run(IgemmArgs a, int iters) {
     a.ntn = cdiv(a.Ng, BN);
     a.nwg = cdiv(a.M, BM) * a.ntn;
     a.fNtn = make_fastdiv(a.ntn);
+    a.fSpt = make_fastdiv(a.Cp / 32);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -47,8 +48,8 @@ static void sweep(const char* name, up_conv_desc d) {
     t[3] = run<BM, BN, 7>(a, 20);
     t[4] = run<BM, BN, 15>(a, 20);
     t[3] = run<BM, BN, 64>(a, 20);
-    t[4] = run<BM, BN, 64, 64>(a, 20);
-    t[5] = run<BM, BN, 0, 64>(a, 20);
+    t[4] = run<BM, BN, 128>(a, 20);
+    t[5] = run<BM, BN, 0>(a, 20);
     {   // effective shader clock while the kernel runs: full vs no-gload
         long long* dbg;
         hipMalloc(&dbg, 1 << 16);
@@ -78,7 +79,7 @@ static void sweep(const char* name, up_conv_desc d) {
         }
         hipFree(dbg);
     }
-    const char* lab[6] = {"full", "no-gload", "no-gload,no-lstore", "double-buffered LDS (K32)", "double-buffered LDS (K64)", "full, K slice 64"};
+    const char* lab[6] = {"full", "no-gload", "no-gload,no-lstore", "single-buffer loop", "DB + pinned interleave", "full again (order check)"};
     printf("%s  tile %dx%d  M=%d N=%d K=%d  WGs=%d\n", name, BM, BN, a.M, a.Ng, a.Ktot, cdiv(a.M, BM) * cdiv(a.Ng, BN));
     for (int i = 0; i < 6; ++i) printf("   %-28s %8.4f ms  %7.1f TFLOP/s\n", lab[i], t[i], fl / t[i] / 1e9);
     hipFree(x);

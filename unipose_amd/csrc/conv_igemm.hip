@@ -31,12 +31,14 @@ namespace up {
 // up_profile_begin() arms it; every igemm/wgrad launch is then bracketed by two hipEvents on the
 // launch stream; up_profile_end() synchronises and returns, per kernel variant, {launches, total ms,
 // total algorithmic flops}.  Off by default: no events, no overhead.
-constexpr int PROF_VARIANTS = 12;
+constexpr int PROF_VARIANTS = 16;
 static const char* const kVariantNames[PROF_VARIANTS] = {
     "igemm_kernel<128,128,aligned>", "igemm_kernel<128,128,generic>", "igemm_kernel<64,128,aligned>",
     "igemm_kernel<64,128,generic>",  "igemm_kernel<128,64,aligned>",  "igemm_kernel<128,64,generic>",
     "igemm_kernel<64,64,aligned>",   "igemm_kernel<64,64,generic>",   "wgrad_kernel<128,128>",
-    "wgrad_kernel<128,64>",          "wgrad_kernel<64,128>",          "wgrad_kernel<64,64>"};
+    "wgrad_kernel<128,64>",          "wgrad_kernel<64,128>",          "wgrad_kernel<64,64>",
+    "igemm_bf16_kernel<128,128>",    "igemm_bf16_kernel<64,128>",     "igemm_bf16_kernel<128,64>",
+    "igemm_bf16_kernel<64,64>"};
 #ifndef UP_EMU
 struct ProfRec {
     hipEvent_t a, b;
@@ -80,6 +82,8 @@ constexpr int BK = 32;   // K slice of the weight-gradient kernel (the conv/dgra
 struct IgemmArgs {
     const float* x;
     const float* w;
+    const uint16_t* w_hi;   // bf16-operand kernels: packed weights as bf16 planes (hi, and lo = bf16(w - hi))
+    const uint16_t* w_lo;
     float* y;
     int M, Ng, Ktot, Cp, Creal;
     long long Ktot_real;  // taps * real channels: the algorithmic reduction length (profiling only)
@@ -90,7 +94,7 @@ struct IgemmArgs {
     int divshift, divmask;        // 0,0 (forward, stride-1 dgrad) or 1,1 (dgrad of a stride-2 conv)
     int ntn;                      // number of n tiles
     int nwg;
-    FastDiv fPQ, fQ, fCp, fS, fNtn;
+    FastDiv fPQ, fQ, fCp, fS, fNtn, fSpt;   // fSpt: K slices per filter tap (aligned kernels)
     const float* scale;
     const float* shift;
     const float* bias;
@@ -133,6 +137,106 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 // the loop, bit 1: no LDS refill + its barrier, bit 2: fragments from registers instead of LDS, bit 3: no
 // barrier at all, bit 4: pin the load/MFMA interleave, bit 5: sample shader clocks) to attribute the
 // MFMA-pipe idle time.
+// Shared epilogue of the fp32 and bf16-operand kernels.  C/D map of the 32x32 MFMA (dtype independent):
+// column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  `smem` must be free (all waves past their last
+// LDS read) and hold >= 2*(BN/64)*32*3 floats.
+template <int BM, int BN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[BM / 64][BN / 64], float* smem,
+                                               int mt, int m0, int n0, int wm, int wn, int l31, int lh) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    const int mrow0 = m0 + wm * (BM / 2) + 4 * lh;
+    const int ncol0 = n0 + wn * (BN / 2) + l31;
+
+    if (a.stats) {
+        float sc[TN], sm[TN], s2[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float cnt = 0.f, sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (m < a.M) {
+                        cnt += 1.f;
+                        sum += acc[i][j][r];
+                    }
+                }
+            float mean = cnt > 0.f ? sum / cnt : 0.f;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (m < a.M) {
+                        float d = acc[i][j][r] - mean;
+                        q += d * d;
+                    }
+                }
+            float c2 = __shfl_xor(cnt, 32), m2 = __shfl_xor(mean, 32), q2 = __shfl_xor(q, 32);
+            if (lh) {  // both halves must merge in the same order to agree bitwise
+                float tc = c2, tm = m2, tq = q2;
+                wf_merge(tc, tm, tq, cnt, mean, q);
+                cnt = tc;
+                mean = tm;
+                q = tq;
+            } else {
+                wf_merge(cnt, mean, q, c2, m2, q2);
+            }
+            sc[j] = cnt;
+            sm[j] = mean;
+            s2[j] = q;
+        }
+        // smem is free: the K loop ended with a barrier after the last LDS read
+        if (wm == 1 && lh == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float* d = smem + ((wn * TN + j) * 32 + l31) * 3;
+                d[0] = sc[j];
+                d[1] = sm[j];
+                d[2] = s2[j];
+            }
+        }
+        __syncthreads();
+        if (wm == 0 && lh == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float* s = smem + ((wn * TN + j) * 32 + l31) * 3;
+                wf_merge(sc[j], sm[j], s2[j], s[0], s[1], s[2]);
+                int n = ncol0 + j * 32;
+                if (n < a.Ng) {
+                    float* o = a.stats + ((size_t)mt * a.Ng + n) * 3;
+                    o[0] = sc[j];
+                    o[1] = sm[j];
+                    o[2] = s2[j];
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = ncol0 + j * 32;
+        if (n >= a.Ng) continue;
+        const float sc = a.scale ? a.scale[n] : 1.f;
+        float sh = a.scale ? a.shift[n] : 0.f;
+        if (a.bias) sh += a.bias[n];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (m < a.M) {
+                    float v = acc[i][j][r] * sc + sh;
+                    if (a.residual) v += a.residual[(size_t)m * a.ldr + n];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    a.y[(size_t)m * a.ldy + n] = v;
+                }
+            }
+    }
+}
+
 // MODE 0: generic (K slices may straddle taps / ragged K: stem, 15-channel LSTM convolutions)
 // MODE 1: aligned (Cp % 32 == 0), per-slice bounds arithmetic (strided data gradient, > 32 taps)
 // MODE 2: aligned + precomputed per-row offset and per-row tap-validity bit mask: one add + one bit test
@@ -227,7 +331,10 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     unsigned g_msk = 0;
     auto gprep = [&](int kt) {
         g_kvalid = true;
-        if (ALIGNED) {
+        if (ALIGNED && (DBG & 128)) {        // stateless: slice index -> (tap, first channel)
+            g_tap = fdiv(kt, a.fSpt);
+            g_ci = (kt - g_tap * (int)a.fSpt.d) * BK + kq * 4;
+        } else if (ALIGNED) {
             g_tap = tap_c;
             g_ci = ci0_c + kq * 4;
         } else {
@@ -332,6 +439,46 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
         // and is written to the OTHER buffer in the middle of this slice's MFMAs; the registers are then
         // refilled with slice kt+2.  One barrier per slice, nothing between the MFMAs but LDS/VMEM issue.
         if (nk > 1) gload(1);
+        if (DBG & 128) {
+            // Branch-free body: the refill always runs (slice indices are clamped to the last slice, whose
+            // reload is harmless), so the whole iteration is ONE scheduling region and the non-MFMA work can be
+            // pinned between the MFMAs with sched_group_barrier instead of piling up between 16-MFMA clusters.
+            if (nk == 1) gload(0);
+            for (int kt = 0; kt < nk; ++kt) {
+                const int cur = kt & 1;
+                const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;
+                float4 af[2][TM], bf[2][TN];
+                auto frag = [&](int g, int b) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        af[b][i] = *reinterpret_cast<const float4*>(Ard + cur * BUF + i * 32 * LDS_LD + g * 8);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        bf[b][j] = *reinterpret_cast<const float4*>(Brd + cur * BUF + j * 32 * LDS_LD + g * 8);
+                };
+                frag(0, 0);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int b = g & 1;
+                    if (g + 1 < G) frag(g + 1, b ^ 1);
+                    if (g == G / 2 - 1) lstore(cur ^ 1);
+                    if (g >= G / 2) {
+                        if (g == G / 2) gprep(k2);
+#pragma unroll
+                        for (int q = 0; q < 8 / G; ++q) gissue((g - G / 2) * (8 / G) + q);
+                    }
+                    mfma_group(af[b], bf[b]);
+                }
+#pragma unroll
+                for (int q = 0; q < G * 4 * TM * TN; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // one MFMA ...
+                    __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);   // ... then one LDS access,
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // a few VALU
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // and one global load
+                }
+                __syncthreads();
+            }
+        } else {
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
             const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
@@ -358,6 +505,7 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
                 mfma_group(af[b], bf[b]);
             }
             __syncthreads();
+        }
         }
     } else {
     for (int kt = 0; kt < nk; ++kt) {
@@ -397,99 +545,247 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
         o[0] = clock64() - dbg_c0;
         o[1] = wall_clock64() - dbg_w0;
     }
-    // ---------------- epilogue ----------------
-    // C/D map of the 32x32 MFMA: column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int mrow0 = m0 + wm * (BM / 2) + 4 * lh;
-    const int ncol0 = n0 + wn * (BN / 2) + l31;
+    igemm_epilogue<BM, BN>(a, acc, smem, mt, m0, n0, wm, wn, l31, lh);
+}
 
-    if (a.stats) {
-        float sc[TN], sm[TN], s2[TN];
+// ------------------------------------------------------------------------------------------
+// bf16-operand variants of the same implicit GEMM on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate)
+//   SPLIT = true : "split-bf16" fp32-equivalent arithmetic.  Every fp32 operand x is carried as hi = bf16(x),
+//                  lo = bf16(x - hi) (16 mantissa bits together) and a*b ~= ah*bh + ah*bl + al*bh with fp32
+//                  accumulation: relative error per product <= 2^-16, three MFMAs instead of eight fp32 ones.
+//   SPLIT = false: plain bf16 operands, fp32 accumulation (BASELINE config 5 arithmetic).
+// HBM data stays fp32 (activations) / pre-split bf16 planes (weights, made by up_pack_weights_bf16); the
+// activation operand is split while it is staged to LDS.  K slice = 64, LDS rows are 128 B + 16 B pad
+// (144/16 = 9 odd: the 16-B fragment reads of 16 lanes hit 16 distinct slots).  A fragment of the MFMA is 8
+// consecutive k of one row: lane l -> row l&31, k = 8*(l>>5)..+7 of each 16-wide step.
+// ------------------------------------------------------------------------------------------
+#ifndef UP_EMU
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo_elem, float hi_elem) {   // RNE, v_cvt_pk_bf16_f32
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    bf16x2 v;
+    v[0] = (__bf16)lo_elem;
+    v[1] = (__bf16)hi_elem;
+    return __builtin_bit_cast(uint32_t, v);
+}
+#endif
+struct u32x2 {
+    uint32_t x, y;
+};
+struct u32x4 {
+    uint32_t x, y, z, w;
+};
+// (hi, lo) bf16 pairs of two floats; element 0 in the low half-word
+__device__ __forceinline__ void split_bf16x2(float a0, float a1, uint32_t& hi, uint32_t& lo) {
+    hi = pack_bf16x2(a0, a1);
+    float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xffff0000u);
+    lo = pack_bf16x2(a0 - h0, a1 - h1);
+}
+
+template <int BM, int BN, int MODE, bool SPLIT>
+__global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
+    static_assert(MODE == 1 || MODE == 2, "bf16 kernels need channel counts that are multiples of the K slice");
+    constexpr bool FAST = MODE == 2;
+    constexpr int KT = 64;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int NP = SPLIT ? 2 : 1;
+    constexpr int RS = KT * 2 + 16;                 // LDS row stride in bytes
+    constexpr int A_PLANE = BM * RS, B_PLANE = BN * RS;
+    constexpr int PA = BM / 16;                     // A staging: 16 rows x 16 float4 per pass
+    constexpr int PB = BN / 32;                     // B staging: 32 rows x 8 chunks (8 bf16) per pass and plane
+    static_assert(PA <= 8, "okmask holds 8 row bits");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NP * (A_PLANE + B_PLANE)];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + NP * A_PLANE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int logical = xcd_remap(blockIdx.x, a.nwg);
+    const int mt = fdiv(logical, a.fNtn);
+    const int nt = logical - mt * a.ntn;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int lrow = tid >> 4, kq = tid & 15;       // A: row within pass, float4 within the 64-wide slice
+    const int brow = tid >> 3, bch = tid & 7;       // B: row within pass, 16-byte chunk (8 bf16) within the slice
+
+    int hb[PA], wb[PA], ib[PA], roff[PA];
+    unsigned tmask[PA];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float cnt = 0.f, sum = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                    if (m < a.M) {
-                        cnt += 1.f;
-                        sum += acc[i][j][r];
-                    }
+    for (int i = 0; i < PA; ++i) {
+        int m = m0 + i * 16 + lrow;
+        int mm = m < a.M ? m : a.M - 1;
+        int img = fdiv(mm, a.fPQ);
+        int rem = mm - img * (a.P * a.Q);
+        int p = fdiv(rem, a.fQ);
+        int q = rem - p * a.Q;
+        hb[i] = p * a.mul + a.off0;
+        wb[i] = q * a.mul + a.off0;
+        ib[i] = img * a.H * a.W;
+        if (FAST) {
+            roff[i] = (ib[i] + hb[i] * a.W + wb[i]) * a.ldx;
+            unsigned mk = 0;
+            for (int t = 0, r = 0, sx = 0; t < a.taps; ++t) {
+                int h = hb[i] + r * a.tapstep, w = wb[i] + sx * a.tapstep;
+                mk |= (h >= 0 && w >= 0 && h < a.H && w < a.W) ? (1u << t) : 0u;
+                if (++sx == a.S) {
+                    sx = 0;
+                    ++r;
                 }
-            float mean = cnt > 0.f ? sum / cnt : 0.f;
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                    if (m < a.M) {
-                        float d = acc[i][j][r] - mean;
-                        q += d * d;
-                    }
-                }
-            float c2 = __shfl_xor(cnt, 32), m2 = __shfl_xor(mean, 32), q2 = __shfl_xor(q, 32);
-            if (lh) {  // both halves must merge in the same order to agree bitwise
-                float tc = c2, tm = m2, tq = q2;
-                wf_merge(tc, tm, tq, cnt, mean, q);
-                cnt = tc;
-                mean = tm;
-                q = tq;
-            } else {
-                wf_merge(cnt, mean, q, c2, m2, q2);
             }
-            sc[j] = cnt;
-            sm[j] = mean;
-            s2[j] = q;
+            tmask[i] = mk;
         }
-        // smem is free: the K loop ended with a barrier after the last LDS read
-        if (wm == 1 && lh == 0) {
+    }
+    size_t wofs[PB];   // bf16-element offset of this thread's chunk in each staged weight row
+#pragma unroll
+    for (int j = 0; j < PB; ++j) {
+        int n = n0 + j * 32 + brow;
+        wofs[j] = (size_t)(n < a.Ng ? n : a.Ng - 1) * a.Ktot + bch * 8;
+    }
+
+    float4 ra[PA];
+    u32x4 rbh[PB], rbl[PB];
+    unsigned okmask = 0;
+    int tap_c = 0, ci0_c = 0;
+
+    auto gload = [&](int kt) {
+        const int tap = tap_c, ci = ci0_c + kq * 4;
+        int r = fdiv(tap, a.fS);
+        int sx = tap - r * a.S;
+        int dh = r * a.tapstep, dw = sx * a.tapstep;
+        unsigned msk = 0;
+        if (FAST) {
+            const int delta = (dh * a.W + dw) * a.ldx + ci;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const bool ok = (tmask[i] >> tap) & 1u;
+                const int off = ok ? roff[i] + delta : 0;
+                ra[i] = *reinterpret_cast<const float4*>(a.x + off);
+                msk |= ok ? (1u << i) : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                int h = hb[i] + dh, w = wb[i] + dw;
+                bool ok = h >= 0 && w >= 0 && !((h | w) & a.divmask);
+                h >>= a.divshift;
+                w >>= a.divshift;
+                ok = ok && h < a.H && w < a.W;
+                size_t off = ok ? (size_t)(ib[i] + h * a.W + w) * a.ldx + ci : (size_t)0;
+                ra[i] = *reinterpret_cast<const float4*>(a.x + off);
+                msk |= ok ? (1u << i) : 0u;
+            }
+        }
+        const size_t koff = (size_t)kt * KT;
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            rbh[j] = *reinterpret_cast<const u32x4*>(a.w_hi + wofs[j] + koff);
+            if (SPLIT) rbl[j] = *reinterpret_cast<const u32x4*>(a.w_lo + wofs[j] + koff);
+        }
+        okmask = msk;
+        ci0_c += KT;
+        if (ci0_c >= a.Cp) {
+            ci0_c = 0;
+            tap_c += 1;
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const float4 v = keep_or_zero((okmask >> i) & 1u, ra[i]);
+            u32x2 hi, lo;
+            if (SPLIT) {
+                split_bf16x2(v.x, v.y, hi.x, lo.x);
+                split_bf16x2(v.z, v.w, hi.y, lo.y);
+            } else {
+                hi.x = pack_bf16x2(v.x, v.y);
+                hi.y = pack_bf16x2(v.z, v.w);
+            }
+            unsigned char* d = As + (i * 16 + lrow) * RS + kq * 8;
+            *reinterpret_cast<u32x2*>(d) = hi;
+            if (SPLIT) *reinterpret_cast<u32x2*>(d + A_PLANE) = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            unsigned char* d = Bs + (j * 32 + brow) * RS + bch * 16;
+            *reinterpret_cast<u32x4*>(d) = rbh[j];
+            if (SPLIT) *reinterpret_cast<u32x4*>(d + B_PLANE) = rbl[j];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = a.Ktot / KT;
+    gload(0);
+    lstore();
+    __syncthreads();
+
+    const unsigned char* Ard = As + (wm * (BM / 2) + l31) * RS + lh * 16;
+    const unsigned char* Brd = Bs + (wn * (BN / 2) + l31) * RS + lh * 16;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload(kt + 1);
+#pragma unroll
+        for (int s = 0; s < KT / 16; ++s) {
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(Ard + i * 32 * RS + s * 32);
+                if (SPLIT) al[i] = *reinterpret_cast<const bf16x8*>(Ard + A_PLANE + i * 32 * RS + s * 32);
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                float* d = smem + ((wn * TN + j) * 32 + l31) * 3;
-                d[0] = sc[j];
-                d[1] = sm[j];
-                d[2] = s2[j];
+                bh[j] = *reinterpret_cast<const bf16x8*>(Brd + j * 32 * RS + s * 32);
+                if (SPLIT) bl[j] = *reinterpret_cast<const bf16x8*>(Brd + B_PLANE + j * 32 * RS + s * 32);
             }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (SPLIT) {   // small cross terms first, the dominant product last
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
         }
         __syncthreads();
-        if (wm == 0 && lh == 0) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const float* s = smem + ((wn * TN + j) * 32 + l31) * 3;
-                wf_merge(sc[j], sm[j], s2[j], s[0], s[1], s[2]);
-                int n = ncol0 + j * 32;
-                if (n < a.Ng) {
-                    float* o = a.stats + ((size_t)mt * a.Ng + n) * 3;
-                    o[0] = sc[j];
-                    o[1] = sm[j];
-                    o[2] = s2[j];
-                }
-            }
+        if (more) {
+            lstore();
+            __syncthreads();
         }
     }
+    igemm_epilogue<BM, BN>(a, acc, reinterpret_cast<float*>(smem), mt, m0, n0, wm, wn, l31, lh);
+}
 
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = ncol0 + j * 32;
-        if (n >= a.Ng) continue;
-        const float sc = a.scale ? a.scale[n] : 1.f;
-        float sh = a.scale ? a.shift[n] : 0.f;
-        if (a.bias) sh += a.bias[n];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                if (m < a.M) {
-                    float v = acc[i][j][r] * sc + sh;
-                    if (a.residual) v += a.residual[(size_t)m * a.ldr + n];
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    a.y[(size_t)m * a.ldy + n] = v;
-                }
-            }
+// OIHW fp32 -> bf16 hi / lo planes in the [rows][tap][channel] order of pack_fwd / pack_dgrad
+__global__ void __launch_bounds__(256) pack_split_kernel(const float* w, uint16_t* hi, uint16_t* lo, int K, int C,
+                                                         int inner_pad, int taps, long long total, int dgrad) {
+    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    int in = (int)(e % inner_pad);
+    long long t = e / inner_pad;
+    int tap = (int)(t % taps);
+    int row = (int)(t / taps);
+    float v = 0.f;
+    if (!dgrad) {
+        if (in < C) v = w[((size_t)row * C + in) * taps + tap];          // row = k, in = c
+    } else {
+        if (in < K) v = w[((size_t)in * C + row) * taps + tap];          // row = c, in = k
     }
+    uint32_t h, l;
+    split_bf16x2(v, 0.f, h, l);
+    hi[e] = (uint16_t)(h & 0xffffu);
+    lo[e] = (uint16_t)(l & 0xffffu);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -730,6 +1026,7 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     a.ntn = cdiv(a.Ng, BN);
     a.nwg = ntm * a.ntn;
     a.fNtn = make_fastdiv(a.ntn);
+    a.fSpt = make_fastdiv(a.Cp >= 32 ? a.Cp / 32 : 1);
     const int vbase = (BM == 128 && BN == 128) ? 0 : (BM == 64 && BN == 128) ? 2 : (BM == 128 && BN == 64) ? 4 : 6;
     ProfScope prof(vbase + (aligned ? 0 : 1), 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st, a.M, a.Ng,
                    a.Ktot, a.nwg);
@@ -739,7 +1036,11 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     // double-buffered LDS (one barrier per slice) pays for long reductions; short ones (1x1 convs with few input
     // channels) are epilogue-bound and prefer the smaller footprint / higher occupancy of the single-buffer loop
     const bool db = a.Ktot >= 1024;
-    if (fast && db)
+    // wide tiles additionally pin the refill between the MFMAs (branch-free body + sched_group_barrier): +2..4 %
+    // on 128-wide tiles, -3 % on 64x64 (probe, warm)
+    if (fast && db && (BM == 128 || BN == 128))
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, 128>), dim3(a.nwg), dim3(256), 0, st, a);
+    else if (fast && db)
         hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, 0>), dim3(a.nwg), dim3(256), 0, st, a);
     else if (fast)
         hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, 64>), dim3(a.nwg), dim3(256), 0, st, a);
@@ -847,14 +1148,11 @@ extern "C" int up_conv2d_fwd(const up_conv_desc* d, const float* x, const float*
     return check_launch("conv2d_fwd");
 }
 
-extern "C" int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
-                                  void* stream) {
-    if (int e = check_desc(d)) return e;
-    UP_REQUIRE(dy && w_dgrad && dx, UP_ERR_INVALID, "conv2d_bwd_data: null pointer");
+namespace up {
+static int fill_dgrad_args(IgemmArgs& a, const up_conv_desc* d, const float* dy, const float* w_dgrad, float* dx) {
     UP_REQUIRE(d->stride <= 2, UP_ERR_UNSUPPORTED, "conv2d_bwd_data: stride %d (only 1 and 2 are implemented)", d->stride);
     UP_REQUIRE(d->Kp % 4 == 0 && d->Kp >= d->K && d->ldy % 4 == 0 && d->ldy >= d->Kp, UP_ERR_INVALID,
                "conv2d_bwd_data: need Kp%%4==0, ldy%%4==0, ldy>=Kp (Kp=%d ldy=%d K=%d)", d->Kp, d->ldy, d->K);
-    IgemmArgs a;
     memset(&a, 0, sizeof(a));
     a.x = dy;
     a.w = w_dgrad;
@@ -882,8 +1180,99 @@ extern "C" int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const 
     a.fQ = make_fastdiv(d->W);
     a.fCp = make_fastdiv(d->Kp);
     a.fS = make_fastdiv(d->S);
+    return UP_OK;
+}
+
+// ---- bf16-operand launches ----
+template <int BM, int BN>
+static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
+    int ntm = cdiv(a.M, BM);
+    a.ntn = cdiv(a.Ng, BN);
+    a.nwg = ntm * a.ntn;
+    a.fNtn = make_fastdiv(a.ntn);
+    const int v = 12 + ((BM == 128 && BN == 128) ? 0 : (BM == 64 && BN == 128) ? 1 : (BM == 128 && BN == 64) ? 2 : 3);
+    ProfScope prof(v, 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st, a.M, a.Ng, a.Ktot, a.nwg);
+    const bool fast = a.taps <= 32 && a.divshift == 0 &&
+                      (long long)a.H * a.W * a.ldx * ((long long)a.M / (a.P * a.Q) + 1) < (1ll << 31);
+    const bool split = math == UP_MATH_BF16X3;
+    if (fast && split)
+        hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 2, true>), dim3(a.nwg), dim3(256), 0, st, a);
+    else if (fast)
+        hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 2, false>), dim3(a.nwg), dim3(256), 0, st, a);
+    else if (split)
+        hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 1, true>), dim3(a.nwg), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 1, false>), dim3(a.nwg), dim3(256), 0, st, a);
+}
+static int run_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
+    UP_REQUIRE(math == UP_MATH_BF16X3 || math == UP_MATH_BF16, UP_ERR_INVALID, "bf16 convolution: math mode %d", math);
+    UP_REQUIRE(a.Cp % 64 == 0, UP_ERR_UNSUPPORTED, "bf16 convolution: padded channel count %d is not a multiple of 64",
+               a.Cp);
+    TileChoice t = choose_tile(a.M, a.Ng);
+    if (t.bm == 128 && t.bn == 128)
+        launch_igemm_bf16<128, 128>(a, math, st);
+    else if (t.bm == 64 && t.bn == 128)
+        launch_igemm_bf16<64, 128>(a, math, st);
+    else if (t.bm == 128 && t.bn == 64)
+        launch_igemm_bf16<128, 64>(a, math, st);
+    else
+        launch_igemm_bf16<64, 64>(a, math, st);
+    return UP_OK;
+}
+}  // namespace up
+
+extern "C" int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
+                                  void* stream) {
+    if (int e = check_desc(d)) return e;
+    UP_REQUIRE(dy && w_dgrad && dx, UP_ERR_INVALID, "conv2d_bwd_data: null pointer");
+    IgemmArgs a;
+    if (int e = fill_dgrad_args(a, d, dy, w_dgrad, dx)) return e;
     run_igemm(a, choose_tile(a.M, a.Ng), as_stream(stream));
     return check_launch("conv2d_bwd_data");
+}
+
+extern "C" int up_pack_weights_bf16(const up_conv_desc* d, const float* w, uint16_t* fwd_hi, uint16_t* fwd_lo,
+                                    uint16_t* dgrad_hi, uint16_t* dgrad_lo, void* stream) {
+    if (int e = check_desc(d)) return e;
+    UP_REQUIRE(w && (fwd_hi == nullptr) == (fwd_lo == nullptr) && (dgrad_hi == nullptr) == (dgrad_lo == nullptr),
+               UP_ERR_INVALID, "pack_weights_bf16: hi/lo planes come in pairs");
+    int taps = d->R * d->S;
+    if (fwd_hi) {
+        long long total = (long long)d->K * taps * d->Cp;
+        hipLaunchKernelGGL(pack_split_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w, fwd_hi, fwd_lo,
+                           d->K, d->C, d->Cp, taps, total, 0);
+    }
+    if (dgrad_hi) {
+        UP_REQUIRE(d->Kp % 4 == 0 && d->Kp >= d->K, UP_ERR_INVALID, "pack_weights_bf16: Kp=%d invalid", d->Kp);
+        long long total = (long long)d->C * taps * d->Kp;
+        hipLaunchKernelGGL(pack_split_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w, dgrad_hi,
+                           dgrad_lo, d->K, d->C, d->Kp, taps, total, 1);
+    }
+    return check_launch("pack_weights_bf16");
+}
+
+extern "C" int up_conv2d_fwd_bf16(const up_conv_desc* d, const float* x, const uint16_t* w_hi, const uint16_t* w_lo,
+                                  float* y, const up_conv_epilogue* ep, int math, void* stream) {
+    if (int e = check_desc(d)) return e;
+    UP_REQUIRE(x && w_hi && y && (w_lo || math == UP_MATH_BF16), UP_ERR_INVALID, "conv2d_fwd_bf16: null pointer");
+    IgemmArgs a;
+    if (int e = fill_fwd_args(a, d, x, nullptr, y, ep)) return e;
+    a.w_hi = w_hi;
+    a.w_lo = w_lo;
+    if (int e = run_igemm_bf16(a, math, as_stream(stream))) return e;
+    return check_launch("conv2d_fwd_bf16");
+}
+
+extern "C" int up_conv2d_bwd_data_bf16(const up_conv_desc* d, const float* dy, const uint16_t* w_hi,
+                                       const uint16_t* w_lo, float* dx, int math, void* stream) {
+    if (int e = check_desc(d)) return e;
+    UP_REQUIRE(dy && w_hi && dx && (w_lo || math == UP_MATH_BF16), UP_ERR_INVALID, "conv2d_bwd_data_bf16: null pointer");
+    IgemmArgs a;
+    if (int e = fill_dgrad_args(a, d, dy, nullptr, dx)) return e;
+    a.w_hi = w_hi;
+    a.w_lo = w_lo;
+    if (int e = run_igemm_bf16(a, math, as_stream(stream))) return e;
+    return check_launch("conv2d_bwd_data_bf16");
 }
 
 namespace up {

@@ -121,6 +121,44 @@ def _packed(weight: torch.Tensor, d: _C.ConvDesc):
     return wf, wd
 
 
+# Arithmetic of the forward / data-gradient convolutions (weight gradients always use the exact fp32 MFMA):
+#   0  exact fp32 (v_mfma_f32_32x32x2_f32)                                  -- default, parity configuration
+#   1  split-bf16: a*b ~= ah*bh + ah*bl + al*bh on bf16 MFMA, fp32-equivalent (2^-16 per product)
+#   2  plain bf16 operands, fp32 accumulation (BASELINE config 5)
+# Layers whose padded channel count is not a multiple of 64 (stem, 15-channel ConvLSTM convs) stay exact.
+MATH_F32, MATH_BF16X3, MATH_BF16 = 0, 1, 2
+CONV_MATH = MATH_F32
+
+
+def set_conv_math(mode):
+    global CONV_MATH
+    CONV_MATH = {"f32": 0, "fp32": 0, "bf16x3": 1, "split": 1, "bf16": 2}.get(mode, mode)
+    if CONV_MATH not in (0, 1, 2):
+        raise ValueError(f"unknown conv math {mode!r}")
+
+
+_PACK16_CACHE = {}
+
+
+def _packed_bf16(weight: torch.Tensor, d: _C.ConvDesc):
+    """bf16 (hi, lo) planes of the forward and data-gradient weight images; cached like _packed()."""
+    key = id(weight)
+    hit = _PACK16_CACHE.get(key)
+    nf, nd = d.K * d.R * d.S * d.Cp, d.C * d.R * d.S * d.Kp
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2].shape[1] == nf and \
+            hit[3].shape[1] == nd:
+        return hit[2], hit[3]
+    wf = torch.empty((2, nf), dtype=torch.int16, device=weight.device)
+    wd = torch.empty((2, nd), dtype=torch.int16, device=weight.device)
+    _C.check(_C.lib().up_pack_weights_bf16(C.byref(d), _dense(weight).data_ptr(), wf[0].data_ptr(), wf[1].data_ptr(),
+                                           wd[0].data_ptr(), wd[1].data_ptr(), _stream(weight)), "pack_weights_bf16")
+    if len(_PACK16_CACHE) > 4096:
+        _PACK16_CACHE.clear()
+    if weight.is_leaf:
+        _PACK16_CACHE[key] = (weakref.ref(weight), weight._version, wf, wd)
+    return wf, wd
+
+
 def packed_fwd(weight: torch.Tensor, d: _C.ConvDesc) -> torch.Tensor:
     return _packed(weight, d)[0]
 
@@ -137,7 +175,6 @@ def conv_fwd_raw(x, weight, cfg, *, scale=None, shift=None, bias=None, residual=
     if out is None:
         alloc = torch.zeros if d.ldy != d.K else torch.empty      # pad channels must read as zeros
         out = alloc((d.N, d.P, d.Q, d.ldy), dtype=torch.float32, device=x.device)
-    wp = packed_fwd(weight, d)
     ep = _C.ConvEpilogue()
     ep.scale, ep.shift, ep.bias = _ptr(scale), _ptr(shift), _ptr(bias)
     ep.residual = _ptr(residual)
@@ -148,21 +185,32 @@ def conv_fwd_raw(x, weight, cfg, *, scale=None, shift=None, bias=None, residual=
         tiles = _C.lib().up_conv_stats_tiles(C.byref(d))
         st = torch.empty((tiles, d.K, 3), dtype=torch.float32, device=x.device)
         ep.stats = st.data_ptr()
-    _C.check(_C.lib().up_conv2d_fwd(C.byref(d), x.data_ptr(), wp.data_ptr(), out.data_ptr(), C.byref(ep),
-                                    _stream(x)), "conv2d_fwd")
+    if CONV_MATH != MATH_F32 and d.Cp % 64 == 0:
+        wf, _ = _packed_bf16(weight, d)
+        _C.check(_C.lib().up_conv2d_fwd_bf16(C.byref(d), x.data_ptr(), wf[0].data_ptr(), wf[1].data_ptr(),
+                                             out.data_ptr(), C.byref(ep), CONV_MATH, _stream(x)), "conv2d_fwd_bf16")
+    else:
+        wp = packed_fwd(weight, d)
+        _C.check(_C.lib().up_conv2d_fwd(C.byref(d), x.data_ptr(), wp.data_ptr(), out.data_ptr(), C.byref(ep),
+                                        _stream(x)), "conv2d_fwd")
     return out, d, st
 
 
 def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev):
-    wd = packed_dgrad(weight, d)
     n, h, w, cp = x_shape
     alloc = torch.zeros if cp != d.C else torch.empty
     dx = alloc((n, h, w, cp), dtype=torch.float32, device=dev)
     dd = _C.ConvDesc.from_buffer_copy(d)
     dd.ldx = cp
     dd.ldy = _nhwc_ok(dy)
-    _C.check(_C.lib().up_conv2d_bwd_data(C.byref(dd), dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), _stream(dy)),
-             "conv2d_bwd_data")
+    if CONV_MATH != MATH_F32 and d.Kp % 64 == 0:
+        _, wd16 = _packed_bf16(weight, d)
+        _C.check(_C.lib().up_conv2d_bwd_data_bf16(C.byref(dd), dy.data_ptr(), wd16[0].data_ptr(), wd16[1].data_ptr(),
+                                                  dx.data_ptr(), CONV_MATH, _stream(dy)), "conv2d_bwd_data_bf16")
+    else:
+        wd = packed_dgrad(weight, d)
+        _C.check(_C.lib().up_conv2d_bwd_data(C.byref(dd), dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), _stream(dy)),
+                 "conv2d_bwd_data")
     return dx
 
 
