@@ -104,3 +104,61 @@ def test_conv_bf16_operand_kernels(emu_backend, cfg, math, tol):
         ops.set_conv_math("f32")
     if math == "bf16":
         assert errs["y"] > 1e-4       # the bf16 kernel really ran (an fp32 result would sit at 1e-6)
+
+
+@pytest.fixture
+def guard_pages(emu_backend, monkeypatch):
+    """Every tensor the host layer allocates (outputs, packed weights, partial slabs, gradients) ends right before a
+    PROT_NONE page and float outputs start as NaN: an out-of-bounds access by a kernel kills the test, an element
+    it forgot to write poisons the comparison."""
+    import sys
+    sys.path.insert(0, __file__.rsplit("/", 1)[0] + "/emu")
+    import guard_alloc
+    from unipose_amd import ops
+    monkeypatch.setattr(ops, "torch", guard_alloc.TorchProxy())
+    monkeypatch.setattr(ops, "_WS", {})
+    monkeypatch.setattr(ops, "_PACK_CACHE", {})
+    monkeypatch.setattr(ops, "_PACK16_CACHE", {})
+    return guard_alloc
+
+
+@pytest.mark.parametrize("cfg", [
+    (2, 16, 6, 5, 32, 1, 1, 0, 1, False, False),
+    (2, 16, 9, 9, 24, 3, 2, 1, 1, False, False),
+    (1, 3, 20, 18, 8, 7, 2, 3, 1, False, False),      # generic path, ragged K slice
+    (2, 32, 5, 5, 14, 1, 1, 0, 1, True, False),       # K=14 -> Kp=16 data gradient (the bug that faulted on the GPU)
+    (1, 15, 6, 6, 14, 3, 1, 1, 1, True, True),
+    (1, 128, 5, 5, 32, 3, 1, 1, 1, False, False),     # double-buffered loop
+    (1, 64, 6, 6, 17, 1, 1, 0, 1, True, False),       # K=17 -> ldy 20
+])
+def test_conv_no_out_of_bounds(guard_pages, cfg):
+    n, c, h, w, k, r, s, p, d, bias, relu = cfg
+    oc.conv_case(torch.device("cpu"), n, c, h, w, k, r, s, p, d, bias=bias, relu=relu)
+
+
+@pytest.mark.parametrize("math", ["bf16x3", "bf16"])
+def test_conv_bf16_no_out_of_bounds(guard_pages, math):
+    from unipose_amd import ops
+    ops.set_conv_math(math)
+    try:
+        oc.conv_case(torch.device("cpu"), 1, 64, 7, 7, 72, 3, 1, 1, 1, tol=3e-2)
+        oc.conv_case(torch.device("cpu"), 2, 64, 9, 9, 64, 3, 2, 1, 1, tol=3e-2)
+    finally:
+        ops.set_conv_math("f32")
+
+
+def test_conv_bn_no_out_of_bounds(guard_pages):
+    oc.conv_bn_case(torch.device("cpu"), 3, 8, 9, 9, 72, 3, 2, 1, 1, relu=True, residual=True, train=True)
+
+
+def test_small_ops_no_out_of_bounds(guard_pages, golden_dir):
+    dev = torch.device("cpu")
+    oc.layout_case(dev)
+    oc.maxpool_case(dev, 1, 4, 7, 9)
+    oc.bilinear_case(dev, 1, 4, 3, 5, 7, 9)
+    oc.gap_case(dev, 2, 8, 3, 5)
+    oc.concat_case(dev)
+    oc.mse_case(dev)
+    oc.avgpool_case(dev, 37, 41)
+    oc.lstm_case(dev)
+    oc.argmax_case(dev, golden_dir)
