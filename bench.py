@@ -24,6 +24,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The weight-gradient side stream must map to its own hardware queue.  ROCm multiplexes HIP streams onto
+# GPU_MAX_HW_QUEUES (default 4) queues round-robin; once RCCL has created its streams the side stream can end up
+# sharing a queue with the main stream, which serialises the two (measured: 82 -> 93 ms per step).  Must be set
+# before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -78,6 +83,12 @@ def main():
     ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "bf16"],
                     help="arithmetic of the forward/data-gradient convolutions: exact fp32 MFMA (default, the parity "
                          "configuration), split-bf16 fp32-equivalent, or plain bf16 operands")
+    ap.add_argument("--model", default="unipose", choices=["unipose", "lstm"],
+                    help="unipose = BASELINE configs[1]/[2] (default, the headline metric); lstm = configs[3]: "
+                         "UniPose-LSTM, 5-frame clips, one backward through all frames, images/sec counts frames")
+    ap.add_argument("--frames", type=int, default=5)
+    ap.add_argument("--force-dp", action="store_true",
+                    help="run the gradient exchange (RCCL all-reduce, buckets, hooks) even with one rank")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=min(os.cpu_count() or 1, 64),
@@ -93,8 +104,14 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or args.force_dp
+    from unipose_amd import ops as _ops
+    _ops._side_stream(dev)          # create it BEFORE RCCL creates its own streams (hardware-queue assignment)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from model.unipose import unipose
@@ -102,19 +119,42 @@ def main():
     from unipose_amd.dist import GradAllReducer, shard_seed
 
     K, B, S = args.num_classes, args.batch, args.size
+    lstm = args.model == "lstm"
+    T = args.frames if lstm else 1
     torch.manual_seed(0)
-    model = unipose("MPII", num_classes=K).to(dev).train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4)        # unipose.py:72 (no weight decay)
     g = torch.Generator(device="cpu").manual_seed(shard_seed(0, rank))
-    x = torch.randn(B, 3, S, S, generator=g).to(dev)
-    t = torch.rand(B, K + 1, S // 8, S // 8, generator=g).to(dev)
+    if lstm:
+        from model.uniposeLSTM import unipose_lstm
+        if args.num_classes == 16:
+            K = 13                                             # Penn Action joints (configs[3])
+        if args.batch == 32:
+            B = 8
+        model = unipose_lstm(num_classes=K).to(dev).train()
+        x = torch.randn(B, T, 3, S, S, generator=g).to(dev)
+        cm = torch.rand(B, T, 1, S, S, generator=g).to(dev)
+        t = torch.rand(B, T, K + 1, S // 8, S // 8, generator=g).to(dev)
+    else:
+        model = unipose("MPII", num_classes=K).to(dev).train()
+        x = torch.randn(B, 3, S, S, generator=g).to(dev)
+        t = torch.rand(B, K + 1, S // 8, S // 8, generator=g).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)        # unipose.py:72 (no weight decay)
     ops.manual_seed(shard_seed(0, rank))
     ops.set_conv_math(args.math)
-    reducer = GradAllReducer(model) if world > 1 else None
+    reducer = GradAllReducer(model, bucket_bytes=256 << 20, force=args.force_dp) if use_dist else None
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = ops.mse_loss(model(x), t)
+        if lstm:                                               # uniposeLSTM.py:116-133: T frames, ONE backward
+            hs = S // 8
+            heat = torch.zeros(K + 1, hs, hs, device=dev)
+            cell = torch.zeros(K + 2, hs, hs, device=dev)
+            hide = torch.zeros(K + 2, hs, hs, device=dev)
+            loss = 0.0
+            for j in range(T):
+                heat, cell, hide = model(x, cm, j, heat, hide, cell)
+                loss = loss + ops.mse_loss(heat, t[:, j])
+        else:
+            loss = ops.mse_loss(model(x), t)
         loss.backward()
         if reducer is not None:
             reducer.finish()
@@ -123,7 +163,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -143,7 +183,7 @@ def main():
     dt = time.perf_counter() - t0
     log(f"timed region: {args.steps} steps in {dt:.3f}s")
     loss_val = float(loss.detach())
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -175,31 +215,36 @@ def main():
                                       for r in rows]}
 
     if rank == 0:
-        ips = world * B * args.steps / dt
+        ips = world * B * T * args.steps / dt
         out = {
-            "metric": "images/sec fwd+bwd, UniPose ResNet-101 368x368",
+            "metric": (f"images/sec fwd+bwd, UniPose-LSTM ResNet-101 {T}-frame clips {S}x{S}" if lstm else
+                       f"images/sec fwd+bwd, UniPose ResNet-101 {S}x{S}"),
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x3": "f32 (split-bf16 MFMA, fp32-equivalent)", "bf16": "bf16"}[args.math],
             "data": "synthetic",
-            "config": {"workload": f"UniPose ResNet-101 (K={K}) train step: fwd + MSE + bwd + Adam, synthetic "
-                                   f"{S}x{S}, batch {B}/GPU (BASELINE.json configs[1]; configs[2] for N>1)",
+            "config": {"workload": (f"UniPose-LSTM ResNet-101 (K={K}) train step: {T}-frame unroll, summed MSE, one "
+                                    f"backward (BPTT) + Adam, synthetic {S}x{S}, batch {B} clips/GPU (BASELINE.json "
+                                    f"configs[3])" if lstm else
+                                    f"UniPose ResNet-101 (K={K}) train step: fwd + MSE + bwd + Adam, synthetic "
+                                    f"{S}x{S}, batch {B}/GPU (BASELINE.json configs[1]; configs[2] for N>1)"),
                        "global_batch": world * B, "per_gpu_batch": B, "input": [3, S, S],
                        "parallelism": f"dp{world}", "optimizer": "Adam(lr=1e-4)",
                        "arithmetic": {"f32": "fp32 MFMA 32x32x2 everywhere",
                                       "bf16x3": "fwd/dgrad: 3x bf16 MFMA 32x32x16 on (hi,lo) split operands; wgrad: fp32 MFMA",
                                       "bf16": "fwd/dgrad: bf16 MFMA 32x32x16; wgrad: fp32 MFMA"}[args.math]},
-            "step_tflops_per_gpu": round(ips / world * FLOP_PER_IMAGE_FWD_BWD * (S / 368.0) ** 2 / 1e12, 2),
+            "step_tflops_per_gpu": round(ips / world * (FLOP_PER_IMAGE_FWD_BWD + (3 * 2 * 8.93e9 if lstm else 0.0))
+                                         * (S / 368.0) ** 2 / 1e12, 2),
             "loss": loss_val,
         }
         if roofline:
             out["roofline"] = roofline
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not lstm:
             log("cpu baseline (oracle on host cores)")
             out["cpu_baseline"] = cpu_baseline(K, S, args.cpu_batch, args.cpu_steps, args.cpu_threads)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -16,7 +16,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -152,25 +154,80 @@ inline int workers() {
     int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
     return n < 1 ? 1 : n;
 }
-inline void launch(dim3 g, dim3 b, const std::function<void()>& body) {
-    long total = (long)g.x * g.y * g.z;
-    std::atomic<long> next(0);
-    auto work = [&]() {
+// Persistent worker pool: fiber stacks (24 MB per worker) are allocated once, not per kernel launch.
+struct Pool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, done_cv;
+    std::function<void(long)> job;
+    long total = 0, generation = 0;
+    std::atomic<long> next{0};
+    int active = 0;
+    bool stop = false;
+    explicit Pool(int n) {
+        for (int i = 0; i < n; ++i) th.emplace_back([this] { loop(); });
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+    void drain() {
         for (;;) {
             long i = next.fetch_add(1);
             if (i >= total) break;
-            dim3 bid((unsigned)(i % g.x), (unsigned)((i / g.x) % g.y), (unsigned)(i / ((long)g.x * g.y)));
-            run_block(bid, b, g, body);
+            job(i);
         }
+    }
+    void loop() {
+        long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(mu);
+                cv.wait(l, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation;
+                ++active;
+            }
+            drain();
+            {
+                std::lock_guard<std::mutex> l(mu);
+                --active;
+            }
+            done_cv.notify_all();
+        }
+    }
+    void run(long n, std::function<void(long)> f) {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            job = std::move(f);
+            total = n;
+            next = 0;
+            ++generation;
+        }
+        cv.notify_all();
+        drain();   // the launching thread works too
+        std::unique_lock<std::mutex> l(mu);
+        done_cv.wait(l, [&] { return active == 0 && next.load() >= total; });
+        total = 0;  // late wakers find nothing to do
+    }
+};
+inline void launch(dim3 g, dim3 b, const std::function<void()>& body) {
+    long total = (long)g.x * g.y * g.z;
+    auto one = [&](long i) {
+        dim3 bid((unsigned)(i % g.x), (unsigned)((i / g.x) % g.y), (unsigned)(i / ((long)g.x * g.y)));
+        run_block(bid, b, g, body);
     };
-    int nw = (int)std::min<long>(workers(), total);
-    if (nw <= 1) {
-        work();
+    static const int nw = workers();
+    if (total <= 2 || nw <= 1) {   // tiny grids: run inline, no hand-off latency
+        for (long i = 0; i < total; ++i) one(i);
         return;
     }
-    std::vector<std::thread> th;
-    for (int i = 0; i < nw; ++i) th.emplace_back(work);
-    for (auto& t : th) t.join();
+    static Pool pool(nw - 1);
+    pool.run(total, one);
 }
 
 inline int lane() { return st().cur->lin & 63; }

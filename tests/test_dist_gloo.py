@@ -3,6 +3,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 
 import torch
 import torch.distributed as dist
@@ -28,13 +29,13 @@ class _Net(torch.nn.Module):
         return self.b(torch.relu(self.a(x)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, overlap):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from unipose_amd.dist import GradAllReducer, shard_seed
     torch.manual_seed(100 + rank)                  # different initial weights: must be overwritten by rank 0's
     net = _Net()
-    red = GradAllReducer(net, bucket_bytes=256)    # tiny buckets -> several of them
+    red = GradAllReducer(net, bucket_bytes=256, overlap=overlap)    # tiny buckets -> several of them
     w0 = [p.detach().numpy().copy() for p in net.parameters()]
     outs = []
     for step in range(3):                          # step 0 = unbucketed path, 1-2 = hooks + buckets
@@ -50,11 +51,12 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_grad_allreduce_world2():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_grad_allreduce_world2(overlap):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])

@@ -1,11 +1,17 @@
 """Data-parallel gradient exchange: one process per GPU, batch sharded, weights replicated, ONE
-all-reduce (sum, then /N) of the parameter gradients per step over RCCL/xGMI
-(``torch.distributed`` backend "nccl" on ROCm), bucketed in reverse-registration (~ reverse autograd)
-order and launched from post-accumulate-grad hooks so the exchange overlaps the rest of backward.
+all-reduce (average) of the parameter gradients per step over RCCL/xGMI (``torch.distributed`` backend
+"nccl" on ROCm), bucketed in reverse-registration (~ reverse autograd) order and launched from
+post-accumulate-grad hooks so the exchange overlaps the rest of backward.
 
 The reference has no distributed code at all; BatchNorm statistics stay per-GPU exactly
 like its plain nn.BatchNorm2d.  Parameters that never receive a gradient (decoder.conv2 / bn2,
 SURVEY D9) are detected on the first step and left out of the buckets.
+
+Stream discipline (GPU): weight gradients are produced on the side stream of ``unipose_amd.ops``; the
+bucket fill (one multi-tensor copy per bucket) and the collective are issued on that same side stream, so
+the main stream — the critical path of backward — never waits for the exchange until ``finish()``.
+After the all-reduce ``param.grad`` simply becomes a view of the bucket (no copy back, no scaling pass:
+the collective averages).
 """
 from __future__ import annotations
 
@@ -13,6 +19,11 @@ from typing import List, Optional
 
 import torch
 import torch.distributed as dist
+
+
+import os
+
+_DEBUG = os.environ.get("UP_DP_DEBUG", "")      # development switch: "hook-only" = hooks fire, nothing is exchanged
 
 
 class _Bucket:
@@ -31,19 +42,46 @@ class _Bucket:
 
 
 class GradAllReducer:
-    def __init__(self, module: torch.nn.Module, bucket_bytes: int = 32 << 20, group=None):
+    def __init__(self, module: torch.nn.Module, bucket_bytes: int = 32 << 20, group=None, force: bool = False,
+                 overlap: bool = False):
+        """force=True runs the whole exchange (broadcast, buckets, collectives) even in a 1-rank group — used to
+        exercise the RCCL path on a single-GPU box.
+
+        overlap=False (default): ONE multi-tensor copy of all gradients into a flat buffer and ONE all-reduce
+        after backward.  The 190 MB exchange takes ~1-2 ms on xGMI against an 80+ ms fp32 step, while merely
+        REGISTERING 345 post-accumulate-grad hooks was measured to cost 8.6 ms per step on the MI355X box
+        (profiles/README.md), so the un-overlapped form is the faster one for this model.
+        overlap=True: bucketed exchange launched from post-accumulate-grad hooks during backward."""
+        self.overlap = overlap
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.bucket_bytes = bucket_bytes
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.buckets: Optional[List[_Bucket]] = None
         self._where = {}
         self._handles = []
+        backend = dist.get_backend(group) if dist.is_initialized() else ""
+        self._avg = backend == "nccl"              # gloo has no AVG: sum, then scale
         # replicate the initial weights / buffers from rank 0 once (documented choice: BN running
         # statistics are NOT re-broadcast per step; each rank keeps its own like the reference would)
-        if self.world > 1:
+        if self.active:
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, 0, group=group)
+
+    # -- streams -------------------------------------------------------------------------------------
+    @staticmethod
+    def _streams(dev):
+        """(main, side) HIP streams for a CUDA device, (None, None) on CPU."""
+        if dev.type != "cuda":
+            return None, None
+        from . import ops
+        return torch.cuda.current_stream(dev), ops._side_stream(dev)
+
+    def _reduce(self, buf):
+        if self._avg:
+            return dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     # -- first step: plain post-backward exchange, then build the buckets from what received a grad --
     def _build(self):
@@ -58,24 +96,34 @@ class GradAllReducer:
         if cur:
             self.buckets.append(_Bucket(cur))
         for bi, b in enumerate(self.buckets):
-            for pi, p in enumerate(b.params):
-                self._where[p] = (bi, pi)
-                self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
+            for p in b.params:
+                self._where[p] = bi
+                if self.overlap:
+                    self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
 
     def _hook(self, p):
-        bi, pi = self._where[p]
-        b = self.buckets[bi]
-        if p.grad.is_cuda:
-            from . import ops
-            ops.wgrad_fence(p.grad.device)      # weight gradients are produced on a side stream
-        b.views[pi].copy_(p.grad)
+        b = self.buckets[self._where[p]]
         b.pending -= 1
-        if b.pending == 0:
-            b.work = dist.all_reduce(b.buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if b.pending:
+            return
+        if _DEBUG == "hook-only":
+            b.pending = len(b.params)
+            return
+        # bucket complete: ONE multi-tensor copy + the collective, both on the side stream
+        grads = [q.grad for q in b.params]
+        main, side = self._streams(b.buf.device)
+        if side is not None:
+            side.wait_stream(main)                 # BN / bias gradients come from the main stream
+            with torch.cuda.stream(side):
+                torch._foreach_copy_(b.views, grads)
+                b.work = self._reduce(b.buf)
+        else:
+            torch._foreach_copy_(b.views, grads)
+            b.work = self._reduce(b.buf)
 
     def finish(self):
-        """Call after loss.backward(): waits for the in-flight buckets and writes averaged grads back."""
-        if self.world == 1:
+        """Call after loss.backward(): waits for the in-flight buckets; param.grad becomes the averaged bucket view."""
+        if not self.active:
             return
         if self.buckets is None:
             grads = [p.grad for p in self.params if p.grad is not None]
@@ -91,14 +139,27 @@ class GradAllReducer:
                 off += g.numel()
             self._build()
             return
-        inv = 1.0 / self.world
+        if _DEBUG == "hook-only":
+            return
+        if not self.overlap:
+            if self.buckets and self.buckets[0].buf.is_cuda:
+                from . import ops
+                ops.wgrad_fence(self.buckets[0].buf.device)
+            for b in self.buckets:
+                grads = [p.grad for p in b.params]
+                if any(g is None for g in grads):
+                    raise RuntimeError("a bucketed parameter received no gradient this step")
+                torch._foreach_copy_(b.views, grads)
+                b.work = self._reduce(b.buf)
+                b.pending = 0
         for b in self.buckets:
             if b.pending != 0:
                 raise RuntimeError("a bucketed parameter received no gradient this step")
-            b.work.wait()
-            b.buf.mul_(inv)
+            b.work.wait()                          # current (main) stream waits for the collective
+            if not self._avg:
+                b.buf.div_(self.world)
             for p, v in zip(b.params, b.views):
-                p.grad.copy_(v)
+                p.grad = v
             b.pending, b.work = len(b.params), None
 
     def payload_bytes(self) -> int:
