@@ -87,7 +87,7 @@ int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const float* w_dg
  * and a*b ~= ah*bh + ah*bl + al*bh (fp32-equivalent, relative error 2^-16 per product);  UP_MATH_BF16: plain bf16
  * operands (BASELINE config 5 arithmetic).  Weights come as bf16 planes made by up_pack_weights_bf16 in the
  * [rows][R*S][padded channels] order of up_pack_weights.  Requires the padded reduction channel count (Cp forward,
- * Kp backward) to be a multiple of 64; otherwise UP_ERR_UNSUPPORTED (use the fp32 entry points). */
+ * Kp backward) to be a multiple of 32; otherwise UP_ERR_UNSUPPORTED (use the fp32 entry points). */
 typedef enum { UP_MATH_F32 = 0, UP_MATH_BF16X3 = 1, UP_MATH_BF16 = 2 } up_math;
 int up_pack_weights_bf16(const up_conv_desc* d, const float* w_oihw, uint16_t* fwd_hi, uint16_t* fwd_lo,
                          uint16_t* dgrad_hi, uint16_t* dgrad_lo, void* stream);

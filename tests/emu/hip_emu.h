@@ -39,6 +39,13 @@ struct float4 {
     float x, y, z, w;
 };
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
+struct uint2 {
+    uint32_t x, y;
+};
+struct uint4 {
+    uint32_t x, y, z, w;
+};
+static inline uint4 make_uint4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return uint4{a, b, c, d}; }
 
 typedef void* hipStream_t;
 typedef int hipError_t;

@@ -569,12 +569,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo_elem, float hi_elem) { 
     return __builtin_bit_cast(uint32_t, v);
 }
 #endif
-struct u32x2 {
-    uint32_t x, y;
-};
-struct u32x4 {
-    uint32_t x, y, z, w;
-};
+// (HIP's native uint2 / uint4 vector types: hand-made structs moved through reinterpret_cast stayed in scratch)
 // (hi, lo) bf16 pairs of two floats; element 0 in the low half-word
 __device__ __forceinline__ void split_bf16x2(float a0, float a1, uint32_t& hi, uint32_t& lo) {
     hi = pack_bf16x2(a0, a1);
@@ -582,21 +577,25 @@ __device__ __forceinline__ void split_bf16x2(float a0, float a1, uint32_t& hi, u
     lo = pack_bf16x2(a0 - h0, a1 - h1);
 }
 
+// Pipeline: K slice = 32.  Slice t is read from LDS buffer t&1 while slice t+1 (held in one of TWO register
+// staging sets) is converted and written to the other buffer and slice t+2 is still in flight in the second set;
+// the freed set is refilled with slice t+3.  Global loads therefore have two full slices (~2 x 768 MFMA cycles x
+// the blocks sharing the SIMD) to land — the bf16 MFMA phase alone (768 cycles) is shorter than the memory
+// latency, which made the first single-stage version of this kernel latency-bound.  One barrier per slice.
+// Slice indices past the end are clamped (harmless reloads): the loop body is branch-free.
 template <int BM, int BN, int MODE, bool SPLIT>
 __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
     static_assert(MODE == 1 || MODE == 2, "bf16 kernels need channel counts that are multiples of the K slice");
     constexpr bool FAST = MODE == 2;
-    constexpr int KT = 64;
+    constexpr int KT = 32;
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int NP = SPLIT ? 2 : 1;
-    constexpr int RS = KT * 2 + 16;                 // LDS row stride in bytes
+    constexpr int RS = KT * 2 + 16;                 // LDS row stride in bytes: 80, 80/16 = 5 odd -> conflict-free
     constexpr int A_PLANE = BM * RS, B_PLANE = BN * RS;
-    constexpr int PA = BM / 16;                     // A staging: 16 rows x 16 float4 per pass
-    constexpr int PB = BN / 32;                     // B staging: 32 rows x 8 chunks (8 bf16) per pass and plane
-    static_assert(PA <= 8, "okmask holds 8 row bits");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[NP * (A_PLANE + B_PLANE)];
-    unsigned char* As = smem;
-    unsigned char* Bs = smem + NP * A_PLANE;
+    constexpr int BUF = NP * (A_PLANE + B_PLANE);
+    constexpr int PA = BM / 32;                     // A staging: 32 rows x 8 float4 per pass
+    constexpr int PB = BN / 64;                     // B staging: 64 rows x 4 chunks (8 bf16) per pass and plane
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -608,14 +607,14 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
     const int nt = logical - mt * a.ntn;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    const int lrow = tid >> 4, kq = tid & 15;       // A: row within pass, float4 within the 64-wide slice
-    const int brow = tid >> 3, bch = tid & 7;       // B: row within pass, 16-byte chunk (8 bf16) within the slice
+    const int lrow = tid >> 3, kq = tid & 7;        // A: row within pass, float4 within the 32-wide slice
+    const int brow = tid >> 2, bch = tid & 3;       // B: row within pass, 16-byte chunk (8 bf16) within the slice
 
     int hb[PA], wb[PA], ib[PA], roff[PA];
     unsigned tmask[PA];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        int m = m0 + i * 16 + lrow;
+        int m = m0 + i * 32 + lrow;
         int mm = m < a.M ? m : a.M - 1;
         int img = fdiv(mm, a.fPQ);
         int rem = mm - img * (a.P * a.Q);
@@ -641,79 +640,91 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
     size_t wofs[PB];   // bf16-element offset of this thread's chunk in each staged weight row
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
-        int n = n0 + j * 32 + brow;
+        int n = n0 + j * 64 + brow;
         wofs[j] = (size_t)(n < a.Ng ? n : a.Ng - 1) * a.Ktot + bch * 8;
     }
 
-    float4 ra[PA];
-    u32x4 rbh[PB], rbl[PB];
-    unsigned okmask = 0;
-    int tap_c = 0, ci0_c = 0;
+    const int nk = a.Ktot / KT;
+    const int spt = (int)a.fSpt.d;                  // K slices per filter tap
 
-    auto gload = [&](int kt) {
-        const int tap = tap_c, ci = ci0_c + kq * 4;
-        int r = fdiv(tap, a.fS);
-        int sx = tap - r * a.S;
-        int dh = r * a.tapstep, dw = sx * a.tapstep;
-        unsigned msk = 0;
-        if (FAST) {
-            const int delta = (dh * a.W + dw) * a.ldx + ci;
-#pragma unroll
-            for (int i = 0; i < PA; ++i) {
-                const bool ok = (tmask[i] >> tap) & 1u;
-                const int off = ok ? roff[i] + delta : 0;
-                ra[i] = *reinterpret_cast<const float4*>(a.x + off);
-                msk |= ok ? (1u << i) : 0u;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < PA; ++i) {
-                int h = hb[i] + dh, w = wb[i] + dw;
-                bool ok = h >= 0 && w >= 0 && !((h | w) & a.divmask);
-                h >>= a.divshift;
-                w >>= a.divshift;
-                ok = ok && h < a.H && w < a.W;
-                size_t off = ok ? (size_t)(ib[i] + h * a.W + w) * a.ldx + ci : (size_t)0;
-                ra[i] = *reinterpret_cast<const float4*>(a.x + off);
-                msk |= ok ? (1u << i) : 0u;
-            }
-        }
-        const size_t koff = (size_t)kt * KT;
-#pragma unroll
-        for (int j = 0; j < PB; ++j) {
-            rbh[j] = *reinterpret_cast<const u32x4*>(a.w_hi + wofs[j] + koff);
-            if (SPLIT) rbl[j] = *reinterpret_cast<const u32x4*>(a.w_lo + wofs[j] + koff);
-        }
-        okmask = msk;
-        ci0_c += KT;
-        if (ci0_c >= a.Cp) {
-            ci0_c = 0;
-            tap_c += 1;
-        }
+    // two register staging sets
+    float4 raX[PA], raY[PA];
+    // B staging registers are named scalars (PB <= 2): as uint4 arrays one set stayed in scratch memory
+    static_assert(PB <= 2, "two weight rows per thread at most");
+    uint4 rbhX0, rbhX1, rblX0, rblX1, rbhY0, rbhY1, rblY0, rblY1;
+    rbhX0 = rbhX1 = rblX0 = rblX1 = rbhY0 = rbhY1 = rblY0 = rblY1 = make_uint4(0u, 0u, 0u, 0u);
+    unsigned okX = 0, okY = 0;
+
+    // The two staging sets are addressed by NAME (macro-generated lambdas capturing the arrays directly): passing
+    // the arrays to one generic lambda by reference kept them in scratch memory.
+#define UP_BF16_STAGE(SFX)                                                                                           \
+    auto gload##SFX = [&](int kt_req) {                                                                              \
+        const int kt = kt_req < nk ? kt_req : nk - 1;                                                                \
+        const int tap = fdiv(kt, a.fSpt);                                                                            \
+        const int ci = (kt - tap * spt) * KT + kq * 4;                                                               \
+        int r = fdiv(tap, a.fS);                                                                                     \
+        int sx = tap - r * a.S;                                                                                      \
+        int dh = r * a.tapstep, dw = sx * a.tapstep;                                                                 \
+        unsigned msk = 0;                                                                                            \
+        if (FAST) {                                                                                                  \
+            const int delta = (dh * a.W + dw) * a.ldx + ci;                                                          \
+            _Pragma("unroll") for (int i = 0; i < PA; ++i) {                                                         \
+                const bool ok = (tmask[i] >> tap) & 1u;                                                              \
+                const int off = ok ? roff[i] + delta : 0;                                                            \
+                ra##SFX[i] = *reinterpret_cast<const float4*>(a.x + off);                                            \
+                msk |= ok ? (1u << i) : 0u;                                                                          \
+            }                                                                                                        \
+        } else {                                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < PA; ++i) {                                                         \
+                int h = hb[i] + dh, w = wb[i] + dw;                                                                  \
+                bool ok = h >= 0 && w >= 0 && !((h | w) & a.divmask);                                                \
+                h >>= a.divshift;                                                                                    \
+                w >>= a.divshift;                                                                                    \
+                ok = ok && h < a.H && w < a.W;                                                                       \
+                size_t off = ok ? (size_t)(ib[i] + h * a.W + w) * a.ldx + ci : (size_t)0;                            \
+                ra##SFX[i] = *reinterpret_cast<const float4*>(a.x + off);                                            \
+                msk |= ok ? (1u << i) : 0u;                                                                          \
+            }                                                                                                        \
+        }                                                                                                            \
+        const size_t koff = (size_t)kt * KT;                                                                         \
+        rbh##SFX##0 = *reinterpret_cast<const uint4*>(a.w_hi + wofs[0] + koff);                                      \
+        if (SPLIT) rbl##SFX##0 = *reinterpret_cast<const uint4*>(a.w_lo + wofs[0] + koff);                           \
+        if (PB > 1) {                                                                                                \
+            rbh##SFX##1 = *reinterpret_cast<const uint4*>(a.w_hi + wofs[PB - 1] + koff);                             \
+            if (SPLIT) rbl##SFX##1 = *reinterpret_cast<const uint4*>(a.w_lo + wofs[PB - 1] + koff);                  \
+        }                                                                                                            \
+        ok##SFX = msk;                                                                                               \
+    };                                                                                                               \
+    auto lstore##SFX = [&](int buf) {                                                                                \
+        unsigned char* As = smem + buf * BUF;                                                                        \
+        unsigned char* Bs = As + NP * A_PLANE;                                                                       \
+        _Pragma("unroll") for (int i = 0; i < PA; ++i) {                                                             \
+            const float4 v = keep_or_zero((ok##SFX >> i) & 1u, ra##SFX[i]);                                          \
+            uint2 hi, lo;                                                                                            \
+            if (SPLIT) {                                                                                             \
+                split_bf16x2(v.x, v.y, hi.x, lo.x);                                                                  \
+                split_bf16x2(v.z, v.w, hi.y, lo.y);                                                                  \
+            } else {                                                                                                 \
+                hi.x = pack_bf16x2(v.x, v.y);                                                                        \
+                hi.y = pack_bf16x2(v.z, v.w);                                                                        \
+            }                                                                                                        \
+            unsigned char* d = As + (i * 32 + lrow) * RS + kq * 8;                                                   \
+            *reinterpret_cast<uint2*>(d) = hi;                                                                       \
+            if (SPLIT) *reinterpret_cast<uint2*>(d + A_PLANE) = lo;                                                  \
+        }                                                                                                            \
+        {                                                                                                            \
+            unsigned char* d = Bs + brow * RS + bch * 16;                                                            \
+            *reinterpret_cast<uint4*>(d) = rbh##SFX##0;                                                              \
+            if (SPLIT) *reinterpret_cast<uint4*>(d + B_PLANE) = rbl##SFX##0;                                         \
+            if (PB > 1) {                                                                                            \
+                *reinterpret_cast<uint4*>(d + 64 * RS) = rbh##SFX##1;                                                \
+                if (SPLIT) *reinterpret_cast<uint4*>(d + 64 * RS + B_PLANE) = rbl##SFX##1;                           \
+            }                                                                                                        \
+        }                                                                                                            \
     };
-    auto lstore = [&]() {
-#pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            const float4 v = keep_or_zero((okmask >> i) & 1u, ra[i]);
-            u32x2 hi, lo;
-            if (SPLIT) {
-                split_bf16x2(v.x, v.y, hi.x, lo.x);
-                split_bf16x2(v.z, v.w, hi.y, lo.y);
-            } else {
-                hi.x = pack_bf16x2(v.x, v.y);
-                hi.y = pack_bf16x2(v.z, v.w);
-            }
-            unsigned char* d = As + (i * 16 + lrow) * RS + kq * 8;
-            *reinterpret_cast<u32x2*>(d) = hi;
-            if (SPLIT) *reinterpret_cast<u32x2*>(d + A_PLANE) = lo;
-        }
-#pragma unroll
-        for (int j = 0; j < PB; ++j) {
-            unsigned char* d = Bs + (j * 32 + brow) * RS + bch * 16;
-            *reinterpret_cast<u32x4*>(d) = rbh[j];
-            if (SPLIT) *reinterpret_cast<u32x4*>(d + B_PLANE) = rbl[j];
-        }
-    };
+    UP_BF16_STAGE(X)
+    UP_BF16_STAGE(Y)
+#undef UP_BF16_STAGE
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -723,46 +734,51 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = a.Ktot / KT;
-    gload(0);
-    lstore();
+    const int a_rd = (wm * (BM / 2) + l31) * RS + lh * 16;
+    const int b_rd = NP * A_PLANE + (wn * (BN / 2) + l31) * RS + lh * 16;
+
+    // one K slice: MFMAs from LDS buffer kt&1; in between, slice kt+1 (register set S) goes to the other buffer
+    // and S is refilled with slice kt+3
+    // one K slice: MFMAs from LDS buffer kt&1; in between, slice kt+1 (register set SFX) goes to the other buffer
+    // and the set is refilled with slice kt+3.  (Generated per set: closures passed as arguments also forced the
+    // staging arrays into scratch.)
+#define UP_BF16_BODY(SFX)                                                                                             \
+    auto body##SFX = [&](int kt) {                                                                                    \
+        const unsigned char* base = smem + (kt & 1) * BUF;                                                            \
+        _Pragma("unroll") for (int s = 0; s < KT / 16; ++s) {                                                         \
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];                                                                    \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                          \
+                ah[i] = *reinterpret_cast<const bf16x8*>(base + a_rd + i * 32 * RS + s * 32);                         \
+                if (SPLIT) al[i] = *reinterpret_cast<const bf16x8*>(base + a_rd + A_PLANE + i * 32 * RS + s * 32);    \
+            }                                                                                                         \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                          \
+                bh[j] = *reinterpret_cast<const bf16x8*>(base + b_rd + j * 32 * RS + s * 32);                         \
+                if (SPLIT) bl[j] = *reinterpret_cast<const bf16x8*>(base + b_rd + B_PLANE + j * 32 * RS + s * 32);    \
+            }                                                                                                         \
+            if (s == 0) lstore##SFX((kt & 1) ^ 1);                                                                    \
+            if (s == KT / 16 - 1) gload##SFX(kt + 3);                                                                 \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) {           \
+                if (SPLIT) { /* small cross terms first, the dominant product last */                                 \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);            \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);            \
+                }                                                                                                     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);                \
+            }                                                                                                         \
+        }                                                                                                             \
+        __syncthreads();                                                                                              \
+    };
+    UP_BF16_BODY(X)
+    UP_BF16_BODY(Y)
+#undef UP_BF16_BODY
+
+    gloadX(0);
+    lstoreX(0);
+    gloadX(1);
+    gloadY(2);
     __syncthreads();
-
-    const unsigned char* Ard = As + (wm * (BM / 2) + l31) * RS + lh * 16;
-    const unsigned char* Brd = Bs + (wn * (BN / 2) + l31) * RS + lh * 16;
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) gload(kt + 1);
-#pragma unroll
-        for (int s = 0; s < KT / 16; ++s) {
-            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                ah[i] = *reinterpret_cast<const bf16x8*>(Ard + i * 32 * RS + s * 32);
-                if (SPLIT) al[i] = *reinterpret_cast<const bf16x8*>(Ard + A_PLANE + i * 32 * RS + s * 32);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bh[j] = *reinterpret_cast<const bf16x8*>(Brd + j * 32 * RS + s * 32);
-                if (SPLIT) bl[j] = *reinterpret_cast<const bf16x8*>(Brd + B_PLANE + j * 32 * RS + s * 32);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (SPLIT) {   // small cross terms first, the dominant product last
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
-        }
-        __syncthreads();
-        if (more) {
-            lstore();
-            __syncthreads();
-        }
+    for (int kt = 0; kt < nk; kt += 2) {
+        bodyX(kt);
+        if (kt + 1 < nk) bodyY(kt + 1);
     }
     igemm_epilogue<BM, BN>(a, acc, reinterpret_cast<float*>(smem), mt, m0, n0, wm, wn, l31, lh);
 }
@@ -1206,8 +1222,9 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
 }
 static int run_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
     UP_REQUIRE(math == UP_MATH_BF16X3 || math == UP_MATH_BF16, UP_ERR_INVALID, "bf16 convolution: math mode %d", math);
-    UP_REQUIRE(a.Cp % 64 == 0, UP_ERR_UNSUPPORTED, "bf16 convolution: padded channel count %d is not a multiple of 64",
+    UP_REQUIRE(a.Cp % 32 == 0, UP_ERR_UNSUPPORTED, "bf16 convolution: padded channel count %d is not a multiple of 32",
                a.Cp);
+    a.fSpt = make_fastdiv(a.Cp / 32);
     TileChoice t = choose_tile(a.M, a.Ng);
     if (t.bm == 128 && t.bn == 128)
         launch_igemm_bf16<128, 128>(a, math, st);

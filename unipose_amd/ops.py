@@ -8,6 +8,7 @@ raw pointers and run on the current stream.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from typing import Optional
 
@@ -125,17 +126,21 @@ def _packed(weight: torch.Tensor, d: _C.ConvDesc):
 #   0  exact fp32 (v_mfma_f32_32x32x2_f32)                                  -- default, parity configuration
 #   1  split-bf16: a*b ~= ah*bh + ah*bl + al*bh on bf16 MFMA, fp32-equivalent (2^-16 per product)
 #   2  plain bf16 operands, fp32 accumulation (BASELINE config 5)
-# Layers whose padded channel count is not a multiple of 64 (stem, 15-channel ConvLSTM convs) stay exact.
+# Layers whose padded channel count is not a multiple of 32 (stem, 15-channel ConvLSTM convs) stay exact.
 MATH_F32, MATH_BF16X3, MATH_BF16 = 0, 1, 2
 CONV_MATH = MATH_F32
+_MATH_NAMES = {"f32": 0, "fp32": 0, "bf16x3": 1, "split": 1, "bf16": 2}
 
 
 def set_conv_math(mode):
     global CONV_MATH
-    CONV_MATH = {"f32": 0, "fp32": 0, "bf16x3": 1, "split": 1, "bf16": 2}.get(mode, mode)
+    CONV_MATH = _MATH_NAMES.get(mode, mode)
     if CONV_MATH not in (0, 1, 2):
         raise ValueError(f"unknown conv math {mode!r}")
 
+
+if os.environ.get("UNIPOSE_CONV_MATH"):           # e.g. UNIPOSE_CONV_MATH=bf16x3 python -m pytest tests -m gpu
+    set_conv_math(os.environ["UNIPOSE_CONV_MATH"])
 
 _PACK16_CACHE = {}
 
@@ -185,7 +190,7 @@ def conv_fwd_raw(x, weight, cfg, *, scale=None, shift=None, bias=None, residual=
         tiles = _C.lib().up_conv_stats_tiles(C.byref(d))
         st = torch.empty((tiles, d.K, 3), dtype=torch.float32, device=x.device)
         ep.stats = st.data_ptr()
-    if CONV_MATH != MATH_F32 and d.Cp % 64 == 0:
+    if CONV_MATH != MATH_F32 and d.Cp % 32 == 0:
         wf, _ = _packed_bf16(weight, d)
         _C.check(_C.lib().up_conv2d_fwd_bf16(C.byref(d), x.data_ptr(), wf[0].data_ptr(), wf[1].data_ptr(),
                                              out.data_ptr(), C.byref(ep), CONV_MATH, _stream(x)), "conv2d_fwd_bf16")
@@ -203,7 +208,7 @@ def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev):
     dd = _C.ConvDesc.from_buffer_copy(d)
     dd.ldx = cp
     dd.ldy = _nhwc_ok(dy)
-    if CONV_MATH != MATH_F32 and d.Kp % 64 == 0:
+    if CONV_MATH != MATH_F32 and d.Kp % 32 == 0:
         _, wd16 = _packed_bf16(weight, d)
         _C.check(_C.lib().up_conv2d_bwd_data_bf16(C.byref(dd), dy.data_ptr(), wd16[0].data_ptr(), wd16[1].data_ptr(),
                                                   dx.data_ptr(), CONV_MATH, _stream(dy)), "conv2d_bwd_data_bf16")
