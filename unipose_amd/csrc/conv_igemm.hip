@@ -583,18 +583,20 @@ __device__ __forceinline__ void split_bf16x2(float a0, float a1, uint32_t& hi, u
 // the blocks sharing the SIMD) to land — the bf16 MFMA phase alone (768 cycles) is shorter than the memory
 // latency, which made the first single-stage version of this kernel latency-bound.  One barrier per slice.
 // Slice indices past the end are clamped (harmless reloads): the loop body is branch-free.
-template <int BM, int BN, int MODE, bool SPLIT>
+template <int BM, int BN, int MODE, bool SPLIT, int KT = 32>
 __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
     static_assert(MODE == 1 || MODE == 2, "bf16 kernels need channel counts that are multiples of the K slice");
     constexpr bool FAST = MODE == 2;
-    constexpr int KT = 32;
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int NP = SPLIT ? 2 : 1;
-    constexpr int RS = KT * 2 + 16;                 // LDS row stride in bytes: 80, 80/16 = 5 odd -> conflict-free
+    constexpr int RS = KT * 2 + 16;                 // LDS row stride in bytes: 80 / 144, (RS/16) odd -> conflict-free
     constexpr int A_PLANE = BM * RS, B_PLANE = BN * RS;
     constexpr int BUF = NP * (A_PLANE + B_PLANE);
-    constexpr int PA = BM / 32;                     // A staging: 32 rows x 8 float4 per pass
-    constexpr int PB = BN / 64;                     // B staging: 64 rows x 4 chunks (8 bf16) per pass and plane
+    constexpr int Q4 = KT / 4, RPA = 256 / Q4;      // A staging: RPA rows x Q4 float4 per pass
+    constexpr int C8 = KT / 8, RPB = 256 / C8;      // B staging: RPB rows x C8 chunks (8 bf16) per pass and plane
+    constexpr int PA = BM / RPA;
+    constexpr int PB = BN / RPB;
+    static_assert(PA <= 8, "okmask holds 8 row bits");
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
 
     const int tid = threadIdx.x;
@@ -607,14 +609,14 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
     const int nt = logical - mt * a.ntn;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    const int lrow = tid >> 3, kq = tid & 7;        // A: row within pass, float4 within the 32-wide slice
-    const int brow = tid >> 2, bch = tid & 3;       // B: row within pass, 16-byte chunk (8 bf16) within the slice
+    const int lrow = tid / Q4, kq = tid % Q4;       // A: row within pass, float4 within the K slice
+    const int brow = tid / C8, bch = tid % C8;      // B: row within pass, 16-byte chunk (8 bf16) within the slice
 
     int hb[PA], wb[PA], ib[PA], roff[PA];
     unsigned tmask[PA];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        int m = m0 + i * 32 + lrow;
+        int m = m0 + i * RPA + lrow;
         int mm = m < a.M ? m : a.M - 1;
         int img = fdiv(mm, a.fPQ);
         int rem = mm - img * (a.P * a.Q);
@@ -640,12 +642,13 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
     size_t wofs[PB];   // bf16-element offset of this thread's chunk in each staged weight row
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
-        int n = n0 + j * 64 + brow;
+        int n = n0 + j * RPB + brow;
         wofs[j] = (size_t)(n < a.Ng ? n : a.Ng - 1) * a.Ktot + bch * 8;
     }
 
     const int nk = a.Ktot / KT;
-    const int spt = (int)a.fSpt.d;                  // K slices per filter tap
+    const int spt = a.Cp / KT;                      // K slices per filter tap
+    const FastDiv fspt = a.fSpt;
 
     // two register staging sets
     float4 raX[PA], raY[PA];
@@ -660,7 +663,7 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
 #define UP_BF16_STAGE(SFX)                                                                                           \
     auto gload##SFX = [&](int kt_req) {                                                                              \
         const int kt = kt_req < nk ? kt_req : nk - 1;                                                                \
-        const int tap = fdiv(kt, a.fSpt);                                                                            \
+        const int tap = fdiv(kt, fspt);                                                                              \
         const int ci = (kt - tap * spt) * KT + kq * 4;                                                               \
         int r = fdiv(tap, a.fS);                                                                                     \
         int sx = tap - r * a.S;                                                                                      \
@@ -708,7 +711,7 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
                 hi.x = pack_bf16x2(v.x, v.y);                                                                        \
                 hi.y = pack_bf16x2(v.z, v.w);                                                                        \
             }                                                                                                        \
-            unsigned char* d = As + (i * 32 + lrow) * RS + kq * 8;                                                   \
+            unsigned char* d = As + (i * RPA + lrow) * RS + kq * 8;                                                  \
             *reinterpret_cast<uint2*>(d) = hi;                                                                       \
             if (SPLIT) *reinterpret_cast<uint2*>(d + A_PLANE) = lo;                                                  \
         }                                                                                                            \
@@ -717,8 +720,8 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
             *reinterpret_cast<uint4*>(d) = rbh##SFX##0;                                                              \
             if (SPLIT) *reinterpret_cast<uint4*>(d + B_PLANE) = rbl##SFX##0;                                         \
             if (PB > 1) {                                                                                            \
-                *reinterpret_cast<uint4*>(d + 64 * RS) = rbh##SFX##1;                                                \
-                if (SPLIT) *reinterpret_cast<uint4*>(d + 64 * RS + B_PLANE) = rbl##SFX##1;                           \
+                *reinterpret_cast<uint4*>(d + RPB * RS) = rbh##SFX##1;                                               \
+                if (SPLIT) *reinterpret_cast<uint4*>(d + RPB * RS + B_PLANE) = rbl##SFX##1;                          \
             }                                                                                                        \
         }                                                                                                            \
     };
@@ -1211,20 +1214,34 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
     const bool fast = a.taps <= 32 && a.divshift == 0 &&
                       (long long)a.H * a.W * a.ldx * ((long long)a.M / (a.P * a.Q) + 1) < (1ll << 31);
     const bool split = math == UP_MATH_BF16X3;
+    // K slice: 64 on the 64x64 tile (6 -> 12 MFMAs per wave and barrier) measured no faster than 32 (141.7 vs 145.1 TF)
+    constexpr int KT = 32;
+    if (a.Cp % KT != 0) {   // e.g. Cp = 32: fall back to the 32-wide slice
+        a.fSpt = make_fastdiv(a.Cp / 32);
+        if (fast && split)
+            hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 2, true, 32>), dim3(a.nwg), dim3(256), 0, st, a);
+        else if (fast)
+            hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 2, false, 32>), dim3(a.nwg), dim3(256), 0, st, a);
+        else if (split)
+            hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 1, true, 32>), dim3(a.nwg), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 1, false, 32>), dim3(a.nwg), dim3(256), 0, st, a);
+        return;
+    }
+    a.fSpt = make_fastdiv(a.Cp / KT);
     if (fast && split)
-        hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 2, true>), dim3(a.nwg), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 2, true, KT>), dim3(a.nwg), dim3(256), 0, st, a);
     else if (fast)
-        hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 2, false>), dim3(a.nwg), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 2, false, KT>), dim3(a.nwg), dim3(256), 0, st, a);
     else if (split)
-        hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 1, true>), dim3(a.nwg), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 1, true, KT>), dim3(a.nwg), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 1, false>), dim3(a.nwg), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 1, false, KT>), dim3(a.nwg), dim3(256), 0, st, a);
 }
 static int run_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
     UP_REQUIRE(math == UP_MATH_BF16X3 || math == UP_MATH_BF16, UP_ERR_INVALID, "bf16 convolution: math mode %d", math);
     UP_REQUIRE(a.Cp % 32 == 0, UP_ERR_UNSUPPORTED, "bf16 convolution: padded channel count %d is not a multiple of 32",
                a.Cp);
-    a.fSpt = make_fastdiv(a.Cp / 32);
     TileChoice t = choose_tile(a.M, a.Ng);
     if (t.bm == 128 && t.bn == 128)
         launch_igemm_bf16<128, 128>(a, math, st);
