@@ -12,8 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libunipose_hip.so")
 
-c_f32p = C.c_void_p       # device pointers travel as integers (tensor.data_ptr())
-c_stream = C.c_void_p
+# device pointers and the hipStream_t travel as integers (tensor.data_ptr(), stream.cuda_stream) -> c_void_p
 
 
 class ConvDesc(C.Structure):

@@ -85,7 +85,7 @@ struct IgemmArgs {
     const uint16_t* w_hi;   // bf16-operand kernels: packed weights as bf16 planes (hi, and lo = bf16(w - hi))
     const uint16_t* w_lo;
     float* y;
-    int M, Ng, Ktot, Cp, Creal;
+    int M, Ng, Ktot, Cp;
     long long Ktot_real;  // taps * real channels: the algorithmic reduction length (profiling only)
     int H, W, P, Q;  // source H,W; destination P,Q
     int ldx, ldy;
@@ -814,7 +814,7 @@ struct WgradArgs {
     const float* x;
     const float* dy;
     float* slab;
-    int M, K, Ncols, Cp, Creal;
+    int M, K, Ncols, Cp;
     int H, W, P, Q;
     int ldx, ldy;
     int S;
@@ -1120,7 +1120,6 @@ static int fill_fwd_args(IgemmArgs& a, const up_conv_desc* d, const float* x, co
     a.M = d->N * d->P * d->Q;
     a.Ng = d->K;
     a.Cp = d->Cp;
-    a.Creal = d->C;
     a.Ktot = d->R * d->S * d->Cp;
     a.Ktot_real = (long long)d->R * d->S * d->C;
     a.H = d->H;
@@ -1179,7 +1178,6 @@ static int fill_dgrad_args(IgemmArgs& a, const up_conv_desc* d, const float* dy,
     a.M = d->N * d->H * d->W;
     a.Ng = d->C;
     a.Cp = d->Kp;
-    a.Creal = d->K;
     a.Ktot = d->R * d->S * d->Kp;
     a.Ktot_real = (long long)d->R * d->S * d->K;
     a.H = d->P;
@@ -1359,7 +1357,6 @@ extern "C" int up_conv2d_bwd_weight(const up_conv_desc* d, const float* x, const
     a.M = d->N * d->P * d->Q;
     a.K = d->K;
     a.Cp = d->Cp;
-    a.Creal = d->C;
     a.Ncols = d->R * d->S * d->Cp;
     a.H = d->H;
     a.W = d->W;

@@ -90,12 +90,6 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* stats, in
     }
 }
 
-struct Apply2D {
-    int64_t rows;
-    int C4;
-    FastDiv fC4;
-};
-
 __global__ void __launch_bounds__(256) bn_apply_kernel(const float* y, int ldy, const float* scale,
                                                        const float* shift, const float* res, int ldr, int relu,
                                                        float* z, int ldz, int64_t total, int C4, FastDiv fC4) {

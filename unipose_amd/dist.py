@@ -1,27 +1,27 @@
-"""Data-parallel gradient exchange: one process per GPU, batch sharded, weights replicated, ONE
-all-reduce (average) of the parameter gradients per step over RCCL/xGMI (``torch.distributed`` backend
-"nccl" on ROCm), bucketed in reverse-registration (~ reverse autograd) order and launched from
-post-accumulate-grad hooks so the exchange overlaps the rest of backward.
+"""Data-parallel gradient exchange: one process per GPU, batch sharded, weights replicated, the parameter
+gradients averaged once per step over RCCL/xGMI (``torch.distributed`` backend "nccl" on ROCm).
 
 The reference has no distributed code at all; BatchNorm statistics stay per-GPU exactly
 like its plain nn.BatchNorm2d.  Parameters that never receive a gradient (decoder.conv2 / bn2,
-SURVEY D9) are detected on the first step and left out of the buckets.
+SURVEY D9) are detected on the first step and left out of the exchange.
 
-Stream discipline (GPU): weight gradients are produced on the side stream of ``unipose_amd.ops``; the
-bucket fill (one multi-tensor copy per bucket) and the collective are issued on that same side stream, so
-the main stream — the critical path of backward — never waits for the exchange until ``finish()``.
-After the all-reduce ``param.grad`` simply becomes a view of the bucket (no copy back, no scaling pass:
+Two forms (``overlap``):
+  * default — after backward: ONE multi-tensor copy of every gradient into flat buffers and one all-reduce per
+    buffer (32 MB granularity); measured faster for this model than the hook form (see ``GradAllReducer``).
+  * ``overlap=True`` — buckets in reverse-registration (~ reverse autograd) order, each launched from
+    post-accumulate-grad hooks on the weight-gradient side stream of ``unipose_amd.ops`` so the main stream — the
+    critical path of backward — never waits for the exchange until ``finish()``.
+After the all-reduce ``param.grad`` simply becomes a view of the flat buffer (no copy back, no scaling pass:
 the collective averages).
 """
 from __future__ import annotations
 
 from typing import List, Optional
 
+import os
+
 import torch
 import torch.distributed as dist
-
-
-import os
 
 _DEBUG = os.environ.get("UP_DP_DEBUG", "")      # development switch: "hook-only" = hooks fire, nothing is exchanged
 

@@ -584,31 +584,6 @@ class ConcatC(Function):
         return (None, *outs)
 
 
-def narrow_c(x, c: int):
-    """First c channels of an NHWC tensor as a dense tensor (used to drop pad channels)."""
-    return SliceC.apply(x, c)
-
-
-class SliceC(Function):
-    @staticmethod
-    def forward(ctx, x, c: int):
-        _dev_ok(x)
-        n, h, w, ld = x.shape
-        y = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
-        _C.check(_C.lib().up_copy2d(x.data_ptr(), _nhwc_ok(x), y.data_ptr(), c, n * h * w, c, _stream(x)), "copy2d")
-        ctx.ld = ld
-        return y
-
-    @staticmethod
-    @once_differentiable
-    def backward(ctx, dy):
-        dy = _dense(dy)
-        n, h, w, c = dy.shape
-        dx = torch.zeros((n, h, w, ctx.ld), dtype=torch.float32, device=dy.device)
-        _C.check(_C.lib().up_copy2d(dy.data_ptr(), c, dx.data_ptr(), ctx.ld, n * h * w, c, _stream(dy)), "copy2d")
-        return dx, None
-
-
 class Dropout(Function):
     """nn.Dropout (wasp.py:63,90; decoder.py:25,29).  `ext_mask` (float 0/1, same shape) injects the
     keep decisions for parity tests; otherwise a counter hash of (seed, element index) is used."""
