@@ -188,7 +188,8 @@ def test_full_size_step_properties():
     with torch.no_grad():
         y = m(x)
         parts = torch.cat([m(x[i:i + 4]) for i in range(0, B, 4)])
-    assert O.max_rel(parts.cpu(), y.cpu()) < 1e-6
+    # not bitwise: which tiles are K-split (another summation order) depends on the launch's tile count
+    assert O.max_rel(parts.cpu(), y.cpu()) < 1e-5
     _, _, idx = ops.heatmap_argmax(y)
     assert torch.equal(idx.cpu().long(), y.cpu().reshape(B, K + 1, -1).argmax(2))
 

@@ -25,6 +25,28 @@ def test_conv_fwd_bwd(emu_backend, cfg):
     oc.conv_case(emu_backend, n, c, h, w, k, r, s, p, d, bias=bias, relu=relu)
 
 
+@pytest.mark.parametrize("cfg,parts", [
+    # short tile tail (tiles % CUs small) -> the tail tiles are split along K into `parts` (include/unipose_hip.h)
+    ((1, 64, 5, 5, 32, 3, 1, 1, 1, False, False), 2),     # K = 576: 18 slices -> 2 parts
+    ((2, 128, 6, 6, 72, 3, 1, 1, 1, False, False), 4),    # 36 slices -> 4 parts; 2 n-tiles, ragged rows
+    ((1, 2048, 3, 3, 16, 1, 1, 0, 1, True, True), 8),     # 64 slices -> 8 parts, bias + ReLU epilogue after the merge
+    ((1, 256, 6, 6, 64, 3, 2, 1, 1, False, False), 8),    # strided: MODE 1 data gradient is split as well
+])
+def test_conv_tail_split(emu_backend, cfg, parts):
+    import ctypes
+    from unipose_amd import _C, ops
+    n, c, h, w, k, r, s, p, d, bias, relu = cfg
+    x = torch.zeros(n, h, w, c)
+    desc = ops.make_desc(x, torch.zeros(k, c, r, r), ops.ConvCfg(s, p, d))
+    assert _C.lib().up_conv_split_parts(ctypes.byref(desc)) == parts
+    oc.conv_case(emu_backend, n, c, h, w, k, r, s, p, d, bias=bias, relu=relu)
+
+
+def test_conv_bn_tail_split(emu_backend):
+    # batch statistics are reduced from the MERGED accumulators of a split tile
+    oc.conv_bn_case(emu_backend, 2, 128, 5, 5, 48, 3, 1, 1, 1, relu=True, residual=True, train=True)
+
+
 def test_conv_multi_tile(emu_backend):
     # M = 2*13*11 = 286 rows -> several 64-row tiles with a ragged tail; K = 80 -> 2 n-tiles of 64
     oc.conv_case(emu_backend, 2, 16, 13, 11, 80, 3, 1, 1, 1)
@@ -130,6 +152,7 @@ def guard_pages(emu_backend, monkeypatch):
     (1, 15, 6, 6, 14, 3, 1, 1, 1, True, True),
     (1, 128, 5, 5, 32, 3, 1, 1, 1, False, False),     # double-buffered loop
     (1, 64, 6, 6, 17, 1, 1, 0, 1, True, False),       # K=17 -> ldy 20
+    (2, 128, 6, 6, 72, 3, 1, 1, 1, False, False),     # K-split tail tiles (4 parts)
 ])
 def test_conv_no_out_of_bounds(guard_pages, cfg):
     n, c, h, w, k, r, s, p, d, bias, relu = cfg

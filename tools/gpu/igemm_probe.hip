@@ -1,25 +1,30 @@
-// Ablation probe for the implicit-GEMM kernel (development tool, not part of the library):
+// Development probe for the implicit-GEMM kernel (not part of the library):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gpu/igemm_probe.hip -o tools/gpu/igemm_probe
-// Times igemm_kernel<BM,BN,true,DBG> for DBG ablations on two real layer shapes with hipEvents.
+// For a few real layer shapes it times the production variant and records a per-workgroup timeline
+// (start / end of the K loop / stores drained + XCC, SE, CU ids) to show where the CUs idle.
 #include "../../unipose_amd/csrc/conv_igemm.hip"
 #include "../../unipose_amd/csrc/norm_act.hip"
 
+#include <algorithm>
+#include <map>
 #include <vector>
 
 using namespace up;
 
-template <int BM, int BN, int DBG, int KT = 32>
+template <int BM, int BN, int DBG>
 static float run(IgemmArgs a, int iters) {
     a.ntn = cdiv(a.Ng, BN);
     a.nwg = cdiv(a.M, BM) * a.ntn;
     a.fNtn = make_fastdiv(a.ntn);
     a.fSpt = make_fastdiv(a.Cp / 32);
+    a.full_blocks = a.nwg;
+    a.parts = 1;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, DBG, KT>), dim3(a.nwg), dim3(256), 0, 0, a);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, DBG>), dim3(a.nwg), dim3(256), 0, 0, a);
     hipEventRecord(e0, 0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, DBG, KT>), dim3(a.nwg), dim3(256), 0, 0, a);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, DBG>), dim3(a.nwg), dim3(256), 0, 0, a);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms;
@@ -27,7 +32,77 @@ static float run(IgemmArgs a, int iters) {
     return ms / iters;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int DBG>
+static void timeline(IgemmArgs a, double mfma_ticks_per_block) {
+    a.ntn = cdiv(a.Ng, BN);
+    a.nwg = cdiv(a.M, BM) * a.ntn;
+    a.fNtn = make_fastdiv(a.ntn);
+    a.fSpt = make_fastdiv(a.Cp / 32);
+    a.full_blocks = a.nwg;
+    a.parts = 1;
+    long long* dbg;
+    hipMalloc(&dbg, (size_t)a.nwg * 32);
+    a.dbg = dbg;
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, DBG | 32>), dim3(a.nwg), dim3(256), 0, 0, a);
+    hipDeviceSynchronize();
+    std::vector<long long> h((size_t)a.nwg * 4);
+    hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+    hipFree(dbg);
+    long long t0 = h[0], t1 = h[2];
+    for (int b = 0; b < a.nwg; ++b) { t0 = std::min(t0, h[4 * b]); t1 = std::max(t1, h[4 * b + 2]); }
+    double span = (double)(t1 - t0);
+    std::map<long long, std::vector<int>> by_cu;
+    double loop = 0, epi = 0;
+    for (int b = 0; b < a.nwg; ++b) {
+        long long id = h[4 * b + 3];
+        long long key = (((id >> 32) & 15) << 16) | (((id >> 13) & 7) << 8) | ((id >> 8) & 15);   // xcc, se, cu
+        by_cu[key].push_back(b);
+        loop += h[4 * b + 1] - h[4 * b];
+        epi += h[4 * b + 2] - h[4 * b + 1];
+    }
+    // residency histogram: fraction of (CU x time) with 0,1,2,3+ workgroups resident
+    double occ[5] = {0, 0, 0, 0, 0}, gap = 0; long gaps = 0;
+    size_t minb = 1 << 30, maxb = 0;
+    for (auto& kv : by_cu) {
+        std::vector<std::pair<long long, int>> ev;
+        for (int b : kv.second) { ev.push_back({h[4 * b], +1}); ev.push_back({h[4 * b + 2], -1}); }
+        std::sort(ev.begin(), ev.end());
+        long long prev = t0; int cur = 0;
+        for (auto& e : ev) { occ[std::min(cur, 4)] += (double)(e.first - prev); prev = e.first; cur += e.second; }
+        occ[0] += (double)(t1 - prev);
+        minb = std::min(minb, kv.second.size()); maxb = std::max(maxb, kv.second.size());
+        // gap: time from a block's end to the next block start on this CU (greedy matching in time order)
+        std::vector<long long> ends, starts;
+        for (int b : kv.second) { ends.push_back(h[4 * b + 2]); starts.push_back(h[4 * b]); }
+        std::sort(ends.begin(), ends.end()); std::sort(starts.begin(), starts.end());
+        size_t si = 0;
+        for (long long e : ends) {
+            while (si < starts.size() && starts[si] < e) ++si;
+            if (si < starts.size()) { gap += (double)(starts[si] - e); ++gaps; ++si; }
+        }
+    }
+    double tot = span * by_cu.size();
+    printf("   timeline: %zu CUs seen, blocks/CU %zu..%zu, span %.1f us; per block: K loop %.2f us, epilogue+drain %.2f us, "
+           "pure-MFMA time %.2f us\n", by_cu.size(), minb, maxb, span / 100.0, loop / a.nwg / 100.0, epi / a.nwg / 100.0,
+           mfma_ticks_per_block / 100.0);
+    printf("             CU residency: 0 WG %.1f%%  1 WG %.1f%%  2 WG %.1f%%  3 WG %.1f%%  4+ %.1f%%;  end->next start on the "
+           "same CU: %.2f us avg (%ld pairs)\n", 100 * occ[0] / tot, 100 * occ[1] / tot, 100 * occ[2] / tot, 100 * occ[3] / tot,
+           100 * occ[4] / tot, gaps ? gap / gaps / 100.0 : 0.0, gaps);
+    printf("             first blocks of XCD 0 (block:se.cu/ldsbase,ldssize):");
+    for (int b = 0, n = 0; b < a.nwg && n < 40; b += 8, ++n) {
+        long long id = h[4 * b + 3];
+        printf(" %d:%d.%d/%d,%d", b, (int)((id >> 13) & 7), (int)((id >> 8) & 15), (int)((id >> 40) & 0xff), (int)((id >> 52) & 0x1ff));
+    }
+    printf("\n");
+    // when do the XCDs finish?
+    std::map<int, long long> xend;
+    for (int b = 0; b < a.nwg; ++b) { int x = (int)((h[4 * b + 3] >> 32) & 15); xend[x] = std::max(xend[x], h[4 * b + 2]); }
+    printf("             XCD finish times (us):");
+    for (auto& kv : xend) printf(" %d:%.1f", kv.first, (kv.second - t0) / 100.0);
+    printf("\n");
+}
+
+template <int BM, int BN, int DBG>
 static void sweep(const char* name, up_conv_desc d) {
     size_t nx = (size_t)d.N * d.H * d.W * d.ldx, nw = (size_t)d.K * d.R * d.S * d.Cp, ny = (size_t)d.N * d.P * d.Q * d.ldy;
     float *x, *w, *y;
@@ -41,47 +116,28 @@ static void sweep(const char* name, up_conv_desc d) {
     IgemmArgs a;
     fill_fwd_args(a, &d, x, w, y, nullptr);
     double fl = 2.0 * a.M * a.Ng * a.Ktot;
-    float t[6];
-    t[0] = run<BM, BN, 0>(a, 20);
-    t[1] = run<BM, BN, 1>(a, 20);
-    t[2] = run<BM, BN, 3>(a, 20);
-    t[3] = run<BM, BN, 7>(a, 20);
-    t[4] = run<BM, BN, 15>(a, 20);
-    t[3] = run<BM, BN, 64>(a, 20);
-    t[4] = run<BM, BN, 128>(a, 20);
-    t[5] = run<BM, BN, 0>(a, 20);
-    {   // effective shader clock while the kernel runs: full vs no-gload
-        long long* dbg;
-        hipMalloc(&dbg, 1 << 16);
-        for (int mode = 0; mode < 2; ++mode) {
-            hipMemset(dbg, 0, 1 << 16);
-            IgemmArgs b = a;
-            b.bias = nullptr;
-            b.ntn = cdiv(b.Ng, BN);
-            b.nwg = cdiv(b.M, BM) * b.ntn;
-            b.fNtn = make_fastdiv(b.ntn);
-            IgemmArgs c = b;
-            c.bias = reinterpret_cast<const float*>(dbg);
-            for (int it = 0; it < 5; ++it) {
-                if (mode == 0) hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, 0>), dim3(b.nwg), dim3(256), 0, 0, b);
-                else hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, 1>), dim3(b.nwg), dim3(256), 0, 0, b);
-            }
-            if (mode == 0) hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, 32>), dim3(c.nwg), dim3(256), 0, 0, c);
-            else hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, 33>), dim3(c.nwg), dim3(256), 0, 0, c);
-            hipDeviceSynchronize();
-            std::vector<long long> h2(64);
-            hipMemcpy(h2.data(), dbg, 64 * 8, hipMemcpyDeviceToHost);
-            double cs = 0, ws = 0;
-            int nb = c.nwg / 97 < 32 ? c.nwg / 97 : 32;
-            for (int i = 0; i < nb; ++i) { cs += h2[2 * i]; ws += h2[2 * i + 1]; }
-            printf("   %s: block lifetime %.0f shader cycles / %.0f wall ticks(100MHz) -> %.3f GHz\n", mode ? "no-gload" : "full    ",
-                   cs / nb, ws / nb, cs / ws * 0.1);
-        }
-        hipFree(dbg);
+    float ta = run<BM, BN, DBG>(a, 20);
+    float tb = run<BM, BN, DBG>(a, 20);   // the first variant timed in a process runs ~10 % slow: time twice
+    printf("%s  tile %dx%d  M=%d N=%d K=%d  WGs=%d\n   %.4f / %.4f ms  %.1f / %.1f TFLOP/s\n", name, BM, BN, a.M, a.Ng, a.Ktot,
+           cdiv(a.M, BM) * cdiv(a.Ng, BN), ta, tb, fl / ta / 1e9, fl / tb / 1e9);
+    // one block's MFMA work alone on a CU: (BM/32)*(BN/32)/4 tiles per wave x K/2 k-steps x 64 cycles @ 2.4 GHz
+    double mfma_ticks = (double)(BM / 32) * (BN / 32) / 4.0 * (a.Ktot / 2.0) * 64.0 / 2.4e9 * 1e8;
+    timeline<BM, BN, DBG>(a, mfma_ticks);
+    {   // the production launch (tile as given, K loop variant and tail split chosen by launch_igemm)
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0);
+        hipEventCreate(&e1);
+        for (int i = 0; i < 3; ++i) launch_igemm<BM, BN>(a, true, 0);
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < 20; ++i) launch_igemm<BM, BN>(a, true, 0);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        ms /= 20;
+        printf("   production launch: full blocks %d + %d tail tiles x %d parts: %.4f ms  %.1f TFLOP/s\n", a.full_blocks,
+               a.nwg - a.full_blocks, a.parts, ms, fl / ms / 1e9);
     }
-    const char* lab[6] = {"full", "no-gload", "no-gload,no-lstore", "single-buffer loop", "DB + pinned interleave", "full again (order check)"};
-    printf("%s  tile %dx%d  M=%d N=%d K=%d  WGs=%d\n", name, BM, BN, a.M, a.Ng, a.Ktot, cdiv(a.M, BM) * cdiv(a.Ng, BN));
-    for (int i = 0; i < 6; ++i) printf("   %-28s %8.4f ms  %7.1f TFLOP/s\n", lab[i], t[i], fl / t[i] / 1e9);
     hipFree(x);
     hipFree(w);
     hipFree(y);
@@ -96,19 +152,31 @@ static up_conv_desc mk(int N, int H, int C, int K, int R, int pad, int dil) {
 }
 
 int main(int argc, char**) {
-    if (argc > 1) {   // channel-stride experiment: power-of-two pixel stride vs not
-        sweep<128, 128>("1x1 256->256 @92^2", mk(32, 92, 256, 256, 1, 0, 1));
-        sweep<128, 128>("1x1 288->256 @92^2", mk(32, 92, 288, 256, 1, 0, 1));
-        sweep<128, 128>("1x1 1024->256 @46^2", mk(32, 46, 1024, 256, 1, 0, 1));
-        sweep<128, 128>("1x1 1056->256 @46^2", mk(32, 46, 1056, 256, 1, 0, 1));
-        up_conv_desc d = mk(32, 46, 1024, 256, 1, 0, 1);
-        d.ldx = 1056;   // same K, padded pixel stride
-        sweep<128, 128>("1x1 1024->256 @46^2 ldx=1056", d);
+    if (argc > 1) {   // tile choice with the tail split available
+        sweep<64, 64, 0>("3x3 256->256 @23^2", mk(32, 23, 256, 256, 3, 1, 1));
+        sweep<64, 128, 128>("3x3 256->256 @23^2", mk(32, 23, 256, 256, 3, 1, 1));
+        sweep<128, 64, 128>("3x3 256->256 @23^2", mk(32, 23, 256, 256, 3, 1, 1));
+        sweep<128, 128, 128>("3x3 256->256 @23^2", mk(32, 23, 256, 256, 3, 1, 1));
+        sweep<64, 64, 0>("1x1 1024->256 @23^2", mk(32, 23, 1024, 256, 1, 0, 1));
+        sweep<64, 128, 128>("1x1 1024->256 @23^2", mk(32, 23, 1024, 256, 1, 0, 1));
+        sweep<128, 128, 128>("1x1 1024->256 @23^2", mk(32, 23, 1024, 256, 1, 0, 1));
+        sweep<128, 128, 64>("1x1 256->1024 @23^2", mk(32, 23, 256, 1024, 1, 0, 1));
+        sweep<64, 128, 64>("1x1 256->1024 @23^2", mk(32, 23, 256, 1024, 1, 0, 1));
+        sweep<64, 128, 128>("3x3 512->512 d2 @23^2", mk(32, 23, 512, 512, 3, 2, 2));
+        sweep<128, 128, 128>("3x3 512->512 d2 @23^2", mk(32, 23, 512, 512, 3, 2, 2));
+        sweep<64, 128, 128>("3x3 128->128 @46^2", mk(32, 46, 128, 128, 3, 1, 1));
+        sweep<128, 128, 128>("3x3 128->128 @46^2", mk(32, 46, 128, 128, 3, 1, 1));
+        sweep<128, 64, 64>("1x1 256->64 @92^2", mk(32, 92, 256, 64, 1, 0, 1));
+        sweep<128, 64, 64>("3x3 64->64 @92^2", mk(32, 92, 64, 64, 3, 1, 1));
         return 0;
     }
-    sweep<128, 128>("1x1 512->256 @92^2 B32", mk(32, 92, 512, 256, 1, 0, 1));
-    sweep<64, 64>("3x3 256->256 @23^2 B32", mk(32, 23, 256, 256, 3, 1, 1));
-    sweep<128, 128>("3x3 256->256 @46^2 B32", mk(32, 46, 256, 256, 3, 1, 1));
-    sweep<64, 128>("3x3 256->256 @46^2 B32 (64x128)", mk(32, 46, 256, 256, 3, 1, 1));
+
+    // production variants (launch_igemm): 128-wide tiles, K >= 1024 -> 128; 64x64, K >= 1024 -> 0; K < 1024 -> 64
+    sweep<128, 128, 64>("1x1 512->256 @92^2", mk(32, 92, 512, 256, 1, 0, 1));
+    sweep<64, 64, 0>("3x3 256->256 @23^2", mk(32, 23, 256, 256, 3, 1, 1));
+    sweep<128, 128, 64>("1x1 256->1024 @23^2", mk(32, 23, 256, 1024, 1, 0, 1));
+    sweep<64, 64, 0>("1x1 1024->256 @23^2", mk(32, 23, 1024, 256, 1, 0, 1));
+    sweep<128, 128, 128>("3x3 256->256 @46^2", mk(32, 46, 256, 256, 3, 1, 1));
+    sweep<64, 128, 128>("3x3 512->512 d2 @23^2", mk(32, 23, 512, 512, 3, 2, 2));
     return 0;
 }

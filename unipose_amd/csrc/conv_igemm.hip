@@ -21,6 +21,12 @@
 // legal as long as A and B use the same one, and it turns 4 ds_read_b32 into one ds_read_b128.
 #include "up_common.h"
 
+#include <map>
+#include <mutex>
+#ifdef UP_EMU
+#include <sched.h>
+#endif
+
 #include <stdlib.h>
 
 #include <vector>
@@ -102,6 +108,12 @@ struct IgemmArgs {
     int ldr;
     int relu;
     float* stats;
+    void* dbg;   // development probes only (tools/gpu/igemm_probe.hip)
+    // tail split (see launch_igemm): blocks [0, full_blocks) compute whole tiles, the rest compute 1/parts of the
+    // K range of a tail tile; parts 0..parts-2 publish raw accumulators, the last part adds them and runs the epilogue
+    int full_blocks, parts;
+    float* partials;
+    int* flags;
 };
 
 __device__ __forceinline__ void wf_merge(float& n1, float& m1, float& s1, float n2, float m2, float s2) {
@@ -125,12 +137,81 @@ __device__ __forceinline__ float4 keep_or_zero(bool k, float4 v) {
     return make_float4(k ? v.x : 0.f, k ? v.y : 0.f, k ? v.z : 0.f, k ? v.w : 0.f);
 }
 
+// agent-scope (device-coherent) accesses for the K-split partials and their ready flags
+#ifdef UP_EMU
+__device__ __forceinline__ void st_agent(float* p, float v) {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    __atomic_store_n(reinterpret_cast<uint32_t*>(p), u, __ATOMIC_RELEASE);
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+    uint32_t u = __atomic_load_n(reinterpret_cast<const uint32_t*>(p), __ATOMIC_ACQUIRE);
+    float v;
+    memcpy(&v, &u, 4);
+    return v;
+}
+__device__ __forceinline__ void st_agent_flag(int* p, int v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+__device__ __forceinline__ void spin_until_set(const int* p) {
+    while (__atomic_load_n(p, __ATOMIC_ACQUIRE) == 0) sched_yield();
+}
+__device__ __forceinline__ void wait_stores() {}
+#else
+__device__ __forceinline__ void st_agent(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent_flag(int* p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void spin_until_set(const int* p) {
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
+}
+__device__ __forceinline__ void wait_stores() { __builtin_amdgcn_s_waitcnt(0); }   // vmcnt(0): stores acknowledged
+#endif
+
 // XCD-aware bijective remap: hardware block b runs on XCD b%8; give every XCD a contiguous run of
 // logical tiles so the n-tiles sharing one A row-panel hit the same L2.
 __device__ __forceinline__ int xcd_remap(int b, int nwg) {
     int q = nwg >> 3, r = nwg & 7;
     int xcd = b & 7, idx = b >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int BM, int BN, bool RES, bool CHECK>
+__device__ __forceinline__ void igemm_store(const IgemmArgs& a, f32x16 (&acc)[BM / 64][BN / 64], int mrow0, int ncol0) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    const bool relu = a.relu != 0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = ncol0 + j * 32;
+        if (n >= a.Ng) continue;
+        const float sc = a.scale ? a.scale[n] : 1.f;
+        float sh = a.scale ? a.shift[n] : 0.f;
+        if (a.bias) sh += a.bias[n];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = mrow0 + i * 32;
+            float res[16];
+            if (RES) {   // all 16 loads first (rows beyond M read a clamped, valid row), then one wait
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    res[r] = a.residual[(size_t)(!CHECK || m < a.M ? m : a.M - 1) * a.ldr + n];
+                }
+            }
+            float* yrow = a.y + (size_t)mb * a.ldy + n;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dm = (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] * sc + sh;
+                if (RES) v += res[r];
+                v = relu ? fmaxf(v, 0.f) : v;
+                if (!CHECK || mb + dm < a.M) yrow[(size_t)dm * a.ldy] = v;
+            }
+        }
+    }
 }
 
 // DBG is 0 in the library; tools/gpu/igemm_probe.hip instantiates ablations (bit 0: no global prefetch in
@@ -215,25 +296,17 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
         }
     }
 
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = ncol0 + j * 32;
-        if (n >= a.Ng) continue;
-        const float sc = a.scale ? a.scale[n] : 1.f;
-        float sh = a.scale ? a.shift[n] : 0.f;
-        if (a.bias) sh += a.bias[n];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                if (m < a.M) {
-                    float v = acc[i][j][r] * sc + sh;
-                    if (a.residual) v += a.residual[(size_t)m * a.ldr + n];
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    a.y[(size_t)m * a.ldy + n] = v;
-                }
-            }
+    // Stores.  Row-bound checks and the residual test are hoisted into four straight-line instantiations: with
+    // either of them inside the store loop the compiler placed an `s_waitcnt vmcnt(0)` in front of EVERY store
+    // (its wait-count state is merged conservatively across the predicated blocks), i.e. each of a thread's 64
+    // stores waited for the previous one to be acknowledged (measured: 23 us of a 103 us workgroup lifetime).
+    const bool full = m0 + BM <= a.M;   // uniform: only the last row tile is ragged
+    if (a.residual) {
+        if (full) igemm_store<BM, BN, true, false>(a, acc, mrow0, ncol0);
+        else igemm_store<BM, BN, true, true>(a, acc, mrow0, ncol0);
+    } else {
+        if (full) igemm_store<BM, BN, false, false>(a, acc, mrow0, ncol0);
+        else igemm_store<BM, BN, false, true>(a, acc, mrow0, ncol0);
     }
 }
 
@@ -263,12 +336,20 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    long long dbg_c0 = 0, dbg_w0 = 0;
-    if ((DBG & 32) && threadIdx.x == 0) {
-        dbg_c0 = clock64();
-        dbg_w0 = wall_clock64();
+    long long dbg_w0 = 0;   // probe bit 5: per-block timeline (start / end of K loop / stores drained, 100 MHz ticks + HW ids)
+    if ((DBG & 32) && threadIdx.x == 0) dbg_w0 = wall_clock64();
+    const int nk = (a.Ktot + BK - 1) / BK;
+    int logical, kb = 0, ke = nk, part = 0, tail = 0;
+    if ((int)blockIdx.x < a.full_blocks) {
+        logical = xcd_remap(blockIdx.x, a.full_blocks);
+    } else {   // K-split tail tile: slices [kb, ke) of tile full_blocks + tail
+        const int j = (int)blockIdx.x - a.full_blocks;
+        tail = j / a.parts;
+        part = j - tail * a.parts;
+        logical = a.full_blocks + tail;
+        kb = (int)((long long)nk * part / a.parts);
+        ke = (int)((long long)nk * (part + 1) / a.parts);
     }
-    const int logical = xcd_remap(blockIdx.x, a.nwg);
     const int mt = fdiv(logical, a.fNtn);
     const int nt = logical - mt * a.ntn;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -320,6 +401,10 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
 
     // aligned path: the 32-wide slice never straddles a tap; (tap, ci0) advance as scalars
     int tap_c = 0, ci0_c = 0;
+    if (ALIGNED && kb > 0) {
+        tap_c = fdiv(kb, a.fSpt);
+        ci0_c = (kb - tap_c * (int)a.fSpt.d) * BK;
+    }
 
     // Branch-free prefetch: every load is issued unconditionally from a clamped (always valid) address; no
     // wait until lstore().  gprep() does the (mostly scalar) per-slice bookkeeping, gissue(part) issues the
@@ -413,8 +498,7 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (a.Ktot + BK - 1) / BK;
-    gload(0);
+    gload(kb);
     lstore();
     __syncthreads();
 
@@ -438,15 +522,15 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
         // slice kt is in LDS buffer kt&1; slice kt+1 sits in the staging registers (loaded during slice kt-1)
         // and is written to the OTHER buffer in the middle of this slice's MFMAs; the registers are then
         // refilled with slice kt+2.  One barrier per slice, nothing between the MFMAs but LDS/VMEM issue.
-        if (nk > 1) gload(1);
+        if (ke - kb > 1) gload(kb + 1);
         if (DBG & 128) {
             // Branch-free body: the refill always runs (slice indices are clamped to the last slice, whose
             // reload is harmless), so the whole iteration is ONE scheduling region and the non-MFMA work can be
             // pinned between the MFMAs with sched_group_barrier instead of piling up between 16-MFMA clusters.
-            if (nk == 1) gload(0);
-            for (int kt = 0; kt < nk; ++kt) {
-                const int cur = kt & 1;
-                const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;
+            if (ke - kb == 1) gload(kb);
+            for (int kt = kb; kt < ke; ++kt) {
+                const int cur = (kt - kb) & 1;
+                const int k2 = kt + 2 < ke ? kt + 2 : ke - 1;
                 float4 af[2][TM], bf[2][TN];
                 auto frag = [&](int g, int b) {
 #pragma unroll
@@ -479,9 +563,9 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
                 __syncthreads();
             }
         } else {
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            const bool has1 = kt + 1 < nk, has2 = kt + 2 < nk;
+        for (int kt = kb; kt < ke; ++kt) {
+            const int cur = (kt - kb) & 1;
+            const bool has1 = kt + 1 < ke, has2 = kt + 2 < ke;
             float4 af[2][TM], bf[2][TN];
             auto frag = [&](int g, int b) {
 #pragma unroll
@@ -508,8 +592,8 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
         }
         }
     } else {
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
+    for (int kt = kb; kt < ke; ++kt) {
+        const bool more = kt + 1 < ke;
         if (more && !(DBG & 1)) gprep(kt + 1);
         // fragments of k-group g+1 are read from LDS while the MFMAs of group g run (static double buffer)
         float4 af[2][TM], bf[2][TN];
@@ -540,10 +624,56 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     }
     }
 
-    if ((DBG & 32) && threadIdx.x == 0 && (blockIdx.x % 97) == 0) {   // shader clocks vs 100 MHz wall ticks
-        long long* o = reinterpret_cast<long long*>(const_cast<float*>(a.bias)) + 2 * (blockIdx.x / 97);
-        o[0] = clock64() - dbg_c0;
-        o[1] = wall_clock64() - dbg_w0;
+    if ((int)blockIdx.x >= a.full_blocks && a.parts > 1) {
+        // Partials are [part][(i*TN+j)*16 + r][256 threads] floats: every access is one coalesced 256-B row per wave.
+        // They are written and read with agent-scope accesses (write-through / cache-bypassing on gfx950), so the
+        // flag needs no L2 write-back fence; readers have a higher block index than writers (no dispatch deadlock).
+        float* pbase = a.partials + (size_t)tail * (a.parts - 1) * (BM * BN);
+        int* flag = a.flags + tail * (a.parts - 1);
+        if (part < a.parts - 1) {
+            float* o = pbase + (size_t)part * (BM * BN) + tid;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st_agent(o + ((i * TN + j) * 16 + r) * 256, acc[i][j][r]);
+            wait_stores();
+            __syncthreads();
+            if (tid == 0) st_agent_flag(flag + part, 1);
+            return;
+        }
+        for (int pp = 0; pp < a.parts - 1; ++pp) {
+            if (tid == 0) spin_until_set(flag + pp);
+            __syncthreads();
+            const float* o = pbase + (size_t)pp * (BM * BN) + tid;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += ld_agent(o + ((i * TN + j) * 16 + r) * 256);
+        }
+        __syncthreads();
+        if (tid < a.parts - 1) st_agent_flag(flag + tid, 0);   // consumed: ready for the next launch on this stream
+    }
+
+    if (DBG & 32) {
+#ifndef UP_EMU
+        long long* o = reinterpret_cast<long long*>(a.dbg) + 4 * (size_t)blockIdx.x;
+        const long long w1 = wall_clock64();
+        igemm_epilogue<BM, BN>(a, acc, smem, mt, m0, n0, wm, wn, l31, lh);
+        __builtin_amdgcn_s_waitcnt(0);
+        if (threadIdx.x == 0) {
+            o[0] = dbg_w0;
+            o[1] = w1;
+            o[2] = wall_clock64();
+            o[3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |                 // HW_REG_HW_ID
+                   ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15) << 32) | // HW_REG_XCC_ID
+                   ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 6) & 0x1fffff) << 40);   // HW_REG_LDS_ALLOC
+        }
+#endif
+        return;
     }
     igemm_epilogue<BM, BN>(a, acc, smem, mt, m0, n0, wm, wn, l31, lh);
 }
@@ -1029,14 +1159,84 @@ static int check_desc(const up_conv_desc* d) {
 struct TileChoice {
     int bm, bn;
 };
-static TileChoice choose_tile(int64_t M, int Ng) {
+// Largest tile that still yields ~4 workgroups per CU (the tail split evens out the remainder).  Short reductions
+// are epilogue-heavy and run better on twice as many, smaller tiles (1x1 256->1024 at 23x23: 64x128 91 TF,
+// 128x128 85 TF).
+static TileChoice choose_tile(int64_t M, int Ng, int Ktot) {
     const int cands[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
+    const int64_t want = Ktot < 512 ? 2000 : 1000;
     for (auto& c : cands) {
         if (Ng <= 64 && c[1] == 128) continue;
         int64_t wgs = (int64_t)cdiv(M, c[0]) * cdiv(Ng, c[1]);
-        if (wgs >= 1000) return {c[0], c[1]};
+        if (wgs >= want) return {c[0], c[1]};
     }
     return {64, 64};
+}
+
+// ---- tail split -------------------------------------------------------------------------------------
+// Workgroups are dispatched round-robin over the CUs (tools/gpu/igemm_probe.hip timeline), so a launch of
+// T = q*CUs + r tiles leaves r CUs with q+1 tiles and the others idle for a whole tile time at the end: 18 % of
+// the launch for the 1060-tile layers of the 23x23 / 46x46 stages (q = 4, r = 36).  When r is small the r tail
+// tiles are split along K into p = CUs/r parts, one per CU, so every CU gets q + 1/p tiles.  Parts 0..p-2 publish
+// their accumulators to a per-stream scratch, the last part of each tile adds them in a fixed order (the result
+// is deterministic) and runs the normal epilogue.
+struct SplitScratch {
+    float* partials = nullptr;
+    int* flags = nullptr;
+};
+static int cu_count() {
+    static const int n = [] {
+        if (const char* e = getenv("UP_CU_COUNT")) return atoi(e) > 0 ? atoi(e) : 256;   // tests shrink the "chip"
+#ifndef UP_EMU
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+            prop.multiProcessorCount > 0)
+            return prop.multiProcessorCount;
+#endif
+        return 256;
+    }();
+    return n;
+}
+static SplitScratch* split_scratch(hipStream_t st) {
+    // at most one partial per CU and launch; launches on one stream are serialised, so one buffer per stream suffices
+    static std::mutex mu;
+    static std::map<hipStream_t, SplitScratch> table;
+    std::lock_guard<std::mutex> lock(mu);
+    SplitScratch& s = table[st];
+    if (!s.partials) {
+        const size_t pbytes = (size_t)cu_count() * 128 * 128 * sizeof(float), fbytes = (size_t)cu_count() * sizeof(int);
+#ifdef UP_EMU
+        s.partials = static_cast<float*>(malloc(pbytes));
+        s.flags = static_cast<int*>(calloc(1, fbytes));
+#else
+        if (hipMalloc(reinterpret_cast<void**>(&s.partials), pbytes) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&s.flags), fbytes) != hipSuccess ||
+            hipMemset(s.flags, 0, fbytes) != hipSuccess) {
+            (void)hipGetLastError();
+            s.partials = nullptr;
+            return nullptr;   // no scratch: the caller falls back to whole tiles
+        }
+#endif
+    }
+    return &s;
+}
+static bool tail_split_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("UP_TAIL_SPLIT");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+// parts each tail tile is split into (1 = no split) for a launch of `tiles` tiles reducing over Ktot
+static int split_parts(int tiles, int Ktot) {
+    if (!tail_split_enabled()) return 1;
+    const int cus = cu_count(), q = tiles / cus, r = tiles % cus, nk = Ktot / BK;
+    int p = r ? cus / r : 1;
+    if (p > nk / 4) p = nk / 4;   // a part keeps >= 4 K slices
+    if (p > 8) p = 8;
+    return (q <= 12 && p >= 2) ? p : 1;
 }
 
 template <int BM, int BN>
@@ -1046,6 +1246,19 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     a.nwg = ntm * a.ntn;
     a.fNtn = make_fastdiv(a.ntn);
     a.fSpt = make_fastdiv(a.Cp >= 32 ? a.Cp / 32 : 1);
+    a.full_blocks = a.nwg;
+    a.parts = 1;
+    int grid = a.nwg;
+    const int p = aligned ? split_parts(a.nwg, a.Ktot) : 1;
+    if (p >= 2) {
+        if (SplitScratch* sc = split_scratch(st)) {
+            a.full_blocks = a.nwg / cu_count() * cu_count();
+            a.parts = p;
+            a.partials = sc->partials;
+            a.flags = sc->flags;
+            grid = a.full_blocks + (a.nwg - a.full_blocks) * p;
+        }
+    }
     const int vbase = (BM == 128 && BN == 128) ? 0 : (BM == 64 && BN == 128) ? 2 : (BM == 128 && BN == 64) ? 4 : 6;
     ProfScope prof(vbase + (aligned ? 0 : 1), 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st, a.M, a.Ng,
                    a.Ktot, a.nwg);
@@ -1058,15 +1271,15 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     // wide tiles additionally pin the refill between the MFMAs (branch-free body + sched_group_barrier): +2..4 %
     // on 128-wide tiles, -3 % on 64x64 (probe, warm)
     if (fast && db && (BM == 128 || BN == 128))
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, 128>), dim3(a.nwg), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, 128>), dim3(grid), dim3(256), 0, st, a);
     else if (fast && db)
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, 0>), dim3(a.nwg), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, 0>), dim3(grid), dim3(256), 0, st, a);
     else if (fast)
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, 64>), dim3(a.nwg), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, 64>), dim3(grid), dim3(256), 0, st, a);
     else if (aligned)
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, 1, 64>), dim3(a.nwg), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, 1, 64>), dim3(grid), dim3(256), 0, st, a);
     else
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, 0, 64>), dim3(a.nwg), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, 0, 64>), dim3(grid), dim3(256), 0, st, a);
 }
 
 static void run_igemm(IgemmArgs& a, TileChoice t, hipStream_t st) {
@@ -1088,7 +1301,15 @@ using namespace up;
 extern "C" int up_conv_stats_tiles(const up_conv_desc* d) {
     if (!d) return UP_ERR_INVALID;
     int64_t M = (int64_t)d->N * d->P * d->Q;
-    return cdiv(M, choose_tile(M, d->K).bm);
+    return cdiv(M, choose_tile(M, d->K, d->R * d->S * d->Cp).bm);
+}
+
+extern "C" int up_conv_split_parts(const up_conv_desc* d) {
+    if (!d || check_desc(d)) return UP_ERR_INVALID;
+    if (d->Cp % BK) return 1;
+    int64_t M = (int64_t)d->N * d->P * d->Q;
+    TileChoice t = choose_tile(M, d->K, d->R * d->S * d->Cp);
+    return split_parts(cdiv(M, t.bm) * cdiv(d->K, t.bn), d->R * d->S * d->Cp);
 }
 
 extern "C" int up_pack_weights(const up_conv_desc* d, const float* w, float* w_fwd, float* w_dgrad, void* stream) {
@@ -1162,7 +1383,7 @@ extern "C" int up_conv2d_fwd(const up_conv_desc* d, const float* x, const float*
     UP_REQUIRE(x && w_fwd && y, UP_ERR_INVALID, "conv2d_fwd: null pointer");
     IgemmArgs a;
     if (int e = fill_fwd_args(a, d, x, w_fwd, y, ep)) return e;
-    run_igemm(a, choose_tile(a.M, a.Ng), as_stream(stream));
+    run_igemm(a, choose_tile(a.M, a.Ng, a.Ktot), as_stream(stream));
     return check_launch("conv2d_fwd");
 }
 
@@ -1240,7 +1461,7 @@ static int run_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
     UP_REQUIRE(math == UP_MATH_BF16X3 || math == UP_MATH_BF16, UP_ERR_INVALID, "bf16 convolution: math mode %d", math);
     UP_REQUIRE(a.Cp % 32 == 0, UP_ERR_UNSUPPORTED, "bf16 convolution: padded channel count %d is not a multiple of 32",
                a.Cp);
-    TileChoice t = choose_tile(a.M, a.Ng);
+    TileChoice t = choose_tile(a.M, a.Ng, a.Ktot);
     if (t.bm == 128 && t.bn == 128)
         launch_igemm_bf16<128, 128>(a, math, st);
     else if (t.bm == 64 && t.bn == 128)
@@ -1259,7 +1480,7 @@ extern "C" int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const 
     UP_REQUIRE(dy && w_dgrad && dx, UP_ERR_INVALID, "conv2d_bwd_data: null pointer");
     IgemmArgs a;
     if (int e = fill_dgrad_args(a, d, dy, w_dgrad, dx)) return e;
-    run_igemm(a, choose_tile(a.M, a.Ng), as_stream(stream));
+    run_igemm(a, choose_tile(a.M, a.Ng, a.Ktot), as_stream(stream));
     return check_launch("conv2d_bwd_data");
 }
 
@@ -1320,11 +1541,25 @@ static WgradPlan plan_wgrad(const up_conv_desc* d) {
     p.ntn = cdiv(ncols, p.bn);
     int64_t M = (int64_t)d->N * d->P * d->Q;
     int tiles = p.ntm * p.ntn;
-    int want = cdiv(1024, tiles);
-    int64_t max_splits = (M + 255) / 256;  // at least 256 pixel rows per split
+    // Split K (pixels) so that the launch fills the CUs evenly: workgroups are dispatched round-robin, two are
+    // resident per CU, so the launch time follows ceil(WGs / CUs).  Take the fewest splits (least slab traffic for
+    // the reduce pass) whose CU utilisation WGs / (CUs * ceil(WGs / CUs)) reaches 93 %, at most 4 workgroups per CU
+    // and at least 256 pixel rows per split.  (Measured: 512-workgroup launches 82.5 ms/step, 1024: 85.2, 2048: 87.4.)
+    const int cus = cu_count();
+    int64_t max_splits = (M + 255) / 256;
     if (max_splits < 1) max_splits = 1;
-    int splits = (int)(want < max_splits ? want : max_splits);
-    if (splits < 1) splits = 1;
+    int splits = 1;
+    double best = 0.0;
+    for (int sp = 1; sp <= max_splits && (int64_t)tiles * sp <= 4 * cus; ++sp) {
+        const int wgs = tiles * sp;
+        // one workgroup per CU leaves nothing to overlap its barriers with (256-workgroup launches: 84.9 ms/step)
+        const double util = (double)wgs / ((double)cus * cdiv(wgs, cus)) * (wgs > cus ? 1.0 : 0.8);
+        if (util > best + 1e-9) {
+            best = util;
+            splits = sp;
+        }
+        if (util >= 0.93) break;
+    }
     int64_t rps = (M + splits - 1) / splits;
     rps = (rps + BK - 1) / BK * BK;
     p.rows_per_split = (int)rps;

@@ -240,7 +240,7 @@ def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws
 # waits for side (a) at the end of the backward pass (engine callback), (b) before a weight that was already
 # seen in this pass returns a second gradient (autograd will ADD the two on the main stream), (c) whenever
 # `wgrad_fence()` is called (the data-parallel reducer does before it reads a gradient).
-ASYNC_WGRAD = True
+ASYNC_WGRAD = os.environ.get("UNIPOSE_SYNC_WGRAD", "") == ""   # development switch: weight gradients on the main stream
 _SIDE = {}
 _PASS = {"seen": set(), "cb": False}
 
