@@ -72,6 +72,15 @@ typedef struct {
  *   w_fwd  [K][R*S][Cp]  (forward, B operand rows = output channel, k-contiguous)
  *   w_dgrad[C ][R*S][Kp] (data-gradient: rows = input channel)           — either may be NULL. */
 int up_pack_weights(const up_conv_desc* d, const float* w_oihw, float* w_fwd, float* w_dgrad, void* stream);
+/* The same for many parameters in ONE launch (every weight changes once per optimizer step): `jobs` is a table in
+ * DEVICE memory; w_fwd / w_dgrad may be NULL per job. */
+typedef struct {
+    const float* w;        /* OIHW */
+    float* w_fwd;
+    float* w_dgrad;
+    int32_t K, C, Cp, Kp, taps, reserved;
+} up_pack_job;
+int up_pack_weights_batched(const up_pack_job* jobs_device, int njobs, void* stream);
 
 /* Forward convolution, implicit GEMM on v_mfma_f32_32x32x2_f32 (replaces aten::convolution, K1-K6,K17). */
 int up_conv2d_fwd(const up_conv_desc* d, const float* x, const float* w_fwd, float* y,

@@ -199,3 +199,34 @@ def lstm_case(dev, K=13, B=1, size=32, T=3, wseed=4, tol=1e-3, train=False):
             if not ok:
                 worst[name] = (eo, er)
         assert not worst, worst
+
+
+def second_step_case(dev, K=16, B=2, size=32, wseed=6):
+    """Two training forwards with an in-place parameter update in between: the second one runs on weight images
+    re-packed by the ONE batched launch and bumps the BatchNorm counters with one multi-tensor add."""
+    from unipose_amd import ops
+    m, _ = build_image_model(K, wseed, dev)
+    m.train()
+    for d in (m.wasp.dropout, m.decoder.last_conv[3], m.decoder.last_conv[7]):
+        d.p = 0.0
+    x = O.synth_input((B, 3, size, size), 21)
+    t = O.synth_input((B, K + 1, size // 8, size // 8), 22, "rand")
+    ops.mse_loss(m(x.to(dev)), t.to(dev)).backward()
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.grad is not None:
+                p.sub_(0.05 * p.grad)                        # in place: bumps every version counter
+    ps = ops._PACK_CACHE[torch.device(dev).index]
+    # (entries of other tests' models may linger, even under a recycled id)
+    mine = [ps.entries[id(p)] for p in m.parameters() if id(p) in ps.entries and ps.entries[id(p)][0]() is p]
+    assert len(mine) > 50 and all(e[1] != e[0]()._version for e in mine if e[0]().grad is not None)
+    with torch.no_grad():
+        y2 = m(x.to(dev))
+    assert ps.table is not None and all(e[1] == e[0]()._version for e in mine)
+    sd2 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        y_ref = O.unipose_forward(sd2, x, train=True, p_drop=(0.0, 0.0, 0.0))
+    assert O.max_rel(y2.cpu(), y_ref) < 1e-3
+    for k, v in m.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == (0 if k.startswith("decoder.bn2") else 2), (k, int(v))

@@ -15,6 +15,10 @@ def test_train_dropout_masks_emu(emu_backend):
     mc.train_case(emu_backend, size=32, dropout_masks=True)
 
 
+def test_second_step_repack_and_counters_emu(emu_backend):
+    mc.second_step_case(emu_backend)
+
+
 def test_lstm_eval_emu(emu_backend):
     mc.lstm_case(emu_backend, size=32, T=3, B=1)
 

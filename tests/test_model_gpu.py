@@ -166,6 +166,10 @@ def test_train_batch1_raises():
         m(torch.zeros(1, 3, 64, 64, device=DEV))
 
 
+def test_second_step_repack_and_counters():
+    mc.second_step_case(DEV, B=2, size=64)
+
+
 def test_full_size_step_properties():
     """BASELINE configs[1] shape (B=32, 368x368, K=16) — too big for the CPU oracle, so size-independent
     properties: finite loss/gradients, every trained parameter gets a gradient, per-sample independence of

@@ -36,6 +36,7 @@ SIGNATURES = {
     "up_abi_version": (_i, []),
     "up_pack_weights": (_i, [_D, _p, _p, _p, _p]),
     "up_conv2d_fwd": (_i, [_D, _p, _p, _p, _E, _p]),
+    "up_pack_weights_batched": (_i, [_p, _i, _p]),
     "up_conv_stats_tiles": (_i, [_D]),
     "up_conv_split_parts": (_i, [_D]),
     "up_conv2d_bwd_data": (_i, [_D, _p, _p, _p, _p]),

@@ -1116,6 +1116,32 @@ __global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* w, float* 
     o[e] = k < K ? w[((size_t)k * C + c) * taps + tap] : 0.f;
 }
 
+// both images of MANY parameters in one launch (blockIdx.y = job): the optimizer changes every weight once per
+// step, and 2 x 115 separate 5-us launches cost more than the packing itself
+__global__ void __launch_bounds__(256) pack_batched_kernel(const up_pack_job* jobs) {
+    const up_pack_job jb = jobs[blockIdx.y];
+    const int taps = jb.taps;
+    const long long nf = jb.w_fwd ? (long long)jb.K * taps * jb.Cp : 0;
+    const long long nd = jb.w_dgrad ? (long long)jb.C * taps * jb.Kp : 0;
+    const long long step = (long long)gridDim.x * 256;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < nf + nd; e += step) {
+        if (e < nf) {
+            int ci = (int)(e % jb.Cp);
+            long long t = e / jb.Cp;
+            int tap = (int)(t % taps);
+            int k = (int)(t / taps);
+            jb.w_fwd[e] = ci < jb.C ? jb.w[((size_t)k * jb.C + ci) * taps + tap] : 0.f;
+        } else {
+            long long f = e - nf;
+            int k = (int)(f % jb.Kp);
+            long long t = f / jb.Kp;
+            int tap = (int)(t % taps);
+            int c = (int)(t / taps);
+            jb.w_dgrad[f] = k < jb.K ? jb.w[((size_t)k * jb.C + c) * taps + tap] : 0.f;
+        }
+    }
+}
+
 // column sums of a [rows][ld] matrix (bias gradient): partial per block, atomically combined
 __global__ void __launch_bounds__(256) colsum_kernel(const float* x, int ld, long long rows, int C, float* out,
                                                      int rows_per_block) {
@@ -1302,6 +1328,12 @@ extern "C" int up_conv_stats_tiles(const up_conv_desc* d) {
     if (!d) return UP_ERR_INVALID;
     int64_t M = (int64_t)d->N * d->P * d->Q;
     return cdiv(M, choose_tile(M, d->K, d->R * d->S * d->Cp).bm);
+}
+
+extern "C" int up_pack_weights_batched(const up_pack_job* jobs_device, int njobs, void* stream) {
+    UP_REQUIRE(jobs_device && njobs > 0 && njobs <= 65535, UP_ERR_INVALID, "pack_weights_batched: bad job table");
+    hipLaunchKernelGGL(pack_batched_kernel, dim3(48, njobs), dim3(256), 0, as_stream(stream), jobs_device);
+    return check_launch("pack_weights_batched");
 }
 
 extern "C" int up_conv_split_parts(const up_conv_desc* d) {

@@ -98,28 +98,73 @@ def make_desc(x: torch.Tensor, weight: torch.Tensor, cfg: ConvCfg, ldy: Optional
     return d
 
 
-_PACK_CACHE = {}
+class _PackSet:
+    """Packed weight images of every convolution parameter seen on one device.
+
+    The images (forward [K][R*S][Cp], data gradient [C][R*S][Kp]) live in persistent buffers; the parameter's
+    in-place version counter tells when they are stale (optimizer steps and load_state_dict bump it).  An optimizer
+    step makes ALL of them stale at once, so the first stale hit re-packs every registered parameter with ONE
+    up_pack_weights_batched launch driven by a job table in device memory (2 x 115 five-microsecond launches per
+    step otherwise)."""
+
+    def __init__(self):
+        self.entries = {}          # id(weight) -> [weakref, version, wf, wd, (K, C, Cp, Kp, taps), data_ptr]
+        self.table = None          # device job table, rebuilt when the membership changes
+        self.order = []
+
+    def get(self, weight, d):
+        key = id(weight)
+        nf, nd = d.K * d.R * d.S * d.Cp, d.C * d.R * d.S * d.Kp
+        e = self.entries.get(key)
+        if e is not None and e[0]() is weight and e[2].numel() == nf and e[3].numel() == nd and \
+                e[5] == weight.data_ptr():                 # `param.data = other` keeps the version but moves the storage
+            if e[1] != weight._version:
+                self.repack(weight)
+            return e[2], e[3]
+        wf = torch.empty(nf, dtype=torch.float32, device=weight.device)
+        wd = torch.empty(nd, dtype=torch.float32, device=weight.device)
+        _C.check(_C.lib().up_pack_weights(C.byref(d), _dense(weight).data_ptr(), wf.data_ptr(), wd.data_ptr(),
+                                          _stream(weight)), "pack_weights")
+        if weight.is_leaf and weight.is_contiguous():
+            if len(self.entries) > 4096:
+                self.entries.clear()
+            self.entries[key] = [weakref.ref(weight), weight._version, wf, wd, (d.K, d.C, d.Cp, d.Kp, d.R * d.S),
+                                 weight.data_ptr()]
+            self.table = None
+        return wf, wd
+
+    def repack(self, weight):
+        if self.table is None:
+            import numpy as np
+            dead = [k for k, e in self.entries.items() if e[0]() is None]
+            for k in dead:
+                del self.entries[k]
+            self.order = list(self.entries)
+            job = np.zeros((len(self.order), 6), dtype=np.int64)      # up_pack_job: 3 pointers + 6 int32
+            for i, k in enumerate(self.order):
+                w, _, wf, wd, (kk, cc, cp, kp, taps), _ = self.entries[k]
+                job[i, 0], job[i, 1], job[i, 2] = w().data_ptr(), wf.data_ptr(), wd.data_ptr()
+                job[i, 3:].view(np.int32)[:] = (kk, cc, cp, kp, taps, 0)
+            self.table = torch.from_numpy(job).to(weight.device)
+        live = [self.entries[k] for k in self.order]
+        if any(e[0]() is None for e in live):                         # a parameter died: its pointer is stale
+            self.table = None
+            return self.repack(weight)
+        _C.check(_C.lib().up_pack_weights_batched(self.table.data_ptr(), len(live), _stream(weight)),
+                 "pack_weights_batched")
+        for e in live:
+            e[1] = e[0]()._version
+
+
+_PACK_CACHE = {}                   # device index -> _PackSet
 
 
 def _packed(weight: torch.Tensor, d: _C.ConvDesc):
-    """(forward image [K][R*S][Cp], data-gradient image [C][R*S][Kp]) of an OIHW parameter, made by ONE
-    up_pack_weights call and cached per parameter object + in-place version counter (optimizer steps and
-    load_state_dict bump the version, so stale images are never used)."""
-    key = id(weight)
-    hit = _PACK_CACHE.get(key)
-    nf, nd = d.K * d.R * d.S * d.Cp, d.C * d.R * d.S * d.Kp
-    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2].numel() == nf and \
-            hit[3].numel() == nd:
-        return hit[2], hit[3]
-    wf = torch.empty(nf, dtype=torch.float32, device=weight.device)
-    wd = torch.empty(nd, dtype=torch.float32, device=weight.device)
-    _C.check(_C.lib().up_pack_weights(C.byref(d), _dense(weight).data_ptr(), wf.data_ptr(), wd.data_ptr(),
-                                      _stream(weight)), "pack_weights")
-    if len(_PACK_CACHE) > 4096:
-        _PACK_CACHE.clear()
-    if weight.is_leaf:
-        _PACK_CACHE[key] = (weakref.ref(weight), weight._version, wf, wd)
-    return wf, wd
+    """(forward image, data-gradient image) of an OIHW parameter, see _PackSet."""
+    ps = _PACK_CACHE.get(weight.device.index)
+    if ps is None:
+        ps = _PACK_CACHE[weight.device.index] = _PackSet()
+    return ps.get(weight, d)
 
 
 # Arithmetic of the forward / data-gradient convolutions (weight gradients always use the exact fp32 MFMA):
@@ -404,6 +449,41 @@ def conv_bn_act_eval_fused(x, weight, gamma, beta, rm, rv, cfg, relu, residual=N
     return y
 
 
+_BN_COUNT = {"mode": None, "seen": None}
+
+
+class bn_counters:
+    """``with ops.bn_counters(model):`` around a model forward: nn.BatchNorm2d bumps ``num_batches_tracked`` once per
+    training forward — 113 one-element kernels per step here.  The first forward records which counters the pass
+    touches (decoder.bn2 is never called, SURVEY D9, and must stay 0 like in the reference); later forwards with the
+    same train/eval pattern bump all of them with ONE multi-tensor add."""
+
+    def __init__(self, module):
+        self.module = module
+
+    def __enter__(self):
+        if _BN_COUNT["mode"] is not None:          # nested: the outer context owns the pass
+            self.own = False
+            return self
+        self.own = True
+        self.sig = tuple((id(m), m.training) for m in self.module.modules() if isinstance(m, torch.nn.BatchNorm2d))
+        plan = self.module.__dict__.get("_up_bn_plan")
+        if plan is not None and plan[0] == self.sig:
+            if plan[1]:
+                torch._foreach_add_(plan[1], 1)
+            _BN_COUNT["mode"] = "skip"
+        else:
+            _BN_COUNT["mode"], _BN_COUNT["seen"] = "record", []
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if self.own:
+            if _BN_COUNT["mode"] == "record" and exc_type is None:
+                self.module.__dict__["_up_bn_plan"] = (self.sig, list(_BN_COUNT["seen"]))
+            _BN_COUNT["mode"], _BN_COUNT["seen"] = None, None
+        return False
+
+
 def conv_bn_act(x, conv, bn, relu=True, residual=None):
     """Dispatch on (bn.training, grad mode) exactly like nn.BatchNorm2d would."""
     cfg = ConvCfg(conv.stride[0], conv.padding[0], conv.dilation[0])
@@ -412,8 +492,10 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None):
     if not train and not need_grad:
         return conv_bn_act_eval_fused(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, cfg, relu,
                                       residual, bn.eps)
-    if train and bn.track_running_stats:
+    if train and bn.track_running_stats and _BN_COUNT["mode"] != "skip":
         bn.num_batches_tracked.add_(1)
+        if _BN_COUNT["mode"] == "record":
+            _BN_COUNT["seen"].append(bn.num_batches_tracked)
     mom = 0.1 if bn.momentum is None else bn.momentum
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     return ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, rm, rv, cfg, relu, train, bn.eps, mom)

@@ -24,13 +24,14 @@ class unipose(nn.Module):
             self.freeze_bn()
 
     def forward(self, input):
-        x = ops.ToNHWC.apply(input)
-        x, low = self.backbone(x)
-        x = self.wasp(x)
-        x = self.decoder(x, low)
-        if self.stride != 8:                # optional 8x bilinear up-sampling to the input size (:31-32)
-            x = ops.Bilinear.apply(x, input.shape[2], input.shape[3])
-        return ops.ToNCHW.apply(x, self.num_classes + 1)
+        with ops.bn_counters(self):
+            x = ops.ToNHWC.apply(input)
+            x, low = self.backbone(x)
+            x = self.wasp(x)
+            x = self.decoder(x, low)
+            if self.stride != 8:            # optional 8x bilinear up-sampling to the input size (:31-32)
+                x = ops.Bilinear.apply(x, input.shape[2], input.shape[3])
+            return ops.ToNCHW.apply(x, self.num_classes + 1)
 
     # The reference versions reference an undefined SynchronizedBatchNorm2d (model/unipose.py:42,51,61)
     # and raise NameError; these do what they were meant to.

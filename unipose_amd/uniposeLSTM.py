@@ -57,10 +57,11 @@ class unipose(nn.Module):
 
     def forward(self, input, centermap, iter, previous, previousHide, previousCell):
         b = input.shape[0]
-        x = ops.ToNHWC.apply(input[:, iter])
-        x, low = self.backbone(x)
-        x = self.wasp(x)
-        x = self.decoder(x, low)                                   # (B,h,w,16), 14 real channels
+        with ops.bn_counters(self):
+            x = ops.ToNHWC.apply(input[:, iter])
+            x, low = self.backbone(x)
+            x = self.wasp(x)
+            x = self.decoder(x, low)                               # (B,h,w,16), 14 real channels
         z = _AddCenter.apply(x, centermap[:, iter], self.num_classes + 1)
         if iter == 0:
             cell, hide = self.lstm_0(z)
