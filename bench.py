@@ -168,10 +168,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    if os.environ.get("UP_MAIN_PRIO"):      # experiment: run the step on a high-priority stream (side stream stays low)
-        hp = torch.cuda.Stream(device=dev, priority=-1)
-        hp.wait_stream(torch.cuda.current_stream(dev))
-        torch.cuda.set_stream(hp)
     log(f"model on {dev}, {sum(p.numel() for p in model.parameters())} parameters; warm-up")
     for i in range(args.warmup):
         step()

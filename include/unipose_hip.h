@@ -87,8 +87,8 @@ int up_conv2d_fwd(const up_conv_desc* d, const float* x, const float* w_fwd, flo
                   const up_conv_epilogue* ep, void* stream);
 int up_conv_stats_tiles(const up_conv_desc* d);   /* row tiles the forward kernel will use */
 /* Load balance: when the tile count leaves a short tail (tiles % CUs small), the forward / data-gradient launch splits
- * each tail tile along K into this many parts (1 = no split) and merges them in a fixed order through a per-stream
- * scratch the library allocates on first use (16 MB + flags).  UP_TAIL_SPLIT=0 disables it.  Informational. */
+ * each tail tile along K into this many parts (1 = no split), one per CU, and merges them in a fixed order through a
+ * per-stream scratch the library allocates on first use (16 MB + flags).  UP_TAIL_SPLIT=0 disables it.  Informational. */
 int up_conv_split_parts(const up_conv_desc* d);
 
 /* Data gradient: dx[N,H,W,ldx(:Cp)] from dy[N,P,Q,ldy(:K)] (replaces convolution_backward, input half).

@@ -26,11 +26,12 @@ def test_conv_fwd_bwd(emu_backend, cfg):
 
 
 @pytest.mark.parametrize("cfg,parts", [
-    # short tile tail (tiles % CUs small) -> the tail tiles are split along K into `parts` (include/unipose_hip.h)
-    ((1, 64, 5, 5, 32, 3, 1, 1, 1, False, False), 4),     # K = 576: 18 slices -> 4 parts of >= 4 slices
-    ((2, 96, 6, 6, 72, 3, 1, 1, 1, False, False), 6),     # 27 slices -> 6 uneven parts; 2 n-tiles, ragged rows
-    ((1, 2048, 3, 3, 16, 1, 1, 0, 1, True, True), 8),     # 64 slices -> 8 parts, bias + ReLU epilogue after the merge
-    ((1, 256, 6, 6, 64, 3, 2, 1, 1, False, False), 8),    # strided: MODE 1 data gradient is split as well
+    # short tile tail (tiles % CUs small) -> the tail tiles are split along K into `parts` (include/unipose_hip.h):
+    # one part per CU, at least 2 K slices each
+    ((1, 64, 5, 5, 32, 3, 1, 1, 1, False, False), 9),     # K = 576: 18 slices -> 9 parts of 2
+    ((2, 96, 6, 6, 72, 3, 1, 1, 1, False, False), 13),    # 27 slices -> 13 uneven parts; 2 n-tiles, ragged rows
+    ((1, 2048, 3, 3, 16, 1, 1, 0, 1, True, True), 32),    # 64 slices -> 32 parts, bias + ReLU epilogue after the merge
+    ((1, 256, 6, 6, 64, 3, 2, 1, 1, False, False), 36),   # strided: MODE 1 data gradient is split as well
 ])
 def test_conv_tail_split(emu_backend, cfg, parts):
     import ctypes
@@ -152,7 +153,7 @@ def guard_pages(emu_backend, monkeypatch):
     (1, 15, 6, 6, 14, 3, 1, 1, 1, True, True),
     (1, 128, 5, 5, 32, 3, 1, 1, 1, False, False),     # double-buffered loop
     (1, 64, 6, 6, 17, 1, 1, 0, 1, True, False),       # K=17 -> ldy 20
-    (2, 96, 6, 6, 72, 3, 1, 1, 1, False, False),      # K-split tail tiles (6 uneven parts)
+    (2, 96, 6, 6, 72, 3, 1, 1, 1, False, False),      # K-split tail tiles (13 uneven parts)
 ])
 def test_conv_no_out_of_bounds(guard_pages, cfg):
     n, c, h, w, k, r, s, p, d, bias, relu = cfg

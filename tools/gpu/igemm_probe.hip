@@ -33,13 +33,25 @@ static float run(IgemmArgs a, int iters) {
 }
 
 template <int BM, int BN, int DBG>
-static void timeline(IgemmArgs a, double mfma_ticks_per_block) {
+static void timeline(IgemmArgs a, double mfma_ticks_per_block, bool split = false) {
     a.ntn = cdiv(a.Ng, BN);
     a.nwg = cdiv(a.M, BM) * a.ntn;
     a.fNtn = make_fastdiv(a.ntn);
     a.fSpt = make_fastdiv(a.Cp / 32);
     a.full_blocks = a.nwg;
     a.parts = 1;
+    const int tiles = a.nwg;
+    if (split) {   // the production tail split (launch_igemm)
+        const int p = split_parts(a.nwg, a.Ktot);
+        if (p >= 2) {
+            SplitScratch* sc = split_scratch(0);
+            a.full_blocks = a.nwg / cu_count() * cu_count();
+            a.parts = p;
+            a.partials = sc->partials;
+            a.flags = sc->flags;
+            a.nwg = a.full_blocks + (tiles - a.full_blocks) * p;   // blocks launched (timeline records per block)
+        }
+    }
     long long* dbg;
     hipMalloc(&dbg, (size_t)a.nwg * 32);
     a.dbg = dbg;
@@ -94,6 +106,14 @@ static void timeline(IgemmArgs a, double mfma_ticks_per_block) {
         printf(" %d:%d.%d/%d,%d", b, (int)((id >> 13) & 7), (int)((id >> 8) & 15), (int)((id >> 40) & 0xff), (int)((id >> 52) & 0x1ff));
     }
     printf("\n");
+    {   // dispatch ramp: when do the blocks start / end (percentiles, us after the first start)
+        std::vector<long long> st, en;
+        for (int b = 0; b < a.nwg; ++b) { st.push_back(h[4 * b] - t0); en.push_back(h[4 * b + 2] - t0); }
+        std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end());
+        auto pc = [&](std::vector<long long>& v, double q) { return v[(size_t)(q * (v.size() - 1))] / 100.0; };
+        printf("             starts p10/p50/p90/p100: %.1f %.1f %.1f %.1f us;  ends p0/p10/p50/p90/p100: %.1f %.1f %.1f %.1f %.1f us\n",
+               pc(st, .1), pc(st, .5), pc(st, .9), pc(st, 1.0), pc(en, 0), pc(en, .1), pc(en, .5), pc(en, .9), pc(en, 1.0));
+    }
     // when do the XCDs finish?
     std::map<int, long long> xend;
     for (int b = 0; b < a.nwg; ++b) { int x = (int)((h[4 * b + 3] >> 32) & 15); xend[x] = std::max(xend[x], h[4 * b + 2]); }
@@ -122,7 +142,10 @@ static void sweep(const char* name, up_conv_desc d) {
            cdiv(a.M, BM) * cdiv(a.Ng, BN), ta, tb, fl / ta / 1e9, fl / tb / 1e9);
     // one block's MFMA work alone on a CU: (BM/32)*(BN/32)/4 tiles per wave x K/2 k-steps x 64 cycles @ 2.4 GHz
     double mfma_ticks = (double)(BM / 32) * (BN / 32) / 4.0 * (a.Ktot / 2.0) * 64.0 / 2.4e9 * 1e8;
-    timeline<BM, BN, DBG>(a, mfma_ticks);
+    if (getenv("PROBE_TIMELINE")) {
+        timeline<BM, BN, DBG>(a, mfma_ticks);
+        timeline<BM, BN, DBG>(a, mfma_ticks, true);
+    }
     {   // the production launch (tile as given, K loop variant and tail split chosen by launch_igemm)
         hipEvent_t e0, e1;
         hipEventCreate(&e0);

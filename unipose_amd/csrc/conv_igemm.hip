@@ -340,7 +340,8 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     if ((DBG & 32) && threadIdx.x == 0) dbg_w0 = wall_clock64();
     const int nk = (a.Ktot + BK - 1) / BK;
     int logical, kb = 0, ke = nk, part = 0, tail = 0;
-    if ((int)blockIdx.x < a.full_blocks) {
+    const bool split = (int)blockIdx.x >= a.full_blocks;
+    if (!split) {
         logical = xcd_remap(blockIdx.x, a.full_blocks);
     } else {   // K-split tail tile: slices [kb, ke) of tile full_blocks + tail
         const int j = (int)blockIdx.x - a.full_blocks;
@@ -624,7 +625,23 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     }
     }
 
-    if ((int)blockIdx.x >= a.full_blocks && a.parts > 1) {
+    long long dbg_w1 = 0;
+    auto dbg_record = [&]() {   // probe bit 5
+#ifndef UP_EMU
+        __builtin_amdgcn_s_waitcnt(0);
+        if (threadIdx.x == 0) {
+            long long* o = reinterpret_cast<long long*>(a.dbg) + 4 * (size_t)blockIdx.x;
+            o[0] = dbg_w0;
+            o[1] = dbg_w1;
+            o[2] = wall_clock64();
+            o[3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |                 // HW_REG_HW_ID
+                   ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15) << 32) | // HW_REG_XCC_ID
+                   ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 6) & 0x1fffff) << 40);   // HW_REG_LDS_ALLOC
+        }
+#endif
+    };
+    if (DBG & 32) dbg_w1 = wall_clock64();
+    if (split) {
         // Partials are [part][(i*TN+j)*16 + r][256 threads] floats: every access is one coalesced 256-B row per wave.
         // They are written and read with agent-scope accesses (write-through / cache-bypassing on gfx950), so the
         // flag needs no L2 write-back fence; readers have a higher block index than writers (no dispatch deadlock).
@@ -641,6 +658,7 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
             wait_stores();
             __syncthreads();
             if (tid == 0) st_agent_flag(flag + part, 1);
+            if (DBG & 32) dbg_record();
             return;
         }
         for (int pp = 0; pp < a.parts - 1; ++pp) {
@@ -658,24 +676,8 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
         if (tid < a.parts - 1) st_agent_flag(flag + tid, 0);   // consumed: ready for the next launch on this stream
     }
 
-    if (DBG & 32) {
-#ifndef UP_EMU
-        long long* o = reinterpret_cast<long long*>(a.dbg) + 4 * (size_t)blockIdx.x;
-        const long long w1 = wall_clock64();
-        igemm_epilogue<BM, BN>(a, acc, smem, mt, m0, n0, wm, wn, l31, lh);
-        __builtin_amdgcn_s_waitcnt(0);
-        if (threadIdx.x == 0) {
-            o[0] = dbg_w0;
-            o[1] = w1;
-            o[2] = wall_clock64();
-            o[3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |                 // HW_REG_HW_ID
-                   ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15) << 32) | // HW_REG_XCC_ID
-                   ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 6) & 0x1fffff) << 40);   // HW_REG_LDS_ALLOC
-        }
-#endif
-        return;
-    }
     igemm_epilogue<BM, BN>(a, acc, smem, mt, m0, n0, wm, wn, l31, lh);
+    if (DBG & 32) dbg_record();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1205,7 +1207,10 @@ static TileChoice choose_tile(int64_t M, int Ng, int Ktot) {
 // the launch for the 1060-tile layers of the 23x23 / 46x46 stages (q = 4, r = 36).  When r is small the r tail
 // tiles are split along K into p = CUs/r parts, one per CU, so every CU gets q + 1/p tiles.  Parts 0..p-2 publish
 // their accumulators to a per-stream scratch, the last part of each tile adds them in a fixed order (the result
-// is deterministic) and runs the normal epilogue.
+// is deterministic) and runs the normal epilogue.  Measured (probe, 3x3 256->256 at 46x46): 108 -> 131 TFLOP/s.
+// Tried and dropped: parts FIRST in the grid (no gain: the whole tiles that start late end up alone on their CU
+// and a lone workgroup is latency bound), 2-4 parts per CU (slower: longer merge chain), a staggered start of the
+// workgroups sharing a CU (no gain).
 struct SplitScratch {
     float* partials = nullptr;
     int* flags = nullptr;
@@ -1259,10 +1264,10 @@ static bool tail_split_enabled() {
 static int split_parts(int tiles, int Ktot) {
     if (!tail_split_enabled()) return 1;
     const int cus = cu_count(), q = tiles / cus, r = tiles % cus, nk = Ktot / BK;
-    int p = r ? cus / r : 1;
-    if (p > nk / 4) p = nk / 4;   // a part keeps >= 4 K slices
-    if (p > 8) p = 8;
-    return (q <= 12 && p >= 2) ? p : 1;
+    if (r == 0 || r > cus / 2 || q > 12) return 1;
+    int p = cus / r;              // one part per CU (finer cuts measured slower: the merge chain grows)
+    if (p > nk / 2) p = nk / 2;   // a part keeps >= 2 K slices
+    return p >= 2 ? p : 1;
 }
 
 template <int BM, int BN>
@@ -1272,6 +1277,29 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     a.nwg = ntm * a.ntn;
     a.fNtn = make_fastdiv(a.ntn);
     a.fSpt = make_fastdiv(a.Cp >= 32 ? a.Cp / 32 : 1);
+    const int vbase = (BM == 128 && BN == 128) ? 0 : (BM == 64 && BN == 128) ? 2 : (BM == 128 && BN == 64) ? 4 : 6;
+    ProfScope prof(vbase + (aligned ? 0 : 1), 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st, a.M, a.Ng,
+                   a.Ktot, a.nwg);
+    // MODE 2 needs <= 32 taps (bit mask), no stride division and 32-bit element offsets
+    const bool fast = aligned && a.taps <= 32 && a.divshift == 0 &&
+                      (long long)a.H * a.W * a.ldx * ((long long)a.M / (a.P * a.Q) + 1) < (1ll << 31);
+    // double-buffered LDS (one barrier per slice) pays for long reductions; short ones (1x1 convs with few input
+    // channels) are epilogue-bound and prefer the smaller footprint / higher occupancy of the single-buffer loop
+    const bool db = a.Ktot >= 1024;
+    // wide tiles additionally pin the refill between the MFMAs (branch-free body + sched_group_barrier): +2..4 %
+    // on 128-wide tiles, -3 % on 64x64 (probe, warm)
+    void (*kernel)(IgemmArgs);
+    if (fast && db && (BM == 128 || BN == 128))
+        kernel = igemm_kernel<BM, BN, 2, 128>;
+    else if (fast && db)
+        kernel = igemm_kernel<BM, BN, 2, 0>;
+    else if (fast)
+        kernel = igemm_kernel<BM, BN, 2, 64>;
+    else if (aligned)
+        kernel = igemm_kernel<BM, BN, 1, 64>;
+    else
+        kernel = igemm_kernel<BM, BN, 0, 64>;
+
     a.full_blocks = a.nwg;
     a.parts = 1;
     int grid = a.nwg;
@@ -1285,27 +1313,7 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
             grid = a.full_blocks + (a.nwg - a.full_blocks) * p;
         }
     }
-    const int vbase = (BM == 128 && BN == 128) ? 0 : (BM == 64 && BN == 128) ? 2 : (BM == 128 && BN == 64) ? 4 : 6;
-    ProfScope prof(vbase + (aligned ? 0 : 1), 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st, a.M, a.Ng,
-                   a.Ktot, a.nwg);
-    // MODE 2 needs <= 32 taps (bit mask), no stride division and 32-bit element offsets
-    const bool fast = aligned && a.taps <= 32 && a.divshift == 0 &&
-                      (long long)a.H * a.W * a.ldx * ((long long)a.M / (a.P * a.Q) + 1) < (1ll << 31);
-    // double-buffered LDS (one barrier per slice) pays for long reductions; short ones (1x1 convs with few input
-    // channels) are epilogue-bound and prefer the smaller footprint / higher occupancy of the single-buffer loop
-    const bool db = a.Ktot >= 1024;
-    // wide tiles additionally pin the refill between the MFMAs (branch-free body + sched_group_barrier): +2..4 %
-    // on 128-wide tiles, -3 % on 64x64 (probe, warm)
-    if (fast && db && (BM == 128 || BN == 128))
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, 128>), dim3(grid), dim3(256), 0, st, a);
-    else if (fast && db)
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, 0>), dim3(grid), dim3(256), 0, st, a);
-    else if (fast)
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, 64>), dim3(grid), dim3(256), 0, st, a);
-    else if (aligned)
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, 1, 64>), dim3(grid), dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, 0, 64>), dim3(grid), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, st, a);
 }
 
 static void run_igemm(IgemmArgs& a, TileChoice t, hipStream_t st) {
