@@ -92,8 +92,11 @@ int up_conv_stats_tiles(const up_conv_desc* d);   /* row tiles the forward kerne
 int up_conv_split_parts(const up_conv_desc* d);
 
 /* Data gradient: dx[N,H,W,ldx(:Cp)] from dy[N,P,Q,ldy(:K)] (replaces convolution_backward, input half).
- * Writes all Cp channels of every input pixel (pad channels get 0). */
-int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const float* w_dgrad, float* dx, void* stream);
+ * Writes all Cp channels of every input pixel (pad channels get 0).  `add` (optional, [N,H,W,ld_add]) is a second
+ * gradient of the same input — the identity branch of a residual block, resnet.py:36-40 — summed in the epilogue
+ * instead of by a separate add kernel. */
+int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
+                       const float* add, int ld_add, void* stream);
 
 /* bf16-operand variants of the forward / data-gradient convolution (v_mfma_f32_32x32x16_bf16, fp32 accumulate,
  * fp32 activations in HBM).  math = UP_MATH_BF16X3: every operand is carried as hi = bf16(x), lo = bf16(x - hi)
@@ -107,7 +110,7 @@ int up_pack_weights_bf16(const up_conv_desc* d, const float* w_oihw, uint16_t* f
 int up_conv2d_fwd_bf16(const up_conv_desc* d, const float* x, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
                        const up_conv_epilogue* ep, int math, void* stream);
 int up_conv2d_bwd_data_bf16(const up_conv_desc* d, const float* dy, const uint16_t* w_hi, const uint16_t* w_lo,
-                            float* dx, int math, void* stream);
+                            float* dx, const float* add, int ld_add, int math, void* stream);
 
 /* Weight gradient into PyTorch OIHW layout (replaces convolution_backward, weight half); `dbias`
  * (K floats) may be NULL.  Split-K partial slabs live in the caller-provided workspace. */

@@ -70,6 +70,24 @@ def conv_case(dev, n, c, h, w, k, r, stride, pad, dil, bias=False, relu=False, s
     return errs
 
 
+def dgrad_add_case(dev, n, c, h, w, k, r, stride, pad, dil, seed=0, tol=2e-5):
+    """up_conv2d_bwd_data with its optional addend: dx = conv_transpose(dy) + add (the skip-connection gradient)."""
+    wt = torch.randn(k, c, r, r, generator=g(seed)) * (2.0 / (c * r * r)) ** 0.5
+    x = torch.zeros(n, c, h, w, requires_grad=True)
+    yr = F.conv2d(x, wt, stride=stride, padding=pad, dilation=dil)
+    dy = torch.randn(yr.shape, generator=g(seed + 1))
+    add = torch.randn(n, c, h, w, generator=g(seed + 2))
+    yr.backward(dy)
+    xd = nhwc(x.detach(), dev)
+    d = ops.make_desc(xd, wt.to(dev), ops.ConvCfg(stride, pad, dil))
+    dx = ops.conv_bwd_data_raw(nhwc(dy, dev), wt.to(dev), d, xd.shape, xd.device, add=nhwc(add, dev))
+    e = rel(nchw(dx, c), x.grad + add)
+    assert e < tol, e
+    if ops.rup4(c) != c:
+        assert float(dx[..., c:].abs().max()) == 0.0
+    return e
+
+
 def conv_bn_case(dev, n, c, h, w, k, r, stride, pad, dil, relu=True, residual=False, train=True, seed=0, tol=5e-5):
     x = torch.randn(n, c, h, w, generator=g(seed)) + 0.3
     conv = torch.nn.Conv2d(c, k, r, stride=stride, padding=pad, dilation=dil, bias=False)

@@ -43,6 +43,15 @@ def test_conv_tail_split(emu_backend, cfg, parts):
     oc.conv_case(emu_backend, n, c, h, w, k, r, s, p, d, bias=bias, relu=relu)
 
 
+@pytest.mark.parametrize("cfg", [
+    (2, 32, 6, 5, 16, 1, 1, 0, 1),       # 1x1: the residual-block case
+    (1, 128, 6, 6, 64, 3, 1, 1, 1),      # K-split tail tile: the addend joins after the merge
+    (1, 14, 6, 6, 15, 3, 1, 1, 1),       # odd channels: pad channel of dx stays 0
+])
+def test_dgrad_with_addend(emu_backend, cfg):
+    oc.dgrad_add_case(emu_backend, *cfg)
+
+
 def test_conv_bn_tail_split(emu_backend):
     # batch statistics are reduced from the MERGED accumulators of a split tile
     oc.conv_bn_case(emu_backend, 2, 128, 5, 5, 48, 3, 1, 1, 1, relu=True, residual=True, train=True)

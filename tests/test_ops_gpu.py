@@ -145,3 +145,12 @@ def test_conv_bf16_operand_kernels(cfg, math, tol):
         assert errs["y"] > 1e-4
     else:
         assert errs["y"] < 5e-5, errs          # split-bf16 keeps ~16 mantissa bits per operand
+
+
+@pytest.mark.parametrize("cfg", [
+    (32, 1024, 23, 23, 256, 1, 1, 0, 1),     # layer3 conv1 at the benchmark batch: 1064-tile launch with K-split tail
+    (2, 256, 92, 92, 64, 1, 1, 0, 1),        # layer1 conv1
+    (8, 256, 23, 23, 256, 3, 1, 1, 1),
+])
+def test_dgrad_with_addend(cfg):
+    oc.dgrad_add_case(DEV, *cfg)

@@ -39,10 +39,10 @@ SIGNATURES = {
     "up_pack_weights_batched": (_i, [_p, _i, _p]),
     "up_conv_stats_tiles": (_i, [_D]),
     "up_conv_split_parts": (_i, [_D]),
-    "up_conv2d_bwd_data": (_i, [_D, _p, _p, _p, _p]),
+    "up_conv2d_bwd_data": (_i, [_D, _p, _p, _p, _p, _i, _p]),
     "up_pack_weights_bf16": (_i, [_D, _p, _p, _p, _p, _p, _p]),
     "up_conv2d_fwd_bf16": (_i, [_D, _p, _p, _p, _p, _E, _i, _p]),
-    "up_conv2d_bwd_data_bf16": (_i, [_D, _p, _p, _p, _p, _i, _p]),
+    "up_conv2d_bwd_data_bf16": (_i, [_D, _p, _p, _p, _p, _p, _i, _i, _p]),
     "up_conv2d_bwd_weight_workspace": (_sz, [_D]),
     "up_conv2d_bwd_weight": (_i, [_D, _p, _p, _p, _p, _p, _sz, _p]),
     "up_bn_eval_coeffs": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),

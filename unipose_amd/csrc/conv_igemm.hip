@@ -1515,11 +1515,14 @@ static int run_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
 }  // namespace up
 
 extern "C" int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
-                                  void* stream) {
+                                  const float* add, int ld_add, void* stream) {
     if (int e = check_desc(d)) return e;
     UP_REQUIRE(dy && w_dgrad && dx, UP_ERR_INVALID, "conv2d_bwd_data: null pointer");
+    UP_REQUIRE(!add || ld_add >= d->C, UP_ERR_INVALID, "conv2d_bwd_data: ld_add=%d < C=%d", ld_add, d->C);
     IgemmArgs a;
     if (int e = fill_dgrad_args(a, d, dy, w_dgrad, dx)) return e;
+    a.residual = add;   // dx = dgrad + add in the epilogue (a second gradient of the same input)
+    a.ldr = ld_add;
     run_igemm(a, choose_tile(a.M, a.Ng, a.Ktot), as_stream(stream));
     return check_launch("conv2d_bwd_data");
 }
@@ -1557,11 +1560,15 @@ extern "C" int up_conv2d_fwd_bf16(const up_conv_desc* d, const float* x, const u
 }
 
 extern "C" int up_conv2d_bwd_data_bf16(const up_conv_desc* d, const float* dy, const uint16_t* w_hi,
-                                       const uint16_t* w_lo, float* dx, int math, void* stream) {
+                                       const uint16_t* w_lo, float* dx, const float* add, int ld_add, int math,
+                                       void* stream) {
     if (int e = check_desc(d)) return e;
     UP_REQUIRE(dy && w_hi && dx && (w_lo || math == UP_MATH_BF16), UP_ERR_INVALID, "conv2d_bwd_data_bf16: null pointer");
+    UP_REQUIRE(!add || ld_add >= d->C, UP_ERR_INVALID, "conv2d_bwd_data_bf16: ld_add=%d < C=%d", ld_add, d->C);
     IgemmArgs a;
     if (int e = fill_dgrad_args(a, d, dy, nullptr, dx)) return e;
+    a.residual = add;
+    a.ldr = ld_add;
     a.w_hi = w_hi;
     a.w_lo = w_lo;
     if (int e = run_igemm_bf16(a, math, as_stream(stream))) return e;

@@ -332,7 +332,7 @@ constexpr int BNB_ROWS = 512;
 using namespace up;
 
 extern "C" const char* up_last_error(void) { return g_err; }
-extern "C" int up_abi_version(void) { return 1; }
+extern "C" int up_abi_version(void) { return 2; }
 
 extern "C" int up_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                  int C, float* scale, float* shift, void* stream) {

@@ -45,11 +45,13 @@ class Bottleneck(nn.Module):
         self.dilation = dilation
 
     def forward(self, x):
-        y = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        # identity blocks: the gradient of the skip connection joins the data gradient of conv1 inside its kernel
+        link = ops.GradLink() if self.downsample is None and x.requires_grad and torch.is_grad_enabled() else None
+        y = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True, link_in=link)
         y = ops.conv_bn_act(y, self.conv2, self.bn2, relu=True)
         if self.downsample is not None:
             x = ops.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
-        return ops.conv_bn_act(y, self.conv3, self.bn3, relu=True, residual=x)
+        return ops.conv_bn_act(y, self.conv3, self.bn3, relu=True, residual=x, link_out=link)
 
 
 class ResNet(nn.Module):

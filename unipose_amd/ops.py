@@ -246,22 +246,38 @@ def conv_fwd_raw(x, weight, cfg, *, scale=None, shift=None, bias=None, residual=
     return out, d, st
 
 
-def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev):
+def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev, add=None):
+    """dx = dgrad(dy) (+ add: another gradient of the same input, summed in the kernel epilogue)."""
     n, h, w, cp = x_shape
     alloc = torch.zeros if cp != d.C else torch.empty
     dx = alloc((n, h, w, cp), dtype=torch.float32, device=dev)
     dd = _C.ConvDesc.from_buffer_copy(d)
     dd.ldx = cp
     dd.ldy = _nhwc_ok(dy)
+    ld_add = _nhwc_ok(add) if add is not None else 0
     if CONV_MATH != MATH_F32 and d.Kp % 32 == 0:
         _, wd16 = _packed_bf16(weight, d)
         _C.check(_C.lib().up_conv2d_bwd_data_bf16(C.byref(dd), dy.data_ptr(), wd16[0].data_ptr(), wd16[1].data_ptr(),
-                                                  dx.data_ptr(), CONV_MATH, _stream(dy)), "conv2d_bwd_data_bf16")
+                                                  dx.data_ptr(), _ptr(add), ld_add, CONV_MATH, _stream(dy)),
+                 "conv2d_bwd_data_bf16")
     else:
         wd = packed_dgrad(weight, d)
-        _C.check(_C.lib().up_conv2d_bwd_data(C.byref(dd), dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), _stream(dy)),
-                 "conv2d_bwd_data")
+        _C.check(_C.lib().up_conv2d_bwd_data(C.byref(dd), dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), _ptr(add),
+                                             ld_add, _stream(dy)), "conv2d_bwd_data")
     return dx
+
+
+class GradLink:
+    """Carries the identity-branch gradient of a residual block from the backward of its last stage (which produces
+    it) to the backward of its first convolution (which adds it in the data-gradient epilogue), so autograd never
+    launches the add of the two gradients of the block input (resnet.py:36-40).  The last stage always runs its
+    backward first (its input depends on the first stage's output); a link that is not picked up — the first stage
+    needs no input gradient — is returned through autograd as usual."""
+    __slots__ = ("grad", "armed")
+
+    def __init__(self):
+        self.grad = None
+        self.armed = False
 
 
 def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws_tag: str = "main"):
@@ -385,7 +401,7 @@ class ConvBnAct(Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, rm, rv, cfg: ConvCfg, relu: bool, train: bool, eps: float,
-                momentum: float):
+                momentum: float, link_in=None, link_out=None):
         L = _C.lib()
         dev = x.device
         k = weight.shape[0]
@@ -414,6 +430,9 @@ class ConvBnAct(Function):
         if relu and _RELU_TRACE is not None:
             _RELU_TRACE.append(z.detach())
         ctx.d, ctx.relu, ctx.train, ctx.has_res = d, relu, train, residual is not None
+        ctx.link_in, ctx.link_out = link_in, link_out
+        if link_in is not None:
+            link_in.armed = True       # this node will compute a data gradient: the producer may hand over
         ctx.save_for_backward(x, weight, gamma, y, z, coef)
         return z
 
@@ -434,9 +453,14 @@ class ConvBnAct(Function):
                              coef[0].data_ptr(), coef[1].data_ptr(), int(ctx.relu), int(ctx.train), dy.data_ptr(),
                              d.ldy, _ptr(dres), d.ldy, dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(),
                              ws.numel(), rows, k, _stream(x)), "bn_bwd")
-        dx = conv_bwd_data_raw(dy, weight, d, x.shape, x.device) if ctx.needs_input_grad[0] else None
+        add = None
+        if ctx.link_in is not None:
+            add, ctx.link_in.grad, ctx.link_in.armed = ctx.link_in.grad, None, False
+        dx = conv_bwd_data_raw(dy, weight, d, x.shape, x.device, add) if ctx.needs_input_grad[0] else add
+        if ctx.link_out is not None and ctx.link_out.armed and dres is not None:
+            ctx.link_out.grad, dres = dres, None          # the block's first convolution adds it to ITS dx
         dw, _ = conv_bwd_weight(x, dy, weight, d, False)
-        return dx, dw, dgb[0], dgb[1], dres, None, None, None, None, None, None, None
+        return dx, dw, dgb[0], dgb[1], dres, None, None, None, None, None, None, None, None, None
 
 
 def conv_bn_act_eval_fused(x, weight, gamma, beta, rm, rv, cfg, relu, residual=None, eps=BN_EPS_DEFAULT):
@@ -484,8 +508,8 @@ class bn_counters:
         return False
 
 
-def conv_bn_act(x, conv, bn, relu=True, residual=None):
-    """Dispatch on (bn.training, grad mode) exactly like nn.BatchNorm2d would."""
+def conv_bn_act(x, conv, bn, relu=True, residual=None, link_in=None, link_out=None):
+    """Dispatch on (bn.training, grad mode) exactly like nn.BatchNorm2d would.  link_in / link_out: see GradLink."""
     cfg = ConvCfg(conv.stride[0], conv.padding[0], conv.dilation[0])
     need_grad = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad or bn.weight.requires_grad)
     train = bn.training
@@ -498,7 +522,8 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None):
             _BN_COUNT["seen"].append(bn.num_batches_tracked)
     mom = 0.1 if bn.momentum is None else bn.momentum
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    return ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, rm, rv, cfg, relu, train, bn.eps, mom)
+    return ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, rm, rv, cfg, relu, train, bn.eps, mom,
+                           link_in, link_out)
 
 
 def conv_bias_act(x, conv, relu=False):
