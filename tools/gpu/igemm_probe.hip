@@ -1,5 +1,5 @@
 // Development probe for the implicit-GEMM kernel (not part of the library):
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gpu/igemm_probe.hip -o tools/gpu/igemm_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DUP_PROBE tools/gpu/igemm_probe.hip -o tools/gpu/igemm_probe
 // For a few real layer shapes it times the production variant and records a per-workgroup timeline
 // (start / end of the K loop / stores drained + XCC, SE, CU ids) to show where the CUs idle.
 #include "../../unipose_amd/csrc/conv_igemm.hip"
@@ -32,34 +32,8 @@ static float run(IgemmArgs a, int iters) {
     return ms / iters;
 }
 
-template <int BM, int BN, int DBG>
-static void timeline(IgemmArgs a, double mfma_ticks_per_block, bool split = false) {
-    a.ntn = cdiv(a.Ng, BN);
-    a.nwg = cdiv(a.M, BM) * a.ntn;
-    a.fNtn = make_fastdiv(a.ntn);
-    a.fSpt = make_fastdiv(a.Cp / 32);
-    a.full_blocks = a.nwg;
-    a.parts = 1;
-    const int tiles = a.nwg;
-    if (split) {   // the production tail split (launch_igemm)
-        const int p = split_parts(a.nwg, a.Ktot);
-        if (p >= 2) {
-            SplitScratch* sc = split_scratch(0);
-            a.full_blocks = a.nwg / cu_count() * cu_count();
-            a.parts = p;
-            a.partials = sc->partials;
-            a.flags = sc->flags;
-            a.nwg = a.full_blocks + (tiles - a.full_blocks) * p;   // blocks launched (timeline records per block)
-        }
-    }
-    long long* dbg;
-    hipMalloc(&dbg, (size_t)a.nwg * 32);
-    a.dbg = dbg;
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, DBG | 32>), dim3(a.nwg), dim3(256), 0, 0, a);
-    hipDeviceSynchronize();
-    std::vector<long long> h((size_t)a.nwg * 4);
-    hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
-    hipFree(dbg);
+static void analyze(std::vector<long long>& h, int nwg, double mfma_ticks_per_block) {
+    struct { int nwg; } a{nwg};
     long long t0 = h[0], t1 = h[2];
     for (int b = 0; b < a.nwg; ++b) { t0 = std::min(t0, h[4 * b]); t1 = std::max(t1, h[4 * b + 2]); }
     double span = (double)(t1 - t0);
@@ -123,6 +97,37 @@ static void timeline(IgemmArgs a, double mfma_ticks_per_block, bool split = fals
 }
 
 template <int BM, int BN, int DBG>
+static void timeline(IgemmArgs a, double mfma_ticks_per_block, bool split = false) {
+    a.ntn = cdiv(a.Ng, BN);
+    a.nwg = cdiv(a.M, BM) * a.ntn;
+    a.fNtn = make_fastdiv(a.ntn);
+    a.fSpt = make_fastdiv(a.Cp / 32);
+    a.full_blocks = a.nwg;
+    a.parts = 1;
+    const int tiles = a.nwg;
+    if (split) {   // the production tail split (launch_igemm)
+        const int p = split_parts(a.nwg, a.Ktot);
+        if (p >= 2) {
+            SplitScratch* sc = split_scratch(0);
+            a.full_blocks = a.nwg / cu_count() * cu_count();
+            a.parts = p;
+            a.partials = sc->partials;
+            a.flags = sc->flags;
+            a.nwg = a.full_blocks + (tiles - a.full_blocks) * p;   // blocks launched (timeline records per block)
+        }
+    }
+    long long* dbg;
+    hipMalloc(&dbg, (size_t)a.nwg * 32);
+    a.dbg = dbg;
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, DBG | 32>), dim3(a.nwg), dim3(256), 0, 0, a);
+    hipDeviceSynchronize();
+    std::vector<long long> h((size_t)a.nwg * 4);
+    hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+    hipFree(dbg);
+    analyze(h, a.nwg, mfma_ticks_per_block);
+}
+
+template <int BM, int BN, int DBG>
 static void sweep(const char* name, up_conv_desc d) {
     size_t nx = (size_t)d.N * d.H * d.W * d.ldx, nw = (size_t)d.K * d.R * d.S * d.Cp, ny = (size_t)d.N * d.P * d.Q * d.ldy;
     float *x, *w, *y;
@@ -174,7 +179,76 @@ static up_conv_desc mk(int N, int H, int C, int K, int R, int pad, int dil) {
     return d;
 }
 
-int main(int argc, char**) {
+
+static void wgrad_sweep(const char* name, up_conv_desc d) {
+    size_t nx = (size_t)d.N * d.H * d.W * d.ldx, ny = (size_t)d.N * d.P * d.Q * d.ldy, nw = (size_t)d.K * d.C * d.R * d.S;
+    float *x, *dy, *dw;
+    void* ws;
+    hipMalloc(&x, nx * 4);
+    hipMalloc(&dy, ny * 4);
+    hipMalloc(&dw, nw * 4);
+    g_wgrad_per_cu = 4;
+    size_t wsb = up_conv2d_bwd_weight_workspace(&d) * 2;
+    g_wgrad_per_cu = 2;
+    hipMalloc(&ws, wsb);
+    std::vector<float> h(nx > ny ? nx : ny);
+    for (size_t i = 0; i < h.size(); ++i) h[i] = (float)((i * 2654435761u >> 8) & 0xffff) / 65536.f - 0.5f;
+    hipMemcpy(x, h.data(), nx * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dy, h.data(), ny * 4, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float ms = 0.f;
+    double fl = 2.0 * d.N * d.P * d.Q * (double)d.K * d.R * d.S * d.C;
+    float best[4] = {1e9f, 1e9f, 1e9f, 1e9f};
+    int wgs[4] = {0, 0, 0, 0};
+    for (int round = 0; round < 4; ++round)       // interleaved rounds, best of each: timings drift upward within a process
+        for (int v = 0; v < 4; ++v) {
+            g_wgrad_single = v >= 1;
+            g_wgrad_per_cu = v == 2 ? 3 : v == 3 ? 4 : 2;
+            WgradPlan q = plan_wgrad(&d);
+            wgs[v] = q.ntm * q.ntn * q.splits;
+            for (int i = 0; i < 2; ++i) up_conv2d_bwd_weight(&d, x, dy, dw, nullptr, ws, wsb, nullptr);
+            hipEventRecord(e0, 0);
+            for (int i = 0; i < 10; ++i) up_conv2d_bwd_weight(&d, x, dy, dw, nullptr, ws, wsb, nullptr);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+            ms /= 10;
+            if (ms < best[v]) best[v] = ms;
+        }
+    for (int v = 0; v < 4; ++v)
+        printf("   [%4d WGs] %s: %.4f ms  %.1f TFLOP/s\n", wgs[v], v ? "single-buffer loop" : "double-buffered loop", best[v],
+               fl / best[v] / 1e9);
+    ms = best[0];
+    g_wgrad_single = false;
+    g_wgrad_per_cu = 2;
+    WgradPlan p = plan_wgrad(&d);
+    printf("wgrad %s: tile %dx%d, %d tiles x %d splits = %d WGs, %d rows per split: %.4f ms (kernel + reduce)  %.1f TFLOP/s\n",
+           name, p.bm, p.bn, p.ntm * p.ntn, p.splits, p.ntm * p.ntn * p.splits, p.rows_per_split, ms, fl / ms / 1e9);
+    long long* dbg;
+    hipMalloc(&dbg, (size_t)8192 * 32);
+    hipMemset(dbg, 0, (size_t)8192 * 32);
+    g_wgrad_dbg = dbg;
+    up_conv2d_bwd_weight(&d, x, dy, dw, nullptr, ws, wsb, nullptr);
+    hipDeviceSynchronize();
+    g_wgrad_dbg = nullptr;
+    std::vector<long long> hh((size_t)g_wgrad_grid * 4);
+    hipMemcpy(hh.data(), dbg, hh.size() * 8, hipMemcpyDeviceToHost);
+    double mfma_ticks = (double)(p.bm / 32) * (p.bn / 32) / 4.0 * (p.rows_per_split / 2.0) * 64.0 / 2.4e9 * 1e8;
+    analyze(hh, g_wgrad_grid, mfma_ticks);
+    hipFree(dbg); hipFree(x); hipFree(dy); hipFree(dw); hipFree(ws);
+}
+int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "wgrad")) {
+        wgrad_sweep("3x3 256->256 @23^2", mk(32, 23, 256, 256, 3, 1, 1));
+        wgrad_sweep("1x1 1024->256 @23^2", mk(32, 23, 1024, 256, 1, 0, 1));
+        wgrad_sweep("1x1 256->1024 @23^2", mk(32, 23, 256, 1024, 1, 0, 1));
+        wgrad_sweep("3x3 512->512 d2 @23^2", mk(32, 23, 512, 512, 3, 2, 2));
+        wgrad_sweep("3x3 64->64 @92^2", mk(32, 92, 64, 64, 3, 1, 1));
+        wgrad_sweep("1x1 64->256 @92^2", mk(32, 92, 64, 256, 1, 0, 1));
+        return 0;
+    }
     if (argc > 1) {   // tile choice with the tail split available
         sweep<64, 64, 0>("3x3 256->256 @23^2", mk(32, 23, 256, 256, 3, 1, 1));
         sweep<64, 128, 128>("3x3 256->256 @23^2", mk(32, 23, 256, 256, 3, 1, 1));

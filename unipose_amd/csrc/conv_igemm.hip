@@ -954,15 +954,19 @@ struct WgradArgs {
     int rows_per_split;
     int ntn;
     FastDiv fPQ, fQ, fCp, fS, fNtn;
+    void* dbg;   // development probes only
 };
 
-template <int BM, int BN>
+// DBG bit 5: per-block timeline (probe); bit 6: the older single-buffer loop (two barriers per slice)
+template <int BM, int BN, int DBG = 0>
 __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) wgrad_kernel(WgradArgs a) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int A4 = BM / 4, B4 = BN / 4;                // float4 per k row
     constexpr int PA = BK * A4 / 256, PB = BK * B4 / 256;  // staging passes
     constexpr int KA = 256 / A4, KB = 256 / B4;            // k rows covered per pass
-    __shared__ __attribute__((aligned(16))) float smem[BK * (BM + BN)];
+    constexpr bool DB = (DBG & 64) == 0;                   // two LDS buffers, ONE barrier per slice
+    constexpr int BUF = BK * (BM + BN);
+    __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * BUF];
     float* As = smem;
     float* Bs = smem + BK * BM;
 
@@ -971,6 +975,8 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) wgrad_k
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
 
+    long long dbg_w0 = 0;
+    if ((DBG & 32) && threadIdx.x == 0) dbg_w0 = wall_clock64();
     const int tile = blockIdx.x;
     const int mt = fdiv(tile, a.fNtn);
     const int nt = tile - mt * a.ntn;
@@ -1019,13 +1025,15 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) wgrad_k
         }
         okmask = msk;
     };
-    auto lstore = [&]() {
+    auto lstore = [&](int buf = 0) {
 #pragma unroll
         for (int p = 0; p < PA; ++p)
-            *reinterpret_cast<float4*>(&As[(p * KA + a_kr) * BM + a_c4 * 4]) = keep_or_zero((okmask >> p) & 1u, ra[p]);
+            *reinterpret_cast<float4*>(&As[buf * BUF + (p * KA + a_kr) * BM + a_c4 * 4]) =
+                keep_or_zero((okmask >> p) & 1u, ra[p]);
 #pragma unroll
         for (int p = 0; p < PB; ++p)
-            *reinterpret_cast<float4*>(&Bs[(p * KB + b_kr) * BN + b_c4 * 4]) = keep_or_zero((okmask >> (8 + p)) & 1u, rb[p]);
+            *reinterpret_cast<float4*>(&Bs[buf * BUF + (p * KB + b_kr) * BN + b_c4 * 4]) =
+                keep_or_zero((okmask >> (8 + p)) & 1u, rb[p]);
     };
 
     f32x16 acc[TM][TN];
@@ -1043,29 +1051,65 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) wgrad_k
     __syncthreads();
     const float* Ard = As + lh * BM + wm * (BM / 2) + l31;
     const float* Brd = Bs + lh * BN + wn * (BN / 2) + l31;
-    for (int kb = mbeg; kb < mend; kb += BK) {
-        const bool more = kb + BK < mend;
-        if (more) gload(kb + BK);
+    // fragments of k-step kk+1 are read from LDS while the MFMAs of step kk run (the compiler does not pipeline
+    // this by itself: it emitted read, s_waitcnt lgkmcnt(0), 4 MFMAs per step — MFMA pipe 74 % busy in the K loop)
+    auto mfma_steps = [&](int cur, int k0, int k1) {
+        float af[2][TM], bf[2][TN];
+        auto frag = [&](int b, int kk) {
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float af[TM], bf[TN];
+            for (int i = 0; i < TM; ++i) af[b][i] = Ard[cur * BUF + 2 * kk * BM + i * 32];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = Ard[2 * kk * BM + i * 32];
+            for (int j = 0; j < TN; ++j) bf[b][j] = Brd[cur * BUF + 2 * kk * BN + j * 32];
+        };
+        frag(0, k0);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Brd[2 * kk * BN + j * 32];
+        for (int kk = k0; kk < k1; ++kk) {
+            const int b = (kk - k0) & 1;
+            if (kk + 1 < k1) frag(b ^ 1, kk + 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[b][i], bf[b][j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
-        if (more) {
-            lstore();
+        // pin the order: reads of step kk+1 BEFORE the MFMAs of step kk (left alone, the scheduler folds the two
+        // fragment sets into one and issues each read right before its use)
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int kk = k0; kk < k1; ++kk) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+        }
+    };
+    if (DB) {
+        // slice t sits in LDS buffer t&1, slice t+1 in the staging registers: it is written to the other buffer in
+        // the middle of slice t's MFMAs and the registers are refilled with slice t+2 — one barrier per slice and
+        // no phase in which the workgroup issues no MFMA (two co-resident workgroups run in lockstep, so the
+        // store-and-barrier phase of the single-buffer loop left the MFMA pipe idle: K loop 188 us for 130 us of MFMA)
+        if (mbeg + BK < mend) gload(mbeg + BK);
+        int cur = 0;
+        for (int kb = mbeg; kb < mend; kb += BK, cur ^= 1) {
+            mfma_steps(cur, 0, BK / 4);
+            if (kb + BK < mend) lstore(cur ^ 1);
+            if (kb + 2 * BK < mend) gload(kb + 2 * BK);
+            mfma_steps(cur, BK / 4, BK / 2);
             __syncthreads();
+        }
+    } else {
+        for (int kb = mbeg; kb < mend; kb += BK) {
+            const bool more = kb + BK < mend;
+            if (more) gload(kb + BK);
+            mfma_steps(0, 0, BK / 2);
+            __syncthreads();
+            if (more) {
+                lstore();
+                __syncthreads();
+            }
         }
     }
 
+    long long dbg_w1 = 0;
+    if (DBG & 32) dbg_w1 = wall_clock64();
     float* out = a.slab + (size_t)blockIdx.y * a.K * a.Ncols;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -1079,6 +1123,19 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) wgrad_k
                 if (co < a.K) out[(size_t)co * a.Ncols + col] = acc[i][j][r];
             }
     }
+#ifndef UP_EMU
+    if (DBG & 32) {   // probe: per-block timeline, same record as igemm_kernel
+        __builtin_amdgcn_s_waitcnt(0);
+        if (threadIdx.x == 0) {
+            long long* o = reinterpret_cast<long long*>(a.dbg) + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+            o[0] = dbg_w0;
+            o[1] = dbg_w1;
+            o[2] = wall_clock64();
+            o[3] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                   ((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15) << 32);
+        }
+    }
+#endif
 }
 
 // sum the split-K slabs and scatter into PyTorch OIHW
@@ -1576,6 +1633,12 @@ extern "C" int up_conv2d_bwd_data_bf16(const up_conv_desc* d, const float* dy, c
 }
 
 namespace up {
+#ifdef UP_PROBE
+static void* g_wgrad_dbg = nullptr;
+static int g_wgrad_grid = 0;
+static bool g_wgrad_single = false;
+#endif
+static int g_wgrad_per_cu = 2;   // workgroups per CU a weight-gradient launch aims for (probe knob)
 struct WgradPlan {
     int bm, bn, ntm, ntn, splits, rows_per_split;
 };
@@ -1590,7 +1653,7 @@ static WgradPlan plan_wgrad(const up_conv_desc* d) {
     int tiles = p.ntm * p.ntn;
     // Split K (pixels) so that the launch fills the CUs evenly: workgroups are dispatched round-robin, two are
     // resident per CU, so the launch time follows ceil(WGs / CUs).  Take the fewest splits (least slab traffic for
-    // the reduce pass) whose CU utilisation WGs / (CUs * ceil(WGs / CUs)) reaches 93 %, at most 4 workgroups per CU
+    // the reduce pass) whose CU utilisation WGs / (CUs * ceil(WGs / CUs)) reaches 95 %, at most 4 workgroups per CU
     // and at least 256 pixel rows per split.  (Measured: 512-workgroup launches 82.5 ms/step, 1024: 85.2, 2048: 87.4.)
     const int cus = cu_count();
     int64_t max_splits = (M + 255) / 256;
@@ -1600,12 +1663,12 @@ static WgradPlan plan_wgrad(const up_conv_desc* d) {
     for (int sp = 1; sp <= max_splits && (int64_t)tiles * sp <= 4 * cus; ++sp) {
         const int wgs = tiles * sp;
         // one workgroup per CU leaves nothing to overlap its barriers with (256-workgroup launches: 84.9 ms/step)
-        const double util = (double)wgs / ((double)cus * cdiv(wgs, cus)) * (wgs > cus ? 1.0 : 0.8);
+        const double util = (double)wgs / ((double)cus * cdiv(wgs, cus)) * (wgs > (g_wgrad_per_cu - 1) * cus ? 1.0 : 0.8);
         if (util > best + 1e-9) {
             best = util;
             splits = sp;
         }
-        if (util >= 0.93) break;
+        if (util >= 0.95) break;
     }
     int64_t rps = (M + splits - 1) / splits;
     rps = (rps + BK - 1) / BK * BK;
@@ -1662,14 +1725,49 @@ extern "C" int up_conv2d_bwd_weight(const up_conv_desc* d, const float* x, const
         const int v = (p.bm == 128 && p.bn == 128) ? 8 : (p.bm == 128 && p.bn == 64) ? 9 : (p.bm == 64 && p.bn == 128) ? 10 : 11;
         ProfScope prof(v, 2.0 * (double)a.M * (double)d->K * (double)d->R * d->S * d->C, st, d->K, a.Ncols, a.M,
                        (int)(grid.x * grid.y));
-        if (p.bm == 128 && p.bn == 128)
-            hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, st, a);
-        else if (p.bm == 128 && p.bn == 64)
-            hipLaunchKernelGGL((wgrad_kernel<128, 64>), grid, dim3(256), 0, st, a);
-        else if (p.bm == 64 && p.bn == 128)
-            hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, st, a);
-        else
-            hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, dim3(256), 0, st, a);
+#ifdef UP_PROBE
+        if (g_wgrad_single && !g_wgrad_dbg) {   // the older single-buffer loop, for comparison
+            if (p.bm == 128 && p.bn == 128)
+                hipLaunchKernelGGL((wgrad_kernel<128, 128, 64>), grid, dim3(256), 0, st, a);
+            else if (p.bm == 64 && p.bn == 128)
+                hipLaunchKernelGGL((wgrad_kernel<64, 128, 64>), grid, dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL((wgrad_kernel<128, 64, 64>), grid, dim3(256), 0, st, a);
+        } else
+        if (g_wgrad_dbg) {   // tools/gpu/igemm_probe.hip: per-block timeline
+            a.dbg = g_wgrad_dbg;
+            g_wgrad_grid = (int)(grid.x * grid.y);
+            if (p.bm == 128 && p.bn == 128)
+                hipLaunchKernelGGL((wgrad_kernel<128, 128, 32>), grid, dim3(256), 0, st, a);
+            else if (p.bm == 64 && p.bn == 128)
+                hipLaunchKernelGGL((wgrad_kernel<64, 128, 32>), grid, dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL((wgrad_kernel<128, 64, 32>), grid, dim3(256), 0, st, a);
+        } else
+#endif
+        {
+            // two LDS buffers (64 KB, two workgroups per CU) when the whole grid is resident at once; launches with more
+            // workgroups (layers with many weight tiles) keep the 32 KB single-buffer loop and 3-4 per CU
+            // (probe, 3x3 512->512: 115 vs 104 TFLOP/s; in the network the double buffer is 0.5 % faster overall)
+            const bool single = (long long)grid.x * grid.y > 2ll * cu_count();
+            if (single) {
+                if (p.bm == 128 && p.bn == 128)
+                    hipLaunchKernelGGL((wgrad_kernel<128, 128, 64>), grid, dim3(256), 0, st, a);
+                else if (p.bm == 128 && p.bn == 64)
+                    hipLaunchKernelGGL((wgrad_kernel<128, 64, 64>), grid, dim3(256), 0, st, a);
+                else if (p.bm == 64 && p.bn == 128)
+                    hipLaunchKernelGGL((wgrad_kernel<64, 128, 64>), grid, dim3(256), 0, st, a);
+                else
+                    hipLaunchKernelGGL((wgrad_kernel<64, 64, 64>), grid, dim3(256), 0, st, a);
+            } else if (p.bm == 128 && p.bn == 128)
+                hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, st, a);
+            else if (p.bm == 128 && p.bn == 64)
+                hipLaunchKernelGGL((wgrad_kernel<128, 64>), grid, dim3(256), 0, st, a);
+            else if (p.bm == 64 && p.bn == 128)
+                hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, dim3(256), 0, st, a);
+        }
     }
     long long total = (long long)d->K * a.Ncols;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)workspace, dw,

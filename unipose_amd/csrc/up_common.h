@@ -50,7 +50,8 @@ static inline FastDiv make_fastdiv(int d) {
     return f;
 }
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
-    return f.d <= 1 ? n : (__umulhi(n, f.mul) >> f.shr);
+    const uint32_t q = __umulhi(n, f.mul) >> f.shr;   // computed unconditionally: a select, not a branch that would
+    return f.d <= 1 ? n : q;                          // split the caller's scheduling region
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
