@@ -999,41 +999,46 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) wgrad_k
     float4 ra[PA], rb[PB];
     unsigned okmask = 0;   // bits 0..PA-1: dY row inside [mbeg,mend); bits 8..8+PB-1: tap inside the image
 
-    // branch-free prefetch (see igemm_kernel): clamped addresses, structural zeros selected at lstore()
+    // branch-free prefetch (see igemm_kernel): clamped addresses, structural zeros selected when the registers are
+    // written to LDS.  One "pass" = one float4 per thread (KA resp. KB pixel rows of the slice).
+    auto gloadA = [&](int p, int kbase) {
+        int m = kbase + p * KA + a_kr;
+        bool ok = m < mend;
+        ra[p] = *reinterpret_cast<const float4*>(a.dy + (size_t)(ok ? m : mbeg) * a.ldy + a_co);
+        okmask = (okmask & ~(1u << p)) | (ok ? (1u << p) : 0u);
+    };
+    auto gloadB = [&](int p, int kbase) {
+        int m = kbase + p * KB + b_kr;
+        int mm = m < mend ? m : mbeg;
+        int img = fdiv(mm, a.fPQ);
+        int rem = mm - img * (a.P * a.Q);
+        int pp = fdiv(rem, a.fQ);
+        int qq = rem - pp * a.Q;
+        int h = pp * a.stride + b_dh, w = qq * a.stride + b_dw;
+        const bool ok = m < mend && h >= 0 && w >= 0 && h < a.H && w < a.W;
+        h = h < 0 ? 0 : (h < a.H ? h : a.H - 1);   // clamped, always valid address: no divergent branch around the load
+        w = w < 0 ? 0 : (w < a.W ? w : a.W - 1);
+        rb[p] = *reinterpret_cast<const float4*>(a.x + (size_t)((img * a.H + h) * a.W + w) * a.ldx + b_ci);
+        okmask = (okmask & ~(1u << (8 + p))) | (ok ? (1u << (8 + p)) : 0u);
+    };
     auto gload = [&](int kbase) {
-        unsigned msk = 0;
 #pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            int m = kbase + p * KA + a_kr;
-            bool ok = m < mend;
-            ra[p] = *reinterpret_cast<const float4*>(a.dy + (size_t)(ok ? m : mbeg) * a.ldy + a_co);
-            msk |= ok ? (1u << p) : 0u;
-        }
+        for (int p = 0; p < PA; ++p) gloadA(p, kbase);
 #pragma unroll
-        for (int p = 0; p < PB; ++p) {
-            int m = kbase + p * KB + b_kr;
-            int mm = m < mend ? m : mbeg;
-            int img = fdiv(mm, a.fPQ);
-            int rem = mm - img * (a.P * a.Q);
-            int pp = fdiv(rem, a.fQ);
-            int qq = rem - pp * a.Q;
-            int h = pp * a.stride + b_dh, w = qq * a.stride + b_dw;
-            bool ok = h >= 0 && w >= 0 && h < a.H && w < a.W;
-            size_t off = ok ? (size_t)((img * a.H + h) * a.W + w) * a.ldx + b_ci : (size_t)0;
-            rb[p] = *reinterpret_cast<const float4*>(a.x + off);
-            msk |= ok ? (1u << (8 + p)) : 0u;
-        }
-        okmask = msk;
+        for (int p = 0; p < PB; ++p) gloadB(p, kbase);
+    };
+    auto lstoreA = [&](int p, int buf) {
+        *reinterpret_cast<float4*>(&As[buf * BUF + (p * KA + a_kr) * BM + a_c4 * 4]) = keep_or_zero((okmask >> p) & 1u, ra[p]);
+    };
+    auto lstoreB = [&](int p, int buf) {
+        *reinterpret_cast<float4*>(&Bs[buf * BUF + (p * KB + b_kr) * BN + b_c4 * 4]) =
+            keep_or_zero((okmask >> (8 + p)) & 1u, rb[p]);
     };
     auto lstore = [&](int buf = 0) {
 #pragma unroll
-        for (int p = 0; p < PA; ++p)
-            *reinterpret_cast<float4*>(&As[buf * BUF + (p * KA + a_kr) * BM + a_c4 * 4]) =
-                keep_or_zero((okmask >> p) & 1u, ra[p]);
+        for (int p = 0; p < PA; ++p) lstoreA(p, buf);
 #pragma unroll
-        for (int p = 0; p < PB; ++p)
-            *reinterpret_cast<float4*>(&Bs[buf * BUF + (p * KB + b_kr) * BN + b_c4 * 4]) =
-                keep_or_zero((okmask >> (8 + p)) & 1u, rb[p]);
+        for (int p = 0; p < PB; ++p) lstoreB(p, buf);
     };
 
     f32x16 acc[TM][TN];
@@ -1086,13 +1091,43 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) wgrad_k
         // the middle of slice t's MFMAs and the registers are refilled with slice t+2 — one barrier per slice and
         // no phase in which the workgroup issues no MFMA (two co-resident workgroups run in lockstep, so the
         // store-and-barrier phase of the single-buffer loop left the MFMA pipe idle: K loop 188 us for 130 us of MFMA)
-        if (mbeg + BK < mend) gload(mbeg + BK);
+        // The body is branch-free (slice starts past the end are clamped to the last slice, whose reload and re-store
+        // are harmless).  In the second half of the slice every k-step also writes ONE staged row set to the other
+        // LDS buffer and refills those registers from global memory, so the store / address arithmetic / load work
+        // is spread between the MFMAs instead of forming an MFMA-free phase; sched_barrier keeps the steps apart
+        // (left alone the scheduler hoists all stores to the top of the iteration, i.e. waits for the loads at once).
+        const int last = mbeg < mend ? mbeg + (mend - mbeg - 1) / BK * BK : mbeg;
+        gload(mbeg + BK <= last ? mbeg + BK : last);
         int cur = 0;
         for (int kb = mbeg; kb < mend; kb += BK, cur ^= 1) {
-            mfma_steps(cur, 0, BK / 4);
-            if (kb + BK < mend) lstore(cur ^ 1);
-            if (kb + 2 * BK < mend) gload(kb + 2 * BK);
-            mfma_steps(cur, BK / 4, BK / 2);
+            const int k2 = kb + 2 * BK <= last ? kb + 2 * BK : last;
+            float af[2][TM], bf[2][TN];
+            auto frag = [&](int b, int kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[b][i] = Ard[cur * BUF + 2 * kk * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[b][j] = Brd[cur * BUF + 2 * kk * BN + j * 32];
+            };
+            frag(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                const int b = kk & 1;
+                if (kk + 1 < BK / 2) frag(b ^ 1, kk + 1);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[b][i], bf[b][j], acc[i][j], 0, 0, 0);
+                const int w = kk - BK / 4;   // staged row set handled by this step
+                if (w >= 0 && w < PA) {
+                    lstoreA(w, cur ^ 1);
+                    gloadA(w, k2);
+                } else if (w >= PA && w < PA + PB) {
+                    lstoreB(w - PA, cur ^ 1);
+                    gloadB(w - PA, k2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
             __syncthreads();
         }
     } else {
