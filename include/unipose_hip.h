@@ -128,14 +128,16 @@ int up_bn_finalize(const float* stats, int tiles, int C, float eps, float moment
                    float* running_mean, float* running_var,
                    const float* gamma, const float* beta,
                    float* mean, float* invstd, float* scale, float* shift, void* stream);
-/* z = relu?(y*scale[c] + shift[c] (+ residual)) */
+/* z = relu?(y*scale[c] + shift[c] (+ residual)).  relu_bits (optional, (rows*C + 31)/32 words): dense bit array,
+ * bit row*C + c = (z > 0) — the backward passes read it instead of z (1/32 of the bytes). */
 int up_bn_apply(const float* y, int ldy, const float* scale, const float* shift,
-                const float* residual, int ldr, int relu, float* z, int ldz,
+                const float* residual, int ldr, int relu, float* z, int ldz, uint32_t* relu_bits,
                 int64_t rows, int C, void* stream);
 /* backward of z = relu?(bn(y) (+res)):  g = dz * (z>0 if relu);  dgamma = sum g*xhat, dbeta = sum g,
  * dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M)  (train)   or   gamma*invstd*g (eval: use_batch_stats=0);
- * dres (optional) = g. */
-int up_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+ * dres (optional) = g.  The ReLU mask comes from relu_bits when given (z may then be NULL), else from z. */
+int up_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const uint32_t* relu_bits,
+              const float* y, int ldy,
               const float* gamma, const float* mean, const float* invstd, int relu, int use_batch_stats,
               float* dy, int lddy, float* dres, int lddres, float* dgamma, float* dbeta,
               float* workspace, size_t workspace_bytes, int64_t rows, int C, void* stream);

@@ -47,8 +47,8 @@ SIGNATURES = {
     "up_conv2d_bwd_weight": (_i, [_D, _p, _p, _p, _p, _p, _sz, _p]),
     "up_bn_eval_coeffs": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
     "up_bn_finalize": (_i, [_p, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "up_bn_apply": (_i, [_p, _i, _p, _p, _p, _i, _i, _p, _i, _i64, _i, _p]),
-    "up_bn_bwd": (_i, [_p, _i, _p, _i, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _sz, _i64, _i, _p]),
+    "up_bn_apply": (_i, [_p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i64, _i, _p]),
+    "up_bn_bwd": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _sz, _i64, _i, _p]),
     "up_bn_bwd_workspace": (_sz, [_i64, _i]),
     "up_relu_bwd": (_i, [_p, _p, _p, _i64, _p]),
     "up_copy2d": (_i, [_p, _i, _p, _i, _i64, _i, _p]),

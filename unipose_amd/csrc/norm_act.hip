@@ -90,33 +90,49 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* stats, in
     }
 }
 
+// relu_bits (optional): bit (row*C + c) of a dense bit array = (z > 0).  The backward passes read this instead of z:
+// 1/32 of the bytes.  One thread produces 4 bits; 8 neighbouring lanes are merged into one 32-bit word.
 __global__ void __launch_bounds__(256) bn_apply_kernel(const float* y, int ldy, const float* scale,
                                                        const float* shift, const float* res, int ldr, int relu,
-                                                       float* z, int ldz, int64_t total, int C4, FastDiv fC4) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        uint32_t row = fdiv((uint32_t)i, fC4);
-        int c = ((int)i - (int)row * C4) * 4;
-        float4 v = *reinterpret_cast<const float4*>(y + (size_t)row * ldy + c);
-        float4 s = *reinterpret_cast<const float4*>(scale + c);
-        float4 h = *reinterpret_cast<const float4*>(shift + c);
-        v.x = v.x * s.x + h.x;
-        v.y = v.y * s.y + h.y;
-        v.z = v.z * s.z + h.z;
-        v.w = v.w * s.w + h.w;
-        if (res) {
-            float4 r = *reinterpret_cast<const float4*>(res + (size_t)row * ldr + c);
-            v.x += r.x;
-            v.y += r.y;
-            v.z += r.z;
-            v.w += r.w;
+                                                       float* z, int ldz, uint32_t* relu_bits, int64_t total, int C4,
+                                                       FastDiv fC4) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63); i0 < total; i0 += (int64_t)gridDim.x * 256) {
+        const int64_t i = i0 + lane;
+        uint32_t nib = 0;
+        if (i < total) {
+            uint32_t row = fdiv((uint32_t)i, fC4);
+            int c = ((int)i - (int)row * C4) * 4;
+            float4 v = *reinterpret_cast<const float4*>(y + (size_t)row * ldy + c);
+            float4 s = *reinterpret_cast<const float4*>(scale + c);
+            float4 h = *reinterpret_cast<const float4*>(shift + c);
+            v.x = v.x * s.x + h.x;
+            v.y = v.y * s.y + h.y;
+            v.z = v.z * s.z + h.z;
+            v.w = v.w * s.w + h.w;
+            if (res) {
+                float4 r = *reinterpret_cast<const float4*>(res + (size_t)row * ldr + c);
+                v.x += r.x;
+                v.y += r.y;
+                v.z += r.z;
+                v.w += r.w;
+            }
+            if (relu) {
+                v.x = fmaxf(v.x, 0.f);
+                v.y = fmaxf(v.y, 0.f);
+                v.z = fmaxf(v.z, 0.f);
+                v.w = fmaxf(v.w, 0.f);
+            }
+            *reinterpret_cast<float4*>(z + (size_t)row * ldz + c) = v;
+            nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
         }
-        if (relu) {
-            v.x = fmaxf(v.x, 0.f);
-            v.y = fmaxf(v.y, 0.f);
-            v.z = fmaxf(v.z, 0.f);
-            v.w = fmaxf(v.w, 0.f);
+        if (relu_bits) {   // wave-uniform
+            uint32_t w = nib << (4 * (lane & 7));
+            w |= __shfl_xor(w, 1);
+            w |= __shfl_xor(w, 2);
+            w |= __shfl_xor(w, 4);
+            if ((lane & 7) == 0 && i < total) relu_bits[i >> 3] = w;
         }
-        *reinterpret_cast<float4*>(z + (size_t)row * ldz + c) = v;
     }
 }
 
@@ -124,10 +140,20 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* y, int ldy, 
 // pass 1: partial[chunk][c] = {sum g, sum g*xhat},   g = dz * (z > 0 if relu)
 // 256 threads = 16 row lanes x 16 channel quads (64 channels): every access is a 16-byte load of 4
 // consecutive channels, rows strided by 16 and unrolled x2 so 6 loads are in flight per thread.
+// the ReLU mask of 4 consecutive channels: from the bit array written by bn_apply_kernel when there is one
+// (relu_bits: 1/32 of the bytes of z), else from z itself
+__device__ __forceinline__ float4 relu_mask4(const uint32_t* bits, int64_t quad, const float* z, size_t zoff) {
+    if (bits) {
+        const uint32_t nib = bits[quad >> 3] >> (4 * (int)(quad & 7));
+        return make_float4((nib & 1u) ? 1.f : 0.f, (nib & 2u) ? 1.f : 0.f, (nib & 4u) ? 1.f : 0.f, (nib & 8u) ? 1.f : 0.f);
+    }
+    return *reinterpret_cast<const float4*>(z + zoff);
+}
+
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* dz, int lddz, const float* z, int ldz,
-                                                            const float* y, int ldy, const float* mean,
-                                                            const float* invstd, int relu, float* partial,
-                                                            int64_t rows, int C, int rows_per_chunk) {
+                                                            const uint32_t* bits, const float* y, int ldy,
+                                                            const float* mean, const float* invstd, int relu,
+                                                            float* partial, int64_t rows, int C, int rows_per_chunk) {
     __shared__ float red[16][64][2];
     const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.y * 64 + cq * 4;
@@ -160,8 +186,8 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* dz, int
             float4 yb = *reinterpret_cast<const float4*>(y + (r + 16) * ldy + c);
             float4 za = ga, zb = gb;
             if (relu) {
-                za = *reinterpret_cast<const float4*>(z + r * ldz + c);
-                zb = *reinterpret_cast<const float4*>(z + (r + 16) * ldz + c);
+                za = relu_mask4(bits, r * (C >> 2) + (c >> 2), z, r * ldz + c);
+                zb = relu_mask4(bits, (r + 16) * (C >> 2) + (c >> 2), z, (r + 16) * ldz + c);
             }
             acc(ga, za, ya);
             acc(gb, zb, yb);
@@ -169,7 +195,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* dz, int
         for (; r < r1; r += 16) {
             float4 ga = *reinterpret_cast<const float4*>(dz + r * lddz + c);
             float4 ya = *reinterpret_cast<const float4*>(y + r * ldy + c);
-            float4 za = relu ? *reinterpret_cast<const float4*>(z + r * ldz + c) : ga;
+            float4 za = relu ? relu_mask4(bits, r * (C >> 2) + (c >> 2), z, r * ldz + c) : ga;
             acc(ga, za, ya);
         }
         const float4 is = *reinterpret_cast<const float4*>(invstd + c);
@@ -216,7 +242,8 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* parti
 }
 // pass 3: dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M);  dres = g
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* dz, int lddz, const float* z, int ldz,
-                                                           const float* y, int ldy, const float* gamma,
+                                                           const uint32_t* bits, const float* y, int ldy,
+                                                           const float* gamma,
                                                            const float* mean, const float* invstd,
                                                            const float* dgamma, const float* dbeta, int relu,
                                                            int use_batch, float inv_m, float* dy, int lddy,
@@ -228,7 +255,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* dz, int 
         float4 g4 = *reinterpret_cast<const float4*>(dz + (size_t)row * lddz + c);
         float g[4] = {g4.x, g4.y, g4.z, g4.w};
         if (relu) {
-            float4 z4 = *reinterpret_cast<const float4*>(z + (size_t)row * ldz + c);
+            float4 z4 = relu_mask4(bits, i, z, (size_t)row * ldz + c);
             if (!(z4.x > 0.f)) g[0] = 0.f;
             if (!(z4.y > 0.f)) g[1] = 0.f;
             if (!(z4.z > 0.f)) g[2] = 0.f;
@@ -332,7 +359,7 @@ constexpr int BNB_ROWS = 512;
 using namespace up;
 
 extern "C" const char* up_last_error(void) { return g_err; }
-extern "C" int up_abi_version(void) { return 2; }
+extern "C" int up_abi_version(void) { return 3; }
 
 extern "C" int up_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                  int C, float* scale, float* shift, void* stream) {
@@ -354,14 +381,15 @@ extern "C" int up_bn_finalize(const float* stats, int tiles, int C, float eps, f
 }
 
 extern "C" int up_bn_apply(const float* y, int ldy, const float* scale, const float* shift, const float* res,
-                           int ldr, int relu, float* z, int ldz, int64_t rows, int C, void* stream) {
+                           int ldr, int relu, float* z, int ldz, uint32_t* relu_bits, int64_t rows, int C,
+                           void* stream) {
     UP_REQUIRE(y && scale && shift && z && rows > 0 && C > 0, UP_ERR_INVALID, "bn_apply: bad argument");
     UP_REQUIRE(C % 4 == 0 && ldy % 4 == 0 && ldz % 4 == 0 && (!res || ldr % 4 == 0), UP_ERR_INVALID,
                "bn_apply: C and strides must be multiples of 4");
     UP_REQUIRE(rows * (C / 4) < (1ll << 31), UP_ERR_UNSUPPORTED, "bn_apply: tensor too large");
     int64_t total = rows * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), y, ldy, scale, shift,
-                       res, ldr, relu, z, ldz, total, C / 4, make_fastdiv(C / 4));
+                       res, ldr, relu, z, ldz, relu_bits, total, C / 4, make_fastdiv(C / 4));
     return check_launch("bn_apply");
 }
 
@@ -369,27 +397,28 @@ extern "C" size_t up_bn_bwd_workspace(int64_t rows, int C) {
     return (size_t)cdiv(rows, BNB_ROWS) * C * 2 * sizeof(float);
 }
 
-extern "C" int up_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const float* y, int ldy,
+extern "C" int up_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const uint32_t* relu_bits,
+                         const float* y, int ldy,
                          const float* gamma, const float* mean, const float* invstd, int relu, int use_batch_stats,
                          float* dy, int lddy, float* dres, int lddres, float* dgamma, float* dbeta,
                          float* workspace, size_t workspace_bytes, int64_t rows, int C, void* stream) {
     UP_REQUIRE(dz && y && gamma && mean && invstd && dy && dgamma && dbeta && workspace, UP_ERR_INVALID,
                "bn_bwd: null pointer");
-    UP_REQUIRE(!relu || z, UP_ERR_INVALID, "bn_bwd: relu needs the forward output z");
-    UP_REQUIRE(C % 4 == 0 && lddz % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && (!relu || ldz % 4 == 0) &&
+    UP_REQUIRE(!relu || z || relu_bits, UP_ERR_INVALID, "bn_bwd: relu needs the forward output z or its sign bits");
+    UP_REQUIRE(C % 4 == 0 && lddz % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && (!relu || relu_bits || ldz % 4 == 0) &&
                    (!dres || lddres % 4 == 0),
                UP_ERR_INVALID, "bn_bwd: C and strides must be multiples of 4");
     UP_REQUIRE(rows * (C / 4) < (1ll << 31), UP_ERR_UNSUPPORTED, "bn_bwd: tensor too large");
     UP_REQUIRE(workspace_bytes >= up_bn_bwd_workspace(rows, C), UP_ERR_WORKSPACE, "bn_bwd: workspace too small");
     hipStream_t st = as_stream(stream);
     int chunks = cdiv(rows, BNB_ROWS);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(chunks, cdiv(C, 64)), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy,
-                       mean, invstd, relu, workspace, rows, C, BNB_ROWS);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(chunks, cdiv(C, 64)), dim3(256), 0, st, dz, lddz, z, ldz, relu_bits, y,
+                       ldy, mean, invstd, relu, workspace, rows, C, BNB_ROWS);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, (const float*)workspace, chunks, C,
                        dgamma, dbeta);
     int64_t total = rows * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, dz, lddz, z, ldz, y, ldy, gamma,
-                       mean, invstd, (const float*)dgamma, (const float*)dbeta, relu, use_batch_stats,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, dz, lddz, z, ldz, relu_bits, y, ldy,
+                       gamma, mean, invstd, (const float*)dgamma, (const float*)dbeta, relu, use_batch_stats,
                        1.0f / (float)rows, dy, lddy, dres, lddres, total, C / 4, make_fastdiv(C / 4));
     return check_launch("bn_bwd");
 }

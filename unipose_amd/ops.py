@@ -424,22 +424,25 @@ class ConvBnAct(Function):
             _C.check(L.up_bn_eval_coeffs(gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), eps, k,
                                          coef[2].data_ptr(), coef[3].data_ptr(), _stream(x)), "bn_eval_coeffs")
         z = torch.empty_like(y)
+        # sign bits of z for the backward passes (1/32 of re-reading z there); only when a backward can follow
+        bits = torch.empty(((rows * k + 31) // 32,), dtype=torch.int32, device=dev) \
+            if relu and any(ctx.needs_input_grad[:5]) else None
         _C.check(L.up_bn_apply(y.data_ptr(), d.ldy, coef[2].data_ptr(), coef[3].data_ptr(), _ptr(residual),
                                _nhwc_ok(residual) if residual is not None else 0, int(relu), z.data_ptr(), d.ldy,
-                               rows, k, _stream(x)), "bn_apply")
+                               _ptr(bits), rows, k, _stream(x)), "bn_apply")
         if relu and _RELU_TRACE is not None:
             _RELU_TRACE.append(z.detach())
         ctx.d, ctx.relu, ctx.train, ctx.has_res = d, relu, train, residual is not None
         ctx.link_in, ctx.link_out = link_in, link_out
         if link_in is not None:
             link_in.armed = True       # this node will compute a data gradient: the producer may hand over
-        ctx.save_for_backward(x, weight, gamma, y, z, coef)
+        ctx.save_for_backward(x, weight, gamma, y, bits, coef)
         return z
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dz):
-        x, weight, gamma, y, z, coef = ctx.saved_tensors
+        x, weight, gamma, y, bits, coef = ctx.saved_tensors
         L, d = _C.lib(), ctx.d
         dz = _dense(dz)
         k = weight.shape[0]
@@ -449,7 +452,7 @@ class ConvBnAct(Function):
         dgb = torch.empty((2, k), dtype=torch.float32, device=x.device)
         need = L.up_bn_bwd_workspace(rows, k)
         ws = workspace(x.device, need)
-        _C.check(L.up_bn_bwd(dz.data_ptr(), d.ldy, z.data_ptr(), d.ldy, y.data_ptr(), d.ldy, gamma.data_ptr(),
+        _C.check(L.up_bn_bwd(dz.data_ptr(), d.ldy, None, 0, _ptr(bits), y.data_ptr(), d.ldy, gamma.data_ptr(),
                              coef[0].data_ptr(), coef[1].data_ptr(), int(ctx.relu), int(ctx.train), dy.data_ptr(),
                              d.ldy, _ptr(dres), d.ldy, dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(),
                              ws.numel(), rows, k, _stream(x)), "bn_bwd")
