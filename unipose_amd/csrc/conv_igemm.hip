@@ -952,8 +952,8 @@ struct WgradArgs {
     int S;
     int stride, pad, dil;
     int rows_per_split;
-    int ntn;
-    FastDiv fPQ, fQ, fCp, fS, fNtn;
+    int ntn, nwg;
+    FastDiv fPQ, fQ, fCp, fS, fNtn, fTiles;
     void* dbg;   // development probes only
 };
 
@@ -977,11 +977,16 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) wgrad_k
 
     long long dbg_w0 = 0;
     if ((DBG & 32) && threadIdx.x == 0) dbg_w0 = wall_clock64();
-    const int tile = blockIdx.x;
+    // 1-D grid of tiles x splits.  Hardware block b runs on XCD b%8: the bijective remap gives every XCD a contiguous
+    // run of (split, tile) pairs, i.e. whole splits, so the pixel rows of a split are fetched into ONE L2 instead of
+    // all eight (the 2-D grid spread the tiles of a split over every XCD: 139 MB fetched per launch for 35 MB of operands)
+    const int logical = xcd_remap(blockIdx.x, a.nwg);
+    const int split = fdiv(logical, a.fTiles);
+    const int tile = logical - split * (int)a.fTiles.d;
     const int mt = fdiv(tile, a.fNtn);
     const int nt = tile - mt * a.ntn;
     const int co0 = mt * BM, col0 = nt * BN;
-    const int mbeg = blockIdx.y * a.rows_per_split;
+    const int mbeg = split * a.rows_per_split;
     const int mend = min(a.M, mbeg + a.rows_per_split);
 
     // A (dY): thread -> (k row within pass, 4 output channels).  Channels >= K are never stored: they only
@@ -1145,7 +1150,7 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) wgrad_k
 
     long long dbg_w1 = 0;
     if (DBG & 32) dbg_w1 = wall_clock64();
-    float* out = a.slab + (size_t)blockIdx.y * a.K * a.Ncols;
+    float* out = a.slab + (size_t)split * a.K * a.Ncols;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         int col = col0 + wn * (BN / 2) + j * 32 + l31;
@@ -1162,7 +1167,7 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) wgrad_k
     if (DBG & 32) {   // probe: per-block timeline, same record as igemm_kernel
         __builtin_amdgcn_s_waitcnt(0);
         if (threadIdx.x == 0) {
-            long long* o = reinterpret_cast<long long*>(a.dbg) + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+            long long* o = reinterpret_cast<long long*>(a.dbg) + 4 * (size_t)blockIdx.x;
             o[0] = dbg_w0;
             o[1] = dbg_w1;
             o[2] = wall_clock64();
@@ -1755,11 +1760,13 @@ extern "C" int up_conv2d_bwd_weight(const up_conv_desc* d, const float* x, const
     a.fCp = make_fastdiv(d->Cp);
     a.fS = make_fastdiv(d->S);
     a.fNtn = make_fastdiv(p.ntn);
-    dim3 grid(p.ntm * p.ntn, p.splits);
+    a.fTiles = make_fastdiv(p.ntm * p.ntn);
+    a.nwg = p.ntm * p.ntn * p.splits;
+    dim3 grid(a.nwg);
     {
         const int v = (p.bm == 128 && p.bn == 128) ? 8 : (p.bm == 128 && p.bn == 64) ? 9 : (p.bm == 64 && p.bn == 128) ? 10 : 11;
         ProfScope prof(v, 2.0 * (double)a.M * (double)d->K * (double)d->R * d->S * d->C, st, d->K, a.Ncols, a.M,
-                       (int)(grid.x * grid.y));
+                       a.nwg);
 #ifdef UP_PROBE
         if (g_wgrad_single && !g_wgrad_dbg) {   // the older single-buffer loop, for comparison
             if (p.bm == 128 && p.bn == 128)
@@ -1771,7 +1778,7 @@ extern "C" int up_conv2d_bwd_weight(const up_conv_desc* d, const float* x, const
         } else
         if (g_wgrad_dbg) {   // tools/gpu/igemm_probe.hip: per-block timeline
             a.dbg = g_wgrad_dbg;
-            g_wgrad_grid = (int)(grid.x * grid.y);
+            g_wgrad_grid = a.nwg;
             if (p.bm == 128 && p.bn == 128)
                 hipLaunchKernelGGL((wgrad_kernel<128, 128, 32>), grid, dim3(256), 0, st, a);
             else if (p.bm == 64 && p.bn == 128)
@@ -1784,7 +1791,7 @@ extern "C" int up_conv2d_bwd_weight(const up_conv_desc* d, const float* x, const
             // two LDS buffers (64 KB, two workgroups per CU) when the whole grid is resident at once; launches with more
             // workgroups (layers with many weight tiles) keep the 32 KB single-buffer loop and 3-4 per CU
             // (probe, 3x3 512->512: 115 vs 104 TFLOP/s; in the network the double buffer is 0.5 % faster overall)
-            const bool single = (long long)grid.x * grid.y > 2ll * cu_count();
+            const bool single = a.nwg > 2 * cu_count();
             if (single) {
                 if (p.bm == 128 && p.bn == 128)
                     hipLaunchKernelGGL((wgrad_kernel<128, 128, 64>), grid, dim3(256), 0, st, a);
