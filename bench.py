@@ -218,6 +218,18 @@ def main():
                                              "ms_per_step": round(tot_ms / args.steps, 3)},
                         "by_kernel": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}
                                       for r in rows]}
+            # HBM traffic of the dominant kernel: PMC counters need their own rocprofv3 passes (profiles/pmc_traffic.json
+            # records the last ones and how they were taken); null when no record matches
+            try:
+                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                                  "pmc_traffic.json")))
+                rec = pmc["kernels"].get(top["kernel"])
+                if rec and args.math == "f32" and not lstm and S == 368 and B == 32:
+                    roofline["traffic"] = round(rec["traffic_mb"] * 1e6)
+                    roofline["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes, " \
+                                               f"profiles/{pmc['tag']}_pmc_summary.txt)"
+            except (OSError, ValueError, KeyError):
+                pass
             # The timed region runs the weight gradients on a second stream, so the event-bracketed durations
             # above include time shared with the other stream's kernels.  A few extra steps with everything on
             # ONE stream give each kernel's own duration (same kernels, same shapes, nothing else resident).
@@ -300,10 +312,18 @@ def main():
         if world == 1 and not args.no_cpu_baseline and not lstm:
             log("cpu baseline (oracle on host cores)")
             out["cpu_baseline"] = cpu_baseline(K, S, args.cpu_batch, args.cpu_steps, args.cpu_threads)
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    # the JSON is the LAST line on stdout: RCCL prints a version banner through C stdio, which (redirected to a file)
+    # would otherwise be flushed after it at process exit
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if line is not None:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
