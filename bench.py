@@ -138,7 +138,8 @@ def main():
         model = unipose("MPII", num_classes=K).to(dev).train()
         x = torch.randn(B, 3, S, S, generator=g).to(dev)
         t = torch.rand(B, K + 1, S // 8, S // 8, generator=g).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4)        # unipose.py:72 (no weight decay)
+    # unipose.py:72 (no weight decay); `fused=True` is torch's own single-kernel implementation of the same update
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)    # 70.3 vs 71.7 ms/step with the foreach default
     ops.manual_seed(shard_seed(0, rank))
     ops.set_conv_math(args.math)
     reducer = GradAllReducer(model, bucket_bytes=256 << 20, force=args.force_dp) if use_dist else None
@@ -297,7 +298,7 @@ def main():
                                     f"UniPose ResNet-101 (K={K}) train step: fwd + MSE + bwd + Adam, synthetic "
                                     f"{S}x{S}, batch {B}/GPU (BASELINE.json configs[1]; configs[2] for N>1)"),
                        "global_batch": world * B, "per_gpu_batch": B, "input": [3, S, S],
-                       "parallelism": f"dp{world}", "optimizer": "Adam(lr=1e-4)",
+                       "parallelism": f"dp{world}", "optimizer": "torch.optim.Adam(lr=1e-4, fused=True)",
                        "arithmetic": {"f32": "fp32 MFMA 32x32x2 everywhere",
                                       "bf16x3": "fwd/dgrad: 3x bf16 MFMA 32x32x16 on (hi,lo) split operands; wgrad: fp32 MFMA",
                                       "bf16": "fwd/dgrad: bf16 MFMA 32x32x16; wgrad: fp32 MFMA"}[args.math]},
