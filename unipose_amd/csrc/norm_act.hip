@@ -179,18 +179,18 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* dz, int
             s2[3] += g.w * (yy.w - mu.w);
         };
         int64_t r = r0 + rl;
-        for (; r + 16 < r1; r += 32) {
-            float4 ga = *reinterpret_cast<const float4*>(dz + r * lddz + c);
-            float4 gb = *reinterpret_cast<const float4*>(dz + (r + 16) * lddz + c);
-            float4 ya = *reinterpret_cast<const float4*>(y + r * ldy + c);
-            float4 yb = *reinterpret_cast<const float4*>(y + (r + 16) * ldy + c);
-            float4 za = ga, zb = gb;
-            if (relu) {
-                za = relu_mask4(bits, r * (C >> 2) + (c >> 2), z, r * ldz + c);
-                zb = relu_mask4(bits, (r + 16) * (C >> 2) + (c >> 2), z, (r + 16) * ldz + c);
+        for (; r + 48 < r1; r += 64) {   // four rows (8 x 16-byte loads + the mask words) in flight per thread
+            float4 g[4], yv[4], zv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g[u] = *reinterpret_cast<const float4*>(dz + (r + 16 * u) * lddz + c);
+                yv[u] = *reinterpret_cast<const float4*>(y + (r + 16 * u) * ldy + c);
             }
-            acc(ga, za, ya);
-            acc(gb, zb, yb);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                zv[u] = relu ? relu_mask4(bits, (r + 16 * u) * (C >> 2) + (c >> 2), z, (r + 16 * u) * ldz + c) : g[u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc(g[u], zv[u], yv[u]);
         }
         for (; r < r1; r += 16) {
             float4 ga = *reinterpret_cast<const float4*>(dz + r * lddz + c);
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(256) mse_bwd_kernel(const float* y, const floa
 }
 
 constexpr int MSE_PARTS = 512;
-constexpr int BNB_ROWS = 512;
+constexpr int BNB_ROWS = 128;   // small chunks: enough workgroups (and bytes in flight) to saturate HBM on 23x23 maps
 
 }  // namespace up
 
