@@ -70,7 +70,9 @@ typedef struct {
 
 /* Re-lay an OIHW fp32 weight (PyTorch layout) for the implicit-GEMM kernels:
  *   w_fwd  [K][R*S][Cp]  (forward, B operand rows = output channel, k-contiguous)
- *   w_dgrad[C ][R*S][Kp] (data-gradient: rows = input channel)           — either may be NULL. */
+ *   w_dgrad[C ][R*S][Kp] (data-gradient: rows = input channel)           — either may be NULL.
+ * The data-gradient image is opaque: for stride-2, dilation-1 convolutions it holds four parity-class sub-images
+ * (same total size); only up_conv2d_bwd_data with the SAME descriptor may read it. */
 int up_pack_weights(const up_conv_desc* d, const float* w_oihw, float* w_fwd, float* w_dgrad, void* stream);
 /* The same for many parameters in ONE launch (every weight changes once per optimizer step): `jobs` is a table in
  * DEVICE memory; w_fwd / w_dgrad may be NULL per job. */
@@ -78,7 +80,9 @@ typedef struct {
     const float* w;        /* OIHW */
     float* w_fwd;
     float* w_dgrad;
-    int32_t K, C, Cp, Kp, taps, reserved;
+    int32_t K, C, Cp, Kp, taps;
+    int32_t geometry;      /* stride | R << 4 | S << 10 | pad << 16 | dilation << 24: selects the data-gradient image layout
+                              (stride-2 convolutions use a parity-class-major one, like up_pack_weights does) */
 } up_pack_job;
 int up_pack_weights_batched(const up_pack_job* jobs_device, int njobs, void* stream);
 

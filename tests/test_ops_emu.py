@@ -18,7 +18,11 @@ import op_cases as oc
     (1, 15, 12, 12, 8, 11, 1, 5, 1, True, True),      # 11x11 (K17)
     (2, 32, 5, 5, 14, 1, 1, 0, 1, True, False),       # K=14: data gradient with a ragged (16 < 32) K slice
     (1, 128, 5, 5, 32, 3, 1, 1, 1, False, False),     # reduction 1152 >= 1024: double-buffered LDS loop
-    (1, 128, 6, 6, 128, 3, 2, 1, 1, False, False),    # same for the strided data gradient (MODE 1)
+    (1, 128, 6, 6, 128, 3, 2, 1, 1, False, False),    # same for the strided data gradient
+    (2, 32, 7, 7, 16, 1, 2, 0, 1, False, False),      # 1x1 stride 2 on an odd size: three of the four parity classes empty
+    (1, 15, 8, 7, 14, 3, 2, 1, 1, True, False),       # stride-2 parity classes on the generic (unaligned) path
+    (1, 4, 10, 9, 8, 7, 2, 3, 1, False, False),       # 7x7 stride 2 pad 3: classes of 4x4, 4x3, 3x4, 3x3 taps
+    (1, 32, 9, 9, 16, 3, 2, 0, 1, False, False),      # stride 2 without padding
 ])
 def test_conv_fwd_bwd(emu_backend, cfg):
     n, c, h, w, k, r, s, p, d, bias, relu = cfg
@@ -163,6 +167,8 @@ def guard_pages(emu_backend, monkeypatch):
     (1, 128, 5, 5, 32, 3, 1, 1, 1, False, False),     # double-buffered loop
     (1, 64, 6, 6, 17, 1, 1, 0, 1, True, False),       # K=17 -> ldy 20
     (2, 96, 6, 6, 72, 3, 1, 1, 1, False, False),      # K-split tail tiles (13 uneven parts)
+    (1, 15, 8, 7, 14, 3, 2, 1, 1, True, False),       # stride-2 parity classes, generic path
+    (2, 32, 7, 7, 16, 1, 2, 0, 1, False, False),      # 1x1 stride 2: memset + one class
 ])
 def test_conv_no_out_of_bounds(guard_pages, cfg):
     n, c, h, w, k, r, s, p, d, bias, relu = cfg

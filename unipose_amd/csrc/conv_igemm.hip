@@ -97,6 +97,7 @@ struct IgemmArgs {
     int ldx, ldy;
     int S, taps;
     int mul, off0, tapstep;       // src = (dst*mul + off0 + r*tapstep) >> divshift (if divisible)
+    int off0w;                    // column offset (== off0 except in the parity classes of a stride-2 data gradient)
     int divshift, divmask;        // 0,0 (forward, stride-1 dgrad) or 1,1 (dgrad of a stride-2 conv)
     int ntn;                      // number of n tiles
     int nwg;
@@ -108,6 +109,10 @@ struct IgemmArgs {
     int ldr;
     int relu;
     float* stats;
+    // output row map of a stride-2 data-gradient parity class: GEMM row m = (img, hc, wc) of the class grid is written
+    // to pixel (img, 2*hc + o_ph, 2*wc + o_pw) of the o_H x o_W image (o_mode 0: rows are written linearly)
+    int o_mode, o_ph, o_pw, o_H, o_W, o_Wc;
+    FastDiv fo_HcWc, fo_Wc;
     void* dbg;   // development probes only (tools/gpu/igemm_probe.hip)
     // tail split (see launch_igemm): blocks [0, full_blocks) compute whole tiles, the rest compute 1/parts of the
     // K range of a tail tile; parts 0..parts-2 publish raw accumulators, the last part adds them and runs the epilogue
@@ -179,7 +184,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN, bool RES, bool CHECK>
+template <int BM, int BN, bool RES, bool CHECK, bool OMAP = false>
 __device__ __forceinline__ void igemm_store(const IgemmArgs& a, f32x16 (&acc)[BM / 64][BN / 64], int mrow0, int ncol0) {
     constexpr int TM = BM / 64, TN = BN / 64;
     const bool relu = a.relu != 0;
@@ -201,14 +206,21 @@ __device__ __forceinline__ void igemm_store(const IgemmArgs& a, f32x16 (&acc)[BM
                     res[r] = a.residual[(size_t)(!CHECK || m < a.M ? m : a.M - 1) * a.ldr + n];
                 }
             }
-            float* yrow = a.y + (size_t)mb * a.ldy + n;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int dm = (r & 3) + 8 * (r >> 2);
+                const int m = mb + (r & 3) + 8 * (r >> 2);
                 float v = acc[i][j][r] * sc + sh;
                 if (RES) v += res[r];
                 v = relu ? fmaxf(v, 0.f) : v;
-                if (!CHECK || mb + dm < a.M) yrow[(size_t)dm * a.ldy] = v;
+                size_t pix = (size_t)m;
+                if (OMAP) {   // stride-2 data-gradient parity class: every other row / column of the image
+                    const int img = fdiv(m, a.fo_HcWc);
+                    const int rem = m - img * (int)a.fo_HcWc.d;
+                    const int hc = fdiv(rem, a.fo_Wc);
+                    const int wc = rem - hc * a.o_Wc;
+                    pix = (size_t)(img * a.o_H + 2 * hc + a.o_ph) * a.o_W + 2 * wc + a.o_pw;
+                }
+                if (!CHECK || m < a.M) a.y[pix * a.ldy + n] = v;
             }
         }
     }
@@ -304,6 +316,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
     if (a.residual) {
         if (full) igemm_store<BM, BN, true, false>(a, acc, mrow0, ncol0);
         else igemm_store<BM, BN, true, true>(a, acc, mrow0, ncol0);
+    } else if (a.o_mode) {
+        if (full) igemm_store<BM, BN, false, false, true>(a, acc, mrow0, ncol0);
+        else igemm_store<BM, BN, false, true, true>(a, acc, mrow0, ncol0);
     } else {
         if (full) igemm_store<BM, BN, false, false>(a, acc, mrow0, ncol0);
         else igemm_store<BM, BN, false, true>(a, acc, mrow0, ncol0);
@@ -372,7 +387,7 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
         int p = fdiv(rem, a.fQ);
         int q = rem - p * a.Q;
         hb[i] = p * a.mul + a.off0;
-        wb[i] = q * a.mul + a.off0;
+        wb[i] = q * a.mul + a.off0w;
         ib[i] = img * a.H * a.W;
         if (FAST) {
             roff[i] = (ib[i] + hb[i] * a.W + wb[i]) * a.ldx;
@@ -1212,6 +1227,53 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* slab, fl
     }
 }
 
+// Parity classes of the data gradient of a stride-2, dilation-1 convolution.  dx pixel (h, w) only receives filter
+// taps with r == (h + pad) mod 2 and s == (w + pad) mod 2, so the four (h%2, w%2) classes are four stride-1-like
+// gathers over the dy grid with 1/4 of the taps on average; computing them as ONE gather with a divisibility test
+// (the older MODE 1 path) multiplies 4x as many zeros.  Class cls = ph*2 + pw uses taps r = r0 + 2*ri, s = s0 + 2*si
+// (ri < Rc, si < Sc); its weight image [C][Rc*Sc][Kp] starts at element base[cls] of the data-gradient image.
+struct S2Classes {
+    int r0[4], s0[4], Rc[4], Sc[4];
+    long long base[4];
+};
+__host__ __device__ inline S2Classes s2_classes(int R, int S, int pad, int C, int Kp) {
+    S2Classes c;
+    long long b = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+        const int ph = cls >> 1, pw = cls & 1;
+        c.r0[cls] = (ph + pad) & 1;
+        c.s0[cls] = (pw + pad) & 1;
+        c.Rc[cls] = c.r0[cls] < R ? (R - c.r0[cls] + 1) / 2 : 0;
+        c.Sc[cls] = c.s0[cls] < S ? (S - c.s0[cls] + 1) / 2 : 0;
+        c.base[cls] = b;
+        b += (long long)C * c.Rc[cls] * c.Sc[cls] * Kp;
+    }
+    return c;
+}
+__host__ __device__ inline bool s2_decomposed(int stride, int dil) { return stride == 2 && dil == 1; }
+// value of element f of the class-major data-gradient image
+__device__ __forceinline__ float s2_dgrad_elem(const float* w, long long f, const S2Classes& c, int K, int Kp, int C, int S,
+                                               int taps) {
+    int cls = 3;
+    while (cls > 0 && f < c.base[cls]) --cls;
+    const long long l = f - c.base[cls];
+    const int tc = c.Rc[cls] * c.Sc[cls];
+    const int k = (int)(l % Kp);
+    const long long t = l / Kp;
+    const int ti = (int)(t % tc);
+    const int ch = (int)(t / tc);
+    const int ri = ti / c.Sc[cls], si = ti - ri * c.Sc[cls];
+    const int tap = (c.r0[cls] + 2 * ri) * S + c.s0[cls] + 2 * si;
+    return k < K ? w[((size_t)k * C + ch) * taps + tap] : 0.f;
+}
+__global__ void __launch_bounds__(256) pack_dgrad_s2_kernel(const float* w, float* o, int K, int Kp, int C, int R, int S,
+                                                            int pad, long long total) {
+    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const S2Classes c = s2_classes(R, S, pad, C, Kp);
+    o[e] = s2_dgrad_elem(w, e, c, K, Kp, C, S, R * S);
+}
+
 __global__ void __launch_bounds__(256) pack_fwd_kernel(const float* w, float* o, int K, int C, int Cp, int taps,
                                                        long long total) {
     long long e = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1242,6 +1304,12 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const up_pack_job* jo
     const long long nf = jb.w_fwd ? (long long)jb.K * taps * jb.Cp : 0;
     const long long nd = jb.w_dgrad ? (long long)jb.C * taps * jb.Kp : 0;
     const long long step = (long long)gridDim.x * 256;
+    // geometry word: stride | R << 4 | S << 10 | pad << 16 | dil << 24 (0 = plain layout)
+    const int gstride = jb.geometry & 15, gR = (jb.geometry >> 4) & 63, gS = (jb.geometry >> 10) & 63;
+    const int gpad = (jb.geometry >> 16) & 255, gdil = (jb.geometry >> 24) & 255;
+    const bool s2 = jb.geometry != 0 && s2_decomposed(gstride, gdil);
+    S2Classes cls;
+    if (s2) cls = s2_classes(gR, gS, gpad, jb.C, jb.Kp);
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < nf + nd; e += step) {
         if (e < nf) {
             int ci = (int)(e % jb.Cp);
@@ -1249,6 +1317,8 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const up_pack_job* jo
             int tap = (int)(t % taps);
             int k = (int)(t / taps);
             jb.w_fwd[e] = ci < jb.C ? jb.w[((size_t)k * jb.C + ci) * taps + tap] : 0.f;
+        } else if (s2) {
+            jb.w_dgrad[e - nf] = s2_dgrad_elem(jb.w, e - nf, cls, jb.K, jb.Kp, jb.C, gS, taps);
         } else {
             long long f = e - nf;
             int k = (int)(f % jb.Kp);
@@ -1481,8 +1551,12 @@ extern "C" int up_pack_weights(const up_conv_desc* d, const float* w, float* w_f
         UP_REQUIRE(d->Kp % 4 == 0 && d->Kp >= d->K, UP_ERR_INVALID, "pack_weights: Kp=%d invalid for K=%d", d->Kp,
                    d->K);
         long long total = (long long)d->C * taps * d->Kp;
-        hipLaunchKernelGGL(pack_dgrad_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w, w_dgrad,
-                           d->K, d->Kp, d->C, taps, total);
+        if (s2_decomposed(d->stride, d->dil))   // class-major image, see S2Classes
+            hipLaunchKernelGGL(pack_dgrad_s2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w, w_dgrad,
+                               d->K, d->Kp, d->C, d->R, d->S, d->pad, total);
+        else
+            hipLaunchKernelGGL(pack_dgrad_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), w, w_dgrad,
+                               d->K, d->Kp, d->C, taps, total);
     }
     return check_launch("pack_weights");
 }
@@ -1509,6 +1583,7 @@ static int fill_fwd_args(IgemmArgs& a, const up_conv_desc* d, const float* x, co
     a.taps = d->R * d->S;
     a.mul = d->stride;
     a.off0 = -d->pad;
+    a.off0w = -d->pad;
     a.tapstep = d->dil;
     a.divshift = 0;
     a.divmask = 0;
@@ -1567,6 +1642,7 @@ static int fill_dgrad_args(IgemmArgs& a, const up_conv_desc* d, const float* dy,
     a.taps = d->R * d->S;
     a.mul = 1;
     a.off0 = d->pad;
+    a.off0w = d->pad;
     a.tapstep = -d->dil;
     a.divshift = d->stride == 2 ? 1 : 0;
     a.divmask = d->stride == 2 ? 1 : 0;
@@ -1639,6 +1715,50 @@ extern "C" int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const 
     if (int e = fill_dgrad_args(a, d, dy, w_dgrad, dx)) return e;
     a.residual = add;   // dx = dgrad + add in the epilogue (a second gradient of the same input)
     a.ldr = ld_add;
+    if (s2_decomposed(d->stride, d->dil)) {
+        UP_REQUIRE(!add, UP_ERR_UNSUPPORTED, "conv2d_bwd_data: an addend with a stride-2 convolution is not implemented");
+        // four parity classes, each a dense stride-1-like gather over the dy grid (see S2Classes): 1/4 of the MACs of
+        // the single strided launch.  Classes without taps (1x1 stride 2: three of four) are covered by a memset.
+        const S2Classes c = s2_classes(d->R, d->S, d->pad, d->C, d->Kp);
+        bool empty = false;
+        for (int cls = 0; cls < 4; ++cls) empty = empty || c.Rc[cls] * c.Sc[cls] == 0;
+        hipStream_t st = as_stream(stream);
+        if (empty && hipMemsetAsync(dx, 0, (size_t)d->N * d->H * d->W * d->ldx * sizeof(float), st) != hipSuccess)
+            return check_launch("conv2d_bwd_data memset");
+        for (int cls = 0; cls < 4; ++cls) {
+            const int ph = cls >> 1, pw = cls & 1, tc = c.Rc[cls] * c.Sc[cls];
+            const int Hc = (d->H - ph + 1) / 2, Wc = (d->W - pw + 1) / 2;
+            if (!tc || Hc <= 0 || Wc <= 0) continue;
+            IgemmArgs b = a;
+            b.w = w_dgrad + c.base[cls];
+            b.M = d->N * Hc * Wc;
+            b.P = Hc;   // destination grid of the class
+            b.Q = Wc;
+            b.S = c.Sc[cls];
+            b.taps = tc;
+            b.Ktot = tc * d->Kp;
+            b.Ktot_real = (long long)tc * d->K;
+            b.mul = 1;
+            b.tapstep = -1;
+            b.off0 = (ph + d->pad - c.r0[cls]) / 2;
+            b.off0w = (pw + d->pad - c.s0[cls]) / 2;
+            b.divshift = 0;
+            b.divmask = 0;
+            b.fPQ = make_fastdiv(Hc * Wc);
+            b.fQ = make_fastdiv(Wc);
+            b.fS = make_fastdiv(c.Sc[cls]);
+            b.o_mode = 1;
+            b.o_ph = ph;
+            b.o_pw = pw;
+            b.o_H = d->H;
+            b.o_W = d->W;
+            b.o_Wc = Wc;
+            b.fo_HcWc = make_fastdiv(Hc * Wc);
+            b.fo_Wc = make_fastdiv(Wc);
+            run_igemm(b, choose_tile(b.M, b.Ng, b.Ktot), st);
+        }
+        return check_launch("conv2d_bwd_data");
+    }
     run_igemm(a, choose_tile(a.M, a.Ng, a.Ktot), as_stream(stream));
     return check_launch("conv2d_bwd_data");
 }

@@ -128,7 +128,8 @@ class _PackSet:
         if weight.is_leaf and weight.is_contiguous():
             if len(self.entries) > 4096:
                 self.entries.clear()
-            self.entries[key] = [weakref.ref(weight), weight._version, wf, wd, (d.K, d.C, d.Cp, d.Kp, d.R * d.S),
+            geom = d.stride | (d.R << 4) | (d.S << 10) | (d.pad << 16) | (d.dil << 24)      # up_pack_job.geometry
+            self.entries[key] = [weakref.ref(weight), weight._version, wf, wd, (d.K, d.C, d.Cp, d.Kp, d.R * d.S, geom),
                                  weight.data_ptr()]
             self.table = None
         return wf, wd
@@ -142,9 +143,9 @@ class _PackSet:
             self.order = list(self.entries)
             job = np.zeros((len(self.order), 6), dtype=np.int64)      # up_pack_job: 3 pointers + 6 int32
             for i, k in enumerate(self.order):
-                w, _, wf, wd, (kk, cc, cp, kp, taps), _ = self.entries[k]
+                w, _, wf, wd, (kk, cc, cp, kp, taps, geom), _ = self.entries[k]
                 job[i, 0], job[i, 1], job[i, 2] = w().data_ptr(), wf.data_ptr(), wd.data_ptr()
-                job[i, 3:].view(np.int32)[:] = (kk, cc, cp, kp, taps, 0)
+                job[i, 3:].view(np.int32)[:] = (kk, cc, cp, kp, taps, geom)
             self.table = torch.from_numpy(job).to(weight.device)
         live = [self.entries[k] for k in self.order]
         if any(e[0]() is None for e in live):                         # a parameter died: its pointer is stale
