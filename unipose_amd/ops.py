@@ -125,7 +125,7 @@ class _PackSet:
         wd = torch.empty(nd, dtype=torch.float32, device=weight.device)
         _C.check(_C.lib().up_pack_weights(C.byref(d), _dense(weight).data_ptr(), wf.data_ptr(), wd.data_ptr(),
                                           _stream(weight)), "pack_weights")
-        if weight.is_leaf and weight.is_contiguous():
+        if isinstance(weight, torch.nn.Parameter) and weight.is_contiguous():      # temporaries are packed per use
             if len(self.entries) > 4096:
                 self.entries.clear()
             geom = d.stride | (d.R << 4) | (d.S << 10) | (d.pad << 16) | (d.dil << 24)      # up_pack_job.geometry
@@ -205,7 +205,7 @@ def _packed_bf16(weight: torch.Tensor, d: _C.ConvDesc):
                                            wd[0].data_ptr(), wd[1].data_ptr(), _stream(weight)), "pack_weights_bf16")
     if len(_PACK16_CACHE) > 4096:
         _PACK16_CACHE.clear()
-    if weight.is_leaf:
+    if isinstance(weight, torch.nn.Parameter):
         _PACK16_CACHE[key] = (weakref.ref(weight), weight._version, wf, wd)
     return wf, wd
 
@@ -514,11 +514,11 @@ class bn_counters:
 
 def conv_bn_act(x, conv, bn, relu=True, residual=None, link_in=None, link_out=None):
     """Dispatch on (bn.training, grad mode) exactly like nn.BatchNorm2d would.  link_in / link_out: see GradLink."""
-    cfg = ConvCfg(conv.stride[0], conv.padding[0], conv.dilation[0])
+    weight, cfg = conv.weight, ConvCfg(conv.stride[0], conv.padding[0], conv.dilation[0])
     need_grad = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad or bn.weight.requires_grad)
     train = bn.training
     if not train and not need_grad:
-        return conv_bn_act_eval_fused(x, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, cfg, relu,
+        return conv_bn_act_eval_fused(x, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, cfg, relu,
                                       residual, bn.eps)
     if train and bn.track_running_stats and _BN_COUNT["mode"] != "skip":
         bn.num_batches_tracked.add_(1)
@@ -526,7 +526,7 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, link_in=None, link_out=No
             _BN_COUNT["seen"].append(bn.num_batches_tracked)
     mom = 0.1 if bn.momentum is None else bn.momentum
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    return ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, rm, rv, cfg, relu, train, bn.eps, mom,
+    return ConvBnAct.apply(x, weight, bn.weight, bn.bias, residual, rm, rv, cfg, relu, train, bn.eps, mom,
                            link_in, link_out)
 
 
