@@ -284,6 +284,17 @@ static void wasp_report(int dil) {
 }
 
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "loops")) {   // single-buffer (64) vs double-buffered (128 / 0) loop at short reductions
+        sweep<128, 128, 64>("1x1 512->256 @92^2 SB", mk(32, 92, 512, 256, 1, 0, 1));
+        sweep<128, 128, 128>("1x1 512->256 @92^2 DB", mk(32, 92, 512, 256, 1, 0, 1));
+        sweep<64, 128, 64>("1x1 256->1024 @23^2 SB", mk(32, 23, 256, 1024, 1, 0, 1));
+        sweep<64, 128, 128>("1x1 256->1024 @23^2 DB", mk(32, 23, 256, 1024, 1, 0, 1));
+        sweep<128, 128, 64>("1x1 512->2048 @23^2 SB", mk(32, 23, 512, 2048, 1, 0, 1));
+        sweep<128, 128, 128>("1x1 512->2048 @23^2 DB", mk(32, 23, 512, 2048, 1, 0, 1));
+        sweep<64, 128, 64>("1x1 512->128 @46^2 SB", mk(32, 46, 512, 128, 1, 0, 1));
+        sweep<64, 128, 128>("1x1 512->128 @46^2 DB", mk(32, 46, 512, 128, 1, 0, 1));
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "wasp")) {
         for (int dil : {6, 12, 18, 24}) wasp_report(dil);
         return 0;

@@ -1469,9 +1469,15 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     // MODE 2 needs <= 32 taps (bit mask), no stride division and 32-bit element offsets
     const bool fast = aligned && a.taps <= 32 && a.divshift == 0 &&
                       (long long)a.H * a.W * a.ldx * ((long long)a.M / (a.P * a.Q) + 1) < (1ll << 31);
-    // double-buffered LDS (one barrier per slice) pays for long reductions; short ones (1x1 convs with few input
-    // channels) are epilogue-bound and prefer the smaller footprint / higher occupancy of the single-buffer loop
-    const bool db = a.Ktot >= 1024;
+    // double-buffered LDS (one barrier per slice) for long reductions.  In isolation it is 3-5 % faster than the
+    // single-buffer loop down to K = 256 (probe), but in the network the rule K >= 1024 is 0.5 % faster per step (A/B in
+    // one session, 70.55 vs 70.95 ms): the 73 KB footprint leaves less room for the weight-gradient workgroups of
+    // the other stream.  UP_DB_MIN_K overrides the threshold.
+    static const int db_min_k = [] {
+        const char* e = getenv("UP_DB_MIN_K");
+        return e && atoi(e) > 0 ? atoi(e) : 1024;
+    }();
+    const bool db = a.Ktot >= db_min_k;
     // wide tiles additionally pin the refill between the MFMAs (branch-free body + sched_group_barrier): +2..4 %
     // on 128-wide tiles, -3 % on 64x64 (probe, warm)
     void (*kernel)(IgemmArgs);
