@@ -1373,12 +1373,16 @@ static int check_desc(const up_conv_desc* d) {
 struct TileChoice {
     int bm, bn;
 };
-// Largest tile that still yields ~4 workgroups per CU (the tail split evens out the remainder).  Short reductions
+// Largest tile that still yields ~6 workgroups per CU (the tail split evens out the remainder).  Short reductions
 // are epilogue-heavy and run better on twice as many, smaller tiles (1x1 256->1024 at 23x23: 64x128 91 TF,
 // 128x128 85 TF).
 static TileChoice choose_tile(int64_t M, int Ng, int Ktot) {
     const int cands[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
-    const int64_t want = Ktot < 512 ? 2000 : 1000;
+    static const int base_want = [] {   // tuning knob (A/B runs): workgroups a launch should at least have
+        const char* e = getenv("UP_TILE_WANT");
+        return e && atoi(e) > 0 ? atoi(e) : 1500;   // A/B in the network: 700 / 1000 / 1500 / 2200 / 4300 -> 70.1 / 69.9 / 69.6 / 69.9 / 69.8 ms
+    }();
+    const int64_t want = Ktot < 512 ? 2 * base_want : base_want;
     for (auto& c : cands) {
         if (Ng <= 64 && c[1] == 128) continue;
         int64_t wgs = (int64_t)cdiv(M, c[0]) * cdiv(Ng, c[1]);
@@ -1450,6 +1454,7 @@ static bool tail_split_enabled() {
 static int split_parts(int tiles, int Ktot) {
     if (!tail_split_enabled()) return 1;
     const int cus = cu_count(), q = tiles / cus, r = tiles % cus, nk = Ktot / BK;
+    // A/B over the whole step: r <= 25 % of the CUs 70.9 ms, 50 % 70.1, 75 % 70.1;  >= 2 / 4 / 8 slices per part 70.1 / 70.1 / 70.3
     if (r == 0 || r > cus / 2 || q > 12) return 1;
     int p = cus / r;              // one part per CU (finer cuts measured slower: the merge chain grows)
     if (p > nk / 2) p = nk / 2;   // a part keeps >= 2 K slices
@@ -1823,7 +1828,10 @@ static void* g_wgrad_dbg = nullptr;
 static int g_wgrad_grid = 0;
 static bool g_wgrad_single = false;
 #endif
-static int g_wgrad_per_cu = 2;   // workgroups per CU a weight-gradient launch aims for (probe knob)
+static int g_wgrad_per_cu = [] {   // workgroups per CU a weight-gradient launch aims for (probe / A-B knob)
+    const char* e = getenv("UP_WGRAD_PER_CU");
+    return e && atoi(e) > 0 ? atoi(e) : 2;
+}();
 struct WgradPlan {
     int bm, bn, ntm, ntn, splits, rows_per_split;
 };
