@@ -117,6 +117,7 @@ struct IgemmArgs {
     // tail split (see launch_igemm): blocks [0, full_blocks) compute whole tiles, the rest compute 1/parts of the
     // K range of a tail tile; parts 0..parts-2 publish raw accumulators, the last part adds them and runs the epilogue
     int full_blocks, parts;
+    int no_tap_skip;   // UP_TAP_SKIP=0 (A/B runs): visit every filter tap
     float* partials;
     int* flags;
 };
@@ -353,18 +354,15 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
 
     long long dbg_w0 = 0;   // probe bit 5: per-block timeline (start / end of K loop / stores drained, 100 MHz ticks + HW ids)
     if ((DBG & 32) && threadIdx.x == 0) dbg_w0 = wall_clock64();
-    const int nk = (a.Ktot + BK - 1) / BK;
-    int logical, kb = 0, ke = nk, part = 0, tail = 0;
+    int logical, part = 0, tail = 0;
     const bool split = (int)blockIdx.x >= a.full_blocks;
     if (!split) {
         logical = xcd_remap(blockIdx.x, a.full_blocks);
-    } else {   // K-split tail tile: slices [kb, ke) of tile full_blocks + tail
+    } else {   // K-split tail tile: a 1/parts share of the K slices of tile full_blocks + tail
         const int j = (int)blockIdx.x - a.full_blocks;
         tail = j / a.parts;
         part = j - tail * a.parts;
         logical = a.full_blocks + tail;
-        kb = (int)((long long)nk * part / a.parts);
-        ke = (int)((long long)nk * (part + 1) / a.parts);
     }
     const int mt = fdiv(logical, a.fNtn);
     const int nt = logical - mt * a.ntn;
@@ -403,6 +401,41 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
             tmask[i] = mk;
         }
     }
+    // Tap skipping (MODE 2, <= 16 taps): a filter tap that reads padding for EVERY row of this tile contributes
+    // nothing, so the K loop only visits the taps of the union of the row masks.  On the dilated convolutions of the
+    // 23x23 stages most vertical taps die this way (WASP d = 18: 77 % of the MACs multiply zeros; a 64-row tile spans
+    // < 3 image rows).  tapmap packs the surviving taps, 4 bits each; slices are numbered over the surviving taps.
+    const int spt = ALIGNED ? (int)a.fSpt.d : 1;
+    unsigned long long tapmap = 0xfedcba9876543210ull;   // identity
+    const bool mapped = FAST && a.taps <= 16;            // 17..32 taps: every tap is visited
+    int nk = (a.Ktot + BK - 1) / BK;
+    if (mapped && a.taps > 1 && !a.no_tap_skip) {
+        unsigned tm = 0;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) tm |= tmask[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) tm |= __shfl_xor(tm, off);
+        unsigned* su = reinterpret_cast<unsigned*>(smem);
+        if (lane == 0) su[wave] = tm;
+        __syncthreads();
+        tm = su[0] | su[1] | su[2] | su[3];
+        __syncthreads();   // smem is about to be overwritten by the first slice
+        int nvt = 0;
+        tapmap = 0;
+        for (int t = 0; t < a.taps; ++t)
+            if ((tm >> t) & 1u) {
+                tapmap |= (unsigned long long)t << (4 * nvt);
+                ++nvt;
+            }
+        if (nvt == 0) nvt = 1;   // (cannot happen for a tile with a real row; keeps the loop well formed)
+        nk = nvt * spt;
+    }
+    int kb = 0, ke = nk;
+    if (split) {
+        kb = (int)((long long)nk * part / a.parts);
+        ke = (int)((long long)nk * (part + 1) / a.parts);
+    }
+
     const float* wrow[PB];
 #pragma unroll
     for (int j = 0; j < PB; ++j) {
@@ -432,11 +465,15 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     unsigned g_msk = 0;
     auto gprep = [&](int kt) {
         g_kvalid = true;
-        if (ALIGNED && (DBG & 128)) {        // stateless: slice index -> (tap, first channel)
-            g_tap = fdiv(kt, a.fSpt);
-            g_ci = (kt - g_tap * (int)a.fSpt.d) * BK + kq * 4;
+        int ci0 = 0;   // first channel of the slice within its tap (aligned paths)
+        if (ALIGNED && (DBG & 128)) {        // stateless: slice index -> (surviving tap, first channel)
+            const int vt = fdiv(kt, a.fSpt);
+            ci0 = (kt - vt * spt) * BK;
+            g_tap = mapped ? (int)((tapmap >> (4 * vt)) & 15ull) : vt;
+            g_ci = ci0 + kq * 4;
         } else if (ALIGNED) {
-            g_tap = tap_c;
+            ci0 = ci0_c;
+            g_tap = mapped ? (int)((tapmap >> (4 * tap_c)) & 15ull) : tap_c;
             g_ci = ci0_c + kq * 4;
         } else {
             int k = kt * BK + kq * 4;
@@ -451,7 +488,7 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
         g_dw = s * a.tapstep;
         g_delta = (g_dh * a.W + g_dw) * a.ldx + g_ci;
         g_msk = g_kvalid ? 0x80000000u : 0u;
-        g_koff = ALIGNED ? (size_t)kt * BK : (g_kvalid ? (size_t)(kt * BK + kq * 4) : (size_t)0);
+        g_koff = ALIGNED ? (size_t)g_tap * a.Cp + ci0 : (g_kvalid ? (size_t)(kt * BK + kq * 4) : (size_t)0);
         if (ALIGNED) {
             ci0_c += BK;
             if (ci0_c >= a.Cp) {
@@ -1499,6 +1536,11 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
 
     a.full_blocks = a.nwg;
     a.parts = 1;
+    static const int no_skip = [] {
+        const char* e = getenv("UP_TAP_SKIP");
+        return e && e[0] == '0' ? 1 : 0;
+    }();
+    a.no_tap_skip = no_skip;
     int grid = a.nwg;
     const int p = aligned ? split_parts(a.nwg, a.Ktot) : 1;
     if (p >= 2) {
