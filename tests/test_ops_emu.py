@@ -23,6 +23,9 @@ import op_cases as oc
     (1, 15, 8, 7, 14, 3, 2, 1, 1, True, False),       # stride-2 parity classes on the generic (unaligned) path
     (1, 4, 10, 9, 8, 7, 2, 3, 1, False, False),       # 7x7 stride 2 pad 3: classes of 4x4, 4x3, 3x4, 3x3 taps
     (1, 32, 9, 9, 16, 3, 2, 0, 1, False, False),      # stride 2 without padding
+    (1, 32, 5, 5, 16, 3, 1, 6, 6, False, False),      # dilation > H: only the centre tap survives the tap skipping; the
+                                                      # K split (4 parts of a 1-slice loop) leaves three parts empty
+    (2, 64, 9, 9, 32, 3, 1, 6, 6, True, True),        # dilation 6 on 9x9: tiles keep different tap subsets
 ])
 def test_conv_fwd_bwd(emu_backend, cfg):
     n, c, h, w, k, r, s, p, d, bias, relu = cfg
@@ -169,6 +172,7 @@ def guard_pages(emu_backend, monkeypatch):
     (2, 96, 6, 6, 72, 3, 1, 1, 1, False, False),      # K-split tail tiles (13 uneven parts)
     (1, 15, 8, 7, 14, 3, 2, 1, 1, True, False),       # stride-2 parity classes, generic path
     (2, 32, 7, 7, 16, 1, 2, 0, 1, False, False),      # 1x1 stride 2: memset + one class
+    (1, 32, 5, 5, 16, 3, 1, 6, 6, False, False),      # tap skipping down to one tap + empty K-split parts
 ])
 def test_conv_no_out_of_bounds(guard_pages, cfg):
     n, c, h, w, k, r, s, p, d, bias, relu = cfg
