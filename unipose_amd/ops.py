@@ -45,6 +45,8 @@ def _dev_ok(*ts):
 
 def _nhwc_ok(t: torch.Tensor):
     n, h, w, c = t.shape
+    if t.is_contiguous() and c % 4 == 0 and t.data_ptr() % 16 == 0:     # the common case, without four stride() calls
+        return c
     ld = t.stride(2)
     if t.stride(3) != 1 or t.stride(1) != w * ld or (n > 1 and t.stride(0) != h * w * ld) or ld % 4 or \
             t.data_ptr() % 16:
@@ -494,7 +496,11 @@ class bn_counters:
             self.own = False
             return self
         self.own = True
-        self.sig = tuple((id(m), m.training) for m in self.module.modules() if isinstance(m, torch.nn.BatchNorm2d))
+        bns = self.module.__dict__.get("_up_bn_list")
+        if bns is None:                            # the BatchNorm layers of a model do not change: walk the tree once
+            bns = self.module.__dict__["_up_bn_list"] = [m for m in self.module.modules()
+                                                         if isinstance(m, torch.nn.BatchNorm2d)]
+        self.sig = tuple(m.training for m in bns)
         plan = self.module.__dict__.get("_up_bn_plan")
         if plan is not None and plan[0] == self.sig:
             if plan[1]:
