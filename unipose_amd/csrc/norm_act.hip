@@ -5,6 +5,7 @@
 #include "up_common.h"
 
 #include <stdarg.h>
+#include <stdlib.h>
 
 namespace up {
 
@@ -24,7 +25,9 @@ int check_launch(const char* what) {
     return UP_OK;
 }
 
-static inline int grid_for(int64_t work_items, int per_block = 256, int cap = 4096) {
+// grid-stride elementwise kernels: workgroup cap from A/B runs of the whole step (2048 / 4096 / 8192 / 16384 workgroups:
+// 70.3 / 69.9 / 69.6 / 69.6 ms) — beside the MFMA kernels of the other stream, many short workgroups fill the gaps better
+static inline int grid_for(int64_t work_items, int per_block = 256, int cap = 16384) {
     int64_t g = (work_items + per_block - 1) / per_block;
     if (g < 1) g = 1;
     return (int)(g > cap ? cap : g);
@@ -353,6 +356,7 @@ __global__ void __launch_bounds__(256) mse_bwd_kernel(const float* y, const floa
 
 constexpr int MSE_PARTS = 512;
 constexpr int BNB_ROWS = 128;   // small chunks: enough workgroups (and bytes in flight) to saturate HBM on 23x23 maps
+                                // (A/B over the whole step: 64 rows 70.8 ms, 128 69.9, 256 69.9)
 
 }  // namespace up
 
