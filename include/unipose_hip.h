@@ -201,6 +201,7 @@ int up_heatmap_argmax(const float* hm, int B, int J, int H, int W,
 int up_profile_variants(void);
 const char* up_profile_variant_name(int i);
 int up_profile_begin(void);
+int up_profile_enable(int on);   /* pause / resume recording between begin and end (sampled profiling) */
 int up_profile_end(double* out, int variants);
 
 #ifdef __cplusplus

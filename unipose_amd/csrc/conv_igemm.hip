@@ -2028,6 +2028,14 @@ extern "C" int up_profile_begin(void) {
 #endif
     return UP_OK;
 }
+extern "C" int up_profile_enable(int on) {
+#ifndef UP_EMU
+    g_prof_on = on != 0;   // records collected so far are kept: lets a caller sample some steps of a timed region
+#else
+    (void)on;
+#endif
+    return UP_OK;
+}
 extern "C" int up_profile_end(double* out /* [variants][3] = launches, ms, flops */, int variants) {
     UP_REQUIRE(out && variants == PROF_VARIANTS, UP_ERR_INVALID, "profile_end: expected %d variants", PROF_VARIANTS);
     for (int i = 0; i < variants * 3; ++i) out[i] = 0.0;
