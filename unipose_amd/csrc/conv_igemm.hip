@@ -23,6 +23,7 @@
 
 #include <map>
 #include <mutex>
+#include <type_traits>
 #ifdef UP_EMU
 #include <sched.h>
 #endif
@@ -447,6 +448,10 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
 
     float4 ra[PA], rb[PB];
     unsigned okmask = 0;   // bit i: ra[i] is real data (else structural zero); bit 31: k slice valid
+    // second staging set of the non-pinned double-buffered loop (three slices in flight; 64x64 tile: two rows of A and
+    // of B per thread).  Named scalars: as arrays the compiler kept this set in scratch memory.
+    float4 ya0, ya1, yb0, yb1;
+    unsigned okmask2 = 0;
 
     // aligned path: the 32-wide slice never straddles a tap; (tap, ci0) advance as scalars
     int tap_c = 0, ci0_c = 0;
@@ -542,6 +547,36 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
             *reinterpret_cast<float4*>(&Bs[buf * BUF + (j * RPP + lrow) * LDS_LD + kq * 4]) =
                 ALIGNED ? rb[j] : keep_or_zero(okmask >> 31, rb[j]);
     };
+    // the same for the second staging set
+    auto gloadY = [&](int i, float4& dst) {
+        const bool ok = (tmask[i] >> g_tap) & 1u;
+        const int off = ok ? roff[i] + g_delta : 0;
+        dst = *reinterpret_cast<const float4*>(a.x + off);
+        g_msk |= ok ? (1u << i) : 0u;
+    };
+    auto gissue2 = [&](int part) {
+        if (part == 0) {
+            gloadY(0, ya0);
+            yb0 = *reinterpret_cast<const float4*>(wrow[0] + g_koff);
+        }
+        if (part == 1) {
+            gloadY(PA - 1, ya1);
+            yb1 = *reinterpret_cast<const float4*>(wrow[PB - 1] + g_koff);
+        }
+        if (part == 3) okmask2 = g_msk;
+    };
+    auto gload2 = [&](int kt) {
+        gprep(kt);
+#pragma unroll
+        for (int part = 0; part < 4; ++part) gissue2(part);
+    };
+    auto lstore2 = [&](int buf) {
+        *reinterpret_cast<float4*>(&As[buf * BUF + lrow * LDS_LD + kq * 4]) = keep_or_zero(okmask2 & 1u, ya0);
+        *reinterpret_cast<float4*>(&As[buf * BUF + ((PA - 1) * RPP + lrow) * LDS_LD + kq * 4]) =
+            keep_or_zero((okmask2 >> (PA - 1)) & 1u, ya1);
+        *reinterpret_cast<float4*>(&Bs[buf * BUF + lrow * LDS_LD + kq * 4]) = yb0;
+        *reinterpret_cast<float4*>(&Bs[buf * BUF + ((PB - 1) * RPP + lrow) * LDS_LD + kq * 4]) = yb1;
+    };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -571,12 +606,12 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     };
     constexpr int G = BK / 8;   // MFMA groups (8 k each) per slice
 
-    if (DB) {
+    if constexpr (DB) {
         // slice kt is in LDS buffer kt&1; slice kt+1 sits in the staging registers (loaded during slice kt-1)
         // and is written to the OTHER buffer in the middle of this slice's MFMAs; the registers are then
         // refilled with slice kt+2.  One barrier per slice, nothing between the MFMAs but LDS/VMEM issue.
         if (ke - kb > 1) gload(kb + 1);
-        if (DBG & 128) {
+        if constexpr ((DBG & 128) != 0) {
             // Branch-free body: the refill always runs (slice indices are clamped to the last slice, whose
             // reload is harmless), so the whole iteration is ONE scheduling region and the non-MFMA work can be
             // pinned between the MFMAs with sched_group_barrier instead of piling up between 16-MFMA clusters.
@@ -616,9 +651,15 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
                 __syncthreads();
             }
         } else {
-        for (int kt = kb; kt < ke; ++kt) {
-            const int cur = (kt - kb) & 1;
-            const bool has1 = kt + 1 < ke, has2 = kt + 2 < ke;
+        // Two staging sets: at the top of slice kt set X holds slice kt+1 and set Y slice kt+2 (X and Y swap roles every
+        // slice: the loop is unrolled by two).  Mid-slice the set holding kt+1 goes to the other LDS buffer and is
+        // refilled with slice kt+3, so a load has two full slices to land instead of one (FAST path only).
+        static_assert(PA == 2 && PB == 2, "the two-set loop is written for the 64x64 tile");
+        if (ke - kb > 2) gload2(kb + 2);
+        auto slice = [&](int kt, auto cur_c, auto use_x_c) {   // compile-time buffer / staging-set choice
+            constexpr int cur = decltype(cur_c)::value;
+            constexpr bool useX = decltype(use_x_c)::value;
+            const bool has1 = kt + 1 < ke, has3 = kt + 3 < ke;
             float4 af[2][TM], bf[2][TN];
             auto frag = [&](int g, int b) {
 #pragma unroll
@@ -633,15 +674,25 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
             for (int g = 0; g < G; ++g) {
                 const int b = g & 1;
                 if (g + 1 < G) frag(g + 1, b ^ 1);
-                if (g == G / 2 - 1 && has1) lstore(cur ^ 1);
-                if (g >= G / 2 && has2) {
-                    if (g == G / 2) gprep(kt + 2);
+                if (g == G / 2 - 1 && has1) {
+                    if constexpr (useX) lstore(cur ^ 1);
+                    else lstore2(cur ^ 1);
+                }
+                if (g >= G / 2 && has3) {
+                    if (g == G / 2) gprep(kt + 3);
 #pragma unroll
-                    for (int q = 0; q < 8 / G; ++q) gissue((g - G / 2) * (8 / G) + q);
+                    for (int q = 0; q < 8 / G; ++q) {
+                        if constexpr (useX) gissue((g - G / 2) * (8 / G) + q);
+                        else gissue2((g - G / 2) * (8 / G) + q);
+                    }
                 }
                 mfma_group(af[b], bf[b]);
             }
             __syncthreads();
+        };
+        for (int kt = kb; kt < ke; kt += 2) {
+            slice(kt, std::integral_constant<int, 0>{}, std::true_type{});
+            if (kt + 1 < ke) slice(kt + 1, std::integral_constant<int, 1>{}, std::false_type{});
         }
         }
     } else {
@@ -1522,11 +1573,10 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     const bool db = a.Ktot >= db_min_k;
     // wide tiles additionally pin the refill between the MFMAs (branch-free body + sched_group_barrier): +2..4 %
     // on 128-wide tiles, -3 % on 64x64 (probe, warm)
+    constexpr int DB_VARIANT = (BM == 128 || BN == 128) ? 128 : 0;   // 64x64: non-pinned loop with two staging sets
     void (*kernel)(IgemmArgs);
-    if (fast && db && (BM == 128 || BN == 128))
-        kernel = igemm_kernel<BM, BN, 2, 128>;
-    else if (fast && db)
-        kernel = igemm_kernel<BM, BN, 2, 0>;
+    if (fast && db)
+        kernel = igemm_kernel<BM, BN, 2, DB_VARIANT>;
     else if (fast)
         kernel = igemm_kernel<BM, BN, 2, 64>;
     else if (aligned)
