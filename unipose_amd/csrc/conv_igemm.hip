@@ -228,10 +228,9 @@ __device__ __forceinline__ void igemm_store(const IgemmArgs& a, f32x16 (&acc)[BM
     }
 }
 
-// DBG is 0 in the library; tools/gpu/igemm_probe.hip instantiates ablations (bit 0: no global prefetch in
-// the loop, bit 1: no LDS refill + its barrier, bit 2: fragments from registers instead of LDS, bit 3: no
-// barrier at all, bit 4: pin the load/MFMA interleave, bit 5: sample shader clocks) to attribute the
-// MFMA-pipe idle time.
+// DBG selects the K-loop form and the probe instrumentation: bit 5 (32) records a per-workgroup timeline (probe only),
+// bit 6 (64) = single LDS buffer with two barriers per slice, bit 7 (128) = double-buffered, branch-free body with the
+// refill pinned between the MFMAs (128-wide tiles); 0 = double-buffered with two register staging sets (64x64 tile).
 // Shared epilogue of the fp32 and bf16-operand kernels.  C/D map of the 32x32 MFMA (dtype independent):
 // column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  `smem` must be free (all waves past their last
 // LDS read) and hold >= 2*(BN/64)*32*3 floats.
@@ -698,30 +697,27 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     } else {
     for (int kt = kb; kt < ke; ++kt) {
         const bool more = kt + 1 < ke;
-        if (more && !(DBG & 1)) gprep(kt + 1);
+        if (more) gprep(kt + 1);
         // fragments of k-group g+1 are read from LDS while the MFMAs of group g run (static double buffer)
         float4 af[2][TM], bf[2][TN];
         auto frag = [&](int g, int b) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[b][i] = (DBG & 4) ? make_float4(lane, kt, g, i)
-                                     : *reinterpret_cast<const float4*>(Ard + i * 32 * LDS_LD + g * 8);
+                af[b][i] = *reinterpret_cast<const float4*>(Ard + i * 32 * LDS_LD + g * 8);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bf[b][j] = (DBG & 4) ? make_float4(g, lane, j, kt)
-                                     : *reinterpret_cast<const float4*>(Brd + j * 32 * LDS_LD + g * 8);
+                bf[b][j] = *reinterpret_cast<const float4*>(Brd + j * 32 * LDS_LD + g * 8);
         };
         frag(0, 0);
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int b = g & 1;
             if (g + 1 < G) frag(g + 1, b ^ 1);
-            if (more && !(DBG & 1) && g % (BK / 32) == 0) gissue(g / (BK / 32));   // a quarter of the next slice's loads
-            if (DBG & 16) __builtin_amdgcn_sched_barrier(0);   // pinning the order measured 4-9 % slower
+            if (more && g % (BK / 32) == 0) gissue(g / (BK / 32));   // a quarter of the next slice's loads
             mfma_group(af[b], bf[b]);
         }
-        if (!(DBG & 8)) __syncthreads();
-        if (more && !(DBG & 2)) {
+        __syncthreads();
+        if (more) {
             lstore();
             __syncthreads();
         }
