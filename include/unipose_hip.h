@@ -195,6 +195,19 @@ int up_lstm_bwd(const float* gates, int ldg, const float* cprev, int ldc, const 
 int up_heatmap_argmax(const float* hm, int B, int J, int H, int W,
                       int32_t* idx, float* preds_xy, float* maxvals, void* stream);
 
+/* ---- PCK / PCKh evaluation (utils/evaluate.py:5-29 calc_dists / dist_acc, :58-172 accuracy) ----
+ * From the joint coordinates of the predicted and the target heat-maps (two up_heatmap_argmax calls), entirely on
+ * the device: per joint the fraction of counted samples (both target coordinates > 1) whose normalised distance is
+ * below 0.5 (acc), thr_pck * torso (pck) and thr_pckh * head (pckh); entry 0 of each is replaced by the mean over
+ * the joints with any counted sample; visible[j] = 1 for those joints, *cnt = their number.  Head and torso sizes
+ * come from the target joints of sample 0, as in the reference.  Arithmetic types follow the reference under
+ * NumPy >= 2 (float32 thresholds, float64 distances). */
+enum { UP_DS_LSP = 0, UP_DS_COCO = 1, UP_DS_PENN_ACTION = 2, UP_DS_NTID = 3, UP_DS_POSETRACK = 4, UP_DS_BBC = 5,
+       UP_DS_MPII = 6 };
+int up_pck_accuracy(const float* pred_xy, const float* target_xy, int B, int J, int H, int W, int dataset,
+                    double thr_pck, double thr_pckh, double* acc, double* pck, double* pckh, double* visible,
+                    int32_t* cnt, void* stream);
+
 /* ---- measurement hooks (bench.py roofline leg; no reference counterpart) ----
  * Between begin/end every MFMA convolution launch is bracketed by two hipEvents on its stream;
  * end() returns per kernel variant {launches, total ms, total algorithmic FLOP}. */

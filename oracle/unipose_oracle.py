@@ -257,6 +257,71 @@ def get_max_preds(hm: np.ndarray):
     return preds, mx[:, :, None]
 
 
+# joints the reference measures head length / torso size on, per dataset (utils/evaluate.py:92-107, 127-153)
+DATASETS = ("LSP", "COCO", "Penn_Action", "NTID", "PoseTrack", "BBC", "MPII")
+
+
+def _head_and_torso(t0: np.ndarray, dataset: str):
+    """Head length (PCKh scale) and torso size (PCK scale) from the TARGET joints of sample 0 only
+    (utils/evaluate.py:92-107 and :127-153).  All arithmetic stays float32 like the reference's
+    np.linalg.norm on float32 coordinates."""
+    n2 = lambda v: np.linalg.norm(np.asarray(v, dtype=np.float32))
+    mid = lambda a, b: (t0[a] + t0[b]) / np.float32(2)
+    if dataset == "LSP":
+        return n2(t0[14] - t0[13]), n2(t0[13] - mid(3, 4))
+    if dataset == "COCO":
+        return n2(t0[4] - t0[5]), n2(t0[13] - mid(12, 13))
+    if dataset == "Penn_Action":
+        return n2(t0[0] - mid(1, 2)), n2(mid(1, 2) - mid(7, 8))
+    if dataset == "NTID":
+        return np.float32(2) * n2(t0[4] - t0[3]), n2(t0[3] - t0[1])
+    if dataset == "PoseTrack":
+        return np.float32(2) * n2(t0[1] - t0[2]), n2(mid(12, 13) - mid(6, 7))
+    if dataset == "BBC":
+        return n2(t0[1] - mid(6, 7)), n2(np.float32(3) * (t0[1, 0] - mid(6, 7)))
+    if dataset == "MPII":
+        return n2(t0[9] - t0[10]), n2(t0[7, 0] - t0[8, 0])
+    raise ValueError(f"unknown dataset {dataset!r}")
+
+
+def accuracy(output: np.ndarray, target: np.ndarray, thr_pck: float, thr_pckh: float, dataset: str):
+    """utils/evaluate.py:58-172 `accuracy(..., hm_type='gaussian')` restated with masks instead of loops:
+    joints from the argmax of both heat-map stacks; distance of prediction and target after dividing x by H/10 and
+    y by W/10 (:68-70, the reference's own order); a joint counts for a sample when both target coordinates exceed
+    1 (:12); per-joint fraction below 0.5 / thr_pckh*head / thr_pck*torso (:22-29); entry 0 of each result is
+    replaced by the mean over the joints that had any valid sample (:75-90, :110-123, :155-170).
+    Returns (acc, PCK, PCKh, cnt, pred, visible) like the reference."""
+    pred, _ = get_max_preds(output)
+    tgt, _ = get_max_preds(target)
+    b, j = pred.shape[:2]
+    h, w = output.shape[2], output.shape[3]
+    norm = np.ones((b, 2)) * np.array([h, w]) / 10                      # float64, as in the reference
+    diff = pred.astype(np.float32) / norm[:, None, :] - tgt.astype(np.float32) / norm[:, None, :]
+    dist = np.stack([[np.linalg.norm(diff[n, c]) for n in range(b)] for c in range(j)])      # (J, B) float64
+    valid = ((tgt[:, :, 0] > 1) & (tgt[:, :, 1] > 1)).T                  # (J, B)
+    nvalid = valid.sum(1)
+    head, torso = _head_and_torso(tgt[0], dataset)
+
+    def per_joint(threshold):
+        below = (np.less(dist, threshold) & valid).sum(1)
+        return np.where(nvalid > 0, below * 1.0 / np.maximum(nvalid, 1), -1.0)
+
+    acc = per_joint(0.5)
+    visible = (acc >= 0).astype(np.float64)
+    cnt = int(visible.sum())
+    out = []
+    for frac in (acc, per_joint(thr_pck * torso), per_joint(thr_pckh * head)):
+        total = 0
+        for v in frac:                                                  # same summation order as the reference
+            if v >= 0:
+                total = total + v
+        res = np.where(frac >= 0, frac, 0.0)
+        if cnt != 0:
+            res[0] = total / cnt
+        out.append(res)
+    return out[0], out[1], out[2], cnt, pred, visible
+
+
 def get_kpts(maps: np.ndarray, img_h: float = 368.0, img_w: float = 368.0):
     """utils/utils.py:94-106: per joint (channel 0 skipped), [x, y] ints in image pixels."""
     out = []

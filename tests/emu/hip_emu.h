@@ -264,6 +264,8 @@ inline T shfl(T v, int src) {
 #define gridDim (::emu::st().gdim)
 #define hipLaunchKernelGGL(k, g, b, sh, strm, ...) ::emu::launch((g), (b), [&]() { k(__VA_ARGS__); })
 
+static inline double __dmul_rn(double a, double b) { return a * b; }
+static inline double __dadd_rn(double a, double b) { return a + b; }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 static inline long long clock64() { return 0; }

@@ -300,3 +300,21 @@ def argmax_case(dev, golden_dir):
         r, c = np.unravel_index(m.argmax(), m.shape)
         ref.append([int(c * 368.0 / 46), int(r * 368.0 / 46)])
     assert kp == ref
+
+
+def accuracy_case(dev, golden_dir):
+    """ops.accuracy (device argmax + PCK kernel) against the reference's own results (G7)."""
+    import os
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, "g7_accuracy.npz"))
+    for ds in ("LSP", "MPII", "Penn_Action"):
+        out = torch.from_numpy(g[ds + "_out"]).to(dev)
+        tgt = torch.from_numpy(g[ds + "_tgt"]).to(dev)
+        for tag in ("std", "tight"):
+            tk, th = (float(v) for v in g[f"{ds}_{tag}_thr"])
+            acc, pck, pckh, cnt, pred, vis = ops.accuracy(out, tgt, tk, th, ds)
+            k = f"{ds}_{tag}_"
+            assert np.array_equal(pred, g[k + "pred"]) and cnt == int(g[k + "cnt"]), (ds, tag)
+            assert np.array_equal(vis, g[k + "vis"]), (ds, tag)
+            for name, got in (("acc", acc), ("pck", pck), ("pckh", pckh)):
+                assert np.array_equal(got, g[k + name]), (ds, tag, name, got, g[k + name])

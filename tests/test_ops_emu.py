@@ -120,6 +120,10 @@ def test_lstm_gates(emu_backend):
     oc.lstm_case(emu_backend)
 
 
+def test_pck_accuracy(emu_backend, golden_dir):
+    oc.accuracy_case(emu_backend, golden_dir)
+
+
 def test_argmax(emu_backend, golden_dir):
     oc.argmax_case(emu_backend, golden_dir)
 

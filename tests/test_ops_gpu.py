@@ -154,3 +154,7 @@ def test_conv_bf16_operand_kernels(cfg, math, tol):
 ])
 def test_dgrad_with_addend(cfg):
     oc.dgrad_add_case(DEV, *cfg)
+
+
+def test_pck_accuracy(golden_dir):
+    oc.accuracy_case(DEV, golden_dir)

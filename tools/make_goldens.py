@@ -168,6 +168,37 @@ def g6_argmax():
     save("g6_argmax.npz", hm=hm, preds=preds, maxvals=maxvals)
 
 
+def g7_accuracy():
+    """G7: the reference's PCK / PCKh `accuracy` (utils/evaluate.py:58-172, numpy only: loaded by file path) on random
+    heat-map stacks for the three datasets the drivers use, with some target joints at coordinates <= 1 (not counted)."""
+    spec = importlib.util.spec_from_file_location("ref_evaluate", os.path.join(REF, "utils", "evaluate.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    rng = np.random.default_rng(7)
+    out = {}
+    for ds, j in (("LSP", 15), ("MPII", 17), ("Penn_Action", 14)):
+        b, hw = 6, 32
+        tgt = np.zeros((b, j, hw, hw), np.float32)
+        outp = rng.standard_normal((b, j, hw, hw)).astype(np.float32) * 0.1
+        for n in range(b):
+            for c in range(j):
+                ty, tx = rng.integers(0, hw, 2)
+                if rng.random() < 0.15:
+                    tx = int(rng.integers(0, 2))                  # x <= 1: joint not counted
+                tgt[n, c, ty, tx] = 1.0
+                dy, dx = rng.integers(-9, 10, 2)                  # prediction near (or far from) the target
+                py, px = int(np.clip(ty + dy, 0, hw - 1)), int(np.clip(tx + dx, 0, hw - 1))
+                outp[n, c, py, px] = 2.0 + rng.random()
+        tgt[1, 3] = 0.0                                           # an all-zero target map: argmax 0, masked to (0, 0)
+        out.update({f"{ds}_out": outp, f"{ds}_tgt": tgt})
+        for tag, (tk, th) in (("std", (0.2, 0.5)), ("tight", (0.03, 0.12))):   # the drivers' thresholds, and discriminating ones
+            acc, pck, pckh, cnt, pred, vis = ev.accuracy(outp, tgt, tk, th, ds)
+            out.update({f"{ds}_{tag}_thr": np.array([tk, th]), f"{ds}_{tag}_acc": acc, f"{ds}_{tag}_pck": pck,
+                        f"{ds}_{tag}_pckh": pckh, f"{ds}_{tag}_cnt": np.array(cnt), f"{ds}_{tag}_pred": pred,
+                        f"{ds}_{tag}_vis": vis})
+    save("g7_accuracy.npz", **out)
+
+
 def g0_keys():
     """G0: the reference's state_dict contract (names, shapes, dtypes, order) for both models."""
     import json
@@ -181,7 +212,7 @@ def g0_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g4", "g5", "g6"]
-    fns = dict(g0=g0_keys, g1=g1_eval_full, g2=g2_taps, g4=g4_train, g5=g5_lstm, g6=g6_argmax)
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g4", "g5", "g6", "g7"]
+    fns = dict(g0=g0_keys, g1=g1_eval_full, g2=g2_taps, g4=g4_train, g5=g5_lstm, g6=g6_argmax, g7=g7_accuracy)
     for w in which:
         fns[w]()

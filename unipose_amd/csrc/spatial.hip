@@ -367,6 +367,100 @@ __global__ void __launch_bounds__(256) argmax_kernel(const float* hm, int maps, 
     }
 }
 
+// ---- PCK / PCKh accuracy on joint coordinates (utils/evaluate.py:5-29,58-172) -------------------------------------
+// One workgroup; thread j owns joint j.  Arithmetic types follow the reference under NumPy >= 2: coordinates float32,
+// head / torso sizes float32 (np.linalg.norm of float32), thresholds float32 products (python float * np.float32),
+// normalised distances float64 (float32 coordinates divided by the float64 [H/10, W/10]).
+__device__ __forceinline__ float pck_norm2(float x, float y) { return sqrtf(x * x + y * y); }
+__device__ void pck_scales(const float* t0 /* (J,2) of sample 0 */, int dataset, float& head, float& torso) {
+    auto X = [&](int j) { return t0[2 * j]; };
+    auto Y = [&](int j) { return t0[2 * j + 1]; };
+    auto midx = [&](int a, int b) { return (X(a) + X(b)) / 2.f; };
+    auto midy = [&](int a, int b) { return (Y(a) + Y(b)) / 2.f; };
+    switch (dataset) {
+        case UP_DS_LSP:
+            head = pck_norm2(X(14) - X(13), Y(14) - Y(13));
+            torso = pck_norm2(X(13) - midx(3, 4), Y(13) - midy(3, 4));
+            break;
+        case UP_DS_COCO:
+            head = pck_norm2(X(4) - X(5), Y(4) - Y(5));
+            torso = pck_norm2(X(13) - midx(12, 13), Y(13) - midy(12, 13));
+            break;
+        case UP_DS_PENN_ACTION:
+            head = pck_norm2(X(0) - midx(1, 2), Y(0) - midy(1, 2));
+            torso = pck_norm2(midx(1, 2) - midx(7, 8), midy(1, 2) - midy(7, 8));
+            break;
+        case UP_DS_NTID:
+            head = 2.f * pck_norm2(X(4) - X(3), Y(4) - Y(3));
+            torso = pck_norm2(X(3) - X(1), Y(3) - Y(1));
+            break;
+        case UP_DS_POSETRACK:
+            head = 2.f * pck_norm2(X(1) - X(2), Y(1) - Y(2));
+            torso = pck_norm2(midx(12, 13) - midx(6, 7), midy(12, 13) - midy(6, 7));
+            break;
+        case UP_DS_BBC:   // the reference subtracts the neck POINT from the x coordinate of joint 1 (evaluate.py:147-149)
+            head = pck_norm2(X(1) - midx(6, 7), Y(1) - midy(6, 7));
+            torso = pck_norm2(3.f * (X(1) - midx(6, 7)), 3.f * (X(1) - midy(6, 7)));
+            break;
+        default:          // UP_DS_MPII
+            head = pck_norm2(X(9) - X(10), Y(9) - Y(10));
+            torso = fabsf(X(7) - X(8));
+            break;
+    }
+}
+__global__ void __launch_bounds__(256) pck_kernel(const float* pred, const float* tgt, int B, int J, int H, int W,
+                                                  int dataset, float thr_pck, float thr_pckh, double* acc, double* pck,
+                                                  double* pckh, double* visible, int32_t* cnt) {
+    __shared__ double s_acc[256], s_pck[256], s_pckh[256];
+    const int j = threadIdx.x;
+    float head, torso;
+    pck_scales(tgt, dataset, head, torso);
+    const double t_h = (double)(thr_pckh * head), t_k = (double)(thr_pck * torso);   // float32 products
+    const double nx = (double)H / 10.0, ny = (double)W / 10.0;   // x is divided by H/10, y by W/10 (evaluate.py:68-70)
+    if (j < J) {
+        int valid = 0, c0 = 0, ch = 0, ck = 0;
+        for (int n = 0; n < B; ++n) {
+            const float tx = tgt[(n * J + j) * 2], ty = tgt[(n * J + j) * 2 + 1];
+            if (tx > 1.f && ty > 1.f) {
+                const double dx = (double)pred[(n * J + j) * 2] / nx - (double)tx / nx;
+                const double dy = (double)pred[(n * J + j) * 2 + 1] / ny - (double)ty / ny;
+                const double d = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));   // no FMA contraction
+                ++valid;
+                c0 += d < 0.5;
+                ch += d < t_h;
+                ck += d < t_k;
+            }
+        }
+        s_acc[j] = valid ? c0 * 1.0 / valid : -1.0;
+        s_pckh[j] = valid ? ch * 1.0 / valid : -1.0;
+        s_pck[j] = valid ? ck * 1.0 / valid : -1.0;
+    }
+    __syncthreads();
+    if (j == 0) {   // the averages, summed in joint order like the reference's loops
+        int c = 0;
+        double sa = 0.0, sh = 0.0, sk = 0.0;
+        for (int i = 0; i < J; ++i) {
+            const bool vis = s_acc[i] >= 0.0;
+            visible[i] = vis ? 1.0 : 0.0;
+            if (vis) {
+                sa += s_acc[i];
+                ++c;
+            }
+            acc[i] = vis ? s_acc[i] : 0.0;
+            if (s_pckh[i] >= 0.0) sh += s_pckh[i];
+            pckh[i] = s_pckh[i] >= 0.0 ? s_pckh[i] : 0.0;
+            if (s_pck[i] >= 0.0) sk += s_pck[i];
+            pck[i] = s_pck[i] >= 0.0 ? s_pck[i] : 0.0;
+        }
+        if (c) {
+            acc[0] = sa / c;
+            pckh[0] = sh / c;
+            pck[0] = sk / c;
+        }
+        *cnt = c;
+    }
+}
+
 }  // namespace up
 
 using namespace up;
@@ -527,4 +621,19 @@ extern "C" int up_heatmap_argmax(const float* hm, int B, int J, int H, int W, in
     hipLaunchKernelGGL(argmax_kernel, dim3(cdiv(maps, 4)), dim3(256), 0, as_stream(stream), hm, maps, H * W, W, idx,
                        preds_xy, maxvals);
     return check_launch("heatmap_argmax");
+}
+
+extern "C" int up_pck_accuracy(const float* pred_xy, const float* target_xy, int B, int J, int H, int W, int dataset,
+                               double thr_pck, double thr_pckh, double* acc, double* pck, double* pckh, double* visible,
+                               int32_t* cnt, void* stream) {
+    UP_REQUIRE(pred_xy && target_xy && acc && pck && pckh && visible && cnt && B > 0 && H > 0 && W > 0, UP_ERR_INVALID,
+               "pck_accuracy: bad argument");
+    UP_REQUIRE(J > 0 && J <= 256, UP_ERR_UNSUPPORTED, "pck_accuracy: %d joints (1..256 supported)", J);
+    static const int need[] = {15, 14, 9, 5, 14, 8, 11};   // joints the head / torso formulas of each dataset touch
+    UP_REQUIRE(dataset >= UP_DS_LSP && dataset <= UP_DS_MPII, UP_ERR_INVALID, "pck_accuracy: unknown dataset id %d", dataset);
+    UP_REQUIRE(J >= need[dataset], UP_ERR_INVALID, "pck_accuracy: dataset %d needs at least %d joint channels, got %d",
+               dataset, need[dataset], J);
+    hipLaunchKernelGGL(pck_kernel, dim3(1), dim3(256), 0, as_stream(stream), pred_xy, target_xy, B, J, H, W, dataset,
+                       (float)thr_pck, (float)thr_pckh, acc, pck, pckh, visible, cnt);
+    return check_launch("pck_accuracy");
 }

@@ -876,6 +876,31 @@ def heatmap_argmax(hm: torch.Tensor):
     return preds, mx, idx
 
 
+DATASET_IDS = {"LSP": 0, "COCO": 1, "Penn_Action": 2, "NTID": 3, "PoseTrack": 4, "BBC": 5, "MPII": 6}
+
+
+def accuracy(output: torch.Tensor, target: torch.Tensor, thr_PCK: float, thr_PCKh: float, dataset: str,
+             hm_type: str = "gaussian", threshold: float = 0.5):
+    """utils/evaluate.py:58-172 ``accuracy`` with the heat-maps left on the device: both argmaxes and the PCK / PCKh
+    arithmetic run as kernels, only the (J,) results and the (B,J,2) predictions come back.  Returns the reference's
+    tuple (acc, PCK, PCKh, cnt, pred, visible) as numpy values.  `threshold` is accepted and unused, as in the
+    reference (its dist_acc calls always use 0.5, evaluate.py:78)."""
+    if hm_type != "gaussian":
+        raise NotImplementedError("only hm_type='gaussian' (the reference defines nothing else, evaluate.py:62)")
+    if dataset not in DATASET_IDS:
+        raise ValueError(f"unknown dataset {dataset!r}")
+    pred, _, _ = heatmap_argmax(output)
+    tgt, _, _ = heatmap_argmax(target)
+    b, j, h, w = output.shape
+    res = torch.empty((4, j), dtype=torch.float64, device=output.device)
+    cnt = torch.empty((1,), dtype=torch.int32, device=output.device)
+    _C.check(_C.lib().up_pck_accuracy(pred.data_ptr(), tgt.data_ptr(), b, j, h, w, DATASET_IDS[dataset], float(thr_PCK),
+                                      float(thr_PCKh), res[0].data_ptr(), res[1].data_ptr(), res[2].data_ptr(),
+                                      res[3].data_ptr(), cnt.data_ptr(), _stream(output)), "pck_accuracy")
+    r = res.cpu().numpy()
+    return r[0], r[1], r[2], int(cnt.item()), pred.cpu().numpy(), r[3]
+
+
 def get_kpts(maps: torch.Tensor, img_h: float = 368.0, img_w: float = 368.0):
     """utils/utils.py:94-106 on top of the device argmax: [[x, y], ...] for joints 1.. of sample 0."""
     _, _, idx = heatmap_argmax(maps[:1])
