@@ -195,6 +195,19 @@ int up_lstm_bwd(const float* gates, int ldg, const float* cprev, int ldc, const 
 int up_heatmap_argmax(const float* hm, int B, int J, int H, int W,
                       int32_t* idx, float* preds_xy, float* maxvals, void* stream);
 
+/* ---- training targets and input normalisation (the step BEFORE the path) ----
+ * up_make_heatmaps: lsp_lspet_data.py:224-236 / mpii_data.py:165-175.  kpt_xy (B,K,2) float64 pixel coordinates of the
+ * input image; joint k of sample b is centred at int(coordinate) / stride on the H x W map; values
+ * exp(-D2 / 2 / sigma^2) computed in float64 (utils/utils.py:200-203), clipped to <= 1, < 0.0099 -> 0, stored float32;
+ * out (B,K+1,H,W): channel 0 = 1 - max over the joint channels, channel k+1 = joint k.
+ * up_make_gaussian_maps: one such map per centre (the centre maps, lsp_lspet_data.py:238-242; centres as given).
+ * up_normalize_image: (pixel - mean) / std and HWC -> CHW (Mytransforms.py:10-41 with mean 128, std 256). */
+int up_make_heatmaps(const double* kpt_xy, int B, int K, int H, int W, double stride, double sigma, float* out,
+                     void* stream);
+int up_make_gaussian_maps(const double* center_xy, int N, int H, int W, double sigma, float* out, void* stream);
+int up_normalize_image(const float* img_hwc, int B, int H, int W, int C, float mean, float stdv, float* out_chw,
+                       void* stream);
+
 /* ---- PCK / PCKh evaluation (utils/evaluate.py:5-29 calc_dists / dist_acc, :58-172 accuracy) ----
  * From the joint coordinates of the predicted and the target heat-maps (two up_heatmap_argmax calls), entirely on
  * the device: per joint the fraction of counted samples (both target coordinates > 1) whose normalised distance is

@@ -257,6 +257,35 @@ def get_max_preds(hm: np.ndarray):
     return preds, mx[:, :, None]
 
 
+def gaussian_kernel(size_w, size_h, center_x, center_y, sigma):
+    """utils/utils.py:200-203 (`guassian_kernel`): exp(-D2 / 2 / sigma^2) on the integer pixel grid, float64."""
+    ys, xs = np.mgrid[0:size_h, 0:size_w]
+    return np.exp(-((xs - center_x) ** 2 + (ys - center_y) ** 2) / 2.0 / sigma / sigma)
+
+
+def _clip_map(m):
+    m = m.copy()
+    m[m > 1] = 1
+    m[m < 0.0099] = 0
+    return m
+
+
+def make_heatmap(kpt, height, width, stride, sigma):
+    """lsp_lspet_data.py:224-236 (same in mpii_data.py:165-175): (K,2) pixel keypoints -> (K+1, h, w) float32 with
+    h = int(height/stride); joint centres int(coordinate) * 1.0 / stride; channel 0 = 1 - max of the joint channels."""
+    h, w = int(height / stride), int(width / stride)
+    out = np.zeros((len(kpt) + 1, h, w), dtype=np.float32)
+    for i, (kx, ky) in enumerate(kpt):
+        out[i + 1] = _clip_map(gaussian_kernel(w, h, int(kx) * 1.0 / stride, int(ky) * 1.0 / stride, sigma))
+    out[0] = 1.0 - np.max(out[1:], axis=0)
+    return out
+
+
+def make_centermap(center, height, width, sigma=3):
+    """lsp_lspet_data.py:238-242: (1, height, width) float32 Gaussian around `center`."""
+    return _clip_map(gaussian_kernel(width, height, center[0], center[1], sigma)).astype(np.float32)[None]
+
+
 # joints the reference measures head length / torso size on, per dataset (utils/evaluate.py:92-107, 127-153)
 DATASETS = ("LSP", "COCO", "Penn_Action", "NTID", "PoseTrack", "BBC", "MPII")
 

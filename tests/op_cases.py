@@ -318,3 +318,36 @@ def accuracy_case(dev, golden_dir):
             assert np.array_equal(vis, g[k + "vis"]), (ds, tag)
             for name, got in (("acc", acc), ("pck", pck), ("pckh", pckh)):
                 assert np.array_equal(got, g[k + name]), (ds, tag, name, got, g[k + name])
+
+
+def targets_case(dev, golden_dir):
+    """ops.make_heatmaps / make_centermaps against maps built with the reference's own Gaussian (G8): bit-exact float32
+    wherever the device exp() agrees with numpy's to the last float64 bit after rounding to float32, which the
+    comparison allows one float32 ulp for; the 0.0099 cut and the clip are compared exactly away from the cut."""
+    import os
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, "g8_targets.npz"))
+
+    def check(got, ref, what):
+        got = got.cpu().numpy()
+        assert got.shape == ref.shape and got.dtype == np.float32, what
+        cut = np.float32(0.0099)
+        # a device exp() one float64 ulp from numpy's may fall on the other side of the 0.0099 cut: tolerate exactly that
+        flipped = ((got == 0) & (np.abs(ref - cut) < 1e-6)) | ((ref == 0) & (np.abs(got - cut) < 1e-6))
+        diff = np.abs(got - ref)[~flipped]
+        assert diff.size and float(diff.max()) <= 1.2e-7, (what, float(diff.max()))       # one float32 ulp below 1
+        assert int(flipped.sum()) <= 2, (what, int(flipped.sum()))
+
+    for tag in ("lsp", "penn_sigma1", "odd_stride4"):
+        stride, sigma = (float(v) for v in g[tag + "_cfg"])
+        hm = ops.make_heatmaps(g[tag + "_kpt"], 368, 368, stride, sigma, dev)
+        check(hm, g[tag + "_hm"], tag)
+    cm = ops.make_centermaps(g["centers"], 96, 80, 3.0, dev)
+    check(cm, g["centermaps"], "centermaps")
+
+
+def normalize_case(dev):
+    img = torch.randint(0, 256, (3, 37, 41, 3), generator=torch.Generator().manual_seed(5)).float()
+    got = ops.normalize_image(img.to(dev))
+    ref = img.permute(0, 3, 1, 2).contiguous().sub(128.0).div(256.0)      # Mytransforms.to_tensor + normalize
+    assert torch.equal(got.cpu(), ref)

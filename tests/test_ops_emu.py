@@ -124,6 +124,11 @@ def test_pck_accuracy(emu_backend, golden_dir):
     oc.accuracy_case(emu_backend, golden_dir)
 
 
+def test_targets(emu_backend, golden_dir):
+    oc.targets_case(emu_backend, golden_dir)
+    oc.normalize_case(emu_backend)
+
+
 def test_argmax(emu_backend, golden_dir):
     oc.argmax_case(emu_backend, golden_dir)
 

@@ -158,3 +158,8 @@ def test_dgrad_with_addend(cfg):
 
 def test_pck_accuracy(golden_dir):
     oc.accuracy_case(DEV, golden_dir)
+
+
+def test_targets(golden_dir):
+    oc.targets_case(DEV, golden_dir)
+    oc.normalize_case(DEV)

@@ -199,6 +199,48 @@ def g7_accuracy():
     save("g7_accuracy.npz", **out)
 
 
+def g8_targets():
+    """G8: target heat-maps and centre maps.  The Gaussian is the reference's OWN function: `guassian_kernel` is extracted
+    from utils/utils.py with `ast` and executed here (the module itself cannot be imported: cv2 / torchvision are absent);
+    the assembly around it (int(coordinate)/stride centres, clip to 1, < 0.0099 -> 0, background channel) follows
+    lsp_lspet_data.py:224-242 statement by statement."""
+    import ast
+    src = open(os.path.join(REF, "utils", "utils.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "guassian_kernel"][0]
+    ns = {"np": np}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "reference:utils/utils.py", "exec"), ns)
+    gk = ns["guassian_kernel"]
+    rng = np.random.default_rng(8)
+    height = width = 368
+    out = {}
+    for tag, stride, sigma, nk in (("lsp", 8, 3, 14), ("penn_sigma1", 8, 1, 13), ("odd_stride4", 4, 3.0, 5)):
+        b = 3
+        kpt = rng.uniform(-20, 400, size=(b, nk, 2))               # some joints outside the image, fractional coordinates
+        kpt[0, 0] = [183.99999999, 92.0]                           # int() truncation right below an integer
+        kpt[1, 1] = [0.0, 367.9]
+        hs, ws = int(height / stride), int(width / stride)
+        hm = np.zeros((b, nk + 1, hs, ws), dtype=np.float32)
+        for n in range(b):
+            for i in range(nk):
+                x = int(kpt[n, i][0]) * 1.0 / stride
+                y = int(kpt[n, i][1]) * 1.0 / stride
+                m = gk(size_h=hs, size_w=ws, center_x=x, center_y=y, sigma=sigma)
+                m[m > 1] = 1
+                m[m < 0.0099] = 0
+                hm[n, i + 1] = m
+            hm[n, 0] = 1.0 - np.max(hm[n, 1:], axis=0)
+        out.update({f"{tag}_kpt": kpt, f"{tag}_hm": hm, f"{tag}_cfg": np.array([stride, sigma], dtype=np.float64)})
+    centers = np.array([[184.3, 190.7], [10.25, 355.5], [400.0, -3.0]])
+    cm = np.zeros((3, 1, 96, 80), dtype=np.float32)                # a small non-square map keeps the fixture small
+    for n in range(3):
+        m = gk(size_h=96, size_w=80, center_x=centers[n, 0] / 4, center_y=centers[n, 1] / 4, sigma=3)
+        m[m > 1] = 1
+        m[m < 0.0099] = 0
+        cm[n, 0] = m
+    out.update(centers=centers / 4, centermaps=cm)
+    save("g8_targets.npz", **out)
+
+
 def g0_keys():
     """G0: the reference's state_dict contract (names, shapes, dtypes, order) for both models."""
     import json
@@ -212,7 +254,8 @@ def g0_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g4", "g5", "g6", "g7"]
-    fns = dict(g0=g0_keys, g1=g1_eval_full, g2=g2_taps, g4=g4_train, g5=g5_lstm, g6=g6_argmax, g7=g7_accuracy)
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g4", "g5", "g6", "g7", "g8"]
+    fns = dict(g0=g0_keys, g1=g1_eval_full, g2=g2_taps, g4=g4_train, g5=g5_lstm, g6=g6_argmax, g7=g7_accuracy,
+               g8=g8_targets)
     for w in which:
         fns[w]()

@@ -72,6 +72,9 @@ SIGNATURES = {
     "up_lstm_fwd": (_i, [_p, _i, _p, _i, _p, _p, _i, _i64, _i, _p]),
     "up_lstm_bwd": (_i, [_p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _i64, _i, _p]),
     "up_heatmap_argmax": (_i, [_p, _i, _i, _i, _i, _p, _p, _p, _p]),
+    "up_make_heatmaps": (_i, [_p, _i, _i, _i, _i, C.c_double, C.c_double, _p, _p]),
+    "up_make_gaussian_maps": (_i, [_p, _i, _i, _i, C.c_double, _p, _p]),
+    "up_normalize_image": (_i, [_p, _i, _i, _i, _i, _f, _f, _p, _p]),
     "up_pck_accuracy": (_i, [_p, _p, _i, _i, _i, _i, _i, C.c_double, C.c_double, _p, _p, _p, _p, _p, _p]),
     "up_profile_variants": (_i, []),
     "up_profile_variant_name": (C.c_char_p, [_i]),

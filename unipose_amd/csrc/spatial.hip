@@ -367,6 +367,59 @@ __global__ void __launch_bounds__(256) argmax_kernel(const float* hm, int maps, 
     }
 }
 
+// ---- training targets (the step before the path: lsp_lspet_data.py:224-245, mpii_data.py:165-187) ----------------
+// Gaussian joint maps exactly as the loaders build them: float64 exp(-D2 / 2.0 / sigma / sigma) on the integer pixel
+// grid (utils/utils.py:200-203), clipped to <= 1, values < 0.0099 set to 0, then stored as float32; channel 0 is
+// 1 - max over the joint channels (float32).  The joint centre is int(coordinate) / stride like the loaders compute it.
+__device__ __forceinline__ float target_gauss(double x, double y, double cx, double cy, double sigma) {
+    const double dx = x - cx, dy = y - cy;
+    const double d2 = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+    double v = exp(-d2 / 2.0 / sigma / sigma);
+    if (v > 1.0) v = 1.0;
+    if (v < 0.0099) v = 0.0;
+    return (float)v;
+}
+__global__ void __launch_bounds__(256) heatmap_target_kernel(const double* kpt, int K, int H, int W, double stride,
+                                                             double sigma, float* out, long long total /* B*H*W */) {
+    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int x = (int)(e % W);
+    const long long t = e / W;
+    const int y = (int)(t % H);
+    const int b = (int)(t / H);
+    float* o = out + (size_t)b * (K + 1) * H * W + (size_t)y * W + x;
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) {
+        const double cx = (double)(long long)kpt[((size_t)b * K + k) * 2] * 1.0 / stride;       // int(kpt) * 1.0 / stride
+        const double cy = (double)(long long)kpt[((size_t)b * K + k) * 2 + 1] * 1.0 / stride;
+        const float g = target_gauss((double)x, (double)y, cx, cy, sigma);
+        o[(size_t)(k + 1) * H * W] = g;
+        mx = fmaxf(mx, g);
+    }
+    o[0] = 1.0f - mx;
+}
+__global__ void __launch_bounds__(256) gaussian_map_kernel(const double* center, int H, int W, double sigma, float* out,
+                                                           long long total /* N*H*W */) {
+    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int x = (int)(e % W);
+    const long long t = e / W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    out[e] = target_gauss((double)x, (double)y, center[2 * n], center[2 * n + 1], sigma);
+}
+// (pixel - mean) / std, HWC -> CHW (Mytransforms.to_tensor + normalize, Mytransforms.py:10-41)
+__global__ void __launch_bounds__(256) normalize_image_kernel(const float* img, int C, int HW, float mean, float stdv,
+                                                              float* out, long long total /* B*HW*C */) {
+    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int c = (int)(e % C);
+    const long long t = e / C;
+    const int p = (int)(t % HW);
+    const long long b = t / HW;
+    out[((size_t)b * C + c) * HW + p] = (img[e] - mean) / stdv;
+}
+
 // ---- PCK / PCKh accuracy on joint coordinates (utils/evaluate.py:5-29,58-172) -------------------------------------
 // One workgroup; thread j owns joint j.  Arithmetic types follow the reference under NumPy >= 2: coordinates float32,
 // head / torso sizes float32 (np.linalg.norm of float32), thresholds float32 products (python float * np.float32),
@@ -621,6 +674,33 @@ extern "C" int up_heatmap_argmax(const float* hm, int B, int J, int H, int W, in
     hipLaunchKernelGGL(argmax_kernel, dim3(cdiv(maps, 4)), dim3(256), 0, as_stream(stream), hm, maps, H * W, W, idx,
                        preds_xy, maxvals);
     return check_launch("heatmap_argmax");
+}
+
+extern "C" int up_make_heatmaps(const double* kpt_xy, int B, int K, int H, int W, double stride, double sigma,
+                                float* out, void* stream) {
+    UP_REQUIRE(kpt_xy && out && B > 0 && K > 0 && H > 0 && W > 0 && stride > 0 && sigma > 0, UP_ERR_INVALID,
+               "make_heatmaps: bad argument");
+    long long total = (long long)B * H * W;
+    hipLaunchKernelGGL(heatmap_target_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), kpt_xy, K, H, W,
+                       stride, sigma, out, total);
+    return check_launch("make_heatmaps");
+}
+extern "C" int up_make_gaussian_maps(const double* center_xy, int N, int H, int W, double sigma, float* out,
+                                     void* stream) {
+    UP_REQUIRE(center_xy && out && N > 0 && H > 0 && W > 0 && sigma > 0, UP_ERR_INVALID, "make_gaussian_maps: bad argument");
+    long long total = (long long)N * H * W;
+    hipLaunchKernelGGL(gaussian_map_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), center_xy, H, W,
+                       sigma, out, total);
+    return check_launch("make_gaussian_maps");
+}
+extern "C" int up_normalize_image(const float* img_hwc, int B, int H, int W, int C, float mean, float stdv,
+                                  float* out_chw, void* stream) {
+    UP_REQUIRE(img_hwc && out_chw && B > 0 && H > 0 && W > 0 && C > 0 && stdv != 0.f, UP_ERR_INVALID,
+               "normalize_image: bad argument");
+    long long total = (long long)B * H * W * C;
+    hipLaunchKernelGGL(normalize_image_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), img_hwc, C,
+                       H * W, mean, stdv, out_chw, total);
+    return check_launch("normalize_image");
 }
 
 extern "C" int up_pck_accuracy(const float* pred_xy, const float* target_xy, int B, int J, int H, int W, int dataset,

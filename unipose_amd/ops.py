@@ -876,6 +876,48 @@ def heatmap_argmax(hm: torch.Tensor):
     return preds, mx, idx
 
 
+def _as_f64(a, dev):
+    t = torch.as_tensor(a, dtype=torch.float64).contiguous()
+    t = t.to(dev) if dev is not None else t
+    if not t.is_cuda and not _C._ALLOW_HOST_POINTERS:
+        raise _C.UniPoseHipError("unipose_amd kernels need CUDA(HIP) tensors; there is no CPU fallback")
+    return t
+
+
+def make_heatmaps(kpt_xy, height: int, width: int, stride: float, sigma: float, device):
+    """Target heat-maps of a batch on the device (lsp_lspet_data.py:224-236, mpii_data.py:165-175): kpt_xy (B,K,2) pixel
+    coordinates (any array-like; kept in float64 like the loaders' annotations), maps of int(height/stride) x
+    int(width/stride); returns (B, K+1, h, w) float32 with the background in channel 0."""
+    k = _as_f64(kpt_xy, device)
+    b, nk, _ = k.shape
+    h, w = int(height / stride), int(width / stride)
+    out = torch.empty((b, nk + 1, h, w), dtype=torch.float32, device=k.device)
+    _C.check(_C.lib().up_make_heatmaps(k.data_ptr(), b, nk, h, w, float(stride), float(sigma), out.data_ptr(),
+                                       _stream(out)), "make_heatmaps")
+    return out
+
+
+def make_centermaps(center_xy, height: int, width: int, sigma: float = 3.0, device=None):
+    """Gaussian centre maps (lsp_lspet_data.py:238-242): center_xy (N,2) -> (N, 1, height, width) float32."""
+    c = _as_f64(center_xy, device)
+    out = torch.empty((c.shape[0], 1, height, width), dtype=torch.float32, device=c.device)
+    _C.check(_C.lib().up_make_gaussian_maps(c.data_ptr(), c.shape[0], height, width, float(sigma), out.data_ptr(),
+                                            _stream(out)), "make_gaussian_maps")
+    return out
+
+
+def normalize_image(img_hwc: torch.Tensor, mean: float = 128.0, std: float = 256.0):
+    """(B,H,W,C) float32 pixels -> (B,C,H,W) (pixel - mean) / std: Mytransforms.to_tensor + normalize as the loaders
+    call them (lsp_lspet_data.py:244-245)."""
+    _dev_ok(img_hwc)
+    x = _dense(img_hwc)
+    b, h, w, c = x.shape
+    out = torch.empty((b, c, h, w), dtype=torch.float32, device=x.device)
+    _C.check(_C.lib().up_normalize_image(x.data_ptr(), b, h, w, c, float(mean), float(std), out.data_ptr(), _stream(x)),
+             "normalize_image")
+    return out
+
+
 DATASET_IDS = {"LSP": 0, "COCO": 1, "Penn_Action": 2, "NTID": 3, "PoseTrack": 4, "BBC": 5, "MPII": 6}
 
 
