@@ -1,0 +1,103 @@
+"""Checkpoint interop — host logic, no GPU.  The "authors' checkpoint" is synthesised from the key /
+shape list dumped from the genuine reference (tests/golden/g0_state_dict_keys.json)."""
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from unipose_amd import checkpoint as ckpt
+from unipose_amd.unipose import unipose
+from unipose_amd.uniposeLSTM import unipose as unipose_lstm
+
+
+def _golden_state(golden_dir, which, seed=0):
+    spec = json.load(open(os.path.join(golden_dir, "g0_state_dict_keys.json")))[which]
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, shape, _ in spec:
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.tensor(7)
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(shape, generator=g) + 0.5
+        else:
+            sd[k] = torch.randn(shape, generator=g)
+    return sd
+
+
+@pytest.fixture(scope="module")
+def image_model():
+    return unipose("LSP", num_classes=14, backbone="resnet", output_stride=16, sync_bn=True, freeze_bn=False, stride=8)
+
+
+def test_reference_checkpoint_round_trip(tmp_path, golden_dir, image_model):
+    which = "unipose_K14"
+    sd = _golden_state(golden_dir, which)
+    path = ckpt.save_checkpoint({"state_dict": sd}, True, str(tmp_path / "authors"))
+    assert path.endswith("authors_best.pth.tar") and os.path.exists(path)
+    assert ckpt.save_checkpoint({"state_dict": sd}, 0, str(tmp_path / "never")) is None
+    assert not os.path.exists(str(tmp_path / "never_best.pth.tar"))
+    rep = ckpt.load_checkpoint(image_model, path)
+    assert not rep.missing and not rep.unexpected and not rep.skipped and len(rep.loaded) == len(sd)
+    own = image_model.state_dict()
+    assert all(torch.equal(own[k], sd[k]) for k in sd)
+    # DataParallel prefix, a foreign key and a head of another dataset: loaded / reported / skipped
+    other = {"module." + k: v for k, v in sd.items()}
+    other["module.fc.weight"] = torch.zeros(3)
+    head = [k for k in sd if k.endswith("last_conv.8.weight")][0]
+    other["module." + head] = torch.zeros(17, 256, 1, 1)
+    before = own[head].clone()
+    rep = ckpt.load_checkpoint(image_model, other)
+    assert rep.unexpected == ["module.fc.weight"] and rep.skipped == ["module." + head] and rep.missing == [head]
+    assert torch.equal(image_model.state_dict()[head], before)
+
+
+def test_torchvision_trunk_file(tmp_path, golden_dir, image_model):
+    which = "unipose_K14"
+    sd = _golden_state(golden_dir, which, seed=3)
+    tv = {k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}
+    tv["fc.weight"], tv["fc.bias"] = torch.zeros(1000, 2048), torch.zeros(1000)
+    path = str(tmp_path / "resnet101-synthetic.pth")
+    torch.save(tv, path)
+    rep = ckpt.load_resnet_pretrained(image_model.backbone, path)
+    assert sorted(rep.unexpected) == ["fc.bias", "fc.weight"] and not rep.missing and not rep.skipped
+    own = image_model.backbone.state_dict()
+    assert all(torch.equal(own[k], v) for k, v in tv.items() if not k.startswith("fc."))
+    image_model.backbone.load_pretrained(path)                      # the method the constructor argument uses
+
+
+def test_lstm_prefix_filter(golden_dir):
+    which = "unipose_lstm_K13"
+    sd = _golden_state(golden_dir, which, seed=5)
+    m = unipose_lstm(num_classes=13)
+    keep = {k: v.clone() for k, v in m.state_dict().items() if k.startswith("lstm")}
+    rep = ckpt.load_checkpoint(m, {"state_dict": sd}, skip_prefix=("lstm",))
+    assert rep.skipped and all(k.startswith("lstm") for k in rep.skipped) and sorted(rep.missing) == sorted(rep.skipped)
+    own = m.state_dict()
+    assert all(torch.equal(own[k], v) for k, v in keep.items())
+    assert all(torch.equal(own[k], sd[k]) for k in rep.loaded)
+
+
+def test_fold_batchnorm(golden_dir, image_model):
+    which = "unipose_K14"
+    image_model.load_state_dict(_golden_state(golden_dir, which, seed=9))
+    pairs = ckpt.conv_bn_pairs(image_model)
+    sd = image_model.state_dict()
+    n_bn = sum(1 for k in sd if k.endswith("running_mean"))
+    assert len(pairs) == n_bn and len({b for _, b in pairs}) == n_bn          # every BatchNorm found exactly once
+    assert ("wasp.conv1", "wasp.bn1") in pairs and not any(c == "wasp.conv2" for c, _ in pairs)
+    assert ("backbone.layer1.0.downsample.0", "backbone.layer1.0.downsample.1") in pairs
+    folded = ckpt.fold_batchnorm(image_model)
+    assert not any("running_" in k or ".bn" in k for k in folded)
+    mods = dict(image_model.named_modules())
+    g = torch.Generator().manual_seed(1)
+    for conv, bn in (pairs[0], ("backbone.layer4.2.conv2", "backbone.layer4.2.bn2"), ("wasp.aspp3.atrous_conv", "wasp.aspp3.bn"),
+                     ("decoder.last_conv.4", "decoder.last_conv.5")):
+        c = mods[conv]
+        x = torch.randn((1, c.in_channels, 9, 9), generator=g)
+        kw = dict(stride=c.stride, padding=c.padding, dilation=c.dilation)
+        ref = F.batch_norm(F.conv2d(x, sd[conv + ".weight"], None, **kw), sd[bn + ".running_mean"],
+                           sd[bn + ".running_var"], sd[bn + ".weight"], sd[bn + ".bias"], False, 0.0, mods[bn].eps)
+        got = F.conv2d(x, folded[conv + ".weight"], folded[conv + ".bias"], **kw)
+        assert torch.allclose(got, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max())), (conv, float((got - ref).abs().max()))
