@@ -1,0 +1,176 @@
+"""the repaired training / validation drivers (unipose_amd/trainer.py, unipose.py, uniposeLSTM.py).
+
+Host logic (learning-rate policy, running metric means, CLI flags) is checked against hand-evaluated restatements of
+the reference statements they follow; the loops run end to end on the emulator here and on the GPU with -m gpu."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _args(**kw):
+    base = dict(dataset="LSP", pretrained=None, model_name=None, model_arch="unipose", train_dir=None, val_dir=None,
+                batch_size=2, size=32, train_batches=2, val_batches=1)
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+def test_adjust_learning_rate_step_policy():
+    from unipose_amd.trainer import adjust_learning_rate
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1.0)
+    # utils/utils.py:42-51 with the drivers' constants (unipose.py:49-52)
+    for iters, want in ((0, 1e-4), (13274, 1e-4), (13275, 1e-4 * 0.333), (2 * 13275 + 1, 1e-4 * 0.333 ** 2)):
+        lr = adjust_learning_rate(opt, iters, 1e-4, policy="step", gamma=0.333, step_size=13275)
+        assert lr == pytest.approx(want, rel=1e-12)
+        assert opt.param_groups[0]["lr"] == lr
+    assert adjust_learning_rate(opt, 99999, 1e-4, 0.333, 13275, policy="fixed") == 1e-4
+    with pytest.raises(ValueError):
+        adjust_learning_rate(opt, 0, 1e-4, 0.333, 13275, policy="poly")
+
+
+def _reference_running_means(evals, n, first_joint):
+    """unipose.py:139-177 (first_joint=1) / uniposeLSTM.py:146-200 (first_joint=0), restated literally."""
+    AP, PCK, PCKh, count = (np.zeros(n + 1) for _ in range(4))
+    for i, (acc, acc_PCK, acc_PCKh, visible) in enumerate(evals):
+        AP[0] = (AP[0] * i + acc[0]) / (i + 1)
+        PCK[0] = (PCK[0] * i + acc_PCK[0]) / (i + 1)
+        PCKh[0] = (PCKh[0] * i + acc_PCKh[0]) / (i + 1)
+        for j in range(first_joint, n + 1):
+            if visible[j] == 1:
+                AP[j] = (AP[j] * count[j] + acc[j]) / (count[j] + 1)
+                PCK[j] = (PCK[j] * count[j] + acc_PCK[j]) / (count[j] + 1)
+                PCKh[j] = (PCKh[j] * count[j] + acc_PCKh[j]) / (count[j] + 1)
+                count[j] += 1
+    return AP, PCK, PCKh, AP[1:].sum() / n, PCK[1:].sum() / n, PCKh[1:].sum() / n
+
+
+@pytest.mark.parametrize("video", [False, True])
+def test_pose_metrics_running_means(video):
+    from unipose_amd.trainer import PoseMetrics
+    n = 5
+    rng = np.random.default_rng(3)
+    evals = []
+    for _ in range(7):
+        vis = (rng.uniform(size=n + 1) < 0.7).astype(np.float64)
+        evals.append((rng.uniform(size=n + 1), rng.uniform(size=n + 1), rng.uniform(size=n + 1), vis))
+    m = PoseMetrics(n)
+    for e in evals:
+        m.update(*e, video=video)
+    AP, PCK, PCKh, mAP, mPCK, mPCKh = _reference_running_means(evals, n, 0 if video else 1)
+    assert np.array_equal(m.AP, AP) and np.array_equal(m.PCK, PCK) and np.array_equal(m.PCKh, PCKh)
+    assert (m.mAP, m.mPCK, m.mPCKh) == (mAP, mPCK, mPCKh)
+    assert "mPCKh" in m.table("LSP")
+
+
+def test_average_meter():
+    from unipose_amd.trainer import AverageMeter
+    a = AverageMeter()
+    a.update(2.0, 3)
+    a.update(4.0)
+    assert (a.val, a.sum, a.count, a.avg) == (4.0, 10.0, 4, 2.5)
+
+
+def test_cli_flags_match_reference():
+    """Same flag names and defaults as unipose.py:248-254 / uniposeLSTM.py:272-289."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    img = importlib.import_module("unipose")
+    vid = importlib.import_module("uniposeLSTM")
+    a = img.parse_args([])
+    assert (a.pretrained, a.dataset, a.model_name, a.model_arch) == (None, "LSP", None, "unipose")
+    a = img.parse_args(["--dataset", "MPII", "--pretrained", "w.pth.tar", "--model_name", "run1"])
+    assert (a.dataset, a.pretrained, a.model_name) == ("MPII", "w.pth.tar", "run1")
+    v = vid.parse_args(["--dataset", "LSP"])
+    assert v.dataset == "Penn_Action" and v.frame_memory == 5      # forced like uniposeLSTM.py:284-286
+
+
+def test_synthetic_data_shapes():
+    from unipose_amd.trainer import SyntheticPoseData
+    items = list(SyntheticPoseData(14, 3, 2, size=64, seed=5))
+    assert len(items) == 2
+    it = items[0]
+    assert it["pixels"].shape == (3, 64, 64, 3) and it["pixels"].dtype == torch.uint8
+    assert it["kpts"].shape == (3, 14, 2) and it["center"].shape == (3, 2)
+    clip = next(iter(SyntheticPoseData(13, 2, 1, size=32, frames=5)))
+    assert clip["pixels"].shape == (2, 5, 32, 32, 3) and clip["kpts"].shape == (2, 5, 13, 2)
+    again = list(SyntheticPoseData(14, 3, 2, size=64, seed=5))
+    assert torch.equal(again[1]["pixels"], items[1]["pixels"]) and np.array_equal(again[1]["kpts"], items[1]["kpts"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def _image_loop(dev, tmp_path):
+    from oracle import unipose_oracle as O
+    from unipose_amd.trainer import DeviceBatcher, SyntheticPoseData, Trainer
+    args = _args(model_name=str(tmp_path / "run"))
+    tr = Trainer(args, device=dev)
+    assert tr.numClasses == 14 and (tr.lr, tr.gamma, tr.step_size, tr.sigma, tr.stride) == (1e-4, 0.333, 13275, 3, 8)
+    # the device-made batch equals the oracle's restatement of the loader arithmetic
+    item = next(iter(SyntheticPoseData(14, 2, 1, size=32, seed=1)))
+    x, heat, cm = DeviceBatcher(dev, 8, 3)(item)
+    assert x.shape == (2, 3, 32, 32) and heat.shape == (2, 15, 4, 4) and cm.shape == (2, 1, 32, 32)
+    want = (item["pixels"].float().permute(0, 3, 1, 2) - 128.0) / 256.0
+    assert torch.equal(x.cpu(), want)
+    hr = np.stack([O.make_heatmap(k, 32, 32, 8, 3) for k in item["kpts"]])
+    assert np.abs(heat.cpu().numpy() - hr).max() <= 1.2e-7
+    w0 = tr.model.backbone.conv1.weight.detach().clone()
+    loss = tr.training(0)
+    assert np.isfinite(loss) and tr.iters == 2
+    assert not torch.equal(w0, tr.model.backbone.conv1.weight.detach())
+    m = tr.validation(0)
+    assert m.evals == 1 and 0.0 <= m.mPCKh <= 1.0
+    if m.mAP > 0:
+        assert os.path.exists(str(tmp_path / "run") + "_best.pth.tar")
+    # key-filtered --pretrained round trip (unipose.py:78-90)
+    path = str(tmp_path / "ck.pth.tar")
+    torch.save({"state_dict": tr.model.state_dict()}, path)
+    tr2 = Trainer(_args(pretrained=path), device=dev)
+    assert not tr2.load_report.missing and not tr2.load_report.skipped
+    assert torch.equal(tr2.model.backbone.conv1.weight.detach().cpu(), tr.model.backbone.conv1.weight.detach().cpu())
+    kpts, up = tr2.test(item["pixels"][0])
+    assert len(kpts) == 14 and up.shape == (1, 15, 32, 32)
+    # reference-style loader tuples are accepted too
+    tup = [(x.cpu(), heat.cpu(), cm.cpu(), ["a", "b"])]
+    tr3 = Trainer(_args(), train_loader=tup, val_loader=tup, device=dev)
+    tr3.training(0)
+    assert tr3.iters == 1
+
+
+def _video_loop(dev, tmp_path):
+    from unipose_amd.trainer import VideoTrainer
+    args = _args(dataset="Penn_Action", batch_size=1, frame_memory=2, train_batches=1, val_batches=1)
+    tr = VideoTrainer(args, device=dev)
+    assert tr.numClasses == 13 and tr.sigma == 1
+    w0 = tr.model.lstm.conv_gx_lstm.weight.detach().clone()
+    loss = tr.training(0)
+    assert np.isfinite(loss) and tr.iters == 1
+    assert not torch.equal(w0, tr.model.lstm.conv_gx_lstm.weight.detach())   # BPTT reached the t>0 cell
+    m = tr.validation(0)
+    assert m.evals == 2
+
+
+def test_image_trainer_emu(emu_backend, tmp_path):
+    os.environ["UNIPOSE_NO_TQDM"] = "1"
+    _image_loop(emu_backend, tmp_path)
+
+
+def test_video_trainer_emu(emu_backend, tmp_path):
+    os.environ["UNIPOSE_NO_TQDM"] = "1"
+    _video_loop(emu_backend, tmp_path)
+
+
+@pytest.mark.gpu
+def test_image_trainer_gpu(tmp_path):
+    os.environ["UNIPOSE_NO_TQDM"] = "1"
+    _image_loop(torch.device("cuda:0"), tmp_path)
+
+
+@pytest.mark.gpu
+def test_video_trainer_gpu(tmp_path):
+    os.environ["UNIPOSE_NO_TQDM"] = "1"
+    _video_loop(torch.device("cuda:0"), tmp_path)
