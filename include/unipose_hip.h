@@ -92,8 +92,15 @@ int up_conv2d_fwd(const up_conv_desc* d, const float* x, const float* w_fwd, flo
 int up_conv_stats_tiles(const up_conv_desc* d);   /* row tiles the forward kernel will use */
 /* Load balance: when the tile count leaves a short tail (tiles % CUs small), the forward / data-gradient launch splits
  * each tail tile along K into this many parts (1 = no split), one per CU, and merges them in a fixed order through a
- * per-stream scratch the library allocates on first use (16 MB + flags).  UP_TAIL_SPLIT=0 disables it.  Informational. */
+ * per-stream scratch the library allocates on first use (32 MB + flags).  UP_TAIL_SPLIT=0 disables it.  Informational. */
 int up_conv_split_parts(const up_conv_desc* d);
+/* Tuning hook: route the fp32 forward / data-gradient launches through the persistent stream-K form of the kernel (one
+ * wave of workgroups, each walking a contiguous range of (tile, K-slice) work units; tiles cut by a range boundary are
+ * merged through the same per-stream scratch, 32 MB + flags).  `grid` = 0 lets the library size the wave (CUs x
+ * occupancy); a positive value overrides it.  Default off; UP_PERSISTENT=1 / UP_PERSIST_GRID set the same at load time.
+ * Results agree with the default form to fp32 round-off (the K split changes the summation order). */
+int up_conv_set_persistent(int on, int grid);
+int up_conv_get_persistent(void);
 
 /* Data gradient: dx[N,H,W,ldx(:Cp)] from dy[N,P,Q,ldy(:K)] (replaces convolution_backward, input half).
  * Writes all Cp channels of every input pixel (pad channels get 0).  `add` (optional, [N,H,W,ld_add]) is a second

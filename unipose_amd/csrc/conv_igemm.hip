@@ -85,6 +85,7 @@ struct ProfScope {
 #endif
 
 constexpr int BK = 32;   // K slice of the weight-gradient kernel (the conv/dgrad kernel takes it as a template parameter)
+constexpr int KT_DEFAULT = 32;   // K slice every fp32 forward / data-gradient launch uses
 
 struct IgemmArgs {
     const float* x;
@@ -121,7 +122,22 @@ struct IgemmArgs {
     int no_tap_skip;   // UP_TAP_SKIP=0 (A/B runs): visit every filter tap
     float* partials;
     int* flags;
+    // persistent stream-K form (igemm_kernel<..., PERSIST = true>, see launch_igemm): the launch is p_U = tiles * p_R
+    // work units (p_R units per tile = its nominal K-slice count); workgroup w of G computes units
+    // [bound(w), bound(w+1)), bound(w) = w * p_U / G snapped to a tile boundary when closer than p_snap units to one
+    int p_R, p_snap;
+    int p_share, p_rem;   // p_U = G * p_share + p_rem: 32-bit, division-free bounds on the device
+    FastDiv fR;
 };
+
+// first work unit of persistent workgroup w (of G); bound(G) = p_U
+__device__ __forceinline__ int persist_bound(const IgemmArgs& a, int w) {
+    int u = w * a.p_share + (w < a.p_rem ? w : a.p_rem);
+    const int r = u - fdiv(u, a.fR) * a.p_R;
+    if (r < a.p_snap) u -= r;
+    else if (a.p_R - r < a.p_snap) u += a.p_R - r;
+    return u;
+}
 
 __device__ __forceinline__ void wf_merge(float& n1, float& m1, float& s1, float n2, float m2, float s2) {
     if (n2 == 0.f) return;
@@ -330,7 +346,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
 // MODE 1: aligned (Cp % 32 == 0), per-slice bounds arithmetic (strided data gradient, > 32 taps)
 // MODE 2: aligned + precomputed per-row offset and per-row tap-validity bit mask: one add + one bit test
 //         per gathered row and K slice (the address arithmetic of MODE 1 was ~20 % of the kernel time)
-template <int BM, int BN, int MODE, int DBG = 0, int KT = 32>
+// PERSIST: persistent stream-K form.  The grid is one wave of workgroups (CUs x occupancy); each walks its contiguous
+//         range of (tile, K slice) work units from the LAST tile of the range down to the first.  A tile cut by a range
+//         boundary is finished by the workgroup that holds its last K slices (the owner): it handles that tile at the
+//         END of its walk, while the workgroups holding the earlier slices (lower block index) handle theirs FIRST and
+//         publish raw accumulators, so the owner normally finds them ready.  Writers always have a lower block index
+//         than their reader and publish before they ever wait: no dependence on co-residency or dispatch gaps.
+template <int BM, int BN, int MODE, int DBG = 0, int KT = 32, bool PERSIST = false>
 __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_kernel(IgemmArgs a) {
     constexpr bool ALIGNED = MODE >= 1, FAST = MODE == 2;
     constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave along m / n
@@ -347,16 +369,38 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     float* As = smem;
     float* Bs = smem + BM * LDS_LD;
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, lh = lane >> 5;
+    int tid_opaque = threadIdx.x;
 
     long long dbg_w0 = 0;   // probe bit 5: per-block timeline (start / end of K loop / stores drained, 100 MHz ticks + HW ids)
     if ((DBG & 32) && threadIdx.x == 0) dbg_w0 = wall_clock64();
+    int p_ub = 0, p_ue = 0;   // PERSIST: work-unit range of this workgroup, tile being walked
+    int p_tile = 0;
+    if constexpr (PERSIST) {
+        p_ub = persist_bound(a, (int)blockIdx.x);
+        p_ue = persist_bound(a, (int)blockIdx.x + 1);
+        if (p_ub >= p_ue) return;   // (uniform) nothing left for this workgroup after snapping
+        p_tile = fdiv(p_ue - 1, a.fR);
+    }
+    for (;;) {   // PERSIST: one pass per tile of the range (non-persistent: exactly one pass)
+#ifndef UP_EMU
+    // every per-thread quantity below derives from this value: making it opaque per pass keeps the compiler from
+    // hoisting the whole address set-up of a tile out of the tile loop (it then stayed live across the K loop:
+    // 92 -> 166 VGPRs on the 64x64 tile, scratch spills on the 128-wide ones)
+    if constexpr (PERSIST) asm volatile("" : "+v"(tid_opaque));
+#endif
+    const int tid = tid_opaque;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
     int logical, part = 0, tail = 0;
-    const bool split = (int)blockIdx.x >= a.full_blocks;
-    if (!split) {
+    int p_lo = 0, p_hi = 0;         // PERSIST: this pass covers units [p_lo, p_hi) of the p_R units of tile p_tile
+    const bool split = !PERSIST && (int)blockIdx.x >= a.full_blocks;
+    if constexpr (PERSIST) {
+        const int t0 = p_tile * a.p_R;
+        p_lo = (p_ub > t0 ? p_ub : t0) - t0;
+        p_hi = (p_ue < t0 + a.p_R ? p_ue : t0 + a.p_R) - t0;
+        logical = p_tile;
+    } else if (!split) {
         logical = xcd_remap(blockIdx.x, a.full_blocks);
     } else {   // K-split tail tile: a 1/parts share of the K slices of tile full_blocks + tail
         const int j = (int)blockIdx.x - a.full_blocks;
@@ -434,6 +478,10 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     if (split) {
         kb = (int)((long long)nk * part / a.parts);
         ke = (int)((long long)nk * (part + 1) / a.parts);
+    }
+    if constexpr (PERSIST) {   // the unit range scales onto the slices this tile really visits (tap skipping)
+        kb = fdiv(nk * p_lo, a.fR);
+        ke = fdiv(nk * p_hi, a.fR);
     }
 
     const float* wrow[PB];
@@ -585,9 +633,11 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    if (!PERSIST || kb < ke) {   // (a persistent share can be empty on a tile that skips most of its taps)
     gload(kb);
     lstore();
     __syncthreads();
+    }
 
     const float* Ard = As + (wm * (BM / 2) + l31) * LDS_LD + lh * 4;
     const float* Brd = Bs + (wn * (BN / 2) + l31) * LDS_LD + lh * 4;
@@ -605,6 +655,7 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     };
     constexpr int G = BK / 8;   // MFMA groups (8 k each) per slice
 
+    if (!PERSIST || kb < ke) {
     if constexpr (DB) {
         // slice kt is in LDS buffer kt&1; slice kt+1 sits in the staging registers (loaded during slice kt-1)
         // and is written to the OTHER buffer in the middle of this slice's MFMAs; the registers are then
@@ -723,6 +774,7 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
         }
     }
     }
+    }
 
     long long dbg_w1 = 0;
     auto dbg_record = [&]() {   // probe bit 5
@@ -740,6 +792,50 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
 #endif
     };
     if (DBG & 32) dbg_w1 = wall_clock64();
+    if constexpr (PERSIST) {
+        // one partial slot + flag per workgroup: a range has at most one tile it does not finish (its last one)
+        const int w = (int)blockIdx.x;
+        if (p_hi < a.p_R) {   // the tile's last slices belong to a later workgroup: publish and move on
+            float* o = a.partials + (size_t)w * (BM * BN) + tid;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st_agent(o + ((i * TN + j) * 16 + r) * 256, acc[i][j][r]);
+            wait_stores();
+            __syncthreads();
+            if (tid == 0) st_agent_flag(a.flags + w, 1);
+        } else {
+            if (p_lo > 0) {   // earlier slices of this tile were computed by the workgroups below: fixed merge order
+                const int t0 = p_tile * a.p_R;
+                int ub_next = p_ub;
+                for (int v = w - 1; v >= 0 && ub_next > t0; --v) {
+                    const int ub_v = persist_bound(a, v);
+                    if (ub_v < ub_next) {   // (a workgroup whose range snapped to nothing published nothing)
+                        if (tid == 0) {
+                            spin_until_set(a.flags + v);
+                            st_agent_flag(a.flags + v, 0);   // consumed: ready for the next launch on this stream
+                        }
+                        __syncthreads();
+                        const float* o = a.partials + (size_t)v * (BM * BN) + tid;
+#pragma unroll
+                        for (int i = 0; i < TM; ++i)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc[i][j][r] += ld_agent(o + ((i * TN + j) * 16 + r) * 256);
+                    }
+                    ub_next = ub_v;
+                }
+            }
+            igemm_epilogue<BM, BN>(a, acc, smem, mt, m0, n0, wm, wn, l31, lh);
+        }
+        if (p_tile * a.p_R <= p_ub) break;   // that was the first tile of the range
+        --p_tile;
+        __syncthreads();   // the epilogue's statistics exchange read smem; the next tile's prologue writes it
+        continue;
+    } else {
     if (split) {
         // Partials are [part][(i*TN+j)*16 + r][256 threads] floats: every access is one coalesced 256-B row per wave.
         // They are written and read with agent-scope accesses (write-through / cache-bypassing on gfx950), so the
@@ -777,6 +873,9 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
 
     igemm_epilogue<BM, BN>(a, acc, smem, mt, m0, n0, wm, wn, l31, lh);
     if (DBG & 32) dbg_record();
+    break;
+    }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1457,6 +1556,20 @@ static int check_desc(const up_conv_desc* d) {
 struct TileChoice {
     int bm, bn;
 };
+// ---- persistent stream-K launches (igemm_kernel<..., PERSIST>) ---------------------------------------
+// Off by default: UP_PERSISTENT=1 (or up_conv_set_persistent) routes every fp32 forward / data-gradient launch
+// through the persistent form.  UP_PERSIST_TPW = tiles (x100) a workgroup should at least own when the tile size is
+// chosen (default 100), UP_PERSIST_GRID / the setter's second argument overrides the grid (tests shrink the "chip").
+static int g_persist = [] {
+    const char* e = getenv("UP_PERSISTENT");
+    return e && atoi(e) > 0 ? 1 : 0;
+}();
+static int g_persist_grid = [] {
+    const char* e = getenv("UP_PERSIST_GRID");
+    return e && atoi(e) > 0 ? atoi(e) : 0;
+}();
+static int cu_count();
+static int persist_occupancy(int bm, int bn) { return (bm == 128 && bn == 128) ? 2 : 3; }   // = __launch_bounds__
 // Largest tile that still yields ~6 workgroups per CU (the tail split evens out the remainder).  Short reductions
 // are epilogue-heavy and run better on twice as many, smaller tiles (1x1 256->1024 at 23x23: 64x128 91 TF,
 // 128x128 85 TF).
@@ -1466,6 +1579,19 @@ static TileChoice choose_tile(int64_t M, int Ng, int Ktot) {
         const char* e = getenv("UP_TILE_WANT");
         return e && atoi(e) > 0 ? atoi(e) : 1500;   // A/B in the network: 700 / 1000 / 1500 / 2200 / 4300 -> 70.1 / 69.9 / 69.6 / 69.9 / 69.8 ms
     }();
+    if (g_persist) {   // stream-K balances any tile count: the largest tile that still gives every workgroup its share
+        static const int tpw = [] {
+            const char* e = getenv("UP_PERSIST_TPW");
+            return e && atoi(e) > 0 ? atoi(e) : 100;
+        }();
+        for (auto& c : cands) {
+            if (Ng <= 64 && c[1] == 128) continue;
+            const int64_t wgs = (int64_t)cdiv(M, c[0]) * cdiv(Ng, c[1]);
+            const int64_t grid = g_persist_grid ? g_persist_grid : (int64_t)cu_count() * persist_occupancy(c[0], c[1]);
+            if (wgs * 100 >= grid * tpw) return {c[0], c[1]};
+        }
+        return {64, 64};
+    }
     const int64_t want = Ktot < 512 ? 2 * base_want : base_want;
     for (auto& c : cands) {
         if (Ng <= 64 && c[1] == 128) continue;
@@ -1488,6 +1614,7 @@ static TileChoice choose_tile(int64_t M, int Ng, int Ktot) {
 struct SplitScratch {
     float* partials = nullptr;
     int* flags = nullptr;
+    size_t pfloats = 0, nflags = 0;   // capacity
 };
 static int cu_count() {
     static const int n = [] {
@@ -1510,7 +1637,11 @@ static SplitScratch* split_scratch(hipStream_t st) {
     std::lock_guard<std::mutex> lock(mu);
     SplitScratch& s = table[st];
     if (!s.partials) {
-        const size_t pbytes = (size_t)cu_count() * 128 * 128 * sizeof(float), fbytes = (size_t)cu_count() * sizeof(int);
+        // tail split: one 128x128 partial per CU; persistent form: one partial + flag per workgroup of the largest grid
+        // (2 x CUs of 128x128, 3 x CUs of the smaller tiles) or of the overriding grid
+        const size_t slots = (size_t)std::max(2 * cu_count(), g_persist_grid);
+        const size_t nflags = (size_t)std::max(3 * cu_count(), g_persist_grid);
+        const size_t pbytes = slots * 128 * 128 * sizeof(float), fbytes = nflags * sizeof(int);
 #ifdef UP_EMU
         s.partials = static_cast<float*>(malloc(pbytes));
         s.flags = static_cast<int*>(calloc(1, fbytes));
@@ -1523,6 +1654,8 @@ static SplitScratch* split_scratch(hipStream_t st) {
             return nullptr;   // no scratch: the caller falls back to whole tiles
         }
 #endif
+        s.pfloats = pbytes / sizeof(float);
+        s.nflags = nflags;
     }
     return &s;
 }
@@ -1580,6 +1713,45 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     else
         kernel = igemm_kernel<BM, BN, 0, 64>;
 
+    if (g_persist) {
+        // Work units: p_R per tile (its nominal K-slice count), dealt out evenly over one wave of workgroups.  A share
+        // never drops below min_part units (>= 2 K slices, >= 1/8 tile), and a range boundary closer than that to a
+        // tile boundary snaps onto it, so no workgroup publishes or merges for a sliver of a tile.
+        const int R = std::max(1, cdiv(a.Ktot, KT_DEFAULT));
+        const int min_part = std::max(2, R / 8);
+        const long long U = (long long)a.nwg * R;
+        long long G = g_persist_grid ? g_persist_grid : (long long)cu_count() * persist_occupancy(BM, BN);
+        G = std::max(1ll, std::min(G, U / min_part));
+        SplitScratch* sc = U < (1ll << 30) ? split_scratch(st) : nullptr;   // 32-bit unit arithmetic on the device
+        if (sc) {
+            G = std::min(G, (long long)std::min(sc->pfloats / (size_t)(BM * BN), sc->nflags));   // one slot per workgroup
+            a.p_R = R;
+            a.p_snap = min_part;
+            a.p_share = (int)(U / G);
+            a.p_rem = (int)(U % G);
+            a.fR = make_fastdiv(R);
+            a.partials = sc->partials;
+            a.flags = sc->flags;
+            a.full_blocks = a.nwg;
+            a.parts = 1;
+            static const int no_skip_p = [] {
+                const char* e = getenv("UP_TAP_SKIP");
+                return e && e[0] == '0' ? 1 : 0;
+            }();
+            a.no_tap_skip = no_skip_p;
+            void (*pk)(IgemmArgs);
+            if (fast && db)
+                pk = igemm_kernel<BM, BN, 2, DB_VARIANT, 32, true>;
+            else if (fast)
+                pk = igemm_kernel<BM, BN, 2, 64, 32, true>;
+            else if (aligned)
+                pk = igemm_kernel<BM, BN, 1, 64, 32, true>;
+            else
+                pk = igemm_kernel<BM, BN, 0, 64, 32, true>;
+            hipLaunchKernelGGL(pk, dim3((unsigned)G), dim3(256), 0, st, a);
+            return;
+        }
+    }
     a.full_blocks = a.nwg;
     a.parts = 1;
     static const int no_skip = [] {
@@ -1628,6 +1800,14 @@ extern "C" int up_pack_weights_batched(const up_pack_job* jobs_device, int njobs
     hipLaunchKernelGGL(pack_batched_kernel, dim3(48, njobs), dim3(256), 0, as_stream(stream), jobs_device);
     return check_launch("pack_weights_batched");
 }
+
+extern "C" int up_conv_set_persistent(int on, int grid) {
+    UP_REQUIRE(grid >= 0, UP_ERR_INVALID, "conv_set_persistent: grid %d", grid);
+    g_persist = on ? 1 : 0;
+    g_persist_grid = grid;
+    return UP_OK;
+}
+extern "C" int up_conv_get_persistent(void) { return g_persist; }
 
 extern "C" int up_conv_split_parts(const up_conv_desc* d) {
     if (!d || check_desc(d)) return UP_ERR_INVALID;
