@@ -101,6 +101,9 @@ int up_conv_split_parts(const up_conv_desc* d);
  * Results agree with the default form to fp32 round-off (the K split changes the summation order). */
 int up_conv_set_persistent(int on, int grid);
 int up_conv_get_persistent(void);
+/* Development knobs of the persistent form (A/B runs): "persist_tpw" = tiles x100 a workgroup should own when the tile
+ * size is chosen (0 = the default form's tile rule), "persist_xcd" = XCD-aware workgroup numbering. */
+int up_conv_tune(const char* key, int value);
 
 /* Data gradient: dx[N,H,W,ldx(:Cp)] from dy[N,P,Q,ldy(:K)] (replaces convolution_backward, input half).
  * Writes all Cp channels of every input pixel (pad channels get 0).  `add` (optional, [N,H,W,ld_add]) is a second

@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--grids", default="0")
+    ap.add_argument("--variants", default="", help="extra persistent variants 'tpw:xcd:grid,...' (e.g. 0:0:0,100:1:0)")
+    ap.add_argument("--csv", default="", help="directory: per-launch timings (one step, both streams serialised) per variant")
     args = ap.parse_args()
     from model.unipose import unipose
     from unipose_amd import _C, ops
@@ -32,8 +34,10 @@ def main():
     t = torch.rand(B, K + 1, S // 8, S // 8).to(dev)
     out = {}
 
-    def mode(on, grid=0):
+    def mode(on, grid=0, tpw=100, xcd=0):
         _C.check(lib.up_conv_set_persistent(on, grid), "set_persistent")
+        _C.check(lib.up_conv_tune(b"persist_tpw", tpw), "tune")
+        _C.check(lib.up_conv_tune(b"persist_xcd", xcd), "tune")
 
     # parity: eval forward (deterministic) default vs persistent
     model.eval()
@@ -64,14 +68,35 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
 
-    variants = [("default", 0, 0)] + [(f"persistent(grid={g})", 1, int(g)) for g in args.grids.split(",")]
-    for name, on, grid in variants:          # warm every variant (scratch, pack buffers, allocator)
-        mode(on, grid)
+    variants = [("default", 0, 0, 100, 0)]
+    if args.grids:
+        variants += [(f"persistent(grid={g})", 1, int(g), 100, 0) for g in args.grids.split(",")]
+    for v in filter(None, args.variants.split(",")):
+        tpw, xcd, grid = (int(q) for q in v.split(":"))
+        variants.append((f"persistent(tpw={tpw},xcd={xcd},grid={grid})", 1, grid, tpw, xcd))
+    for name, on, grid, tpw, xcd in variants:          # warm every variant (scratch, pack buffers, allocator)
+        mode(on, grid, tpw, xcd)
         timed(2)
-    res = {name: [] for name, _, _ in variants}
+    if args.csv:
+        import ctypes
+        os.makedirs(args.csv, exist_ok=True)
+        nv = lib.up_profile_variants()
+        for i, (name, on, grid, tpw, xcd) in enumerate(variants):
+            mode(on, grid, tpw, xcd)
+            os.environ["UP_PROFILE_CSV"] = os.path.join(args.csv, f"v{i}.csv")
+            torch.cuda.synchronize()
+            lib.up_profile_begin()
+            step()
+            torch.cuda.synchronize()
+            arr = (ctypes.c_double * (nv * 3))()
+            lib.up_profile_end(arr, nv)
+            with open(os.path.join(args.csv, f"v{i}.name"), "w") as f:
+                f.write(name)
+        os.environ.pop("UP_PROFILE_CSV", None)
+    res = {name: [] for name, *_ in variants}
     for r in range(args.rounds):
-        for name, on, grid in variants:
-            mode(on, grid)
+        for name, on, grid, tpw, xcd in variants:
+            mode(on, grid, tpw, xcd)
             timed(1)
             res[name].append(round(timed(args.steps), 3))
         print("round", r, {k: v[-1] for k, v in res.items()}, flush=True)

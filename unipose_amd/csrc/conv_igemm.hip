@@ -127,6 +127,7 @@ struct IgemmArgs {
     // [bound(w), bound(w+1)), bound(w) = w * p_U / G snapped to a tile boundary when closer than p_snap units to one
     int p_R, p_snap;
     int p_share, p_rem;   // p_U = G * p_share + p_rem: 32-bit, division-free bounds on the device
+    int p_xcd;            // workgroup index = xcd_remap(block index) (hardware only; the emulator keeps the identity)
     FastDiv fR;
 };
 
@@ -374,10 +375,14 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     long long dbg_w0 = 0;   // probe bit 5: per-block timeline (start / end of K loop / stores drained, 100 MHz ticks + HW ids)
     if ((DBG & 32) && threadIdx.x == 0) dbg_w0 = wall_clock64();
     int p_ub = 0, p_ue = 0;   // PERSIST: work-unit range of this workgroup, tile being walked
-    int p_tile = 0;
+    int p_tile = 0, p_w = 0;
     if constexpr (PERSIST) {
-        p_ub = persist_bound(a, (int)blockIdx.x);
-        p_ue = persist_bound(a, (int)blockIdx.x + 1);
+        p_w = (int)blockIdx.x;
+#ifndef UP_EMU
+        if (a.p_xcd) p_w = xcd_remap(p_w, (int)gridDim.x);
+#endif
+        p_ub = persist_bound(a, p_w);
+        p_ue = persist_bound(a, p_w + 1);
         if (p_ub >= p_ue) return;   // (uniform) nothing left for this workgroup after snapping
         p_tile = fdiv(p_ue - 1, a.fR);
     }
@@ -794,7 +799,7 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     if (DBG & 32) dbg_w1 = wall_clock64();
     if constexpr (PERSIST) {
         // one partial slot + flag per workgroup: a range has at most one tile it does not finish (its last one)
-        const int w = (int)blockIdx.x;
+        const int w = p_w;
         if (p_hi < a.p_R) {   // the tile's last slices belong to a later workgroup: publish and move on
             float* o = a.partials + (size_t)w * (BM * BN) + tid;
 #pragma unroll
@@ -1568,6 +1573,14 @@ static int g_persist_grid = [] {
     const char* e = getenv("UP_PERSIST_GRID");
     return e && atoi(e) > 0 ? atoi(e) : 0;
 }();
+static int g_persist_tpw = [] {   // 0: keep the tile rule of the default form
+    const char* e = getenv("UP_PERSIST_TPW");
+    return e && atoi(e) >= 0 ? atoi(e) : 100;
+}();
+static int g_persist_xcd = [] {   // 1: workgroup index = XCD-aware remap of the block index (neighbouring ranges share an L2)
+    const char* e = getenv("UP_PERSIST_XCD");
+    return e && atoi(e) > 0 ? 1 : 0;
+}();
 static int cu_count();
 static int persist_occupancy(int bm, int bn) { return (bm == 128 && bn == 128) ? 2 : 3; }   // = __launch_bounds__
 // Largest tile that still yields ~6 workgroups per CU (the tail split evens out the remainder).  Short reductions
@@ -1579,11 +1592,8 @@ static TileChoice choose_tile(int64_t M, int Ng, int Ktot) {
         const char* e = getenv("UP_TILE_WANT");
         return e && atoi(e) > 0 ? atoi(e) : 1500;   // A/B in the network: 700 / 1000 / 1500 / 2200 / 4300 -> 70.1 / 69.9 / 69.6 / 69.9 / 69.8 ms
     }();
-    if (g_persist) {   // stream-K balances any tile count: the largest tile that still gives every workgroup its share
-        static const int tpw = [] {
-            const char* e = getenv("UP_PERSIST_TPW");
-            return e && atoi(e) > 0 ? atoi(e) : 100;
-        }();
+    if (g_persist && g_persist_tpw > 0) {   // stream-K balances any tile count: the largest tile that still gives every
+        const int tpw = g_persist_tpw;      // workgroup its share
         for (auto& c : cands) {
             if (Ng <= 64 && c[1] == 128) continue;
             const int64_t wgs = (int64_t)cdiv(M, c[0]) * cdiv(Ng, c[1]);
@@ -1730,6 +1740,7 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
             a.p_share = (int)(U / G);
             a.p_rem = (int)(U % G);
             a.fR = make_fastdiv(R);
+            a.p_xcd = g_persist_xcd;
             a.partials = sc->partials;
             a.flags = sc->flags;
             a.full_blocks = a.nwg;
@@ -1808,6 +1819,13 @@ extern "C" int up_conv_set_persistent(int on, int grid) {
     return UP_OK;
 }
 extern "C" int up_conv_get_persistent(void) { return g_persist; }
+extern "C" int up_conv_tune(const char* key, int value) {
+    UP_REQUIRE(key, UP_ERR_INVALID, "conv_tune: null key");
+    if (!strcmp(key, "persist_tpw")) g_persist_tpw = value < 0 ? 0 : value;
+    else if (!strcmp(key, "persist_xcd")) g_persist_xcd = value ? 1 : 0;
+    else UP_REQUIRE(false, UP_ERR_INVALID, "conv_tune: unknown key '%s'", key);
+    return UP_OK;
+}
 
 extern "C" int up_conv_split_parts(const up_conv_desc* d) {
     if (!d || check_desc(d)) return UP_ERR_INVALID;
