@@ -101,8 +101,13 @@ int up_conv_split_parts(const up_conv_desc* d);
  * Results agree with the default form to fp32 round-off (the K split changes the summation order). */
 int up_conv_set_persistent(int on, int grid);
 int up_conv_get_persistent(void);
-/* Development knobs of the persistent form (A/B runs): "persist_tpw" = tiles x100 a workgroup should own when the tile
- * size is chosen (0 = the default form's tile rule), "persist_xcd" = XCD-aware workgroup numbering. */
+/* Development knobs (A/B runs inside one process; each also has an environment variable read at load time):
+ * "tile_want" (UP_TILE_WANT) workgroups a launch should at least have when the tile size is chosen ("short_k" /
+ * "short_k_mult": reductions shorter than short_k want short_k_mult / 2 times as many), "db_min_k"
+ * (UP_DB_MIN_K) shortest reduction that uses the double-buffered K loop, "tail_split" (UP_TAIL_SPLIT), "tap_skip"
+ * (UP_TAP_SKIP), "wgrad_per_cu" (UP_WGRAD_PER_CU); persistent form: "persist_tpw" = tiles x100 a workgroup should own
+ * when the tile size is chosen (0 = the default form's tile rule), "persist_xcd" = XCD-aware workgroup numbering.
+ * Change them only between steps: workspace sizes and the BatchNorm partial-row count follow the tile choice. */
 int up_conv_tune(const char* key, int value);
 
 /* Data gradient: dx[N,H,W,ldx(:Cp)] from dy[N,P,Q,ldy(:K)] (replaces convolution_backward, input half).

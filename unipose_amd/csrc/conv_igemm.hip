@@ -1581,6 +1581,18 @@ static int g_persist_xcd = [] {   // 1: workgroup index = XCD-aware remap of the
     const char* e = getenv("UP_PERSIST_XCD");
     return e && atoi(e) > 0 ? 1 : 0;
 }();
+// knobs of the default form (environment at load time, up_conv_tune at run time)
+static int env_int(const char* name, int dflt, int min_ok) {
+    const char* e = getenv(name);
+    return e && atoi(e) >= min_ok ? atoi(e) : dflt;
+}
+static int g_tile_want = env_int("UP_TILE_WANT", 1500, 1);   // A/B in the network: 700 / 1000 / 1500 / 2200 / 4300 -> 70.1 / 69.9 / 69.6 / 69.9 / 69.8 ms
+static int g_db_min_k = env_int("UP_DB_MIN_K", 1024, 1);
+static int g_short_k = env_int("UP_SHORT_K", 512, 1);             // reductions shorter than this are epilogue-heavy:
+static int g_short_k_mult = env_int("UP_SHORT_K_MULT", 4, 1);     // they want g_short_k_mult / 2 times as many workgroups
+static int g_tail_split = env_int("UP_TAIL_SPLIT", 1, 0);
+static int g_tap_skip = env_int("UP_TAP_SKIP", 1, 0);
+static int g_wgrad_per_cu = env_int("UP_WGRAD_PER_CU", 2, 1);   // workgroups per CU a weight-gradient launch aims for
 static int cu_count();
 static int persist_occupancy(int bm, int bn) { return (bm == 128 && bn == 128) ? 2 : 3; }   // = __launch_bounds__
 // Largest tile that still yields ~6 workgroups per CU (the tail split evens out the remainder).  Short reductions
@@ -1588,10 +1600,7 @@ static int persist_occupancy(int bm, int bn) { return (bm == 128 && bn == 128) ?
 // 128x128 85 TF).
 static TileChoice choose_tile(int64_t M, int Ng, int Ktot) {
     const int cands[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
-    static const int base_want = [] {   // tuning knob (A/B runs): workgroups a launch should at least have
-        const char* e = getenv("UP_TILE_WANT");
-        return e && atoi(e) > 0 ? atoi(e) : 1500;   // A/B in the network: 700 / 1000 / 1500 / 2200 / 4300 -> 70.1 / 69.9 / 69.6 / 69.9 / 69.8 ms
-    }();
+    const int base_want = g_tile_want;   // tuning knob (A/B runs): workgroups a launch should at least have
     if (g_persist && g_persist_tpw > 0) {   // stream-K balances any tile count: the largest tile that still gives every
         const int tpw = g_persist_tpw;      // workgroup its share
         for (auto& c : cands) {
@@ -1602,7 +1611,7 @@ static TileChoice choose_tile(int64_t M, int Ng, int Ktot) {
         }
         return {64, 64};
     }
-    const int64_t want = Ktot < 512 ? 2 * base_want : base_want;
+    const int64_t want = Ktot < g_short_k ? (int64_t)g_short_k_mult * base_want / 2 : base_want;
     for (auto& c : cands) {
         if (Ng <= 64 && c[1] == 128) continue;
         int64_t wgs = (int64_t)cdiv(M, c[0]) * cdiv(Ng, c[1]);
@@ -1669,13 +1678,7 @@ static SplitScratch* split_scratch(hipStream_t st) {
     }
     return &s;
 }
-static bool tail_split_enabled() {
-    static const bool on = [] {
-        const char* e = getenv("UP_TAIL_SPLIT");
-        return !(e && e[0] == '0');
-    }();
-    return on;
-}
+static bool tail_split_enabled() { return g_tail_split != 0; }
 
 // parts each tail tile is split into (1 = no split) for a launch of `tiles` tiles reducing over Ktot
 static int split_parts(int tiles, int Ktot) {
@@ -1705,11 +1708,7 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     // single-buffer loop down to K = 256 (probe), but in the network the rule K >= 1024 is 0.5 % faster per step (A/B in
     // one session, 70.55 vs 70.95 ms): the 73 KB footprint leaves less room for the weight-gradient workgroups of
     // the other stream.  UP_DB_MIN_K overrides the threshold.
-    static const int db_min_k = [] {
-        const char* e = getenv("UP_DB_MIN_K");
-        return e && atoi(e) > 0 ? atoi(e) : 1024;
-    }();
-    const bool db = a.Ktot >= db_min_k;
+    const bool db = a.Ktot >= g_db_min_k;
     // wide tiles additionally pin the refill between the MFMAs (branch-free body + sched_group_barrier): +2..4 %
     // on 128-wide tiles, -3 % on 64x64 (probe, warm)
     constexpr int DB_VARIANT = (BM == 128 || BN == 128) ? 128 : 0;   // 64x64: non-pinned loop with two staging sets
@@ -1745,11 +1744,7 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
             a.flags = sc->flags;
             a.full_blocks = a.nwg;
             a.parts = 1;
-            static const int no_skip_p = [] {
-                const char* e = getenv("UP_TAP_SKIP");
-                return e && e[0] == '0' ? 1 : 0;
-            }();
-            a.no_tap_skip = no_skip_p;
+            a.no_tap_skip = g_tap_skip ? 0 : 1;
             void (*pk)(IgemmArgs);
             if (fast && db)
                 pk = igemm_kernel<BM, BN, 2, DB_VARIANT, 32, true>;
@@ -1765,11 +1760,7 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     }
     a.full_blocks = a.nwg;
     a.parts = 1;
-    static const int no_skip = [] {
-        const char* e = getenv("UP_TAP_SKIP");
-        return e && e[0] == '0' ? 1 : 0;
-    }();
-    a.no_tap_skip = no_skip;
+    a.no_tap_skip = g_tap_skip ? 0 : 1;
     int grid = a.nwg;
     const int p = aligned ? split_parts(a.nwg, a.Ktot) : 1;
     if (p >= 2) {
@@ -1823,6 +1814,13 @@ extern "C" int up_conv_tune(const char* key, int value) {
     UP_REQUIRE(key, UP_ERR_INVALID, "conv_tune: null key");
     if (!strcmp(key, "persist_tpw")) g_persist_tpw = value < 0 ? 0 : value;
     else if (!strcmp(key, "persist_xcd")) g_persist_xcd = value ? 1 : 0;
+    else if (!strcmp(key, "tile_want") && value > 0) g_tile_want = value;
+    else if (!strcmp(key, "db_min_k") && value > 0) g_db_min_k = value;
+    else if (!strcmp(key, "short_k") && value > 0) g_short_k = value;
+    else if (!strcmp(key, "short_k_mult") && value > 0) g_short_k_mult = value;
+    else if (!strcmp(key, "tail_split")) g_tail_split = value ? 1 : 0;
+    else if (!strcmp(key, "tap_skip")) g_tap_skip = value ? 1 : 0;
+    else if (!strcmp(key, "wgrad_per_cu") && value > 0) g_wgrad_per_cu = value;
     else UP_REQUIRE(false, UP_ERR_INVALID, "conv_tune: unknown key '%s'", key);
     return UP_OK;
 }
@@ -2114,10 +2112,6 @@ static void* g_wgrad_dbg = nullptr;
 static int g_wgrad_grid = 0;
 static bool g_wgrad_single = false;
 #endif
-static int g_wgrad_per_cu = [] {   // workgroups per CU a weight-gradient launch aims for (probe / A-B knob)
-    const char* e = getenv("UP_WGRAD_PER_CU");
-    return e && atoi(e) > 0 ? atoi(e) : 2;
-}();
 struct WgradPlan {
     int bm, bn, ntm, ntn, splits, rows_per_split;
 };
