@@ -236,6 +236,17 @@ int up_pck_accuracy(const float* pred_xy, const float* target_xy, int B, int J, 
                     double thr_pck, double thr_pckh, double* acc, double* pck, double* pckh, double* visible,
                     int32_t* cnt, void* stream);
 
+/* ---- multi-person decode of the optional box head (utils/uniPose.py:14-200 uniPose_kpts) ----
+ * up_peak_mask: mask[e] = 1 where maps[e] > 0 and >= each in-bounds neighbour of its 3x3 neighbourhood — the peaks the
+ * reference extracts with scipy's maximum_filter / binary_erosion on the centre and the four corner maps; maps is
+ * (nmaps,H,W) fp32, mask (nmaps,H,W) bytes.
+ * up_box_argmax: maps (C,H,W) of ONE sample; boxes (P,4) int32 = row0,row1,col0,col1 (half-open, non-empty, inside the
+ * map: the caller checks, as numpy would raise); for every person and channel ch0..ch0+nch-1 the position of the first
+ * maximum inside the box, relative to the box, row-major: out_hw (P,nch,2) int32 = (row, col). */
+int up_peak_mask(const float* maps, int nmaps, int H, int W, uint8_t* mask, void* stream);
+int up_box_argmax(const float* maps, int C, int H, int W, const int32_t* boxes, int P, int ch0, int nch,
+                  int32_t* out_hw, void* stream);
+
 /* ---- measurement hooks (bench.py roofline leg; no reference counterpart) ----
  * Between begin/end every MFMA convolution launch is bracketed by two hipEvents on its stream;
  * end() returns per kernel variant {launches, total ms, total algorithmic FLOP}. */

@@ -351,6 +351,45 @@ def accuracy(output: np.ndarray, target: np.ndarray, thr_pck: float, thr_pckh: f
     return out[0], out[1], out[2], cnt, pred, visible
 
 
+# first box channel (centre; then top-left, bottom-left, top-right, bottom-right) per dataset (utils/uniPose.py:20-49)
+BOX_CHANNEL0 = {"LSP": 15, "MPII": 17, "PoseTrack": 18, "NTID": 20, "NTID_small": 20}
+
+
+def local_peaks(m: np.ndarray):
+    """utils/uniPose.py:52-70 for one map: negatives -> 0, `maximum_filter(3x3) == map` XOR the eroded zero background.
+    scipy reflects the border for the maximum and counts it as background for the erosion, so both reduce to the
+    in-bounds neighbours: a pixel is kept iff it is > 0 and >= each in-bounds neighbour.  Returns [[row, col], ...] in
+    row-major order like the reference's double loop."""
+    c = np.where(m < 0, 0, m).astype(m.dtype)
+    h, w = c.shape
+    pad = np.full((h + 2, w + 2), -np.inf, dtype=c.dtype)
+    pad[1:-1, 1:-1] = c
+    nb = np.max(np.stack([pad[1 + dy:1 + dy + h, 1 + dx:1 + dx + w] for dy in (-1, 0, 1) for dx in (-1, 0, 1)]), axis=0)
+    keep = (c > 0) & (c == nb)
+    return [[int(i), int(j)] for i, j in np.argwhere(keep)]
+
+
+def unipose_kpts_multi(maps: np.ndarray, dataset: str):
+    """utils/uniPose.py:14-200 `uniPose_kpts`: maps (1, C, H, W) with the box head's five extra channels.  For every
+    centre peak idx: the 14 joint channels 1..14 (hard-wired `box[1:15]`, :161) are arg-maxed inside the box spanned by the
+    idx-th top-left and bottom-right peaks; returns [[idx, x, y], ...] (14 joints, centre, four corners per person).
+    Raises like the reference: IndexError when a corner list is shorter than the centre list, ValueError for an empty box."""
+    if dataset not in BOX_CHANNEL0:
+        raise ValueError(f"no box channels defined for dataset {dataset!r}")
+    mapping = np.asarray(maps)[0]
+    f = BOX_CHANNEL0[dataset]
+    center, tl, bl, tr, br = (local_peaks(mapping[f + i]) for i in range(5))
+    kpts = []
+    for idx in range(len(center)):
+        box = mapping[:, tl[idx][0]:br[idx][0], tl[idx][1]:br[idx][1]]
+        for m in box[1:15]:
+            h, w = np.unravel_index(m.argmax(), m.shape)
+            kpts.append([idx, int(w + tl[idx][1]), int(h + tl[idx][0])])
+        for lst in (center, tl, bl, tr, br):
+            kpts.append([idx, lst[idx][1], lst[idx][0]])
+    return kpts
+
+
 def get_kpts(maps: np.ndarray, img_h: float = 368.0, img_w: float = 368.0):
     """utils/utils.py:94-106: per joint (channel 0 skipped), [x, y] ints in image pixels."""
     out = []

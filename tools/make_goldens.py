@@ -241,6 +241,76 @@ def g8_targets():
     save("g8_targets.npz", **out)
 
 
+def g9_multi_person():
+    """G9: multi-person decode.  `uniPose_kpts` is extracted from utils/uniPose.py with `ast` (the module imports skimage
+    and cv2, which are absent) and executed with the scipy it needs; inputs are synthetic (1, C, 46, 46) maps: Gaussian
+    blobs for people (centre + four corners + joints inside the box), plateaus, negatives, and cases where the
+    reference raises (a corner peak missing -> IndexError, an empty box -> ValueError)."""
+    import ast
+    import warnings
+    src = open(os.path.join(REF, "utils", "uniPose.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "uniPose_kpts"][0]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from scipy.ndimage import binary_erosion, generate_binary_structure, maximum_filter
+    ns = {"np": np, "torch": torch, "maximum_filter": maximum_filter, "binary_erosion": binary_erosion,
+          "generate_binary_structure": generate_binary_structure}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "reference:utils/uniPose.py", "exec"), ns)
+    ref = ns["uniPose_kpts"]
+    rng = np.random.default_rng(9)
+    first = {"LSP": 15, "MPII": 17, "PoseTrack": 18, "NTID": 20}
+
+    def blob(m, y, x, amp=1.0, sigma=1.5):
+        ys, xs = np.mgrid[0:m.shape[0], 0:m.shape[1]]
+        m += amp * np.exp(-((ys - y) ** 2 + (xs - x) ** 2) / 2.0 / sigma / sigma).astype(np.float32)
+
+    def scene(dataset, people, noise=0.0, H=46, W=46):
+        c = first[dataset] + 5
+        maps = (rng.standard_normal((1, c, H, W)).astype(np.float32) * noise - 6.0 * noise).astype(np.float32)   # noise stays negative: clamped away
+        f = first[dataset]
+        for (y0, x0, y1, x1) in people:
+            blob(maps[0, f], (y0 + y1) // 2, (x0 + x1) // 2)       # integer centre: a half-pixel one gives two equal peaks
+            blob(maps[0, f + 1], y0, x0)
+            blob(maps[0, f + 2], y1, x0)
+            blob(maps[0, f + 3], y0, x1)
+            blob(maps[0, f + 4], y1, x1)
+            for j in range(1, f):
+                blob(maps[0, j], rng.uniform(y0, y1), rng.uniform(x0, x1), amp=rng.uniform(0.5, 1.0))
+        return maps
+
+    cases = {}
+    cases["lsp_one"] = ("LSP", scene("LSP", [(5, 6, 30, 28)]))
+    cases["lsp_two"] = ("LSP", scene("LSP", [(3, 4, 20, 18), (24, 22, 43, 41)]))
+    cases["mpii_two_noise"] = ("MPII", scene("MPII", [(2, 2, 18, 20), (22, 25, 44, 44)], noise=0.01))
+    cases["mpii_noise_peaks_raises"] = ("MPII", scene("MPII", [(2, 2, 18, 20)]) + rng.standard_normal((1, 22, 46, 46)).astype(np.float32) * 0.01)
+    cases["posetrack_three"] = ("PoseTrack", scene("PoseTrack", [(1, 1, 12, 12), (15, 16, 28, 30), (31, 30, 44, 45)]))
+    cases["ntid_one_rect"] = ("NTID", scene("NTID", [(4, 3, 25, 40)], H=32, W=48))
+    m = scene("LSP", [(6, 6, 30, 30)])
+    m[0, 15, 17:19, 17:19] = m[0, 15].max() + 1.0        # a 2x2 plateau: four centre peaks, one set of corners
+    cases["lsp_plateau_raises"] = ("LSP", m)
+    m = scene("LSP", [(5, 6, 30, 28)])
+    m[0, 19] = -1.0                                      # no bottom-right peak at all
+    cases["lsp_missing_corner_raises"] = ("LSP", m)
+    m = scene("LSP", [(5, 6, 30, 28)])
+    m[0, 16], m[0, 19] = m[0, 19].copy(), m[0, 16].copy()   # top-left below bottom-right: empty box
+    cases["lsp_empty_box_raises"] = ("LSP", m)
+    m = np.full((1, 20, 46, 46), -0.5, dtype=np.float32)    # nothing anywhere: no people, empty list
+    cases["lsp_nothing"] = ("LSP", m)
+    out = {}
+    for name, (ds, maps) in cases.items():
+        out[name + "_maps"] = maps
+        out[name + "_dataset"] = np.array(ds)
+        try:
+            k = ref(torch.from_numpy(maps.copy()), ds)
+            out[name + "_kpts"] = np.asarray(k, dtype=np.int64).reshape(-1, 3)
+            out[name + "_error"] = np.array("")
+        except (IndexError, ValueError) as e:
+            out[name + "_kpts"] = np.zeros((0, 3), dtype=np.int64)
+            out[name + "_error"] = np.array(type(e).__name__)
+        print("g9", name, ds, out[name + "_kpts"].shape, str(out[name + "_error"]))
+    save("g9_multi_person.npz", **out)
+
+
 def g0_keys():
     """G0: the reference's state_dict contract (names, shapes, dtypes, order) for both models."""
     import json
@@ -254,8 +324,8 @@ def g0_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9"]
     fns = dict(g0=g0_keys, g1=g1_eval_full, g2=g2_taps, g4=g4_train, g5=g5_lstm, g6=g6_argmax, g7=g7_accuracy,
-               g8=g8_targets)
+               g8=g8_targets, g9=g9_multi_person)
     for w in which:
         fns[w]()

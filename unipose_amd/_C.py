@@ -79,6 +79,8 @@ SIGNATURES = {
     "up_make_gaussian_maps": (_i, [_p, _i, _i, _i, C.c_double, _p, _p]),
     "up_normalize_image": (_i, [_p, _i, _i, _i, _i, _f, _f, _p, _p]),
     "up_pck_accuracy": (_i, [_p, _p, _i, _i, _i, _i, _i, C.c_double, C.c_double, _p, _p, _p, _p, _p, _p]),
+    "up_peak_mask": (_i, [_p, _i, _i, _i, _p, _p]),
+    "up_box_argmax": (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _p, _p]),
     "up_profile_variants": (_i, []),
     "up_profile_variant_name": (C.c_char_p, [_i]),
     "up_profile_begin": (_i, []),

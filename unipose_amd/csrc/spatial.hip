@@ -367,6 +367,62 @@ __global__ void __launch_bounds__(256) argmax_kernel(const float* hm, int maps, 
     }
 }
 
+// ---- multi-person decode (the step after the path for the box head; utils/uniPose.py:14-200) -----------------------
+// Peaks of a map as the reference finds them: negatives clamped to 0, then `maximum_filter(3x3) == map` XOR the eroded
+// zero background (scipy, borders reflected / counted as background) — which is exactly: value > 0 and >= each of its
+// in-bounds 8 neighbours (plateaus mark every member).
+__global__ void __launch_bounds__(256) peak_mask_kernel(const float* maps, long long total, int H, int W, uint8_t* mask) {
+    long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int w = (int)(e % W);
+    const int h = (int)((e / W) % H);
+    const float v = maps[e];
+    bool peak = v > 0.f;
+    for (int dh = -1; dh <= 1; ++dh)
+        for (int dw = -1; dw <= 1; ++dw) {
+            const int hh = h + dh, ww = w + dw;
+            if (hh < 0 || ww < 0 || hh >= H || ww >= W) continue;
+            peak = peak && v >= maps[e + (long long)dh * W + dw];
+        }
+    mask[e] = peak ? 1 : 0;
+}
+// argmax of channels ch0 .. ch0+nch-1 inside one box per person: one wavefront per (person, channel); position
+// relative to the box, first maximum in the row-major order of the BOX (np.argmax of the sliced array)
+__global__ void __launch_bounds__(256) box_argmax_kernel(const float* maps, int H, int W, const int32_t* boxes, int P,
+                                                         int ch0, int nch, int32_t* out_hw) {
+    const int job = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (job >= P * nch) return;
+    const int p = job / nch, c = job - p * nch;
+    const int r0 = boxes[p * 4], r1 = boxes[p * 4 + 1], c0 = boxes[p * 4 + 2], c1 = boxes[p * 4 + 3];
+    const int bw = c1 - c0, n = (r1 - r0) * bw;
+    const float* m = maps + (size_t)(ch0 + c) * H * W;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = lane; i < n; i += 64) {
+        const int rr = i / bw, cc = i - rr * bw;
+        const float v = m[(size_t)(r0 + rr) * W + c0 + cc];
+        if (am_better(v, i, bv, bi)) {
+            bv = v;
+            bi = i;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        float ov = __shfl_down(bv, off);
+        int oi = __shfl_down(bi, off);
+        if (am_better(ov, oi, bv, bi)) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    if (lane == 0) {
+        if (bi == 0x7fffffff) bi = 0;   // a box of -inf only: np.argmax returns 0
+        out_hw[job * 2] = bi / bw;
+        out_hw[job * 2 + 1] = bi - (bi / bw) * bw;
+    }
+}
+
 // ---- training targets (the step before the path: lsp_lspet_data.py:224-245, mpii_data.py:165-187) ----------------
 // Gaussian joint maps exactly as the loaders build them: float64 exp(-D2 / 2.0 / sigma / sigma) on the integer pixel
 // grid (utils/utils.py:200-203), clipped to <= 1, values < 0.0099 set to 0, then stored as float32; channel 0 is
@@ -701,6 +757,22 @@ extern "C" int up_normalize_image(const float* img_hwc, int B, int H, int W, int
     hipLaunchKernelGGL(normalize_image_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), img_hwc, C,
                        H * W, mean, stdv, out_chw, total);
     return check_launch("normalize_image");
+}
+
+extern "C" int up_peak_mask(const float* maps, int nmaps, int H, int W, uint8_t* mask, void* stream) {
+    UP_REQUIRE(maps && mask && nmaps > 0 && H > 0 && W > 0, UP_ERR_INVALID, "peak_mask: bad argument");
+    long long total = (long long)nmaps * H * W;
+    hipLaunchKernelGGL(peak_mask_kernel, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), maps, total, H, W, mask);
+    return check_launch("peak_mask");
+}
+extern "C" int up_box_argmax(const float* maps, int C, int H, int W, const int32_t* boxes, int P, int ch0, int nch,
+                             int32_t* out_hw, void* stream) {
+    UP_REQUIRE(maps && boxes && out_hw && C > 0 && H > 0 && W > 0 && P > 0, UP_ERR_INVALID, "box_argmax: bad argument");
+    UP_REQUIRE(ch0 >= 0 && nch > 0 && ch0 + nch <= C, UP_ERR_INVALID, "box_argmax: channels %d..%d of %d", ch0,
+               ch0 + nch - 1, C);
+    hipLaunchKernelGGL(box_argmax_kernel, dim3(cdiv((long long)P * nch, 4)), dim3(256), 0, as_stream(stream), maps, H, W,
+                       boxes, P, ch0, nch, out_hw);
+    return check_launch("box_argmax");
 }
 
 extern "C" int up_pck_accuracy(const float* pred_xy, const float* target_xy, int B, int J, int H, int W, int dataset,

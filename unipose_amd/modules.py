@@ -190,9 +190,11 @@ def build_wasp(backbone, output_stride, BatchNorm, video=False):
 
 
 class Decoder(nn.Module):
-    """decoder.py:6-64 (conv2/bn2 are defined-but-unused there too: kept for state_dict parity)."""
+    """decoder.py:6-64 (conv2/bn2 are defined-but-unused there too: kept for state_dict parity).  `bbox=True` builds the
+    output layer the reference keeps commented out next to the active one (decoder.py:31): five more channels (person
+    centre and the four box corners) for the multi-person decode of utils/uniPose.py."""
 
-    def __init__(self, dataset, num_classes, backbone, BatchNorm):
+    def __init__(self, dataset, num_classes, backbone, BatchNorm, bbox=False):
         super().__init__()
         if backbone != "resnet":
             raise NotImplementedError
@@ -205,7 +207,7 @@ class Decoder(nn.Module):
                                        nn.ReLU(), nn.Dropout(0.5),
                                        nn.Conv2d(256, 256, 3, stride=1, padding=1, bias=False), BatchNorm(256),
                                        nn.ReLU(), nn.Dropout(0.1),
-                                       nn.Conv2d(256, num_classes + 1, 1, stride=1))
+                                       nn.Conv2d(256, num_classes + (6 if bbox else 1), 1, stride=1))
         self.maxpool = nn.MaxPool2d(3, 2, 1)
         _kaiming_all(self)
 
@@ -220,8 +222,8 @@ class Decoder(nn.Module):
         return ops.conv_bias_act(y, lc[8])
 
 
-def build_decoder(dataset, num_classes, backbone, BatchNorm):
-    return Decoder(dataset, num_classes, backbone, BatchNorm)
+def build_decoder(dataset, num_classes, backbone, BatchNorm, bbox=False):
+    return Decoder(dataset, num_classes, backbone, BatchNorm, bbox)
 
 
 class LSTM_0(nn.Module):

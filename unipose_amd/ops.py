@@ -943,6 +943,51 @@ def accuracy(output: torch.Tensor, target: torch.Tensor, thr_PCK: float, thr_PCK
     return r[0], r[1], r[2], int(cnt.item()), pred.cpu().numpy(), r[3]
 
 
+BOX_CHANNEL0 = {"LSP": 15, "MPII": 17, "PoseTrack": 18, "NTID": 20, "NTID_small": 20}   # utils/uniPose.py:20-49
+
+
+def uniPose_kpts(maps: torch.Tensor, dataset: str, img_h: float = 368.0, img_w: float = 368.0):
+    """utils/uniPose.py:14-200 (multi-person decode of the optional box head) with the maps left on the device: one
+    kernel marks the peaks of the centre and the four corner maps, a second one arg-maxes the 14 joint channels inside
+    every person's box; only the peak coordinates and the (P,14,2) results cross to the host.  Returns the reference's
+    list [[idx, x, y], ...]; `img_h`/`img_w` are accepted and unused like there.  Error behaviour follows numpy's in
+    the reference: IndexError when a corner map has fewer peaks than the centre map, ValueError for an empty box."""
+    if dataset not in BOX_CHANNEL0:
+        raise ValueError(f"no box channels defined for dataset {dataset!r}")
+    _dev_ok(maps)
+    m = _dense(maps.detach()[0].float())
+    c, h, w = m.shape
+    f = BOX_CHANNEL0[dataset]
+    if c < f + 5:
+        raise IndexError(f"index {f + 4} is out of bounds for axis 0 with size {c}")
+    mask = torch.empty((5, h, w), dtype=torch.uint8, device=m.device)
+    _C.check(_C.lib().up_peak_mask(m[f:f + 5].data_ptr(), 5, h, w, mask.data_ptr(), _stream(m)), "peak_mask")
+    nz = torch.nonzero(mask).cpu().tolist()                       # (channel, row, col), lexicographic = row-major per map
+    center, tl, bl, tr, br = ([[i, j] for ch, i, j in nz if ch == k] for k in range(5))
+    if not center:
+        return []
+    boxes = []
+    for idx in range(len(center)):
+        r0, c0 = tl[idx]                                          # IndexError like the reference's list indexing
+        r1, c1 = br[idx]
+        if r1 <= r0 or c1 <= c0:
+            raise ValueError("attempt to get argmax of an empty sequence")
+        boxes.append([r0, r1, c0, c1])
+        _ = bl[idx], tr[idx]
+    bx = torch.tensor(boxes, dtype=torch.int32).to(m.device)
+    out = torch.empty((len(boxes), 14, 2), dtype=torch.int32, device=m.device)
+    _C.check(_C.lib().up_box_argmax(m.data_ptr(), c, h, w, bx.data_ptr(), len(boxes), 1, 14, out.data_ptr(), _stream(m)),
+             "box_argmax")
+    rel = out.cpu().tolist()
+    kpts = []
+    for idx, (r0, _, c0, _) in enumerate(boxes):
+        for hh, ww in rel[idx]:
+            kpts.append([idx, int(ww + c0), int(hh + r0)])
+        for lst in (center, tl, bl, tr, br):
+            kpts.append([idx, lst[idx][1], lst[idx][0]])
+    return kpts
+
+
 def get_kpts(maps: torch.Tensor, img_h: float = 368.0, img_w: float = 368.0):
     """utils/utils.py:94-106 on top of the device argmax: [[x, y], ...] for joints 1.. of sample 0."""
     _, _, idx = heatmap_argmax(maps[:1])

@@ -11,15 +11,19 @@ from .modules import build_backbone, build_decoder, build_wasp
 
 class unipose(nn.Module):
     def __init__(self, dataset, backbone="resnet", output_stride=16, num_classes=21, sync_bn=True, freeze_bn=False,
-                 stride=8):
+                 stride=8, bbox=False):
+        """`bbox=True` (not a reference argument; default off) enables the variant the reference keeps as comments
+        (model/unipose.py:34-35, decoder.py:31): num_classes+5+1 output channels, forward returns
+        ``(x[:, :num_classes+1], x[:, num_classes+1:])`` = key-point maps and the five box maps."""
         super().__init__()
         self.stride = stride
         self.num_classes = num_classes
+        self.bbox = bool(bbox)
         BatchNorm = nn.BatchNorm2d          # the reference ignores sync_bn the same way (model/unipose.py:14)
         self.pool_center = nn.AvgPool2d(kernel_size=9, stride=8, padding=1)   # unused, kept for parity (:18)
         self.backbone = build_backbone(backbone, output_stride, BatchNorm)
         self.wasp = build_wasp(backbone, output_stride, BatchNorm)
-        self.decoder = build_decoder(dataset, num_classes, backbone, BatchNorm)
+        self.decoder = build_decoder(dataset, num_classes, backbone, BatchNorm, self.bbox)
         if freeze_bn:
             self.freeze_bn()
 
@@ -31,6 +35,9 @@ class unipose(nn.Module):
             x = self.decoder(x, low)
             if self.stride != 8:            # optional 8x bilinear up-sampling to the input size (:31-32)
                 x = ops.Bilinear.apply(x, input.shape[2], input.shape[3])
+            if self.bbox:                   # model/unipose.py:34-35
+                y = ops.ToNCHW.apply(x, self.num_classes + 6)
+                return y[:, 0:self.num_classes + 1, :, :], y[:, self.num_classes + 1:, :, :]
             return ops.ToNCHW.apply(x, self.num_classes + 1)
 
     # The reference versions reference an undefined SynchronizedBatchNorm2d (model/unipose.py:42,51,61)
