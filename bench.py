@@ -70,6 +70,48 @@ def cpu_baseline(num_classes, size, batch, steps, threads):
                       f"torch {torch.__version__} CPU, after 1 warm-up step"}
 
 
+def wasp_dilated_leg(dev, batch=32, hw=23, iters=20):
+    """The quantity BASELINE.json's north_star names for the WASP branch: the three dilated 3x3 256->256 convolutions
+    (wasp.py:46-49, dilation 6 / 12 / 18 at 23x23) timed alone with HIP events on the launch stream.  Reported per
+    dilation: nominal and effective (taps that touch the image) TFLOP/s against the fp32 MFMA peak, and the
+    algorithmic bytes (input once + output once + weights once, SURVEY 8d: 37.0 MB at B=32) per second against the
+    8 TB/s HBM peak.  These kernels are compute-bound in fp32 (AI ~540 FLOP/B): the HBM fraction is stated because the
+    north star asks for it, the MFMA fraction is the meaningful one."""
+    from unipose_amd import _C, ops
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn(batch, hw, hw, 256, generator=g).to(dev)
+    w = (torch.randn(256, 256, 3, 3, generator=g) * 0.02).to(dev)
+    rows = []
+    for dil in (6, 12, 18):
+        cfg = ops.ConvCfg(1, dil, dil)
+        y, _, _ = ops.conv_fwd_raw(x, w, cfg)
+        for _ in range(3):
+            ops.conv_fwd_raw(x, w, cfg, out=y)
+        torch.cuda.synchronize(dev)
+        # per-launch HIP events inside the library (the same instrument as the main roofline figure): the kernel's own
+        # duration, free of the Python time between launches
+        lib = _C.lib()
+        nv = lib.up_profile_variants()
+        arr = (ctypes.c_double * (nv * 3))()
+        lib.up_profile_begin()
+        for _ in range(iters):
+            ops.conv_fwd_raw(x, w, cfg, out=y)
+        torch.cuda.synchronize(dev)
+        _C.check(lib.up_profile_end(arr, nv), "profile_end")
+        launches = sum(arr[i * 3] for i in range(nv))
+        ms = sum(arr[i * 3 + 1] for i in range(nv)) / max(launches, 1.0)
+        live = sum(1 for p in range(hw) for r in (-1, 0, 1) if 0 <= p + r * dil < hw) ** 2 / float(hw * hw * 9)
+        flop = 2.0 * batch * hw * hw * 256 * 256 * 9
+        nbytes = 4.0 * (x.numel() + batch * hw * hw * 256 + w.numel())
+        rows.append({"dilation": dil, "ms": round(ms, 4), "live_tap_fraction": round(live, 3),
+                     "nominal_tflops": round(flop / ms / 1e9, 1),
+                     "effective_tflops": round(flop * live / ms / 1e9, 1),
+                     "effective_mfma_frac": round(flop * live / ms / 1e9 / F32_MFMA_PEAK_TFLOPS, 3),
+                     "algorithmic_gbps": round(nbytes / ms / 1e6, 1),
+                     "hbm_frac": round(nbytes / ms / 1e6 / 8000.0, 4)})
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,6 +132,7 @@ def main():
     ap.add_argument("--force-dp", action="store_true",
                     help="run the gradient exchange (RCCL all-reduce, buckets, hooks) even with one rank")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the extra split-bf16 timing loop")
+    ap.add_argument("--wasp-only", action="store_true", help="only the WASP dilated-convolution roofline leg")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=min(os.cpu_count() or 1, 64),
@@ -118,6 +161,9 @@ def main():
     from model.unipose import unipose
     from unipose_amd import _C, ops
     from unipose_amd.dist import GradAllReducer, shard_seed
+    if args.wasp_only:
+        print(json.dumps({"wasp_dilated": wasp_dilated_leg(dev)}), flush=True)
+        return
 
     K, B, S = args.num_classes, args.batch, args.size
     lstm = args.model == "lstm"
@@ -258,6 +304,12 @@ def main():
                     "all_mfma_kernels": {"achieved": round(x_fl / x_ms, 2),
                                          "frac": round(x_fl / x_ms / F32_MFMA_PEAK_TFLOPS, 4),
                                          "ms_per_step": round(x_ms / nx, 3)}}
+
+    if roofline is not None and args.math == "f32":
+        try:
+            roofline["wasp_dilated"] = wasp_dilated_leg(dev)
+        except Exception as e:      # a reporting extra must never cost the bench line
+            log(f"wasp leg skipped: {e}")
 
     # second arithmetic on the same workload (reported as `alt_math`, never as `value`): the split-bf16
     # fp32-equivalent convolution kernels (parity 1.6e-5 on the reference golden, argmax bit-exact)
