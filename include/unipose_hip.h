@@ -105,10 +105,15 @@ int up_conv_get_persistent(void);
  * "tile_want" (UP_TILE_WANT) workgroups a launch should at least have when the tile size is chosen ("short_k" /
  * "short_k_mult": reductions shorter than short_k want short_k_mult / 2 times as many), "db_min_k"
  * (UP_DB_MIN_K) shortest reduction that uses the double-buffered K loop, "tail_split" (UP_TAIL_SPLIT), "tap_skip"
- * (UP_TAP_SKIP), "wgrad_per_cu" (UP_WGRAD_PER_CU); persistent form: "persist_tpw" = tiles x100 a workgroup should own
+ * (UP_TAP_SKIP), "tap_sort" (UP_TAP_SORT: GEMM rows ordered by their set of live filter taps so that the tile-level tap
+ * skipping becomes near exact; default off until measured), "wgrad_per_cu" (UP_WGRAD_PER_CU); persistent form: "persist_tpw" = tiles x100 a workgroup should own
  * when the tile size is chosen (0 = the default form's tile rule), "persist_xcd" = XCD-aware workgroup numbering.
  * Change them only between steps: workspace sizes and the BatchNorm partial-row count follow the tile choice. */
 int up_conv_tune(const char* key, int value);
+/* Analysis (host only, no launch): share of (row tile, filter tap) pairs the K loop of the forward (data_gradient = 0) or
+ * data-gradient launch of `d` visits with its rows in image order and in tap-sorted order ("tap_sort" knob), and the share
+ * of (pixel, tap) pairs that touch the image at all (`live`: what a perfect skip would visit).  Aligned fast path only. */
+int up_conv_tap_visits(const up_conv_desc* d, int data_gradient, double* image_order, double* tap_sorted, double* live);
 
 /* Data gradient: dx[N,H,W,ldx(:Cp)] from dy[N,P,Q,ldy(:K)] (replaces convolution_backward, input half).
  * Writes all Cp channels of every input pixel (pad channels get 0).  `add` (optional, [N,H,W,ld_add]) is a second

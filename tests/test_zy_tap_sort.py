@@ -1,0 +1,88 @@
+"""Tap-sorted row order of the forward / data-gradient kernel (knob "tap_sort", default off): GEMM rows ordered by their
+set of live filter taps so that the tile-level tap skipping becomes near exact on dilated and padded convolutions.
+Parity with the knob on, and the host-side prediction of the visited (tile, tap) pairs (`up_conv_tap_visits`)."""
+import ctypes
+
+import pytest
+import torch
+
+import model_cases as mc
+import op_cases as oc
+
+CASES = [
+    # n, c,  h,  w,  k, r, stride, pad, dil, bias, relu
+    (1, 32, 9, 8, 16, 3, 1, 1, 1, False, False),      # plain padded 3x3: border classes
+    (1, 128, 5, 5, 32, 3, 1, 1, 1, False, False),     # double-buffered loop
+    (2, 96, 6, 6, 72, 3, 1, 1, 1, False, False),      # K-split tail tiles on top of the permutation
+    (1, 32, 5, 5, 16, 3, 1, 6, 6, False, False),      # dilation > H: a single class (no permutation is built)
+    (2, 64, 9, 9, 32, 3, 1, 6, 6, True, True),        # dilation 6 on 9x9: nine classes, bias + ReLU
+    (3, 32, 23, 23, 32, 3, 1, 18, 18, False, True),   # the WASP geometry: several tiles per class, three images
+    (2, 32, 12, 10, 32, 3, 1, 2, 2, True, False),     # rectangular map
+    (2, 32, 11, 11, 32, 5, 1, 2, 1, False, False),    # 5x5 (25 taps > 16: no tap map, rows still permuted? no: image order)
+    (2, 16, 9, 9, 24, 3, 1, 1, 1, False, False),      # 16 channels: generic path, knob has no effect
+]
+
+
+@pytest.fixture
+def tap_sort():
+    from unipose_amd import _C
+    _C.check(_C.lib().up_conv_tune(b"tap_sort", 1), "conv_tune")
+    yield
+    _C.check(_C.lib().up_conv_tune(b"tap_sort", 0), "conv_tune")
+
+
+def _suite(dev, cases):
+    for n, c, h, w, k, r, s, p, d, bias, relu in cases:
+        oc.conv_case(dev, n, c, h, w, k, r, s, p, d, bias=bias, relu=relu)
+    oc.conv_bn_case(dev, 2, 32, 9, 9, 48, 3, 1, 2, 2, relu=True, residual=False, train=True)   # statistics of permuted tiles
+    oc.conv_bn_case(dev, 2, 128, 5, 5, 48, 3, 1, 1, 1, relu=True, residual=True, train=True)   # residual: image order
+    oc.dgrad_add_case(dev, 1, 128, 6, 6, 64, 3, 1, 1, 1)                                       # addend: image order
+
+
+def test_tap_sort_ops_emu(emu_backend, tap_sort):
+    _suite(emu_backend, CASES)
+
+
+def test_tap_sort_model_emu(emu_backend, tap_sort):
+    assert mc.eval_case(emu_backend, size=64) < 1e-4
+    mc.train_case(emu_backend, size=32)
+
+
+def _visits(n, h, w, c, k, r, dil, dgrad=0):
+    from unipose_amd import _C
+    pad = (r // 2) * dil
+    d = _C.ConvDesc(n, h, w, c, c, c, k, r, r, 1, pad, dil, h, w, k, k)
+    a, b, live = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+    _C.check(_C.lib().up_conv_tap_visits(ctypes.byref(d), dgrad, ctypes.byref(a), ctypes.byref(b), ctypes.byref(live)),
+             "conv_tap_visits")
+    return a.value, b.value, live.value
+
+
+def test_tap_visit_prediction(emu_backend):
+    """BASELINE configs[1] shapes: sorted rows visit (nearly) only live taps; image order keeps most dead ones."""
+    for dil, live_want in ((18, 0.229), (12, 0.425), (6, 0.682)):            # 23 %, 43 %, 68 %
+        for dgrad in (0, 1):
+            img, srt, live = _visits(32, 23, 23, 256, 256, 3, dil, dgrad)
+            assert abs(live - live_want) < 2e-3
+            assert live <= srt <= live + 0.01 and srt < img
+    img, srt, live = _visits(32, 23, 23, 256, 256, 3, 18)
+    assert img > 2.2 * srt                                                   # 0.54 -> 0.23 of the K loop
+    img, srt, live = _visits(32, 23, 23, 256, 256, 3, 1)                      # layer3 3x3: the border taps, 5.7 % of the MACs
+    assert img == 1.0 and abs(live - (21 * 21 * 9 + 84 * 6 + 4 * 4) / (529 * 9.0)) < 1e-9 and srt < 0.95
+    img, srt, live = _visits(32, 23, 23, 256, 256, 1, 1)                      # 1x1: one tap, nothing to skip
+    assert img == srt == live == 1.0
+
+
+@pytest.mark.gpu
+def test_tap_sort_ops_gpu(tap_sort):
+    dev = torch.device("cuda:0")
+    _suite(dev, [(4, 256, 23, 23, 256, 3, 1, 18, 18, False, False), (4, 256, 23, 23, 256, 3, 1, 6, 6, False, True),
+                 (4, 256, 23, 23, 256, 3, 1, 1, 1, False, False), (2, 512, 23, 23, 512, 3, 1, 8, 8, False, False),
+                 (2, 128, 46, 46, 128, 3, 1, 1, 1, True, True)])
+
+
+@pytest.mark.gpu
+def test_tap_sort_model_gpu(tap_sort):
+    dev = torch.device("cuda:0")
+    assert mc.eval_case(dev, size=368, B=1, K=16, tol=1e-4) < 1e-4           # 23x23 top maps: the real WASP geometry
+    mc.train_case(dev, size=96, B=4)

@@ -21,6 +21,7 @@
 // legal as long as A and B use the same one, and it turns 4 ds_read_b32 into one ds_read_b128.
 #include "up_common.h"
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -128,6 +129,9 @@ struct IgemmArgs {
     int p_R, p_snap;
     int p_share, p_rem;   // p_U = G * p_share + p_rem: 32-bit, division-free bounds on the device
     int p_xcd;            // workgroup index = xcd_remap(block index) (hardware only; the emulator keeps the identity)
+    // tap-sorted row order (igemm_kernel<..., PERM = true>, see TapSort): GEMM row m is output pixel perm[m]; pixels
+    // with the same set of live filter taps are contiguous, so the tile-level tap skipping drops (nearly) every dead tap
+    const int* perm;
     FastDiv fR;
 };
 
@@ -203,7 +207,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN, bool RES, bool CHECK, bool OMAP = false>
+template <int BM, int BN, bool RES, bool CHECK, bool OMAP = false, bool PMAP = false>
 __device__ __forceinline__ void igemm_store(const IgemmArgs& a, f32x16 (&acc)[BM / 64][BN / 64], int mrow0, int ncol0) {
     constexpr int TM = BM / 64, TN = BN / 64;
     const bool relu = a.relu != 0;
@@ -239,6 +243,7 @@ __device__ __forceinline__ void igemm_store(const IgemmArgs& a, f32x16 (&acc)[BM
                     const int wc = rem - hc * a.o_Wc;
                     pix = (size_t)(img * a.o_H + 2 * hc + a.o_ph) * a.o_W + 2 * wc + a.o_pw;
                 }
+                if (PMAP) pix = (size_t)a.perm[!CHECK || m < a.M ? m : a.M - 1];   // tap-sorted rows: scatter to the pixel
                 if (!CHECK || m < a.M) a.y[pix * a.ldy + n] = v;
             }
         }
@@ -251,7 +256,7 @@ __device__ __forceinline__ void igemm_store(const IgemmArgs& a, f32x16 (&acc)[BM
 // Shared epilogue of the fp32 and bf16-operand kernels.  C/D map of the 32x32 MFMA (dtype independent):
 // column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  `smem` must be free (all waves past their last
 // LDS read) and hold >= 2*(BN/64)*32*3 floats.
-template <int BM, int BN>
+template <int BM, int BN, bool PERM = false>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[BM / 64][BN / 64], float* smem,
                                                int mt, int m0, int n0, int wm, int wn, int l31, int lh) {
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -331,6 +336,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
     // (its wait-count state is merged conservatively across the predicated blocks), i.e. each of a thread's 64
     // stores waited for the previous one to be acknowledged (measured: 23 us of a 103 us workgroup lifetime).
     const bool full = m0 + BM <= a.M;   // uniform: only the last row tile is ragged
+    if constexpr (PERM) {   // (launched without residual / output row map)
+        if (full) igemm_store<BM, BN, false, false, false, true>(a, acc, mrow0, ncol0);
+        else igemm_store<BM, BN, false, true, false, true>(a, acc, mrow0, ncol0);
+        return;
+    }
     if (a.residual) {
         if (full) igemm_store<BM, BN, true, false>(a, acc, mrow0, ncol0);
         else igemm_store<BM, BN, true, true>(a, acc, mrow0, ncol0);
@@ -353,8 +363,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
 //         END of its walk, while the workgroups holding the earlier slices (lower block index) handle theirs FIRST and
 //         publish raw accumulators, so the owner normally finds them ready.  Writers always have a lower block index
 //         than their reader and publish before they ever wait: no dependence on co-residency or dispatch gaps.
-template <int BM, int BN, int MODE, int DBG = 0, int KT = 32, bool PERSIST = false>
+// PERM:    GEMM rows are output pixels in tap-sorted order (a.perm), MODE 2 only.
+template <int BM, int BN, int MODE, int DBG = 0, int KT = 32, bool PERSIST = false, bool PERM = false>
 __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_kernel(IgemmArgs a) {
+    static_assert(!PERM || (MODE == 2 && !PERSIST), "tap-sorted rows: aligned fast path of the default form only");
     constexpr bool ALIGNED = MODE >= 1, FAST = MODE == 2;
     constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave along m / n
     constexpr int Q4 = KT / 4;                   // float4 per K slice row
@@ -429,6 +441,7 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     for (int i = 0; i < PA; ++i) {
         int m = m0 + i * RPP + lrow;
         int mm = m < a.M ? m : a.M - 1;
+        if constexpr (PERM) mm = a.perm[mm];
         int img = fdiv(mm, a.fPQ);
         int rem = mm - img * (a.P * a.Q);
         int p = fdiv(rem, a.fQ);
@@ -876,7 +889,7 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
         if (tid < a.parts - 1) st_agent_flag(flag + tid, 0);   // consumed: ready for the next launch on this stream
     }
 
-    igemm_epilogue<BM, BN>(a, acc, smem, mt, m0, n0, wm, wn, l31, lh);
+    igemm_epilogue<BM, BN, PERM>(a, acc, smem, mt, m0, n0, wm, wn, l31, lh);
     if (DBG & 32) dbg_record();
     break;
     }
@@ -1691,6 +1704,107 @@ static int split_parts(int tiles, int Ktot) {
     return p >= 2 ? p : 1;
 }
 
+// ---- tap-sorted row order -----------------------------------------------------------------------------
+// The K loop of a tile skips the filter taps that are dead (read padding) for ALL of its rows.  With rows in image
+// order a 64-row tile spans ~3 image rows of a 23x23 map and therefore every column class, so horizontally nothing
+// is ever skipped, and tiles that straddle two images keep all taps: the dilation-18 WASP branch still multiplied
+// 3.3 of 9 taps per pixel where 2.1 are live (effective MFMA fraction 19 %).  Sorting the GEMM rows by their tap mask
+// (classes with more live taps first, image order inside a class) makes the masks of a tile (nearly) uniform: the
+// tile-level skipping then drops (nearly) every dead tap — also the border taps of ordinary padded 3x3 convolutions
+// (5.7 % of the MACs at 23x23).  The permutation depends only on the geometry; it is built once on the host and
+// kept on the device.  Knob "tap_sort" (UP_TAP_SORT), default off until measured.
+static int g_tap_sort = env_int("UP_TAP_SORT", 0, 0);
+struct TapSortKey {
+    int M, H, W, P, Q, taps, S, mul, off0, off0w, tapstep;
+    bool operator<(const TapSortKey& o) const { return memcmp(this, &o, sizeof(*this)) < 0; }
+};
+// tap mask of every pixel of ONE image of the destination grid (bit t: tap t reads a real source pixel)
+static std::vector<unsigned> tap_masks(const IgemmArgs& a) {
+    std::vector<unsigned> mask((size_t)a.P * a.Q);
+    for (int p = 0; p < a.P; ++p)
+        for (int q = 0; q < a.Q; ++q) {
+            const int hb = p * a.mul + a.off0, wb = q * a.mul + a.off0w;
+            unsigned mk = 0;
+            for (int t = 0; t < a.taps; ++t) {
+                const int h = hb + (t / a.S) * a.tapstep, w = wb + (t % a.S) * a.tapstep;
+                if (h >= 0 && w >= 0 && h < a.H && w < a.W) mk |= 1u << t;
+            }
+            mask[(size_t)p * a.Q + q] = mk;
+        }
+    return mask;
+}
+// rows in tap-sorted order: classes with more live taps first (the longest tiles start first), then by mask value;
+// image order inside a class.  Empty when every pixel has the same mask (nothing to gain).
+static std::vector<int> tap_sort_order(const IgemmArgs& a, const std::vector<unsigned>& mask) {
+    std::vector<unsigned> classes;
+    for (unsigned mk : mask) {
+        bool seen = false;
+        for (unsigned c : classes) seen = seen || c == mk;
+        if (!seen) classes.push_back(mk);
+    }
+    std::vector<int> perm;
+    if (classes.size() < 2) return perm;
+    std::sort(classes.begin(), classes.end(), [](unsigned x, unsigned y) {
+        const int px = __builtin_popcount(x), py = __builtin_popcount(y);
+        return px != py ? px > py : x < y;
+    });
+    const int PQ = a.P * a.Q, imgs = a.M / PQ;
+    perm.reserve(a.M);
+    for (unsigned c : classes)
+        for (int img = 0; img < imgs; ++img)
+            for (int e = 0; e < PQ; ++e)
+                if (mask[e] == c) perm.push_back(img * PQ + e);
+    return perm;
+}
+static const int* tap_sort_perm(const IgemmArgs& a) {
+    static std::mutex mu;
+    static std::map<TapSortKey, int*> table;
+    TapSortKey key;
+    memset(&key, 0, sizeof(key));
+    key.M = a.M; key.H = a.H; key.W = a.W; key.P = a.P; key.Q = a.Q; key.taps = a.taps; key.S = a.S;
+    key.mul = a.mul; key.off0 = a.off0; key.off0w = a.off0w; key.tapstep = a.tapstep;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = table.find(key);
+    if (it != table.end()) return it->second;
+    const std::vector<int> perm = tap_sort_order(a, tap_masks(a));
+    int* dev = nullptr;
+    if ((int)perm.size() == a.M) {
+#ifdef UP_EMU
+        dev = static_cast<int*>(malloc(sizeof(int) * a.M));
+        memcpy(dev, perm.data(), sizeof(int) * a.M);
+#else
+        if (hipMalloc(reinterpret_cast<void**>(&dev), sizeof(int) * a.M) != hipSuccess ||
+            hipMemcpy(dev, perm.data(), sizeof(int) * a.M, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            dev = nullptr;   // no permutation: the launch keeps the image order
+        }
+#endif
+    }
+    table[key] = dev;
+    return dev;
+}
+// share of (row tile, filter tap) pairs the K loop of a launch visits, for rows in image order or tap-sorted order;
+// *live = share of (pixel, tap) pairs that touch the image at all (what a perfect skip would visit)
+static double visited_tap_fraction(const IgemmArgs& a, int bm, bool sorted, double* live) {
+    const std::vector<unsigned> mask = tap_masks(a);
+    const int PQ = a.P * a.Q;
+    std::vector<int> perm;
+    if (sorted && a.M % PQ == 0) perm = tap_sort_order(a, mask);
+    long long visited = 0, alive = 0;
+    const int tiles = cdiv(a.M, bm);
+    for (int t = 0; t < tiles; ++t) {
+        unsigned u = 0;
+        for (int m = t * bm; m < (t + 1) * bm; ++m) {
+            const int mm = m < a.M ? m : a.M - 1;   // rows past the end are clamped like in the kernel
+            u |= mask[(perm.empty() ? mm : perm[mm]) % PQ];
+        }
+        visited += __builtin_popcount(u);
+    }
+    for (unsigned mk : mask) alive += __builtin_popcount(mk);
+    if (live) *live = (double)alive / ((double)PQ * a.taps);
+    return (double)visited / ((double)tiles * a.taps);
+}
+
 template <int BM, int BN>
 static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     int ntm = cdiv(a.M, BM);
@@ -1713,7 +1827,16 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     // on 128-wide tiles, -3 % on 64x64 (probe, warm)
     constexpr int DB_VARIANT = (BM == 128 || BN == 128) ? 128 : 0;   // 64x64: non-pinned loop with two staging sets
     void (*kernel)(IgemmArgs);
-    if (fast && db)
+    a.no_tap_skip = g_tap_skip ? 0 : 1;
+    a.perm = nullptr;
+    if (g_tap_sort && !g_persist && fast && a.taps > 1 && a.taps <= 16 && !a.residual && !a.o_mode && !a.no_tap_skip &&
+        a.M % (a.P * a.Q) == 0)
+        a.perm = tap_sort_perm(a);
+    if (a.perm && db)
+        kernel = igemm_kernel<BM, BN, 2, DB_VARIANT, 32, false, true>;
+    else if (a.perm)
+        kernel = igemm_kernel<BM, BN, 2, 64, 32, false, true>;
+    else if (fast && db)
         kernel = igemm_kernel<BM, BN, 2, DB_VARIANT>;
     else if (fast)
         kernel = igemm_kernel<BM, BN, 2, 64>;
@@ -1820,6 +1943,7 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "short_k_mult") && value > 0) g_short_k_mult = value;
     else if (!strcmp(key, "tail_split")) g_tail_split = value ? 1 : 0;
     else if (!strcmp(key, "tap_skip")) g_tap_skip = value ? 1 : 0;
+    else if (!strcmp(key, "tap_sort")) g_tap_sort = value ? 1 : 0;
     else if (!strcmp(key, "wgrad_per_cu") && value > 0) g_wgrad_per_cu = value;
     else UP_REQUIRE(false, UP_ERR_INVALID, "conv_tune: unknown key '%s'", key);
     return UP_OK;
@@ -2000,6 +2124,25 @@ static int run_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
     return UP_OK;
 }
 }  // namespace up
+
+extern "C" int up_conv_tap_visits(const up_conv_desc* d, int data_gradient, double* image_order, double* tap_sorted,
+                                  double* live) {
+    if (int e = check_desc(d)) return e;
+    UP_REQUIRE(image_order && tap_sorted && live, UP_ERR_INVALID, "conv_tap_visits: null output");
+    UP_REQUIRE(!data_gradient || !s2_decomposed(d->stride, d->dil), UP_ERR_UNSUPPORTED,
+               "conv_tap_visits: the stride-2 data gradient runs as four parity-class launches");
+    IgemmArgs a;
+    if (data_gradient) {
+        if (int e = fill_dgrad_args(a, d, nullptr, nullptr, nullptr)) return e;
+    } else if (int e = fill_fwd_args(a, d, nullptr, nullptr, nullptr, nullptr)) {
+        return e;
+    }
+    UP_REQUIRE(a.taps <= 32 && a.divshift == 0, UP_ERR_UNSUPPORTED, "conv_tap_visits: %d taps / strided gather", a.taps);
+    const int bm = choose_tile(a.M, a.Ng, a.Ktot).bm;
+    *image_order = visited_tap_fraction(a, bm, false, live);
+    *tap_sorted = visited_tap_fraction(a, bm, true, nullptr);
+    return UP_OK;
+}
 
 extern "C" int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
                                   const float* add, int ld_add, void* stream) {
