@@ -114,6 +114,10 @@ int up_conv_tune(const char* key, int value);
  * data-gradient launch of `d` visits with its rows in image order and in tap-sorted order ("tap_sort" knob), and the share
  * of (pixel, tap) pairs that touch the image at all (`live`: what a perfect skip would visit).  Aligned fast path only. */
 int up_conv_tap_visits(const up_conv_desc* d, int data_gradient, double* image_order, double* tap_sorted, double* live);
+/* The same for the weight gradient with the "wgrad_rect" knob (UP_WGRAD_RECT, default off until measured): each column
+ * tile of the weight-gradient GEMM reduces over the bounding rectangle of the output pixels on which its filter taps read
+ * real input (instead of all N*P*Q pixels); *rect_fraction = share of (pixel, column tile) pairs still visited. */
+int up_conv_wgrad_visits(const up_conv_desc* d, double* rect_fraction);
 
 /* Data gradient: dx[N,H,W,ldx(:Cp)] from dy[N,P,Q,ldy(:K)] (replaces convolution_backward, input half).
  * Writes all Cp channels of every input pixel (pad channels get 0).  `add` (optional, [N,H,W,ld_add]) is a second

@@ -1,6 +1,8 @@
-"""Tap-sorted row order of the forward / data-gradient kernel (knob "tap_sort", default off): GEMM rows ordered by their
-set of live filter taps so that the tile-level tap skipping becomes near exact on dilated and padded convolutions.
-Parity with the knob on, and the host-side prediction of the visited (tile, tap) pairs (`up_conv_tap_visits`)."""
+"""Two optional forms that stop multiplying structural zeros of dilated / padded convolutions (both default off):
+* "tap_sort": GEMM rows of the forward / data-gradient kernel ordered by their set of live filter taps, so that the
+  tile-level tap skipping becomes near exact;
+* "wgrad_rect": the weight-gradient reduction of a column tile runs over the live rectangle of its filter taps only.
+Parity with the knobs on, and the host-side predictions (`up_conv_tap_visits`, `up_conv_wgrad_visits`)."""
 import ctypes
 
 import pytest
@@ -29,6 +31,54 @@ def tap_sort():
     _C.check(_C.lib().up_conv_tune(b"tap_sort", 1), "conv_tune")
     yield
     _C.check(_C.lib().up_conv_tune(b"tap_sort", 0), "conv_tune")
+
+
+@pytest.fixture
+def wgrad_rect():
+    from unipose_amd import _C
+    _C.check(_C.lib().up_conv_tune(b"wgrad_rect", 1), "conv_tune")
+    yield
+    _C.check(_C.lib().up_conv_tune(b"wgrad_rect", 0), "conv_tune")
+
+
+WGRAD_CASES = CASES + [
+    (2, 16, 9, 9, 24, 3, 2, 1, 1, False, False),      # stride 2: rectangles in output coordinates
+    (1, 3, 20, 18, 8, 7, 2, 3, 1, False, False),      # stem 7x7 stride 2: many taps per column tile (bounding rectangle)
+    (1, 15, 12, 12, 8, 11, 1, 5, 1, True, True),      # 11x11
+    (1, 16, 7, 7, 16, 3, 1, 4, 4, False, False),      # dilation > H/2: corner taps see a 3x3 patch
+    (2, 32, 8, 8, 20, 1, 2, 0, 1, False, False),      # 1x1 stride 2: one full rectangle (plain form is kept)
+    (1, 32, 9, 9, 16, 3, 2, 0, 1, False, False),      # no padding: every tap sees everything
+    (1, 32, 4, 4, 16, 3, 1, 5, 5, False, False),      # dilation > H: eight taps never live (empty rectangles)
+]
+
+
+def _wgrad_visits(n, h, w, c, k, r, dil, stride=1):
+    from unipose_amd import _C
+    pad = (r // 2) * dil
+    po = (h + 2 * pad - dil * (r - 1) - 1) // stride + 1
+    qo = (w + 2 * pad - dil * (r - 1) - 1) // stride + 1
+    d = _C.ConvDesc(n, h, w, c, c, c, k, r, r, stride, pad, dil, po, qo, k, k)
+    f = ctypes.c_double()
+    _C.check(_C.lib().up_conv_wgrad_visits(ctypes.byref(d), ctypes.byref(f)), "conv_wgrad_visits")
+    return f.value
+
+
+def test_wgrad_rect_ops_emu(emu_backend, wgrad_rect):
+    for n, c, h, w, k, r, s, p, d, bias, relu in WGRAD_CASES:
+        oc.conv_case(emu_backend, n, c, h, w, k, r, s, p, d, bias=bias, relu=relu)
+
+
+def test_wgrad_rect_model_emu(emu_backend, wgrad_rect, tap_sort):
+    mc.train_case(emu_backend, size=32)                  # both knobs together, every parameter gradient
+
+
+def test_wgrad_visit_prediction(emu_backend):
+    """One tap per column tile (Cp >= 128): the rectangle is exact, i.e. the live share of SURVEY 8d."""
+    for dil, live in ((18, 0.229), (12, 0.425), (6, 0.682)):
+        assert abs(_wgrad_visits(32, 23, 23, 256, 256, 3, dil) - live) < 2e-3
+    assert abs(_wgrad_visits(32, 23, 23, 256, 256, 3, 1) - (21 * 21 * 9 + 84 * 6 + 4 * 4) / (529 * 9.0)) < 1e-9
+    assert _wgrad_visits(32, 23, 23, 256, 256, 1, 1) == 1.0
+    assert 0.98 < _wgrad_visits(32, 92, 92, 64, 64, 3, 1) < 1.0      # two taps per 128-column tile: bounding rectangle
 
 
 def _suite(dev, cases):
@@ -79,6 +129,17 @@ def test_tap_sort_ops_gpu(tap_sort):
     _suite(dev, [(4, 256, 23, 23, 256, 3, 1, 18, 18, False, False), (4, 256, 23, 23, 256, 3, 1, 6, 6, False, True),
                  (4, 256, 23, 23, 256, 3, 1, 1, 1, False, False), (2, 512, 23, 23, 512, 3, 1, 8, 8, False, False),
                  (2, 128, 46, 46, 128, 3, 1, 1, 1, True, True)])
+
+
+@pytest.mark.gpu
+def test_wgrad_rect_gpu(wgrad_rect, tap_sort):
+    dev = torch.device("cuda:0")
+    for cfg in [(4, 256, 23, 23, 256, 3, 1, 18, 18, False, False), (4, 256, 23, 23, 256, 3, 1, 1, 1, False, False),
+                (2, 512, 23, 23, 512, 3, 1, 8, 8, False, False), (2, 64, 92, 92, 64, 3, 1, 1, 1, False, False),
+                (2, 128, 92, 92, 128, 3, 2, 1, 1, False, False), (2, 3, 96, 96, 64, 7, 2, 3, 1, False, False)]:
+        n, c, h, w, k, r, s, p, d, bias, relu = cfg
+        oc.conv_case(dev, n, c, h, w, k, r, s, p, d, bias=bias, relu=relu)
+    mc.train_case(dev, size=128, B=4)
 
 
 @pytest.mark.gpu

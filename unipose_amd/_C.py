@@ -42,6 +42,7 @@ SIGNATURES = {
     "up_conv_set_persistent": (_i, [_i, _i]),
     "up_conv_get_persistent": (_i, []),
     "up_conv_tune": (_i, [C.c_char_p, _i]),
+    "up_conv_wgrad_visits": (_i, [_D, C.POINTER(C.c_double)]),
     "up_conv_tap_visits": (_i, [_D, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "up_conv2d_bwd_data": (_i, [_D, _p, _p, _p, _p, _i, _p]),
     "up_pack_weights_bf16": (_i, [_D, _p, _p, _p, _p, _p, _p]),

@@ -1171,10 +1171,16 @@ struct WgradArgs {
     int ntn, nwg;
     FastDiv fPQ, fQ, fCp, fS, fNtn, fTiles;
     void* dbg;   // development probes only
+    // RECT form: per column tile 12 ints {p_lo, q_lo, rows, cols, FastDiv(rows*cols), FastDiv(cols), rows per split,
+    // pixels} — the rectangle of output pixels (per image) on which ANY filter tap of the tile reads a real input pixel
+    const int* rect;
 };
+constexpr int WGRAD_RECT_INTS = 12;
 
 // DBG bit 5: per-block timeline (probe); bit 6: the older single-buffer loop (two barriers per slice)
-template <int BM, int BN, int DBG = 0>
+// RECT: the reduction of a column tile runs over the live rectangle of its filter taps only (see WgradRect) instead of
+//       all N*P*Q output pixels: the pixels outside multiply structural zeros (77 % of them on the dilation-18 branch).
+template <int BM, int BN, int DBG = 0, bool RECT = false>
 __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) wgrad_kernel(WgradArgs a) {
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int A4 = BM / 4, B4 = BN / 4;                // float4 per k row
@@ -1202,8 +1208,30 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) wgrad_k
     const int mt = fdiv(tile, a.fNtn);
     const int nt = tile - mt * a.ntn;
     const int co0 = mt * BM, col0 = nt * BN;
-    const int mbeg = split * a.rows_per_split;
-    const int mend = min(a.M, mbeg + a.rows_per_split);
+    int mbeg = split * a.rows_per_split;
+    int mend = min(a.M, mbeg + a.rows_per_split);
+    // RECT: reduction index m enumerates (image, row, column) of the tile's live rectangle
+    int r_pl = 0, r_ql = 0, r_wr = 0, r_hw = 0;
+    FastDiv r_fhw = {0, 0, 0}, r_fw = {0, 0, 0};
+    if constexpr (RECT) {
+        const int* rc = a.rect + WGRAD_RECT_INTS * nt;
+        r_pl = rc[0];
+        r_ql = rc[1];
+        r_wr = rc[3];
+        r_hw = rc[2] * rc[3];
+        r_fhw = FastDiv{(uint32_t)rc[4], (uint32_t)rc[5], (uint32_t)rc[6]};
+        r_fw = FastDiv{(uint32_t)rc[7], (uint32_t)rc[8], (uint32_t)rc[9]};
+        mbeg = split * rc[10];
+        mend = min(rc[11], mbeg + rc[10]);
+    }
+    // (image, output row, output column) of reduction index mm; RECT only
+    auto rect_pixel = [&](int mm, int& img, int& pp, int& qq) {
+        img = fdiv(mm, r_fhw);
+        const int rem = mm - img * r_hw;
+        const int i = fdiv(rem, r_fw);
+        pp = r_pl + i;
+        qq = r_ql + (rem - i * r_wr);
+    };
 
     // A (dY): thread -> (k row within pass, 4 output channels).  Channels >= K are never stored: they only
     // need a valid address.
@@ -1225,16 +1253,28 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) wgrad_k
     auto gloadA = [&](int p, int kbase) {
         int m = kbase + p * KA + a_kr;
         bool ok = m < mend;
-        ra[p] = *reinterpret_cast<const float4*>(a.dy + (size_t)(ok ? m : mbeg) * a.ldy + a_co);
+        size_t row = (size_t)(ok ? m : mbeg);
+        if constexpr (RECT) {
+            int img, pp, qq;
+            rect_pixel(m, img, pp, qq);
+            row = ok ? (size_t)(img * a.P + pp) * a.Q + qq : (size_t)0;   // (an empty rectangle has no valid m at all)
+        }
+        ra[p] = *reinterpret_cast<const float4*>(a.dy + row * a.ldy + a_co);
         okmask = (okmask & ~(1u << p)) | (ok ? (1u << p) : 0u);
     };
     auto gloadB = [&](int p, int kbase) {
         int m = kbase + p * KB + b_kr;
         int mm = m < mend ? m : mbeg;
-        int img = fdiv(mm, a.fPQ);
-        int rem = mm - img * (a.P * a.Q);
-        int pp = fdiv(rem, a.fQ);
-        int qq = rem - pp * a.Q;
+        int img, pp, qq;
+        if constexpr (RECT) {
+            rect_pixel(m, img, pp, qq);
+            if (m >= mend) img = pp = qq = 0;
+        } else {
+            img = fdiv(mm, a.fPQ);
+            int rem = mm - img * (a.P * a.Q);
+            pp = fdiv(rem, a.fQ);
+            qq = rem - pp * a.Q;
+        }
         int h = pp * a.stride + b_dh, w = qq * a.stride + b_dw;
         const bool ok = m < mend && h >= 0 && w >= 0 && h < a.H && w < a.W;
         h = h < 0 ? 0 : (h < a.H ? h : a.H - 1);   // clamped, always valid address: no divergent branch around the load
@@ -1606,6 +1646,7 @@ static int g_short_k_mult = env_int("UP_SHORT_K_MULT", 4, 1);     // they want g
 static int g_tail_split = env_int("UP_TAIL_SPLIT", 1, 0);
 static int g_tap_skip = env_int("UP_TAP_SKIP", 1, 0);
 static int g_wgrad_per_cu = env_int("UP_WGRAD_PER_CU", 2, 1);   // workgroups per CU a weight-gradient launch aims for
+static int g_wgrad_rect = env_int("UP_WGRAD_RECT", 0, 0);      // weight-gradient reduction over live rectangles (see WgradRectKey)
 static int cu_count();
 static int persist_occupancy(int bm, int bn) { return (bm == 128 && bn == 128) ? 2 : 3; }   // = __launch_bounds__
 // Largest tile that still yields ~6 workgroups per CU (the tail split evens out the remainder).  Short reductions
@@ -1944,6 +1985,7 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "tail_split")) g_tail_split = value ? 1 : 0;
     else if (!strcmp(key, "tap_skip")) g_tap_skip = value ? 1 : 0;
     else if (!strcmp(key, "tap_sort")) g_tap_sort = value ? 1 : 0;
+    else if (!strcmp(key, "wgrad_rect")) g_wgrad_rect = value ? 1 : 0;
     else if (!strcmp(key, "wgrad_per_cu") && value > 0) g_wgrad_per_cu = value;
     else UP_REQUIRE(false, UP_ERR_INVALID, "conv_tune: unknown key '%s'", key);
     return UP_OK;
@@ -2292,7 +2334,102 @@ static WgradPlan plan_wgrad(const up_conv_desc* d) {
     p.splits = (int)((M + rps - 1) / rps);
     return p;
 }
+
+// ---- live rectangles of the weight-gradient column tiles (wgrad_kernel<..., RECT>) ----------------------
+// Filter tap (r, s) reads a real input pixel only for output rows p with 0 <= p*stride - pad + r*dil < H (columns
+// likewise): a rectangle of the output grid.  A column tile of the weight-gradient GEMM holds one or two taps, so
+// its reduction can run over the bounding rectangle of its taps instead of all P x Q pixels of every image — on the
+// dilation-18 WASP convolution the corner taps see 5 x 5 of 23 x 23 pixels.  Knob "wgrad_rect" (UP_WGRAD_RECT),
+// default off until measured.
+struct WgradRectKey {
+    int N, H, W, P, Q, R, S, stride, pad, dil, Cp, bn, splits;
+    bool operator<(const WgradRectKey& o) const { return memcmp(this, &o, sizeof(*this)) < 0; }
+};
+// fills `tab` (ntn x WGRAD_RECT_INTS); returns the share of (pixel, column tile) pairs the reduction still visits
+static double wgrad_rect_table(const up_conv_desc* d, const WgradPlan& p, std::vector<int>& tab) {
+    const int ncols = d->R * d->S * d->Cp;
+    tab.assign((size_t)p.ntn * WGRAD_RECT_INTS, 0);
+    auto live = [](int size_in, int size_out, int stride, int pad, int off, int& lo, int& hi) {
+        // 0 <= o*stride - pad + off <= size_in - 1
+        const int a = pad - off;
+        lo = a <= 0 ? 0 : (a + stride - 1) / stride;
+        const int b = size_in - 1 + pad - off;
+        hi = b < 0 ? -1 : b / stride;
+        if (hi > size_out - 1) hi = size_out - 1;
+    };
+    double visited = 0.0;
+    for (int nt = 0; nt < p.ntn; ++nt) {
+        const int c_lo = nt * p.bn, c_hi = std::min(ncols, (nt + 1) * p.bn) - 1;
+        int pl = d->P, ph = -1, ql = d->Q, qh = -1;
+        for (int t = c_lo / d->Cp; t <= c_hi / d->Cp; ++t) {
+            int lo, hi;
+            live(d->H, d->P, d->stride, d->pad, (t / d->S) * d->dil, lo, hi);
+            if (lo <= hi) {
+                pl = std::min(pl, lo);
+                ph = std::max(ph, hi);
+            }
+            live(d->W, d->Q, d->stride, d->pad, (t % d->S) * d->dil, lo, hi);
+            if (lo <= hi) {
+                ql = std::min(ql, lo);
+                qh = std::max(qh, hi);
+            }
+        }
+        const int hr = ph >= pl ? ph - pl + 1 : 0, wr = qh >= ql ? qh - ql + 1 : 0;
+        const int rows = (hr && wr) ? hr : 0, cols = (hr && wr) ? wr : 0;
+        const long long mt = (long long)d->N * rows * cols;
+        long long rps = (mt + p.splits - 1) / p.splits;
+        rps = std::max<long long>(BK, (rps + BK - 1) / BK * BK);
+        const FastDiv fhw = make_fastdiv(rows * cols), fw = make_fastdiv(cols);
+        int* e = &tab[(size_t)nt * WGRAD_RECT_INTS];
+        e[0] = rows ? pl : 0;
+        e[1] = rows ? ql : 0;
+        e[2] = rows;
+        e[3] = cols;
+        e[4] = (int)fhw.mul; e[5] = (int)fhw.shr; e[6] = (int)fhw.d;
+        e[7] = (int)fw.mul;  e[8] = (int)fw.shr;  e[9] = (int)fw.d;
+        e[10] = (int)rps;
+        e[11] = (int)mt;
+        visited += (double)mt;
+    }
+    return visited / ((double)p.ntn * d->N * d->P * d->Q);
+}
+static const int* wgrad_rect_device(const up_conv_desc* d, const WgradPlan& p) {
+    static std::mutex mu;
+    static std::map<WgradRectKey, int*> table;
+    WgradRectKey key;
+    memset(&key, 0, sizeof(key));
+    key.N = d->N; key.H = d->H; key.W = d->W; key.P = d->P; key.Q = d->Q; key.R = d->R; key.S = d->S;
+    key.stride = d->stride; key.pad = d->pad; key.dil = d->dil; key.Cp = d->Cp; key.bn = p.bn; key.splits = p.splits;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = table.find(key);
+    if (it != table.end()) return it->second;
+    std::vector<int> tab;
+    int* dev = nullptr;
+    if (wgrad_rect_table(d, p, tab) < 0.999) {   // every tile sees the whole image (1x1, unpadded): keep the plain form
+        const size_t bytes = tab.size() * sizeof(int);
+#ifdef UP_EMU
+        dev = static_cast<int*>(malloc(bytes));
+        memcpy(dev, tab.data(), bytes);
+#else
+        if (hipMalloc(reinterpret_cast<void**>(&dev), bytes) != hipSuccess ||
+            hipMemcpy(dev, tab.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipGetLastError();
+            dev = nullptr;
+        }
+#endif
+    }
+    table[key] = dev;
+    return dev;
+}
 }  // namespace up
+
+extern "C" int up_conv_wgrad_visits(const up_conv_desc* d, double* rect_fraction) {
+    if (int e = check_desc(d)) return e;
+    UP_REQUIRE(rect_fraction, UP_ERR_INVALID, "conv_wgrad_visits: null output");
+    std::vector<int> tab;
+    *rect_fraction = wgrad_rect_table(d, plan_wgrad(d), tab);
+    return UP_OK;
+}
 
 extern "C" size_t up_conv2d_bwd_weight_workspace(const up_conv_desc* d) {
     if (!d || check_desc(d)) return 0;
@@ -2368,7 +2505,26 @@ extern "C" int up_conv2d_bwd_weight(const up_conv_desc* d, const float* x, const
             // workgroups (layers with many weight tiles) keep the 32 KB single-buffer loop and 3-4 per CU
             // (probe, 3x3 512->512: 115 vs 104 TFLOP/s; in the network the double buffer is 0.5 % faster overall)
             const bool single = a.nwg > 2 * cu_count();
-            if (single) {
+            a.rect = (g_wgrad_rect && (int64_t)d->N * d->P * d->Q < (1ll << 30)) ? wgrad_rect_device(d, p) : nullptr;
+            if (a.rect && single) {
+                if (p.bm == 128 && p.bn == 128)
+                    hipLaunchKernelGGL((wgrad_kernel<128, 128, 64, true>), grid, dim3(256), 0, st, a);
+                else if (p.bm == 128 && p.bn == 64)
+                    hipLaunchKernelGGL((wgrad_kernel<128, 64, 64, true>), grid, dim3(256), 0, st, a);
+                else if (p.bm == 64 && p.bn == 128)
+                    hipLaunchKernelGGL((wgrad_kernel<64, 128, 64, true>), grid, dim3(256), 0, st, a);
+                else
+                    hipLaunchKernelGGL((wgrad_kernel<64, 64, 64, true>), grid, dim3(256), 0, st, a);
+            } else if (a.rect) {
+                if (p.bm == 128 && p.bn == 128)
+                    hipLaunchKernelGGL((wgrad_kernel<128, 128, 0, true>), grid, dim3(256), 0, st, a);
+                else if (p.bm == 128 && p.bn == 64)
+                    hipLaunchKernelGGL((wgrad_kernel<128, 64, 0, true>), grid, dim3(256), 0, st, a);
+                else if (p.bm == 64 && p.bn == 128)
+                    hipLaunchKernelGGL((wgrad_kernel<64, 128, 0, true>), grid, dim3(256), 0, st, a);
+                else
+                    hipLaunchKernelGGL((wgrad_kernel<64, 64, 0, true>), grid, dim3(256), 0, st, a);
+            } else if (single) {
                 if (p.bm == 128 && p.bn == 128)
                     hipLaunchKernelGGL((wgrad_kernel<128, 128, 64>), grid, dim3(256), 0, st, a);
                 else if (p.bm == 128 && p.bn == 64)
