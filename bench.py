@@ -279,26 +279,31 @@ def main():
                                                f"profiles/{pmc['tag']}_pmc_summary.txt)"
             except (OSError, ValueError, KeyError):
                 pass
-            # The timed region runs the weight gradients on a second stream, so the event-bracketed durations
-            # above include time shared with the other stream's kernels.  A few extra steps with everything on
-            # ONE stream give each kernel's own duration (same kernels, same shapes, nothing else resident).
-            was_async, ops.ASYNC_WGRAD = ops.ASYNC_WGRAD, False
-            step()
-            fence()
+
+    # The timed region runs the weight gradients on a second stream, so the event-bracketed durations above include
+    # time shared with the other stream's kernels.  A few extra steps with everything on ONE stream give each kernel's
+    # own duration (same kernels, same shapes, nothing else resident).  EVERY rank runs these steps — they contain the
+    # gradient exchange and the barriers of fence() — only rank 0 records events.
+    if not args.no_profile:
+        was_async, ops.ASYNC_WGRAD = ops.ASYNC_WGRAD, False
+        step()
+        fence()
+        if profile:
             _C.lib().up_profile_begin()
-            nx = min(args.steps, 5)
-            for _ in range(nx):
-                step()
-            fence()
-            ops.ASYNC_WGRAD = was_async
+        nx = min(args.steps, 5)
+        for _ in range(nx):
+            step()
+        fence()
+        ops.ASYNC_WGRAD = was_async
+        if profile:
             xrows = profile_rows()
-            same = [r for r in xrows if r["kernel"] == top["kernel"]]
+            same = [r for r in xrows if roofline is not None and r["kernel"] == roofline["kernel"]]
             if same:
                 x_ms = sum(r["total_ms"] for r in xrows)
                 x_fl = sum(r["tflops"] * r["total_ms"] for r in xrows)
                 roofline["exclusive"] = {
                     "note": "same step with both streams serialised: the kernel's own duration",
-                    "kernel": top["kernel"], "achieved": round(same[0]["tflops"], 2),
+                    "kernel": roofline["kernel"], "achieved": round(same[0]["tflops"], 2),
                     "frac": round(same[0]["tflops"] / F32_MFMA_PEAK_TFLOPS, 4),
                     "avg_launch_ms": round(same[0]["avg_ms"], 4), "launches": same[0]["launches"],
                     "all_mfma_kernels": {"achieved": round(x_fl / x_ms, 2),
