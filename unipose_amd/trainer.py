@@ -169,6 +169,11 @@ class DeviceBatcher:
         return inp.to(self.dev), heat.to(self.dev), cm.to(self.dev)
 
 
+def _rank_seed(base: int) -> int:
+    """Every rank of a data-parallel run draws its own synthetic shard (seed = base + 1000 * rank)."""
+    return base + 1000 * int(os.environ.get("RANK", "0"))
+
+
 def _progress(loader, desc):
     try:
         from tqdm import tqdm
@@ -247,7 +252,7 @@ class Trainer(_TrainerBase):
         size = getattr(args, "size", 368)
         dev = torch.device(device)
         self.train_loader = train_loader if train_loader is not None else SyntheticPoseData(
-            self.numClasses, self.batch_size, getattr(args, "train_batches", 4), size, seed=1)
+            self.numClasses, self.batch_size, getattr(args, "train_batches", 4), size, seed=_rank_seed(1))
         self.val_loader = val_loader if val_loader is not None else SyntheticPoseData(
             self.numClasses, self.batch_size, getattr(args, "val_batches", 2), size, seed=2)
         self.batcher = DeviceBatcher(dev, self.stride, self.sigma)
@@ -321,7 +326,7 @@ class VideoTrainer(_TrainerBase):
         dev = torch.device(device)
         mk = lambda n, seed: SyntheticPoseData(self.numClasses, self.batch_size, n, size, frames=self.frame_memory,  # noqa: E731
                                                seed=seed)
-        self.train_loader = train_loader if train_loader is not None else mk(getattr(args, "train_batches", 2), 1)
+        self.train_loader = train_loader if train_loader is not None else mk(getattr(args, "train_batches", 2), _rank_seed(1))
         self.val_loader = val_loader if val_loader is not None else mk(getattr(args, "val_batches", 1), 2)
         self.batcher = DeviceBatcher(dev, self.stride, self.sigma)
         model = unipose_lstm(num_classes=self.numClasses, backbone="resnet", output_stride=16, sync_bn=True,
