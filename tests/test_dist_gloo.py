@@ -77,3 +77,51 @@ def test_grad_allreduce_world2(overlap):
             assert np.allclose(ra[i], want, atol=1e-7) and np.allclose(rb[i], want, atol=1e-7), (step, i)
     n_live = sum(p.numel() for n, p in _Net().named_parameters() if not n.startswith("unused"))
     assert bytes_a == 4 * n_live                   # the unused parameters are not in the exchange
+
+
+def _trainer_worker(rank, world, port, q):
+    """unipose_amd.trainer under WORLD_SIZE=2 (what `torch.distributed.run unipose.py` sets up), kernels on the emulator."""
+    import argparse
+    import sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), UNIPOSE_NO_TQDM="1", UP_EMU_THREADS="2")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests", "emu"))
+    import build_emu
+    from unipose_amd import _C
+    _C.load(build_emu.build())
+    _C._ALLOW_HOST_POINTERS = True
+    from unipose_amd.trainer import Trainer, init_distributed
+    r, w, dev = init_distributed()                 # gloo on a GPU-less box
+    assert (r, w, dev.type) == (rank, world, "cpu") and dist.get_backend() == "gloo"
+    torch.manual_seed(50 + rank)                   # different initial weights: rank 0's must win
+    args = argparse.Namespace(dataset="LSP", pretrained=None, model_name=None, model_arch="unipose", train_dir=None,
+                              val_dir=None, batch_size=2, size=32, train_batches=2, val_batches=1)
+    tr = Trainer(args, device=dev)
+    assert tr.reducer is not None and tr.reducer.active
+    first = next(iter(tr.train_loader))["kpts"].copy()
+    w0 = tr.model.wasp.conv2.weight.detach().clone()
+    tr.training(0)
+    w1 = tr.model.wasp.conv2.weight.detach().clone()
+    q.put((rank, first, w0.numpy(), w1.numpy(), tr.iters))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (_, k_a, w0_a, w1_a, it_a), (_, k_b, w0_b, w1_b, it_b) = res
+    assert it_a == it_b == 2
+    assert not np.array_equal(k_a, k_b)            # every rank draws its own shard
+    assert np.array_equal(w0_a, w0_b)              # weights replicated from rank 0 before the first step
+    assert not np.array_equal(w0_a, w1_a)          # the steps moved them
+    assert np.array_equal(w1_a, w1_b)              # identical averaged gradients -> identical weights after Adam
