@@ -133,6 +133,10 @@ def main():
                     help="run the gradient exchange (RCCL all-reduce, buckets, hooks) even with one rank")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the extra split-bf16 timing loop")
     ap.add_argument("--wasp-only", action="store_true", help="only the WASP dilated-convolution roofline leg")
+    ap.add_argument("--dry-run-emu", action="store_true",
+                    help="TEST INFRASTRUCTURE (tests/test_bench_flow.py): walk the whole control flow of this script — warm-up, "
+                         "timed region, exclusive pass, alt-math loop, every barrier and collective — on the CPU kernel "
+                         "emulator with the gloo backend.  Prints a line marked dry_run; never a measurement")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=min(os.cpu_count() or 1, 64),
@@ -144,19 +148,32 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    emu = args.dry_run_emu
     use_dist = world > 1 or args.force_dp
-    from unipose_amd import ops as _ops
-    _ops._side_stream(dev)          # create it BEFORE RCCL creates its own streams (hardware-queue assignment)
+    if emu:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "emu"))
+        import build_emu
+        from unipose_amd import _C as _Cemu
+        _Cemu.load(build_emu.build())
+        _Cemu._ALLOW_HOST_POINTERS = True
+        dev = torch.device("cpu")
+        torch.cuda.synchronize = lambda *a, **k: None      # this process only: the script's fences become no-ops
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        from unipose_amd import ops as _ops
+        _ops._side_stream(dev)          # create it BEFORE RCCL creates its own streams (hardware-queue assignment)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if emu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from model.unipose import unipose
     from unipose_amd import _C, ops
@@ -185,7 +202,7 @@ def main():
         x = torch.randn(B, 3, S, S, generator=g).to(dev)
         t = torch.rand(B, K + 1, S // 8, S // 8, generator=g).to(dev)
     # unipose.py:72 (no weight decay); `fused=True` is torch's own single-kernel implementation of the same update
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)    # 70.3 vs 71.7 ms/step with the foreach default
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=not emu)  # 70.3 vs 71.7 ms/step with the foreach default
     ops.manual_seed(shard_seed(0, rank))
     ops.set_conv_math(args.math)
     reducer = GradAllReducer(model, bucket_bytes=256 << 20, force=args.force_dp) if use_dist else None
@@ -365,6 +382,9 @@ def main():
                                          * (S / 368.0) ** 2 / 1e12, 2),
             "loss": loss_val,
         }
+        if emu:
+            out["dry_run"] = "CPU emulator + gloo: control-flow test only, the numbers mean nothing"
+            out["metric"] = "DRY RUN (not a measurement): " + out["metric"]
         if roofline:
             out["roofline"] = roofline
         if alt:

@@ -1,0 +1,56 @@
+"""bench.py's control flow under N > 1, on a GPU-less box: the script is launched exactly like the driver launches it
+(`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 ...`) with `--dry-run-emu`, which swaps the
+device for the CPU kernel emulator and RCCL for gloo and changes nothing else: warm-up, timed region, the exclusive
+profiling pass, the alt-math loop, every barrier and every collective run on both ranks.  A rank-dependent branch that
+issues a collective (the exclusive pass once ran on rank 0 only) shows up here as a hang or a gloo size mismatch."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(nproc, extra=()):
+    env = dict(os.environ, UP_EMU_THREADS="4", OMP_NUM_THREADS="2")
+    # the emulator needs ~10 s per training step of the full ResNet-101: one warm-up and one timed step, no alt-math loop
+    # (that loop has no rank-dependent branch)
+    args = ["--gpus", str(nproc), "--steps", "1", "--warmup", "1", "--batch", "2", "--size", "32", "--dry-run-emu",
+            "--no-alt-math", *extra]
+    if nproc == 1:
+        cmd = [sys.executable, "bench.py", *args]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", *args]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # ONE JSON line, from rank 0 only
+    return json.loads(lines[0])
+
+
+def test_bench_flow_two_ranks():
+    out = _run(2)
+    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["warmup"] == 1
+    assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    assert "dry_run" in out and out["metric"].startswith("DRY RUN")
+    assert "cpu_baseline" not in out                   # rank 0 at N = 1 only
+
+
+def test_bench_flow_single_rank_contract():
+    out = _run(1, ["--no-profile", "--warmup", "0", "--cpu-steps", "1", "--cpu-batch", "2"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "cpu_baseline"):
+        assert key in out, key
+    assert out["warmup"] == 0 and out["n_gpus"] == 1 and out["scaling"] == "weak" and out["higher_is_better"] is True
+    assert out["vs_baseline"] is None and out["dtype"] == "f32" and out["data"] == "synthetic"
+    assert set(out["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and out["cpu_baseline"]["kind"] == "port"

@@ -57,8 +57,7 @@ def test_persistent_setter(emu_backend):
 
 def test_persistent_model_emu(emu_backend, persistent):
     persistent(5)
-    assert mc.eval_case(emu_backend, size=32, B=1) < 1e-4
-    mc.train_case(emu_backend, size=32)
+    mc.train_case(emu_backend, size=32)      # forward output, loss, every parameter gradient, running statistics
 
 
 # ---- on the MI355X: real layer shapes, the library's own grid and two overrides ------------------------------
