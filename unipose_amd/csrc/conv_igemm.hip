@@ -1646,7 +1646,7 @@ static int g_short_k_mult = env_int("UP_SHORT_K_MULT", 4, 1);     // they want g
 static int g_tail_split = env_int("UP_TAIL_SPLIT", 1, 0);
 static int g_tap_skip = env_int("UP_TAP_SKIP", 1, 0);
 static int g_wgrad_per_cu = env_int("UP_WGRAD_PER_CU", 2, 1);   // workgroups per CU a weight-gradient launch aims for
-static int g_wgrad_single = env_int("UP_WGRAD_SINGLE", 0, 0);  // 0: by grid size; 1: always the 32 KB single-buffer loop; 2: always two buffers
+static int g_wgrad_loop = env_int("UP_WGRAD_SINGLE", 0, 0);  // 0: by grid size; 1: always the 32 KB single-buffer loop; 2: always two buffers
 static int g_wgrad_rect = env_int("UP_WGRAD_RECT", 0, 0);      // weight-gradient reduction over live rectangles (see WgradRectKey)
 static int cu_count();
 static int persist_occupancy(int bm, int bn) { return (bm == 128 && bn == 128) ? 2 : 3; }   // = __launch_bounds__
@@ -1987,7 +1987,7 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "tap_skip")) g_tap_skip = value ? 1 : 0;
     else if (!strcmp(key, "tap_sort")) g_tap_sort = value ? 1 : 0;
     else if (!strcmp(key, "wgrad_rect")) g_wgrad_rect = value ? 1 : 0;
-    else if (!strcmp(key, "wgrad_single") && value >= 0 && value <= 2) g_wgrad_single = value;
+    else if (!strcmp(key, "wgrad_single") && value >= 0 && value <= 2) g_wgrad_loop = value;
     else if (!strcmp(key, "wgrad_per_cu") && value > 0) g_wgrad_per_cu = value;
     else UP_REQUIRE(false, UP_ERR_INVALID, "conv_tune: unknown key '%s'", key);
     return UP_OK;
@@ -2506,7 +2506,7 @@ extern "C" int up_conv2d_bwd_weight(const up_conv_desc* d, const float* x, const
             // two LDS buffers (64 KB, two workgroups per CU) when the whole grid is resident at once; launches with more
             // workgroups (layers with many weight tiles) keep the 32 KB single-buffer loop and 3-4 per CU
             // (probe, 3x3 512->512: 115 vs 104 TFLOP/s; in the network the double buffer is 0.5 % faster overall)
-            const bool single = g_wgrad_single ? g_wgrad_single == 1 : a.nwg > 2 * cu_count();
+            const bool single = g_wgrad_loop ? g_wgrad_loop == 1 : a.nwg > 2 * cu_count();
             a.rect = (g_wgrad_rect && (int64_t)d->N * d->P * d->Q < (1ll << 30)) ? wgrad_rect_device(d, p) : nullptr;
             if (a.rect && single) {
                 if (p.bm == 128 && p.bn == 128)
