@@ -132,6 +132,10 @@ def main():
     ap.add_argument("--force-dp", action="store_true",
                     help="run the gradient exchange (RCCL all-reduce, buckets, hooks) even with one rank")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the extra split-bf16 timing loop")
+    ap.add_argument("--main-priority", default="default", choices=["default", "high"],
+                    help="high: run every step on a HIGH-priority HIP stream, so the critical path of backward (data "
+                         "gradients, BatchNorm) is dispatched ahead of the weight-gradient side stream (default "
+                         "priority).  Off until measured (tools/gpu/tune_ab.py main_hi=1)")
     ap.add_argument("--wasp-only", action="store_true", help="only the WASP dilated-convolution roofline leg")
     ap.add_argument("--dry-run-emu", action="store_true",
                     help="TEST INFRASTRUCTURE (tests/test_bench_flow.py): walk the whole control flow of this script — warm-up, "
@@ -206,6 +210,13 @@ def main():
     ops.manual_seed(shard_seed(0, rank))
     ops.set_conv_math(args.math)
     reducer = GradAllReducer(model, bucket_bytes=256 << 20, force=args.force_dp) if use_dist else None
+
+    hi_stream = None
+    if args.main_priority == "high" and not emu:
+        lo_p, hi_p = torch.cuda.Stream.priority_range()
+        hi_stream = torch.cuda.Stream(device=dev, priority=min(lo_p, hi_p))
+        hi_stream.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(hi_stream)       # everything below (steps, fences, events) runs on it
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -375,6 +386,7 @@ def main():
                                     f"{S}x{S}, batch {B}/GPU (BASELINE.json configs[1]; configs[2] for N>1)"),
                        "global_batch": world * B, "per_gpu_batch": B, "input": [3, S, S],
                        "parallelism": f"dp{world}", "optimizer": "torch.optim.Adam(lr=1e-4, fused=True)",
+                       "main_stream_priority": args.main_priority,
                        "arithmetic": {"f32": "fp32 MFMA 32x32x2 everywhere",
                                       "bf16x3": "fwd/dgrad: 3x bf16 MFMA 32x32x16 on (hi,lo) split operands; wgrad: fp32 MFMA",
                                       "bf16": "fwd/dgrad: bf16 MFMA 32x32x16; wgrad: fp32 MFMA"}[args.math]},
