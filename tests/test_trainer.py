@@ -136,9 +136,9 @@ def _image_loop(dev, tmp_path):
     assert len(kpts) == 14 and up.shape == (1, 15, 32, 32)
     # reference-style loader tuples are accepted too
     tup = [(x.cpu(), heat.cpu(), cm.cpu(), ["a", "b"])]
-    tr3 = Trainer(_args(), train_loader=tup, val_loader=tup, device=dev)
-    tr3.training(0)
-    assert tr3.iters == 1
+    tr2.train_loader = tup
+    tr2.training(0)
+    assert tr2.iters == 1
 
 
 def _video_loop(dev, tmp_path):
