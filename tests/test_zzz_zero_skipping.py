@@ -81,6 +81,39 @@ def test_wgrad_visit_prediction(emu_backend):
     assert 0.98 < _wgrad_visits(32, 92, 92, 64, 64, 3, 1) < 1.0      # two taps per 128-column tile: bounding rectangle
 
 
+@pytest.fixture
+def occ64():
+    from unipose_amd import _C
+
+    def set_(v):
+        _C.check(_C.lib().up_conv_tune(b"occ64", v), "conv_tune")
+    yield set_
+    set_(0)
+
+
+@pytest.mark.parametrize("occ", [7, 8])
+def test_occ64_ops_emu(emu_backend, occ64, occ):
+    """"occ64": the 64x64 short-reduction kernel compiled for 7 / 8 waves per SIMD (same source; on the emulator this only
+    exercises the dispatch, the register budget matters on the GPU)."""
+    occ64(occ)
+    for n, c, h, w, k, r, s, p, d, bias, relu in CASES[:3]:
+        oc.conv_case(emu_backend, n, c, h, w, k, r, s, p, d, bias=bias, relu=relu)
+    from unipose_amd import _C
+    assert _C.lib().up_conv_tune(b"occ64", 5) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("occ", [7, 8])
+def test_occ64_ops_gpu(occ64, occ):
+    occ64(occ)
+    dev = torch.device("cuda:0")
+    for cfg in [(4, 256, 23, 23, 1024, 1, 1, 0, 1, False, False), (4, 256, 23, 23, 256, 1, 1, 0, 1, False, True),
+                (2, 64, 46, 46, 64, 3, 1, 1, 1, True, False)]:
+        n, c, h, w, k, r, s, p, d, bias, relu = cfg
+        oc.conv_case(dev, n, c, h, w, k, r, s, p, d, bias=bias, relu=relu)
+    oc.conv_bn_case(dev, 4, 256, 23, 23, 1024, 1, 1, 0, 1, relu=False, residual=True, train=True)
+
+
 def _suite(dev, cases):
     for n, c, h, w, k, r, s, p, d, bias, relu in cases:
         oc.conv_case(dev, n, c, h, w, k, r, s, p, d, bias=bias, relu=relu)

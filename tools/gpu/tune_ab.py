@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch  # noqa: E402
 
-DEFAULTS = {"short_k": 512, "short_k_mult": 4, "tile_want": 1500, "db_min_k": 1024, "tail_split": 1, "tap_skip": 1, "tap_sort": 0, "wgrad_rect": 0, "wgrad_single": 0, "wgrad_per_cu": 2, "persist_tpw": 100,
+DEFAULTS = {"short_k": 512, "short_k_mult": 4, "tile_want": 1500, "db_min_k": 1024, "tail_split": 1, "tap_skip": 1, "tap_sort": 0, "occ64": 0, "wgrad_rect": 0, "wgrad_single": 0, "wgrad_per_cu": 2, "persist_tpw": 100,
             "persist_xcd": 0, "persistent": 0, "persist_grid": 0,
             # host-side variants (not library knobs): main_hi=1 runs the step on a HIGH-priority stream, so the critical path
             # (data gradients, BatchNorm) is dispatched ahead of the weight-gradient side stream (default priority)

@@ -364,8 +364,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
 //         publish raw accumulators, so the owner normally finds them ready.  Writers always have a lower block index
 //         than their reader and publish before they ever wait: no dependence on co-residency or dispatch gaps.
 // PERM:    GEMM rows are output pixels in tap-sorted order (a.perm), MODE 2 only.
-template <int BM, int BN, int MODE, int DBG = 0, int KT = 32, bool PERSIST = false, bool PERM = false>
-__global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_kernel(IgemmArgs a) {
+// MINOCC:  waves per SIMD the register allocation must leave room for (0 = the tile's default).  A short reduction
+//          makes a workgroup latency-bound (8 K slices: ~3.4 us of MFMA in a ~33 us life at K = 256), so the launch lives
+//          on occupancy: 78 VGPRs allow 6 workgroups per CU, 72 / 64 allow 7 / 8 (4 resp. 10 registers then spill, all
+//          outside the K loop).  64x64 single-buffer kernel only, knob "occ64".
+template <int BM, int BN, int MODE, int DBG = 0, int KT = 32, bool PERSIST = false, bool PERM = false, int MINOCC = 0>
+__global__ void __launch_bounds__(256, MINOCC ? MINOCC : ((BM == 128 && BN == 128) ? 2 : 3)) igemm_kernel(IgemmArgs a) {
     static_assert(!PERM || (MODE == 2 && !PERSIST), "tap-sorted rows: aligned fast path of the default form only");
     constexpr bool ALIGNED = MODE >= 1, FAST = MODE == 2;
     constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave along m / n
@@ -1756,6 +1760,7 @@ static int split_parts(int tiles, int Ktot) {
 // (5.7 % of the MACs at 23x23).  The permutation depends only on the geometry; it is built once on the host and
 // kept on the device.  Knob "tap_sort" (UP_TAP_SORT), default off until measured.
 static int g_tap_sort = env_int("UP_TAP_SORT", 0, 0);
+static int g_occ64 = env_int("UP_OCC64", 0, 0);   // 7 / 8: register budget of the 64x64 short-reduction kernel (see MINOCC)
 struct TapSortKey {
     int M, H, W, P, Q, taps, S, mul, off0, off0w, tapstep;
     bool operator<(const TapSortKey& o) const { return memcmp(this, &o, sizeof(*this)) < 0; }
@@ -1880,6 +1885,10 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
         kernel = igemm_kernel<BM, BN, 2, 64, 32, false, true>;
     else if (fast && db)
         kernel = igemm_kernel<BM, BN, 2, DB_VARIANT>;
+    else if (fast && BM == 64 && BN == 64 && g_occ64 == 7)
+        kernel = igemm_kernel<64, 64, 2, 64, 32, false, false, 7>;
+    else if (fast && BM == 64 && BN == 64 && g_occ64 == 8)
+        kernel = igemm_kernel<64, 64, 2, 64, 32, false, false, 8>;
     else if (fast)
         kernel = igemm_kernel<BM, BN, 2, 64>;
     else if (aligned)
@@ -1986,6 +1995,7 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "tail_split")) g_tail_split = value ? 1 : 0;
     else if (!strcmp(key, "tap_skip")) g_tap_skip = value ? 1 : 0;
     else if (!strcmp(key, "tap_sort")) g_tap_sort = value ? 1 : 0;
+    else if (!strcmp(key, "occ64") && (value == 0 || value == 7 || value == 8)) g_occ64 = value;
     else if (!strcmp(key, "wgrad_rect")) g_wgrad_rect = value ? 1 : 0;
     else if (!strcmp(key, "wgrad_single") && value >= 0 && value <= 2) g_wgrad_loop = value;
     else if (!strcmp(key, "wgrad_per_cu") && value > 0) g_wgrad_per_cu = value;
