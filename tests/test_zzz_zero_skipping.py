@@ -180,3 +180,39 @@ def test_tap_sort_model_gpu(tap_sort):
     dev = torch.device("cuda:0")
     assert mc.eval_case(dev, size=368, B=1, K=16, tol=1e-4) < 1e-4           # 23x23 top maps: the real WASP geometry
     mc.train_case(dev, size=96, B=4)
+
+
+def test_random_knob_combinations_emu(emu_backend):
+    """Random geometries x random combinations of every run-time kernel switch (tap_sort, wgrad_rect, occ64, tail_split,
+    persistent form with random grids): forward, data gradient, weight gradient and BatchNorm statistics stay within the
+    operator tolerances.  (The same generator ran over several hundred cases when the switches were written.)"""
+    import random
+    from unipose_amd import _C
+    lib = _C.lib()
+    rnd = random.Random(20260927)
+    try:
+        done = 0
+        while done < 24:
+            c, k = rnd.choice([32, 64, 96, 16]), rnd.choice([16, 24, 32, 72])
+            r = rnd.choice([1, 3, 3, 3, 5])
+            stride = rnd.choice([1, 1, 1, 2])
+            dil = rnd.choice([1, 1, 2, 3, 6]) if r > 1 else 1
+            pad = rnd.choice([0, (r // 2) * dil, (r // 2) * dil]) if r > 1 else 0
+            h, w, n = rnd.randint(4, 16), rnd.randint(4, 16), rnd.randint(1, 3)
+            if h + 2 * pad < dil * (r - 1) + 1 or w + 2 * pad < dil * (r - 1) + 1:
+                continue
+            for key, val in (("tap_sort", rnd.randint(0, 1)), ("wgrad_rect", rnd.randint(0, 1)),
+                             ("occ64", rnd.choice([0, 7, 8])), ("tail_split", rnd.randint(0, 1))):
+                _C.check(lib.up_conv_tune(key.encode(), val), key)
+            _C.check(lib.up_conv_set_persistent(rnd.choice([0, 0, 1]), rnd.choice([0, 1, 3, 7])), "persistent")
+            if done % 3 == 2 and r == 3 and stride == 1:
+                oc.conv_bn_case(emu_backend, n, c, h, w, k, r, stride, dil, dil, relu=rnd.random() < 0.5,
+                                residual=rnd.random() < 0.4, train=True, seed=done)
+            else:
+                oc.conv_case(emu_backend, n, c, h, w, k, r, stride, pad, dil, bias=rnd.random() < 0.3,
+                             relu=rnd.random() < 0.3, seed=done)
+            done += 1
+    finally:
+        for key, val in (("tap_sort", 0), ("wgrad_rect", 0), ("occ64", 0), ("tail_split", 1)):
+            lib.up_conv_tune(key.encode(), val)
+        lib.up_conv_set_persistent(0, 0)
