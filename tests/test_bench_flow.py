@@ -22,9 +22,9 @@ def _free_port():
 
 def _run(nproc, extra=()):
     env = dict(os.environ, UP_EMU_THREADS="4", OMP_NUM_THREADS="2")
-    # the emulator needs ~10 s per training step of the full ResNet-101: one warm-up and one timed step, no alt-math loop
-    # (that loop has no rank-dependent branch)
-    args = ["--gpus", str(nproc), "--steps", "1", "--warmup", "1", "--batch", "2", "--size", "32", "--dry-run-emu",
+    # the emulator needs ~10-20 s per training step of the full ResNet-101: no warm-up, one timed step (plus the two of the
+    # exclusive pass), no alt-math loop (that loop has no rank-dependent branch)
+    args = ["--gpus", str(nproc), "--steps", "1", "--warmup", "0", "--batch", "2", "--size", "32", "--dry-run-emu",
             "--no-alt-math", *extra]
     if nproc == 1:
         cmd = [sys.executable, "bench.py", *args]
@@ -40,14 +40,14 @@ def _run(nproc, extra=()):
 
 def test_bench_flow_two_ranks():
     out = _run(2)
-    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["warmup"] == 1
+    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["warmup"] == 0
     assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     assert "dry_run" in out and out["metric"].startswith("DRY RUN")
     assert "cpu_baseline" not in out                   # rank 0 at N = 1 only
 
 
 def test_bench_flow_single_rank_contract():
-    out = _run(1, ["--no-profile", "--warmup", "0", "--cpu-steps", "1", "--cpu-batch", "2"])
+    out = _run(1, ["--no-profile", "--cpu-steps", "1", "--cpu-batch", "2"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "cpu_baseline"):
         assert key in out, key

@@ -127,8 +127,7 @@ def test_tap_sort_ops_emu(emu_backend, tap_sort):
 
 
 def test_tap_sort_model_emu(emu_backend, tap_sort):
-    assert mc.eval_case(emu_backend, size=32, B=1) < 1e-4
-    mc.train_case(emu_backend, size=32)
+    assert mc.eval_case(emu_backend, size=64, B=1) < 1e-4       # (the train step runs with both knobs below)
 
 
 def _visits(n, h, w, c, k, r, dil, dgrad=0):
