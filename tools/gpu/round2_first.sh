@@ -16,3 +16,6 @@ tail -1 $OUT/tune_ab.log
 timeout 40 python bench.py --wasp-only > $OUT/wasp_default.json 2>/dev/null
 UP_TAP_SORT=1 timeout 40 python bench.py --wasp-only > $OUT/wasp_tap_sort.json 2>/dev/null
 cat $OUT/wasp_default.json $OUT/wasp_tap_sort.json
+# 4. weight-gradient split plan in both stream modes (an unexplained 252-vs-504 workgroup difference in round 1's CSVs)
+timeout 60 python tools/gpu/q_wgrad_live.py > $OUT/wgrad_plan.log 2>&1
+tail -12 $OUT/wgrad_plan.log
