@@ -112,6 +112,119 @@ def wasp_dilated_leg(dev, batch=32, hw=23, iters=20):
     return rows
 
 
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA (32x32x16)
+HBM_PEAK_TBPS = 8.0
+
+
+def make_workload(dev, lstm, K, B, S, T, seed, emu=False):
+    """Model + resident synthetic batch + the train step of the reference's loops (unipose.py:100-131 /
+    uniposeLSTM.py:116-133).  Returns (model, optimizer, step(reducer=None))."""
+    from unipose_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    if lstm:
+        from model.uniposeLSTM import unipose_lstm
+        model = unipose_lstm(num_classes=K).to(dev).train()
+        x = torch.randn(B, T, 3, S, S, generator=g).to(dev)
+        cm = torch.rand(B, T, 1, S, S, generator=g).to(dev)
+        t = torch.rand(B, T, K + 1, S // 8, S // 8, generator=g).to(dev)
+    else:
+        from model.unipose import unipose
+        model = unipose("MPII", num_classes=K).to(dev).train()
+        x = torch.randn(B, 3, S, S, generator=g).to(dev)
+        t = torch.rand(B, K + 1, S // 8, S // 8, generator=g).to(dev)
+    # unipose.py:72 (no weight decay); `fused=True` is torch's own single-kernel implementation of the same update
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=not emu)  # 70.3 vs 71.7 ms/step with the foreach default
+
+    def step(reducer=None):
+        opt.zero_grad(set_to_none=True)
+        if lstm:                                               # uniposeLSTM.py:116-133: T frames, ONE backward
+            hs = S // 8
+            heat = torch.zeros(K + 1, hs, hs, device=dev)
+            cell = torch.zeros(K + 2, hs, hs, device=dev)
+            hide = torch.zeros(K + 2, hs, hs, device=dev)
+            loss = 0.0
+            for j in range(T):
+                heat, cell, hide = model(x, cm, j, heat, hide, cell)
+                loss = loss + ops.mse_loss(heat, t[:, j])
+        else:
+            loss = ops.mse_loss(model(x), t)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        return loss
+    return model, opt, step
+
+
+def profile_rows(lib, steps_profiled=1):
+    nv = lib.up_profile_variants()
+    arr = (ctypes.c_double * (nv * 3))()
+    from unipose_amd import _C
+    _C.check(lib.up_profile_end(arr, nv), "profile_end")
+    rows = []
+    for i in range(nv):
+        n, ms, fl = arr[i * 3], arr[i * 3 + 1], arr[i * 3 + 2]
+        if n:
+            name = lib.up_profile_variant_name(i).decode()
+            peak = BF16_MFMA_PEAK_TFLOPS if "bf16" in name else F32_MFMA_PEAK_TFLOPS
+            rows.append({"kernel": name, "launches": int(n), "avg_ms": ms / n, "total_ms": ms,
+                         "tflops": fl / ms / 1e9, "peak_tflops": peak})
+    rows.sort(key=lambda r: -r["total_ms"])
+    return rows
+
+
+def other_config_leg(dev, name):
+    """A BASELINE.json configuration other than the headline one, timed by the same driver run (rank 0, N=1 only, a few
+    seconds each): its own throughput and the roofline of its dominant MFMA kernel from per-launch HIP events."""
+    from unipose_amd import _C, ops
+    lib = _C.lib()
+    if name == "lstm":        # configs[3]: UniPose-LSTM, K=13, 8 clips x 5 frames per GPU, BPTT
+        lstm, K, B, S, T, math, steps = True, 13, 8, 368, 5, "f32", 3
+        work = (f"UniPose-LSTM ResNet-101 (K={K}) train step: {T}-frame unroll, summed MSE, one backward (BPTT) + Adam, "
+                f"synthetic {S}x{S}, batch {B} clips/GPU (BASELINE.json configs[3])")
+        flop_img = FLOP_PER_IMAGE_FWD_BWD + 3 * 2 * 8.93e9
+    else:                     # configs[4]: 736x736, B=16/GPU, bf16 MFMA arithmetic
+        lstm, K, B, S, T, math, steps = False, 16, 16, 736, 1, "bf16", 3
+        work = (f"UniPose ResNet-101 (K={K}) train step: fwd + MSE + bwd + Adam, synthetic {S}x{S}, batch {B}/GPU, "
+                f"bf16 MFMA arithmetic (BASELINE.json configs[4])")
+        flop_img = FLOP_PER_IMAGE_FWD_BWD * 4.0
+    ops.set_conv_math(math)
+    try:
+        model, opt, step = make_workload(dev, lstm, K, B, S, T, seed=7)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)
+        dt = (time.perf_counter() - t0) / steps
+        lib.up_profile_begin()
+        step()
+        torch.cuda.synchronize(dev)
+        rows = profile_rows(lib)
+    finally:
+        ops.set_conv_math("f32")
+    ips = B * T / dt
+    out = {"config": {"workload": work, "per_gpu_batch": B, "input": [3, S, S], "frames": T},
+           "metric": "images/sec fwd+bwd" + (" (frames)" if lstm else ""), "value": round(ips, 2), "unit": "images/sec",
+           "ms_per_step": round(1e3 * dt, 3), "steps": steps, "warmup": 2,
+           "dtype": {"f32": "f32", "bf16": "bf16 (storage per DESIGN 3.3)"}[math],
+           "step_tflops": round(ips * flop_img / 1e12, 2)}
+    if rows:
+        top = rows[0]
+        tot_ms = sum(r["total_ms"] for r in rows)
+        out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": round(top["tflops"], 2),
+                           "peak": top["peak_tflops"], "unit": "TFLOP/s", "frac": round(top["tflops"] / top["peak_tflops"], 4),
+                           "traffic": None, "avg_launch_ms": round(top["avg_ms"], 4), "launches": top["launches"],
+                           "mfma_ms_per_step": round(tot_ms, 3),
+                           "by_kernel": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}
+                                         for r in rows[:6]]}
+    del model, opt, step
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,10 +245,8 @@ def main():
     ap.add_argument("--force-dp", action="store_true",
                     help="run the gradient exchange (RCCL all-reduce, buckets, hooks) even with one rank")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the extra split-bf16 timing loop")
-    ap.add_argument("--main-priority", default="default", choices=["default", "high"],
-                    help="high: run every step on a HIGH-priority HIP stream, so the critical path of backward (data "
-                         "gradients, BatchNorm) is dispatched ahead of the weight-gradient side stream (default "
-                         "priority).  Off until measured (tools/gpu/tune_ab.py main_hi=1)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the BASELINE configs[3] (LSTM) and configs[4] (736x736 bf16) legs appended at N=1")
     ap.add_argument("--wasp-only", action="store_true", help="only the WASP dilated-convolution roofline leg")
     ap.add_argument("--dry-run-emu", action="store_true",
                     help="TEST INFRASTRUCTURE (tests/test_bench_flow.py): walk the whole control flow of this script — warm-up, "
@@ -190,52 +301,18 @@ def main():
     lstm = args.model == "lstm"
     T = args.frames if lstm else 1
     torch.manual_seed(0)
-    g = torch.Generator(device="cpu").manual_seed(shard_seed(0, rank))
     if lstm:
-        from model.uniposeLSTM import unipose_lstm
         if args.num_classes == 16:
             K = 13                                             # Penn Action joints (configs[3])
         if args.batch == 32:
             B = 8
-        model = unipose_lstm(num_classes=K).to(dev).train()
-        x = torch.randn(B, T, 3, S, S, generator=g).to(dev)
-        cm = torch.rand(B, T, 1, S, S, generator=g).to(dev)
-        t = torch.rand(B, T, K + 1, S // 8, S // 8, generator=g).to(dev)
-    else:
-        model = unipose("MPII", num_classes=K).to(dev).train()
-        x = torch.randn(B, 3, S, S, generator=g).to(dev)
-        t = torch.rand(B, K + 1, S // 8, S // 8, generator=g).to(dev)
-    # unipose.py:72 (no weight decay); `fused=True` is torch's own single-kernel implementation of the same update
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=not emu)  # 70.3 vs 71.7 ms/step with the foreach default
+    model, opt, step1 = make_workload(dev, lstm, K, B, S, T, seed=shard_seed(0, rank), emu=emu)
     ops.manual_seed(shard_seed(0, rank))
     ops.set_conv_math(args.math)
     reducer = GradAllReducer(model, bucket_bytes=256 << 20, force=args.force_dp) if use_dist else None
 
-    hi_stream = None
-    if args.main_priority == "high" and not emu:
-        lo_p, hi_p = torch.cuda.Stream.priority_range()
-        hi_stream = torch.cuda.Stream(device=dev, priority=min(lo_p, hi_p))
-        hi_stream.wait_stream(torch.cuda.current_stream(dev))
-        torch.cuda.set_stream(hi_stream)       # everything below (steps, fences, events) runs on it
-
     def step():
-        opt.zero_grad(set_to_none=True)
-        if lstm:                                               # uniposeLSTM.py:116-133: T frames, ONE backward
-            hs = S // 8
-            heat = torch.zeros(K + 1, hs, hs, device=dev)
-            cell = torch.zeros(K + 2, hs, hs, device=dev)
-            hide = torch.zeros(K + 2, hs, hs, device=dev)
-            loss = 0.0
-            for j in range(T):
-                heat, cell, hide = model(x, cm, j, heat, hide, cell)
-                loss = loss + ops.mse_loss(heat, t[:, j])
-        else:
-            loss = ops.mse_loss(model(x), t)
-        loss.backward()
-        if reducer is not None:
-            reducer.finish()
-        opt.step()
-        return loss
+        return step1(reducer)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -266,22 +343,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    def profile_rows():
-        nv = _C.lib().up_profile_variants()
-        arr = (ctypes.c_double * (nv * 3))()
-        _C.check(_C.lib().up_profile_end(arr, nv), "profile_end")
-        rows = []
-        for i in range(nv):
-            n, ms, fl = arr[i * 3], arr[i * 3 + 1], arr[i * 3 + 2]
-            if n:
-                rows.append({"kernel": _C.lib().up_profile_variant_name(i).decode(), "launches": int(n),
-                             "avg_ms": ms / n, "total_ms": ms, "tflops": fl / ms / 1e9})
-        rows.sort(key=lambda r: -r["total_ms"])
-        return rows
-
     roofline = None
     if profile:
-        rows = profile_rows()
+        rows = profile_rows(_C.lib())
         if rows:
             top = rows[0]
             tot_ms = sum(r["total_ms"] for r in rows)
@@ -293,8 +357,8 @@ def main():
                         "all_mfma_kernels": {"achieved": round(tot_fl / tot_ms, 2),
                                              "frac": round(tot_fl / tot_ms / F32_MFMA_PEAK_TFLOPS, 4),
                                              "ms_per_step": round(tot_ms / ((args.steps + 3) // 4), 3)},
-                        "by_kernel": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}
-                                      for r in rows]}
+                        "by_kernel": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()
+                                       if k != "peak_tflops"} for r in rows]}
             # HBM traffic of the dominant kernel: PMC counters need their own rocprofv3 passes (profiles/pmc_traffic.json
             # records the last ones and how they were taken); null when no record matches
             try:
@@ -324,7 +388,7 @@ def main():
         fence()
         ops.ASYNC_WGRAD = was_async
         if profile:
-            xrows = profile_rows()
+            xrows = profile_rows(_C.lib())
             same = [r for r in xrows if roofline is not None and r["kernel"] == roofline["kernel"]]
             if same:
                 x_ms = sum(r["total_ms"] for r in xrows)
@@ -386,7 +450,6 @@ def main():
                                     f"{S}x{S}, batch {B}/GPU (BASELINE.json configs[1]; configs[2] for N>1)"),
                        "global_batch": world * B, "per_gpu_batch": B, "input": [3, S, S],
                        "parallelism": f"dp{world}", "optimizer": "torch.optim.Adam(lr=1e-4, fused=True)",
-                       "main_stream_priority": args.main_priority,
                        "arithmetic": {"f32": "fp32 MFMA 32x32x2 everywhere",
                                       "bf16x3": "fwd/dgrad: 3x bf16 MFMA 32x32x16 on (hi,lo) split operands; wgrad: fp32 MFMA",
                                       "bf16": "fwd/dgrad: bf16 MFMA 32x32x16; wgrad: fp32 MFMA"}[args.math]},
@@ -401,6 +464,14 @@ def main():
             out["roofline"] = roofline
         if alt:
             out["alt_math"] = alt
+        if world == 1 and not emu and not args.no_other_configs and not lstm and S == 368 and args.math == "f32":
+            out["other_configs"] = []
+            for name in ("lstm", "736_bf16"):
+                try:
+                    log(f"other config: {name}")
+                    out["other_configs"].append(other_config_leg(dev, name))
+                except Exception as e:      # a reporting extra must never cost the bench line
+                    log(f"other config {name} skipped: {type(e).__name__}: {e}")
         if world == 1 and not args.no_cpu_baseline and not lstm:
             log("cpu baseline (oracle on host cores)")
             out["cpu_baseline"] = cpu_baseline(K, S, args.cpu_batch, args.cpu_steps, args.cpu_threads)

@@ -106,10 +106,8 @@ int up_conv_get_persistent(void);
  * "short_k_mult": reductions shorter than short_k want short_k_mult / 2 times as many), "db_min_k"
  * (UP_DB_MIN_K) shortest reduction that uses the double-buffered K loop, "tail_split" (UP_TAIL_SPLIT), "tap_skip"
  * (UP_TAP_SKIP), "tap_sort" (UP_TAP_SORT: GEMM rows ordered by their set of live filter taps so that the tile-level tap
- * skipping becomes near exact; default off until measured), "occ64" (UP_OCC64: 7 or 8 = register budget of the 64x64 short-reduction kernel for that many waves per SIMD; those
- * launches are latency-bound and live on occupancy), "wgrad_per_cu" (UP_WGRAD_PER_CU), "wgrad_single" (UP_WGRAD_SINGLE: 0 = K-loop form of the weight gradient by
- * grid size, 1 = always the 32 KB single-buffer loop, which leaves LDS for the other stream's workgroups, 2 = always two
- * buffers), "wgrad_rect" (UP_WGRAD_RECT, see up_conv_wgrad_visits); persistent form: "persist_tpw" = tiles x100 a workgroup should own
+ * skipping becomes near exact; default on since the round-2 A/B), "wgrad_per_cu" (UP_WGRAD_PER_CU), "wgrad_rect" (UP_WGRAD_RECT, see
+ * up_conv_wgrad_visits; default on since the round-2 A/B); persistent form: "persist_tpw" = tiles x100 a workgroup should own
  * when the tile size is chosen (0 = the default form's tile rule), "persist_xcd" = XCD-aware workgroup numbering.
  * Change them only between steps: workspace sizes and the BatchNorm partial-row count follow the tile choice. */
 int up_conv_tune(const char* key, int value);

@@ -60,7 +60,30 @@ class relu_masks_from:
             raise AssertionError(f"{left} recorded ReLU outputs were not consumed: call order mismatch")
 
 
+_RELU_RECORD = None     # list collecting the oracle's own ReLU PRE-activations (NCHW), see relu_record()
+
+
+class relu_record:
+    """Collect the pre-activation of every ReLU the oracle evaluates, in call order (NCHW tensors, detached): lets a test
+    state HOW the sign patterns of the implementation under test differ from the oracle's own — how many elements, and
+    that each of them sits within round-off of zero — instead of only replaying them (relu_masks_from)."""
+
+    def __init__(self):
+        self.pre = []
+
+    def __enter__(self):
+        global _RELU_RECORD
+        _RELU_RECORD = self.pre
+        return self
+
+    def __exit__(self, *a):
+        global _RELU_RECORD
+        _RELU_RECORD = None
+
+
 def _relu(x):
+    if _RELU_RECORD is not None:
+        _RELU_RECORD.append(x.detach())
     if _RELU_MASKS is None:
         return F.relu(x)
     z = next(_RELU_MASKS)

@@ -47,6 +47,26 @@ def yardstick(ours, ref32, ref64, slack=10.0, floor=2e-5):
     return e_our <= slack * e_ref + floor, e_our, e_ref
 
 
+def relu_sign_agreement(ours_nhwc, oracle_pre_nchw, max_frac=1e-4, near=1e-4):
+    """The replayed sign patterns (relu_masks_from) must be the oracle's OWN patterns up to round-off ties: per ReLU site
+    the two masks may differ only where the oracle's pre-activation is within `near` x (the site's largest magnitude) of
+    zero, and over the whole network on fewer than `max_frac` of the elements.  Returns (differing, total)."""
+    assert len(ours_nhwc) == len(oracle_pre_nchw), (len(ours_nhwc), len(oracle_pre_nchw))
+    diff = tot = 0
+    for i, (z, pre) in enumerate(zip(ours_nhwc, oracle_pre_nchw)):
+        mo = z[..., :pre.shape[1]].permute(0, 3, 1, 2) > 0
+        assert mo.shape == pre.shape, (i, mo.shape, pre.shape)
+        d = mo != (pre > 0)
+        n = int(d.sum())
+        if n:
+            worst = float(pre[d].abs().max()) / max(float(pre.abs().max()), 1e-30)
+            assert worst < near, f"ReLU site {i}: a flipped element has |pre-activation| {worst:.2e} of the site maximum"
+        diff += n
+        tot += pre.numel()
+    assert diff <= max_frac * tot, f"{diff} of {tot} ReLU decisions differ from the oracle's own"
+    return diff, tot
+
+
 def train_case(dev, K=16, B=2, size=32, wseed=3, dropout_masks=False):
     """fwd + MSE + bwd in train mode; dropouts disabled (p=0) or injected; compares loss, output, every
     parameter gradient and all BN running statistics against the oracle (see `yardstick`)."""
@@ -82,9 +102,10 @@ def train_case(dev, K=16, B=2, size=32, wseed=3, dropout_masks=False):
         ops.set_relu_trace(None)
     trace = [z.cpu() for z in trace]
     # forward values: plain oracle;  gradients: oracle differentiating with OUR ReLU sign patterns
-    with torch.no_grad():
+    with torch.no_grad(), O.relu_record() as rec:
         y_plain = O.unipose_forward(O.clone_sd(sd), x, train=True, drop_masks=m32, p_drop=pdrop)
     assert O.max_rel(y.detach().cpu(), y_plain) < 1e-3
+    relu_sign_agreement(trace, rec.pre)
     with O.relu_masks_from(trace):
         y32 = O.unipose_forward(sd32, x, train=True, drop_masks=m32, p_drop=pdrop)
     l32 = torch.nn.functional.mse_loss(y32, t)

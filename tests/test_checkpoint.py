@@ -101,3 +101,44 @@ def test_fold_batchnorm(golden_dir, image_model):
                            sd[bn + ".running_var"], sd[bn + ".weight"], sd[bn + ".bias"], False, 0.0, mods[bn].eps)
         got = F.conv2d(x, folded[conv + ".weight"], folded[conv + ".bias"], **kw)
         assert torch.allclose(got, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max())), (conv, float((got - ref).abs().max()))
+
+
+def _folded_vs_unfolded(dev, size, K=14, B=1):
+    """fold_batchnorm() -> load_folded(): the BN-free network (one conv + bias (+ residual) (+ ReLU) kernel per layer) against
+    the unfolded eval network on the same device; returns (max_rel, folded output, unfolded output)."""
+    from oracle import unipose_oracle as O
+    sd = O.synth_state_dict(K, 1)
+    m = unipose("LSP", num_classes=K)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    folded = ckpt.fold_batchnorm(m)
+    f = ckpt.load_folded(unipose("LSP", num_classes=K).to(dev), folded)
+    assert sorted(f.state_dict().keys()) == sorted(folded.keys())
+    assert not any(isinstance(q, torch.nn.BatchNorm2d) for q in f.modules())
+    x = O.synth_input((B, 3, size, size), 11).to(dev)
+    with torch.no_grad():
+        y0, y1 = m(x), f(x)
+    with pytest.raises(NotImplementedError):
+        f(x.clone().requires_grad_(True))                 # inference export only
+    return O.max_rel(y1.cpu(), y0.cpu()), y1, y0
+
+
+def test_load_folded_runs_on_the_kernels_emu(emu_backend):
+    e, _, _ = _folded_vs_unfolded(emu_backend, 64)
+    assert e < 1e-5, e
+
+
+@pytest.mark.gpu
+def test_load_folded_gpu(golden_dir):
+    """N1 on the device: folded eval == unfolded eval (<= 1e-5) and == the reference's G1 golden (<= 1e-3, argmax exact)."""
+    import numpy as np
+    from oracle import unipose_oracle as O
+    from unipose_amd import ops
+    dev = torch.device("cuda:0")
+    e, y1, _ = _folded_vs_unfolded(dev, 368, K=14, B=2)
+    assert e < 1e-5, e
+    g = np.load(os.path.join(golden_dir, "g1_eval_368.npz"))
+    assert tuple(int(v) for v in g["meta"]) == (14, 1, 11)
+    assert O.max_rel(y1.cpu(), g["out"]) < 1e-3
+    _, _, idx = ops.heatmap_argmax(y1)
+    assert np.array_equal(idx.cpu().numpy(), g["argmax"])

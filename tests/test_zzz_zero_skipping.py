@@ -1,4 +1,5 @@
-"""Two optional forms that stop multiplying structural zeros of dilated / padded convolutions (both default off):
+"""Two forms that stop multiplying structural zeros of dilated / padded convolutions (both ON by default since the round-2 A/B,
+profiles/r02_a_knob_ab.txt; the plain forms stay reachable through up_conv_tune and are covered here too):
 * "tap_sort": GEMM rows of the forward / data-gradient kernel ordered by their set of live filter taps, so that the
   tile-level tap skipping becomes near exact;
 * "wgrad_rect": the weight-gradient reduction of a column tile runs over the live rectangle of its filter taps only.
@@ -30,7 +31,7 @@ def tap_sort():
     from unipose_amd import _C
     _C.check(_C.lib().up_conv_tune(b"tap_sort", 1), "conv_tune")
     yield
-    _C.check(_C.lib().up_conv_tune(b"tap_sort", 0), "conv_tune")
+    _C.check(_C.lib().up_conv_tune(b"tap_sort", 1), "conv_tune")
 
 
 @pytest.fixture
@@ -38,7 +39,18 @@ def wgrad_rect():
     from unipose_amd import _C
     _C.check(_C.lib().up_conv_tune(b"wgrad_rect", 1), "conv_tune")
     yield
-    _C.check(_C.lib().up_conv_tune(b"wgrad_rect", 0), "conv_tune")
+    _C.check(_C.lib().up_conv_tune(b"wgrad_rect", 1), "conv_tune")
+
+
+@pytest.fixture
+def plain_forms():
+    """Both switches off: rows in image order, weight-gradient reduction over every pixel."""
+    from unipose_amd import _C
+    for key in (b"tap_sort", b"wgrad_rect"):
+        _C.check(_C.lib().up_conv_tune(key, 0), "conv_tune")
+    yield
+    for key in (b"tap_sort", b"wgrad_rect"):
+        _C.check(_C.lib().up_conv_tune(key, 1), "conv_tune")
 
 
 WGRAD_CASES = CASES + [
@@ -63,6 +75,20 @@ def _wgrad_visits(n, h, w, c, k, r, dil, stride=1):
     return f.value
 
 
+def test_plain_forms_ops_emu(emu_backend, plain_forms):
+    for n, c, h, w, k, r, s, p, d, bias, relu in CASES[:6] + WGRAD_CASES[-7:-4]:
+        oc.conv_case(emu_backend, n, c, h, w, k, r, s, p, d, bias=bias, relu=relu)
+
+
+@pytest.mark.gpu
+def test_plain_forms_ops_gpu(plain_forms):
+    dev = torch.device("cuda:0")
+    for n, c, h, w, k, r, s, p, d, bias, relu in CASES + WGRAD_CASES[-7:]:
+        oc.conv_case(dev, n, c, h, w, k, r, s, p, d, bias=bias, relu=relu)
+    oc.conv_case(dev, 4, 256, 23, 23, 256, 3, 1, 18, 18)
+    assert mc.eval_case(dev, size=368, B=1, K=16, tol=1e-4) < 1e-4
+
+
 def test_wgrad_rect_ops_emu(emu_backend, wgrad_rect):
     for n, c, h, w, k, r, s, p, d, bias, relu in WGRAD_CASES:
         oc.conv_case(emu_backend, n, c, h, w, k, r, s, p, d, bias=bias, relu=relu)
@@ -79,39 +105,6 @@ def test_wgrad_visit_prediction(emu_backend):
     assert abs(_wgrad_visits(32, 23, 23, 256, 256, 3, 1) - (21 * 21 * 9 + 84 * 6 + 4 * 4) / (529 * 9.0)) < 1e-9
     assert _wgrad_visits(32, 23, 23, 256, 256, 1, 1) == 1.0
     assert 0.98 < _wgrad_visits(32, 92, 92, 64, 64, 3, 1) < 1.0      # two taps per 128-column tile: bounding rectangle
-
-
-@pytest.fixture
-def occ64():
-    from unipose_amd import _C
-
-    def set_(v):
-        _C.check(_C.lib().up_conv_tune(b"occ64", v), "conv_tune")
-    yield set_
-    set_(0)
-
-
-@pytest.mark.parametrize("occ", [7, 8])
-def test_occ64_ops_emu(emu_backend, occ64, occ):
-    """"occ64": the 64x64 short-reduction kernel compiled for 7 / 8 waves per SIMD (same source; on the emulator this only
-    exercises the dispatch, the register budget matters on the GPU)."""
-    occ64(occ)
-    for n, c, h, w, k, r, s, p, d, bias, relu in CASES[:3]:
-        oc.conv_case(emu_backend, n, c, h, w, k, r, s, p, d, bias=bias, relu=relu)
-    from unipose_amd import _C
-    assert _C.lib().up_conv_tune(b"occ64", 5) != 0
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("occ", [7, 8])
-def test_occ64_ops_gpu(occ64, occ):
-    occ64(occ)
-    dev = torch.device("cuda:0")
-    for cfg in [(4, 256, 23, 23, 1024, 1, 1, 0, 1, False, False), (4, 256, 23, 23, 256, 1, 1, 0, 1, False, True),
-                (2, 64, 46, 46, 64, 3, 1, 1, 1, True, False)]:
-        n, c, h, w, k, r, s, p, d, bias, relu = cfg
-        oc.conv_case(dev, n, c, h, w, k, r, s, p, d, bias=bias, relu=relu)
-    oc.conv_bn_case(dev, 4, 256, 23, 23, 1024, 1, 1, 0, 1, relu=False, residual=True, train=True)
 
 
 def _suite(dev, cases):
@@ -182,7 +175,7 @@ def test_tap_sort_model_gpu(tap_sort):
 
 
 def test_random_knob_combinations_emu(emu_backend):
-    """Random geometries x random combinations of every run-time kernel switch (tap_sort, wgrad_rect, occ64, tail_split,
+    """Random geometries x random combinations of every run-time kernel switch (tap_sort, wgrad_rect, tail_split,
     persistent form with random grids): forward, data gradient, weight gradient and BatchNorm statistics stay within the
     operator tolerances.  (The same generator ran over several hundred cases when the switches were written.)"""
     import random
@@ -201,7 +194,7 @@ def test_random_knob_combinations_emu(emu_backend):
             if h + 2 * pad < dil * (r - 1) + 1 or w + 2 * pad < dil * (r - 1) + 1:
                 continue
             for key, val in (("tap_sort", rnd.randint(0, 1)), ("wgrad_rect", rnd.randint(0, 1)),
-                             ("occ64", rnd.choice([0, 7, 8])), ("tail_split", rnd.randint(0, 1))):
+                             ("tail_split", rnd.randint(0, 1))):
                 _C.check(lib.up_conv_tune(key.encode(), val), key)
             _C.check(lib.up_conv_set_persistent(rnd.choice([0, 0, 1]), rnd.choice([0, 1, 3, 7])), "persistent")
             if done % 3 == 2 and r == 3 and stride == 1:
@@ -212,6 +205,6 @@ def test_random_knob_combinations_emu(emu_backend):
                              relu=rnd.random() < 0.3, seed=done)
             done += 1
     finally:
-        for key, val in (("tap_sort", 0), ("wgrad_rect", 0), ("occ64", 0), ("tail_split", 1)):
+        for key, val in (("tap_sort", 1), ("wgrad_rect", 1), ("tail_split", 1)):
             lib.up_conv_tune(key.encode(), val)
         lib.up_conv_set_persistent(0, 0)

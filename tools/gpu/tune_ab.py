@@ -12,11 +12,9 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch  # noqa: E402
 
-DEFAULTS = {"short_k": 512, "short_k_mult": 4, "tile_want": 1500, "db_min_k": 1024, "tail_split": 1, "tap_skip": 1, "tap_sort": 0, "occ64": 0, "wgrad_rect": 0, "wgrad_single": 0, "wgrad_per_cu": 2, "persist_tpw": 100,
-            "persist_xcd": 0, "persistent": 0, "persist_grid": 0,
-            # host-side variants (not library knobs): main_hi=1 runs the step on a HIGH-priority stream, so the critical path
-            # (data gradients, BatchNorm) is dispatched ahead of the weight-gradient side stream (default priority)
-            "main_hi": 0}
+DEFAULTS = {"short_k": 512, "short_k_mult": 4, "tile_want": 1500, "db_min_k": 1024, "tail_split": 1, "tap_skip": 1, "tap_sort": 1,
+            "wgrad_rect": 1, "wgrad_per_cu": 2, "persist_tpw": 100, "persist_xcd": 0, "persistent": 0, "persist_grid": 0}
+# (round 2, profiles/r02_a_knob_ab.txt: occ64, wgrad_single and the high-priority main stream measured no gain and were removed)
 
 
 def main():
@@ -39,17 +37,12 @@ def main():
     t = torch.rand(B, K + 1, S // 8, S // 8).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
 
-    state = {"main_hi": 0}
-    lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
-    hi_stream = torch.cuda.Stream(device=dev, priority=min(lo, hi))
-
     def apply(spec):
         kv = dict(DEFAULTS)
         if spec != "base":
             for item in spec.split("+"):
                 k, v = item.split("=")
                 kv[k] = int(v)
-        state["main_hi"] = kv.pop("main_hi")
         _C.check(lib.up_conv_set_persistent(kv.pop("persistent"), kv.pop("persist_grid")), "set_persistent")
         for k, v in kv.items():
             _C.check(lib.up_conv_tune(k.encode(), v), "tune " + k)
@@ -67,14 +60,8 @@ def main():
     def timed(n):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        if state["main_hi"]:
-            hi_stream.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(hi_stream):
-                for _ in range(n):
-                    step()
-        else:
-            for _ in range(n):
-                step()
+        for _ in range(n):
+            step()
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
 

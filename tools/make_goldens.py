@@ -311,6 +311,62 @@ def g9_multi_person():
     save("g9_multi_person.npz", **out)
 
 
+def g10_eval_736():
+    """G10: eval forward at BASELINE configs[4]'s resolution, K=16, B=1, 736x736 -> (1,17,92,92) (model/unipose.py:27-38)."""
+    m = ref_image_model(16, 5).eval()
+    x = O.synth_input((1, 3, 736, 736), 41)
+    with torch.no_grad():
+        y = m(x)
+    assert y.shape == (1, 17, 92, 92)
+    save("g10_eval_736.npz", out=y.numpy(), argmax=y.reshape(1, 17, -1).argmax(2).numpy().astype(np.int32),
+         meta=np.array([16, 5, 41]))
+
+
+def g11_train_b8():
+    """G11: a better-conditioned train step than G4 (B=8 at 128x128: 512 samples per channel in the 8x8 stages instead of
+    128): loss, output, gradients (same key list and sub-sampling as G4), running statistics — and, per gradient, the
+    relative L2 distance between the reference evaluated in fp32 and in fp64 (`noise/...`): the accuracy the fp32 reference
+    itself has on this input, which is what a tolerance for another fp32 implementation can be stated against."""
+    K, B = 16, 8
+    x = O.synth_input((B, 3, 128, 128), 43)
+    t = O.synth_input((B, K + 1, 16, 16), 44, "rand")
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        m = ref_image_model(K, 7).to(dt).train()
+        m.wasp.dropout.p = 0.0
+        m.decoder.last_conv[3].p = 0.0
+        m.decoder.last_conv[7].p = 0.0
+        y = m(x.to(dt))
+        loss = torch.nn.MSELoss()(y, t.to(dt))
+        loss.backward()
+        res[dt] = (m, y.detach(), loss.detach())
+    m, y, loss = res[torch.float32]
+    m64, y64, loss64 = res[torch.float64]
+    g, g64 = dict(m.named_parameters()), dict(m64.named_parameters())
+    keys = ["backbone.conv1.weight", "backbone.layer1.0.conv2.weight", "backbone.layer2.0.downsample.0.weight",
+            "backbone.layer3.5.bn2.weight", "backbone.layer3.5.bn2.bias", "backbone.layer3.11.conv1.weight",
+            "backbone.layer4.2.conv2.weight", "wasp.conv2.weight", "wasp.aspp2.atrous_conv.weight",
+            "wasp.global_avg_pool.1.weight", "decoder.conv1.weight", "decoder.last_conv.0.weight",
+            "decoder.last_conv.8.weight", "decoder.last_conv.8.bias"]
+    arrs = {}
+    for k in keys:
+        a, a64 = g[k].grad, g64[k].grad
+        arrs["noise/" + k] = np.array(float((a.double() - a64).norm() / a64.norm()))
+        a = a.numpy()
+        arrs["grad/" + k] = a[::SUB, ::SUB] if a.size > 100_000 else a
+    names = sorted(g)
+    arrs["grad_norms"] = np.array([g[k].grad.double().norm().item() if g[k].grad is not None else -1.0 for k in names])
+    arrs["grad_norms64"] = np.array([g64[k].grad.norm().item() if g64[k].grad is not None else -1.0 for k in names])
+    sd = m.state_dict()
+    for k in ("backbone.bn1", "backbone.layer3.5.bn2", "wasp.bn1", "wasp.global_avg_pool.2", "decoder.last_conv.5"):
+        arrs["rm/" + k] = sd[k + ".running_mean"].numpy()
+        arrs["rv/" + k] = sd[k + ".running_var"].numpy()
+    print("g11 fp32-vs-fp64 output", O.max_rel(y, y64.float()), "loss", float(loss), float(loss64))
+    print("g11 gradient noise (rel L2, fp32 vs fp64 reference):", {k: float(arrs["noise/" + k]) for k in keys})
+    save("g11_train_b8_128.npz", out=y.numpy(), out_noise=np.array(O.max_rel(y, y64.float())), loss=np.array(loss.item()),
+         loss64=np.array(loss64.item()), **arrs, meta=np.array([K, 7, 43, 44, B]))
+
+
 def g0_keys():
     """G0: the reference's state_dict contract (names, shapes, dtypes, order) for both models."""
     import json
@@ -324,8 +380,8 @@ def g0_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     fns = dict(g0=g0_keys, g1=g1_eval_full, g2=g2_taps, g4=g4_train, g5=g5_lstm, g6=g6_argmax, g7=g7_accuracy,
-               g8=g8_targets, g9=g9_multi_person)
+               g8=g8_targets, g9=g9_multi_person, g10=g10_eval_736, g11=g11_train_b8)
     for w in which:
         fns[w]()

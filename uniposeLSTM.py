@@ -38,6 +38,9 @@ def main(argv=None):
         trainer.training(epoch)
         if rank == 0:
             trainer.validation(epoch)
+        if world > 1:                 # the other ranks wait here, not inside the next epoch's first gradient all-reduce
+            import torch.distributed as dist
+            dist.barrier()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -8,11 +8,15 @@
 * ``fold_batchnorm``   — inference export: every convolution followed by a BatchNorm becomes weight + bias
   (``w * gamma / sqrt(var + eps)``, ``beta - mean * gamma / sqrt(var + eps)``), the arithmetic the inference fast path
   of ``ops.conv_bn_act`` applies in its convolution epilogue (``up_bn_eval_coeffs``).
+* ``load_folded``      — the consumer of that export: turns a freshly built model into the BN-free inference network
+  (every BatchNorm2d replaced by ``ops.FoldedBatchNorm``, convolutions gain a bias) whose ``state_dict`` IS the folded
+  dict; its forward runs one ``up_conv2d_fwd`` per layer with the bias (+ residual) (+ ReLU) epilogue.
 
 Host-side logic only: nothing here touches the device.
 """
 from __future__ import annotations
 
+import os
 import re
 from collections import OrderedDict
 from typing import Dict, Iterable, List, NamedTuple, Optional, Tuple
@@ -42,7 +46,7 @@ def load_checkpoint(model: nn.Module, source, skip_prefix: Optional[Iterable[str
     exactly like the reference's loop; ``skip_prefix`` is the ``prefix`` filter of ``uniposeLSTM.py:81-88``.
     A tensor whose shape differs from the model's (e.g. a 15-channel LSP head into a 17-channel MPII model) is skipped and
     reported — the reference would raise from ``load_state_dict`` at that point."""
-    src = _unwrap(torch.load(source, map_location=map_location) if isinstance(source, (str, bytes)) or
+    src = _unwrap(torch.load(source, map_location=map_location) if isinstance(source, (str, bytes, os.PathLike)) or
                   hasattr(source, "read") else source)
     skip = tuple(skip_prefix) if skip_prefix else ()
     own = model.state_dict()
@@ -122,3 +126,25 @@ def fold_batchnorm(model: nn.Module) -> "OrderedDict[str, torch.Tensor]":
         for leaf in ("weight", "bias", "running_mean", "running_var", "num_batches_tracked"):
             out.pop(f"{bn}.{leaf}", None)
     return out
+
+
+def load_folded(model: nn.Module, folded: Dict[str, torch.Tensor]) -> nn.Module:
+    """Consume ``fold_batchnorm``'s output: `model` (a freshly built ``unipose`` / ``unipose_lstm``, any device) becomes the
+    inference network without BatchNorm layers.  Every (convolution, BatchNorm) pair loses the BatchNorm (replaced by the
+    parameter-less ``ops.FoldedBatchNorm`` marker, so attribute paths and Sequential indices stay valid) and the
+    convolution gains ``.bias``; afterwards ``model.state_dict()`` has exactly the keys of `folded`, which is loaded
+    strictly.  The result is inference-only (``ops.conv_bn_act`` refuses to differentiate through it)."""
+    from . import ops
+    mods = dict(model.named_modules())
+    for conv, bn in conv_bn_pairs(model):
+        c = mods[conv]
+        if c.bias is None:
+            c.bias = nn.Parameter(torch.zeros(c.out_channels, dtype=c.weight.dtype, device=c.weight.device))
+        parent, _, leaf = bn.rpartition(".")
+        (mods[parent] if parent else model)._modules[leaf] = ops.FoldedBatchNorm()
+    missing, unexpected = model.load_state_dict(folded, strict=False)
+    if missing or unexpected:
+        raise KeyError(f"load_folded: missing {list(missing)[:4]} unexpected {list(unexpected)[:4]}")
+    for p in model.parameters():
+        p.requires_grad_(False)
+    return model.eval()

@@ -364,12 +364,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
 //         publish raw accumulators, so the owner normally finds them ready.  Writers always have a lower block index
 //         than their reader and publish before they ever wait: no dependence on co-residency or dispatch gaps.
 // PERM:    GEMM rows are output pixels in tap-sorted order (a.perm), MODE 2 only.
-// MINOCC:  waves per SIMD the register allocation must leave room for (0 = the tile's default).  A short reduction
-//          makes a workgroup latency-bound (8 K slices: ~3.4 us of MFMA in a ~33 us life at K = 256), so the launch lives
-//          on occupancy: 78 VGPRs allow 6 workgroups per CU, 72 / 64 allow 7 / 8 (4 resp. 10 registers then spill, all
-//          outside the K loop).  64x64 single-buffer kernel only, knob "occ64".
-template <int BM, int BN, int MODE, int DBG = 0, int KT = 32, bool PERSIST = false, bool PERM = false, int MINOCC = 0>
-__global__ void __launch_bounds__(256, MINOCC ? MINOCC : ((BM == 128 && BN == 128) ? 2 : 3)) igemm_kernel(IgemmArgs a) {
+// (Measured and removed in round 2: the 64x64 short-reduction kernel compiled for 7 / 8 waves per SIMD — 72 / 64 VGPRs with
+//  4 / 10 spills outside the K loop — was 0.2 / 0.7 ms per step SLOWER than the natural 78-VGPR build, profiles/r02_a_knob_ab.txt.)
+template <int BM, int BN, int MODE, int DBG = 0, int KT = 32, bool PERSIST = false, bool PERM = false>
+__global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_kernel(IgemmArgs a) {
     static_assert(!PERM || (MODE == 2 && !PERSIST), "tap-sorted rows: aligned fast path of the default form only");
     constexpr bool ALIGNED = MODE >= 1, FAST = MODE == 2;
     constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave along m / n
@@ -1650,8 +1648,7 @@ static int g_short_k_mult = env_int("UP_SHORT_K_MULT", 4, 1);     // they want g
 static int g_tail_split = env_int("UP_TAIL_SPLIT", 1, 0);
 static int g_tap_skip = env_int("UP_TAP_SKIP", 1, 0);
 static int g_wgrad_per_cu = env_int("UP_WGRAD_PER_CU", 2, 1);   // workgroups per CU a weight-gradient launch aims for
-static int g_wgrad_loop = env_int("UP_WGRAD_SINGLE", 0, 0);  // 0: by grid size; 1: always the 32 KB single-buffer loop; 2: always two buffers
-static int g_wgrad_rect = env_int("UP_WGRAD_RECT", 0, 0);      // weight-gradient reduction over live rectangles (see WgradRectKey)
+static int g_wgrad_rect = env_int("UP_WGRAD_RECT", 1, 0);      // weight-gradient reduction over live rectangles (see WgradRectKey); on since r02_a (-0.65 ms per step)
 static int cu_count();
 static int persist_occupancy(int bm, int bn) { return (bm == 128 && bn == 128) ? 2 : 3; }   // = __launch_bounds__
 // Largest tile that still yields ~6 workgroups per CU (the tail split evens out the remainder).  Short reductions
@@ -1758,9 +1755,9 @@ static int split_parts(int tiles, int Ktot) {
 // (classes with more live taps first, image order inside a class) makes the masks of a tile (nearly) uniform: the
 // tile-level skipping then drops (nearly) every dead tap — also the border taps of ordinary padded 3x3 convolutions
 // (5.7 % of the MACs at 23x23).  The permutation depends only on the geometry; it is built once on the host and
-// kept on the device.  Knob "tap_sort" (UP_TAP_SORT), default off until measured.
-static int g_tap_sort = env_int("UP_TAP_SORT", 0, 0);
-static int g_occ64 = env_int("UP_OCC64", 0, 0);   // 7 / 8: register budget of the 64x64 short-reduction kernel (see MINOCC)
+// kept on the device.  Knob "tap_sort" (UP_TAP_SORT).  Measured (profiles/r02_a_*): WASP d = 12 / 18 forward 0.166 -> 0.099 /
+// 0.157 -> 0.093 ms, whole step -0.45 ms: on by default.
+static int g_tap_sort = env_int("UP_TAP_SORT", 1, 0);
 struct TapSortKey {
     int M, H, W, P, Q, taps, S, mul, off0, off0w, tapstep;
     bool operator<(const TapSortKey& o) const { return memcmp(this, &o, sizeof(*this)) < 0; }
@@ -1885,10 +1882,6 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
         kernel = igemm_kernel<BM, BN, 2, 64, 32, false, true>;
     else if (fast && db)
         kernel = igemm_kernel<BM, BN, 2, DB_VARIANT>;
-    else if (fast && BM == 64 && BN == 64 && g_occ64 == 7)
-        kernel = igemm_kernel<64, 64, 2, 64, 32, false, false, 7>;
-    else if (fast && BM == 64 && BN == 64 && g_occ64 == 8)
-        kernel = igemm_kernel<64, 64, 2, 64, 32, false, false, 8>;
     else if (fast)
         kernel = igemm_kernel<BM, BN, 2, 64>;
     else if (aligned)
@@ -1995,9 +1988,7 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "tail_split")) g_tail_split = value ? 1 : 0;
     else if (!strcmp(key, "tap_skip")) g_tap_skip = value ? 1 : 0;
     else if (!strcmp(key, "tap_sort")) g_tap_sort = value ? 1 : 0;
-    else if (!strcmp(key, "occ64") && (value == 0 || value == 7 || value == 8)) g_occ64 = value;
     else if (!strcmp(key, "wgrad_rect")) g_wgrad_rect = value ? 1 : 0;
-    else if (!strcmp(key, "wgrad_single") && value >= 0 && value <= 2) g_wgrad_loop = value;
     else if (!strcmp(key, "wgrad_per_cu") && value > 0) g_wgrad_per_cu = value;
     else UP_REQUIRE(false, UP_ERR_INVALID, "conv_tune: unknown key '%s'", key);
     return UP_OK;
@@ -2516,7 +2507,7 @@ extern "C" int up_conv2d_bwd_weight(const up_conv_desc* d, const float* x, const
             // two LDS buffers (64 KB, two workgroups per CU) when the whole grid is resident at once; launches with more
             // workgroups (layers with many weight tiles) keep the 32 KB single-buffer loop and 3-4 per CU
             // (probe, 3x3 512->512: 115 vs 104 TFLOP/s; in the network the double buffer is 0.5 % faster overall)
-            const bool single = g_wgrad_loop ? g_wgrad_loop == 1 : a.nwg > 2 * cu_count();
+            const bool single = a.nwg > 2 * cu_count();
             a.rect = (g_wgrad_rect && (int64_t)d->N * d->P * d->Q < (1ll << 30)) ? wgrad_rect_device(d, p) : nullptr;
             if (a.rect && single) {
                 if (p.bm == 128 && p.bn == 128)

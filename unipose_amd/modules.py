@@ -172,8 +172,12 @@ class WASP(nn.Module):
         x2 = self.aspp2(x1)
         x3 = self.aspp3(x2)
         x4 = self.aspp4(x3)
-        # the SAME 1x1 weight twice on each branch, nothing in between (wasp.py:72-80)
-        br = [ops.conv_bias_act(ops.conv_bias_act(t, self.conv2), self.conv2) for t in (x1, x2, x3, x4)]
+        # the SAME 1x1 weight twice on each branch, nothing in between (wasp.py:72-80): the four branches are stacked
+        # along the batch axis, so the eight 1x1 convolutions are TWO implicit GEMMs over 4*B*H*W rows (2 + 2 + 2 launches
+        # per step instead of 8 + 8 + 8, each a full-occupancy shape: M = 67 712 at B = 32)
+        n = x1.shape[0]
+        ys = ops.conv_bias_act(ops.conv_bias_act(torch.cat((x1, x2, x3, x4), 0), self.conv2), self.conv2)
+        br = [ys[i * n:(i + 1) * n] for i in range(4)]
         g = ops.GlobalAvgPool.apply(x)
         if self.video:
             g = ops.conv_bias_act(g, self.global_avg_pool[1], relu=True)

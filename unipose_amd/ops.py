@@ -199,8 +199,8 @@ def _packed_bf16(weight: torch.Tensor, d: _C.ConvDesc):
     hit = _PACK16_CACHE.get(key)
     nf, nd = d.K * d.R * d.S * d.Cp, d.C * d.R * d.S * d.Kp
     if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2].shape[1] == nf and \
-            hit[3].shape[1] == nd:
-        return hit[2], hit[3]
+            hit[3].shape[1] == nd and hit[4] == weight.data_ptr() and hit[2].device == weight.device:
+        return hit[2], hit[3]                       # (`param.data = other` keeps the version but moves the storage)
     wf = torch.empty((2, nf), dtype=torch.int16, device=weight.device)
     wd = torch.empty((2, nd), dtype=torch.int16, device=weight.device)
     _C.check(_C.lib().up_pack_weights_bf16(C.byref(d), _dense(weight).data_ptr(), wf[0].data_ptr(), wf[1].data_ptr(),
@@ -208,7 +208,7 @@ def _packed_bf16(weight: torch.Tensor, d: _C.ConvDesc):
     if len(_PACK16_CACHE) > 4096:
         _PACK16_CACHE.clear()
     if isinstance(weight, torch.nn.Parameter):
-        _PACK16_CACHE[key] = (weakref.ref(weight), weight._version, wf, wd)
+        _PACK16_CACHE[key] = (weakref.ref(weight), weight._version, wf, wd, weight.data_ptr())
     return wf, wd
 
 
@@ -306,7 +306,7 @@ def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws
 # `wgrad_fence()` is called (the data-parallel reducer does before it reads a gradient).
 ASYNC_WGRAD = os.environ.get("UNIPOSE_SYNC_WGRAD", "") == ""   # development switch: weight gradients on the main stream
 _SIDE = {}
-_PASS = {"seen": set(), "cb": False}
+_PASS = {"seen": set(), "task": None}      # task: id of the autograd graph task whose end-of-backward callback is queued
 
 
 def _side_stream(dev):
@@ -327,7 +327,17 @@ def wgrad_fence(dev=None):
 def _end_of_backward():
     wgrad_fence()
     _PASS["seen"].clear()
-    _PASS["cb"] = False
+    _PASS["task"] = None
+
+
+def _graph_task_id():
+    """Id of the running autograd graph task (-1 outside a backward pass).  The engine DROPS queued callbacks when a
+    backward raises, so the callback state is keyed on the task: a new task always queues its own fence, whatever an
+    aborted earlier pass left behind."""
+    try:
+        return torch._C._current_graph_task_id()
+    except AttributeError:                 # (older torch: fall back to "a backward is running")
+        return 0
 
 
 def conv_bwd_weight(x, dy, weight, d, want_bias):
@@ -336,11 +346,17 @@ def conv_bwd_weight(x, dy, weight, d, want_bias):
         return conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias)
     dev = dy.device
     main, side = torch.cuda.current_stream(dev), _side_stream(dev)
-    if not _PASS["cb"]:
+    task = _graph_task_id()
+    if task == -1:                    # not inside an autograd backward pass: stay synchronous
+        return conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias)
+    if _PASS["task"] != task:
+        if _PASS["task"] is not None:             # an earlier backward died before its callback ran: fence for it now
+            wgrad_fence(dev)
+            _PASS["seen"].clear()
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
-            _PASS["cb"] = True
-        except RuntimeError:          # not inside an autograd backward pass: stay synchronous
+            _PASS["task"] = task
+        except RuntimeError:
             return conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias)
     side.wait_stream(main)
     with torch.cuda.stream(side):
@@ -391,7 +407,11 @@ class ConvBias(Function):
                      "relu_bwd")
             dy = g
         dx = conv_bwd_data_raw(dy, weight, ctx.d, x.shape, x.device) if ctx.needs_input_grad[0] else None
-        dw, db = conv_bwd_weight(x, dy, weight, ctx.d, ctx.has_bias)
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            dw, db = conv_bwd_weight(x, dy, weight, ctx.d, ctx.has_bias and ctx.needs_input_grad[2])
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.reshape(-1, dy.shape[3]).sum(0)[:weight.shape[0]]
         return dx, dw, db, None, None
 
 
@@ -465,7 +485,7 @@ class ConvBnAct(Function):
         dx = conv_bwd_data_raw(dy, weight, d, x.shape, x.device, add) if ctx.needs_input_grad[0] else add
         if ctx.link_out is not None and ctx.link_out.armed and dres is not None:
             ctx.link_out.grad, dres = dres, None          # the block's first convolution adds it to ITS dx
-        dw, _ = conv_bwd_weight(x, dy, weight, d, False)
+        dw = conv_bwd_weight(x, dy, weight, d, False)[0] if ctx.needs_input_grad[1] else None   # frozen weight: no launch
         return dx, dw, dgb[0], dgb[1], dres, None, None, None, None, None, None, None, None, None
 
 
@@ -518,9 +538,18 @@ class bn_counters:
         return False
 
 
+class FoldedBatchNorm(torch.nn.Identity):
+    """Stands where a BatchNorm2d stood after ``checkpoint.load_folded``: its affine map lives in the preceding
+    convolution's weight and bias (inference export).  No parameters, no buffers, inference only."""
+
+
 def conv_bn_act(x, conv, bn, relu=True, residual=None, link_in=None, link_out=None):
     """Dispatch on (bn.training, grad mode) exactly like nn.BatchNorm2d would.  link_in / link_out: see GradLink."""
     weight, cfg = conv.weight, ConvCfg(conv.stride[0], conv.padding[0], conv.dilation[0])
+    if isinstance(bn, FoldedBatchNorm):       # BN-folded network: ONE kernel, conv + bias (+ residual) (+ ReLU) epilogue
+        if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+            raise NotImplementedError("a BatchNorm-folded network is an inference export: run it under torch.no_grad()")
+        return conv_fwd_raw(x, weight, cfg, bias=conv.bias, residual=residual, relu=relu)[0]
     need_grad = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad or bn.weight.requires_grad)
     train = bn.training
     if not train and not need_grad:
@@ -530,7 +559,12 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, link_in=None, link_out=No
         bn.num_batches_tracked.add_(1)
         if _BN_COUNT["mode"] == "record":
             _BN_COUNT["seen"].append(bn.num_batches_tracked)
-    mom = 0.1 if bn.momentum is None else bn.momentum
+    if bn.momentum is not None:
+        mom = bn.momentum
+    elif train and bn.track_running_stats:      # nn.BatchNorm2d(momentum=None): cumulative average, factor 1 / batches seen
+        mom = 1.0 / float(max(int(bn.num_batches_tracked.item()), 1))      # (already bumped above / by bn_counters)
+    else:
+        mom = 0.0
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     return ConvBnAct.apply(x, weight, bn.weight, bn.bias, residual, rm, rv, cfg, relu, train, bn.eps, mom,
                            link_in, link_out)

@@ -219,6 +219,7 @@ class _TrainerBase:
     def _optim_step(self):
         if self.reducer is not None:
             self.reducer.finish()
+        ops.wgrad_fence(self.device)          # weight gradients of the side stream (also fenced at the end of backward)
         self.optimizer.step()
         self.iters += 1
 
