@@ -96,9 +96,11 @@ def test_736_b16_train_step_properties(math):
 
 
 def test_g11_train_b8_vs_reference_golden(golden_dir):
-    """Gradients of a B=8 train step against the genuine reference.  The fixture records, per gradient, how far the fp32
-    reference is from its own fp64 evaluation on this input (0.03 % ... 1.6 %: ReLU decisions at round-off flip between any
-    two evaluations); another fp32 implementation is held to 4x that distance (+1e-5 for the well-conditioned head)."""
+    """Gradients of a B=8 train step against the genuine reference.  The fixture records, per gradient, two yardsticks taken
+    with the reference itself (tools/make_goldens.py g11): its distance from its own fp64 evaluation (`noise`) and from the
+    same modules with BatchNorm evaluated by an exact-statistics formula (`alt`, i.e. "another correct fp32
+    implementation": 0.3 % ... 1.7 %, ReLU decisions at round-off flip between any two evaluations).  This implementation is
+    held to 2x the larger of the two (+1e-5 for the well-conditioned head); measured on the MI355X: 0.9 ... 1.3x."""
     from unipose_amd import ops
     g = np.load(os.path.join(golden_dir, "g11_train_b8_128.npz"))
     K, wseed, xseed, tseed, B = (int(v) for v in g["meta"])
@@ -125,10 +127,12 @@ def test_g11_train_b8_vs_reference_golden(golden_dir):
             if tuple(gr.shape) != tuple(ref.shape):
                 gr = gr[::4, ::4]
             l2 = float((gr.double() - ref).norm() / ref.norm())
-            noise = float(g["noise/" + k[5:]])
-            print(f"{k[5:]:45s} rel-L2 vs reference {l2:.2e}  (reference fp32 vs fp64: {noise:.2e}, ratio {l2 / noise:.2f})")
-            if l2 > 4.0 * noise + 1e-5:
-                worst[k] = (l2, noise)
+            noise, alt = float(g["noise/" + k[5:]]), float(g["alt/" + k[5:]])
+            bar = max(noise, alt)
+            print(f"{k[5:]:45s} rel-L2 vs reference {l2:.2e}  (reference fp32 vs fp64 {noise:.2e}, exact-statistics BN "
+                  f"variant {alt:.2e}; ratio to the larger {l2 / bar:.2f})")
+            if l2 > 2.0 * bar + 1e-5:
+                worst[k] = (l2, noise, alt)
     assert not worst, worst
     names = sorted(n for n, q in m.named_parameters())
     norms = np.array([p[n].grad.double().norm().item() if p[n].grad is not None else -1.0 for n in names])
