@@ -146,6 +146,11 @@ int up_conv2d_bwd_data_bf16(const up_conv_desc* d, const float* dy, const uint16
 size_t up_conv2d_bwd_weight_workspace(const up_conv_desc* d);
 int up_conv2d_bwd_weight(const up_conv_desc* d, const float* x, const float* dy, float* dw_oihw,
                          float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+/* The same on v_mfma_f32_32x32x16_bf16 (BASELINE configs[4] arithmetic: operands rounded to bf16 while they are staged,
+ * fp32 accumulation, fp32 split-K slabs and result; same workspace).  Falls back to the fp32 kernel for tensors of more
+ * than 2^31 elements. */
+int up_conv2d_bwd_weight_bf16(const up_conv_desc* d, const float* x, const float* dy, float* dw_oihw,
+                              float* dbias, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- BatchNorm (nn.BatchNorm2d, K7; every bnX site, e.g. resnet.py:11,14,16; wasp.py:11,53,61) ---- */
 /* eval: scale = g/sqrt(rv+eps), shift = b - rm*scale */

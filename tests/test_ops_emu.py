@@ -199,6 +199,46 @@ def test_conv_bf16_no_out_of_bounds(guard_pages, math):
         ops.set_conv_math("f32")
 
 
+WGRAD_BF16_CASES = [
+    # n, c,  h,  w,  k, r, stride, pad, dil, bias
+    (2, 16, 9, 9, 24, 3, 2, 1, 1, False),        # stride 2, 64x64 tile (K <= 64), rectangles in output coordinates
+    (1, 3, 20, 18, 8, 7, 2, 3, 1, False),        # stem 7x7 stride 2: Cp = 4, many taps per column tile
+    (1, 15, 12, 12, 8, 11, 1, 5, 1, True),       # 11x11 (Cp = 16), bias gradient
+    (2, 32, 8, 8, 20, 1, 2, 0, 1, False),        # 1x1 stride 2: no rectangle table (plain reduction domain)
+    (1, 32, 4, 4, 16, 3, 1, 5, 5, False),        # dilation > H: eight taps never live (empty rectangles)
+    (3, 32, 23, 23, 72, 3, 1, 18, 18, False),    # WASP geometry, three images, 128-row tile with K = 72 (ragged rows)
+    (2, 160, 7, 7, 136, 3, 1, 1, 1, False),      # two row tiles x several column tiles, channel counts not multiples of 128
+    (1, 64, 33, 35, 64, 1, 1, 0, 1, False),      # 1155 pixels: several slices + a ragged last one, split over workgroups
+]
+
+
+@pytest.mark.parametrize("cfg", WGRAD_BF16_CASES)
+def test_wgrad_bf16_kernel(emu_backend, cfg):
+    """Weight gradient on the bf16 MFMA (up_conv2d_bwd_weight_bf16: operands rounded to bf16 while staged, transposed by the
+    pack itself, fp32 accumulation): every geometry class of the fp32 kernel's tests, with and without live rectangles."""
+    from unipose_amd import _C, ops
+    n, c, h, w, k, r, s, p, d, bias = cfg
+    ops.set_conv_math("bf16")
+    try:
+        for rect in (1, 0):
+            _C.check(_C.lib().up_conv_tune(b"wgrad_rect", rect), "tune")
+            errs = oc.conv_case(emu_backend, n, c, h, w, k, r, s, p, d, bias=bias, tol=3e-2)
+            assert 1e-5 < errs["dw"] < 2e-2, errs      # bf16 rounding is visible, yet far inside the tolerance
+    finally:
+        _C.lib().up_conv_tune(b"wgrad_rect", 1)
+        ops.set_conv_math("f32")
+
+
+def test_wgrad_bf16_no_out_of_bounds(guard_pages):
+    from unipose_amd import ops
+    ops.set_conv_math("bf16")
+    try:
+        for n, c, h, w, k, r, s, p, d, bias in WGRAD_BF16_CASES[:6]:
+            oc.conv_case(torch.device("cpu"), n, c, h, w, k, r, s, p, d, bias=bias, tol=3e-2)
+    finally:
+        ops.set_conv_math("f32")
+
+
 def test_conv_bn_no_out_of_bounds(guard_pages):
     oc.conv_bn_case(torch.device("cpu"), 3, 8, 9, 9, 72, 3, 2, 1, 1, relu=True, residual=True, train=True)
 

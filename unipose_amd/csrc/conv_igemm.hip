@@ -39,14 +39,15 @@ namespace up {
 // up_profile_begin() arms it; every igemm/wgrad launch is then bracketed by two hipEvents on the
 // launch stream; up_profile_end() synchronises and returns, per kernel variant, {launches, total ms,
 // total algorithmic flops}.  Off by default: no events, no overhead.
-constexpr int PROF_VARIANTS = 16;
+constexpr int PROF_VARIANTS = 20;
 static const char* const kVariantNames[PROF_VARIANTS] = {
     "igemm_kernel<128,128,aligned>", "igemm_kernel<128,128,generic>", "igemm_kernel<64,128,aligned>",
     "igemm_kernel<64,128,generic>",  "igemm_kernel<128,64,aligned>",  "igemm_kernel<128,64,generic>",
     "igemm_kernel<64,64,aligned>",   "igemm_kernel<64,64,generic>",   "wgrad_kernel<128,128>",
     "wgrad_kernel<128,64>",          "wgrad_kernel<64,128>",          "wgrad_kernel<64,64>",
     "igemm_bf16_kernel<128,128>",    "igemm_bf16_kernel<64,128>",     "igemm_bf16_kernel<128,64>",
-    "igemm_bf16_kernel<64,64>"};
+    "igemm_bf16_kernel<64,64>",      "wgrad_bf16_kernel<128,128>",    "wgrad_bf16_kernel<128,64>",
+    "wgrad_bf16_kernel<64,128>",     "wgrad_bf16_kernel<64,64>"};
 #ifndef UP_EMU
 struct ProfRec {
     hipEvent_t a, b;
@@ -1436,6 +1437,201 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) wgrad_k
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradient on v_mfma_f32_32x32x16_bf16 (BASELINE configs[4] arithmetic: bf16 operands, fp32 accumulation).
+//   dW[co][col] = sum_m dY[m][co] * Xg[m][col],  col = tap * Cp + ci,  m = output pixel (the reduction index).
+// The MFMA wants, per lane, EIGHT CONSECUTIVE k of one row; here k is the pixel index while both operands are
+// channel-contiguous in HBM, i.e. each operand has to be transposed on its way to the fragment registers.  With fp32
+// data in HBM the bf16 conversion does it for free: a thread owns 4 channels x 8 consecutive pixels (eight 16-byte
+// loads), and v_cvt_pk_bf16_f32 packs (pixel 2j, pixel 2j+1) of ONE channel from two different load registers, so
+// four packs give the 16 bytes "8 pixels of channel c" that one ds_write_b128 puts into the [row][pixel] LDS image.
+// LDS image of a 32-pixel slice: (BM + BN) rows of 64 B + 16 B pad (80/16 = 5 odd: the 16-lane groups of the
+// ds_read_b128 fragment reads hit 16 distinct 16-B slots).  Tile row R holds channel (R % (BM/4)) * 4 + R / (BM/4):
+// with that order the ds_write_b128 of consecutive lanes (consecutive channel quads, same e) go to consecutive rows,
+// 20 dwords apart, i.e. to eight disjoint bank quads per 8-lane group instead of two.
+// Pipeline: as igemm_bf16_kernel — slice t in LDS buffer t&1, slices t+1 / t+2 in two register staging sets, the set
+// holding t+1 is converted and written to the other buffer mid-slice and refilled with t+3; one barrier per slice.
+// Reduction range: all N*P*Q pixels split over `splits` workgroups, or (a.rect) the live rectangle of the column
+// tile's filter taps; both are walked as (image, row, column) with an incremental carry, two FastDivs per slice.
+// Output: fp32 split-K slabs, summed by wgrad_reduce_kernel (unchanged).
+// ------------------------------------------------------------------------------------------
+constexpr int WB_KS = 32;           // pixels per slice
+constexpr int WB_RS = WB_KS * 2 + 16;   // LDS row stride in bytes
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradArgs a) {
+    static_assert(BM % 64 == 0 && BN % 64 == 0 && BM + BN <= 256, "one staging unit per thread, wave-uniform roles");
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int A_BYTES = BM * WB_RS, BUF = (BM + BN) * WB_RS;
+    constexpr int QA = BM / 4, QB = BN / 4;   // channel quads per tile side
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int logical = xcd_remap(blockIdx.x, a.nwg);
+    const int split = fdiv(logical, a.fTiles);
+    const int tile = logical - split * (int)a.fTiles.d;
+    const int mt = fdiv(tile, a.fNtn);
+    const int nt = tile - mt * a.ntn;
+    const int co0 = mt * BM, col0 = nt * BN;
+
+    // reduction domain of this workgroup: pixels [mbeg, mend) of a (images x rows x cols) box at (r_pl, r_ql)
+    int r_pl = 0, r_ql = 0, r_h = a.P, r_w = a.Q;
+    FastDiv r_fhw = a.fPQ, r_fw = a.fQ;
+    int mbeg = split * a.rows_per_split;
+    int mend = min(a.M, mbeg + a.rows_per_split);
+    if (a.rect) {
+        const int* rc = a.rect + WGRAD_RECT_INTS * nt;
+        r_pl = rc[0];
+        r_ql = rc[1];
+        r_h = rc[2];
+        r_w = rc[3];
+        r_fhw = FastDiv{(uint32_t)rc[4], (uint32_t)rc[5], (uint32_t)rc[6]};
+        r_fw = FastDiv{(uint32_t)rc[7], (uint32_t)rc[8], (uint32_t)rc[9]};
+        mbeg = split * rc[10];
+        mend = min(rc[11], mbeg + rc[10]);
+    }
+    const int r_hw = r_h * r_w;
+    const int nslices = mbeg < mend ? (mend - mbeg + WB_KS - 1) / WB_KS : 0;
+
+    // staging role of this thread: one unit = 4 channels (columns) x 8 consecutive pixels of the slice
+    const bool isA = tid < BM, isB = !isA && tid < BM + BN;
+    const int u = isA ? tid : tid - BM;
+    const int q4 = isA ? u % QA : u % QB;          // channel quad within the tile side
+    const int pg = isA ? u / QA : u / QB;          // pixel group 0..3
+    int ch_off = 0, b_dh = 0, b_dw = 0;
+    if (isA) {
+        ch_off = (co0 + q4 * 4 < a.ldy) ? co0 + q4 * 4 : 0;      // channels >= K are never stored: any valid address
+    } else {
+        const int col = (col0 + q4 * 4 < a.Ncols) ? col0 + q4 * 4 : 0;
+        const int tap = fdiv(col, a.fCp);
+        ch_off = col - tap * a.Cp;
+        const int r = fdiv(tap, a.fS);
+        b_dh = r * a.dil - a.pad;
+        b_dw = (tap - r * a.S) * a.dil - a.pad;
+    }
+    const float* src = isA ? a.dy : a.x;
+    // LDS destination of channel e of the quad: row e * Q + q4 of the side, pixel group pg
+    const int lds_dst = (isA ? 0 : A_BYTES) + q4 * WB_RS + pg * 16;
+    const int lds_estride = (isA ? QA : QB) * WB_RS;
+
+    float4 stX[8], stY[8];
+    unsigned okX = 0, okY = 0;
+#define UP_WB_STAGE(SFX)                                                                                          \
+    auto gload##SFX = [&](int slice_req) {                                                                        \
+        if (!(isA || isB)) return;                                                                                \
+        const int sl = slice_req < nslices ? slice_req : nslices - 1;                                             \
+        const int m0 = mbeg + sl * WB_KS + pg * 8;                                                                \
+        int img = fdiv(m0, r_fhw);                                                                                \
+        const int rem = m0 - img * r_hw;                                                                          \
+        int pi = fdiv(rem, r_fw);                                                                                 \
+        int qi = rem - pi * r_w;                                                                                  \
+        unsigned msk = 0;                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                           \
+            bool ok = m0 + j < mend;                                                                              \
+            int off;                                                                                              \
+            if (isA) {                                                                                            \
+                off = ((img * a.P + r_pl + pi) * a.Q + r_ql + qi) * a.ldy;                                        \
+            } else {                                                                                              \
+                const int h = (r_pl + pi) * a.stride + b_dh, w = (r_ql + qi) * a.stride + b_dw;                   \
+                ok = ok && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;                            \
+                off = ((img * a.H + h) * a.W + w) * a.ldx;                                                        \
+            }                                                                                                     \
+            st##SFX[j] = *reinterpret_cast<const float4*>(src + (ok ? off : 0) + ch_off);                         \
+            msk |= ok ? (1u << j) : 0u;                                                                           \
+            if (++qi == r_w) {                                                                                    \
+                qi = 0;                                                                                           \
+                if (++pi == r_h) {                                                                                \
+                    pi = 0;                                                                                       \
+                    ++img;                                                                                        \
+                }                                                                                                 \
+            }                                                                                                     \
+        }                                                                                                         \
+        ok##SFX = msk;                                                                                            \
+    };                                                                                                            \
+    auto lstore##SFX = [&](int buf) {                                                                             \
+        if (!(isA || isB)) return;                                                                                \
+        float4 v[8];                                                                                              \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] = keep_or_zero((ok##SFX >> j) & 1u, st##SFX[j]);      \
+        unsigned char* d = smem + buf * BUF + lds_dst;                                                            \
+        *reinterpret_cast<uint4*>(d) = make_uint4(pack_bf16x2(v[0].x, v[1].x), pack_bf16x2(v[2].x, v[3].x),      \
+                                                  pack_bf16x2(v[4].x, v[5].x), pack_bf16x2(v[6].x, v[7].x));      \
+        *reinterpret_cast<uint4*>(d + lds_estride) =                                                              \
+            make_uint4(pack_bf16x2(v[0].y, v[1].y), pack_bf16x2(v[2].y, v[3].y), pack_bf16x2(v[4].y, v[5].y),    \
+                       pack_bf16x2(v[6].y, v[7].y));                                                              \
+        *reinterpret_cast<uint4*>(d + 2 * lds_estride) =                                                          \
+            make_uint4(pack_bf16x2(v[0].z, v[1].z), pack_bf16x2(v[2].z, v[3].z), pack_bf16x2(v[4].z, v[5].z),    \
+                       pack_bf16x2(v[6].z, v[7].z));                                                              \
+        *reinterpret_cast<uint4*>(d + 3 * lds_estride) =                                                          \
+            make_uint4(pack_bf16x2(v[0].w, v[1].w), pack_bf16x2(v[2].w, v[3].w), pack_bf16x2(v[4].w, v[5].w),    \
+                       pack_bf16x2(v[6].w, v[7].w));                                                              \
+    };
+    UP_WB_STAGE(X)
+    UP_WB_STAGE(Y)
+#undef UP_WB_STAGE
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int a_rd = (wm * (BM / 2) + l31) * WB_RS + lh * 16;
+    const int b_rd = A_BYTES + (wn * (BN / 2) + l31) * WB_RS + lh * 16;
+#define UP_WB_BODY(SFX)                                                                                           \
+    auto body##SFX = [&](int kt) {                                                                                \
+        const unsigned char* base = smem + (kt & 1) * BUF;                                                        \
+        _Pragma("unroll") for (int s = 0; s < WB_KS / 16; ++s) {                                                  \
+            bf16x8 af[TM], bf[TN];                                                                                \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                        \
+                af[i] = *reinterpret_cast<const bf16x8*>(base + a_rd + i * 32 * WB_RS + s * 32);                  \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                        \
+                bf[j] = *reinterpret_cast<const bf16x8*>(base + b_rd + j * 32 * WB_RS + s * 32);                  \
+            if (s == 0) lstore##SFX((kt & 1) ^ 1);                                                                \
+            if (s == WB_KS / 16 - 1) gload##SFX(kt + 3);                                                          \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)         \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);            \
+        }                                                                                                         \
+        __syncthreads();                                                                                          \
+    };
+    UP_WB_BODY(X)
+    UP_WB_BODY(Y)
+#undef UP_WB_BODY
+
+    if (nslices > 0) {
+        gloadX(0);
+        lstoreX(0);
+        gloadX(1);
+        gloadY(2);
+        __syncthreads();
+        for (int kt = 0; kt < nslices; kt += 2) {
+            bodyX(kt);
+            if (kt + 1 < nslices) bodyY(kt + 1);
+        }
+    }
+
+    float* out = a.slab + (size_t)split * a.K * a.Ncols;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int cc = wn * (BN / 2) + j * 32 + l31;            // tile column -> GEMM column (see the LDS row order)
+        const int col = col0 + (cc % QB) * 4 + cc / QB;
+        if (col >= a.Ncols) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int co = co0 + (rr % QA) * 4 + rr / QA;
+                if (co < a.K) out[(size_t)co * a.Ncols + col] = acc[i][j][r];
+            }
+    }
+}
+
 // sum the split-K slabs and scatter into PyTorch OIHW
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* slab, float* dw, int splits, int K, int C,
                                                           int Cp, int taps, long long total4 /* K*taps*Cp / 4 */) {
@@ -2440,8 +2636,20 @@ extern "C" size_t up_conv2d_bwd_weight_workspace(const up_conv_desc* d) {
     return (size_t)p.splits * d->K * d->R * d->S * d->Cp * sizeof(float);
 }
 
+namespace up {
+static int conv2d_bwd_weight_impl(const up_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                                  void* workspace, size_t workspace_bytes, int bf16, void* stream);
+}
 extern "C" int up_conv2d_bwd_weight(const up_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
                                     void* workspace, size_t workspace_bytes, void* stream) {
+    return conv2d_bwd_weight_impl(d, x, dy, dw, dbias, workspace, workspace_bytes, 0, stream);
+}
+extern "C" int up_conv2d_bwd_weight_bf16(const up_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+    return conv2d_bwd_weight_impl(d, x, dy, dw, dbias, workspace, workspace_bytes, 1, stream);
+}
+static int up::conv2d_bwd_weight_impl(const up_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                                      void* workspace, size_t workspace_bytes, int bf16, void* stream) {
     if (int e = check_desc(d)) return e;
     UP_REQUIRE(x && dy && dw && workspace, UP_ERR_INVALID, "conv2d_bwd_weight: null pointer");
     UP_REQUIRE(d->ldy % 4 == 0, UP_ERR_INVALID, "conv2d_bwd_weight: ldy=%d must be a multiple of 4", d->ldy);
@@ -2479,7 +2687,23 @@ extern "C" int up_conv2d_bwd_weight(const up_conv_desc* d, const float* x, const
     a.fTiles = make_fastdiv(p.ntm * p.ntn);
     a.nwg = p.ntm * p.ntn * p.splits;
     dim3 grid(a.nwg);
-    {
+    // bf16-operand form (BASELINE configs[4] arithmetic): 32-bit element offsets inside the kernel
+    const bool use_bf16 = bf16 && (int64_t)d->N * d->H * d->W * d->ldx < (1ll << 31) &&
+                          (int64_t)d->N * d->P * d->Q * d->ldy < (1ll << 31);
+    if (use_bf16) {
+        const int v = (p.bm == 128 && p.bn == 128) ? 16 : (p.bm == 128 && p.bn == 64) ? 17 : (p.bm == 64 && p.bn == 128) ? 18 : 19;
+        ProfScope prof(v, 2.0 * (double)a.M * (double)d->K * (double)d->R * d->S * d->C, st, d->K, a.Ncols, a.M,
+                       a.nwg);
+        a.rect = (g_wgrad_rect && (int64_t)d->N * d->P * d->Q < (1ll << 30)) ? wgrad_rect_device(d, p) : nullptr;
+        if (p.bm == 128 && p.bn == 128)
+            hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128>), grid, dim3(256), 0, st, a);
+        else if (p.bm == 128 && p.bn == 64)
+            hipLaunchKernelGGL((wgrad_bf16_kernel<128, 64>), grid, dim3(256), 0, st, a);
+        else if (p.bm == 64 && p.bn == 128)
+            hipLaunchKernelGGL((wgrad_bf16_kernel<64, 128>), grid, dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((wgrad_bf16_kernel<64, 64>), grid, dim3(256), 0, st, a);
+    } else {
         const int v = (p.bm == 128 && p.bn == 128) ? 8 : (p.bm == 128 && p.bn == 64) ? 9 : (p.bm == 64 && p.bn == 128) ? 10 : 11;
         ProfScope prof(v, 2.0 * (double)a.M * (double)d->K * (double)d->R * d->S * d->C, st, d->K, a.Ncols, a.M,
                        a.nwg);

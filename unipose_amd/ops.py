@@ -170,10 +170,11 @@ def _packed(weight: torch.Tensor, d: _C.ConvDesc):
     return ps.get(weight, d)
 
 
-# Arithmetic of the forward / data-gradient convolutions (weight gradients always use the exact fp32 MFMA):
+# Arithmetic of the convolutions:
 #   0  exact fp32 (v_mfma_f32_32x32x2_f32)                                  -- default, parity configuration
-#   1  split-bf16: a*b ~= ah*bh + ah*bl + al*bh on bf16 MFMA, fp32-equivalent (2^-16 per product)
-#   2  plain bf16 operands, fp32 accumulation (BASELINE config 5)
+#   1  split-bf16: a*b ~= ah*bh + ah*bl + al*bh on bf16 MFMA, fp32-equivalent (2^-16 per product); weight gradients
+#      stay on the exact fp32 MFMA
+#   2  plain bf16 operands, fp32 accumulation (BASELINE config 5): forward, data gradient AND weight gradient
 # Layers whose padded channel count is not a multiple of 32 (stem, 15-channel ConvLSTM convs) stay exact.
 MATH_F32, MATH_BF16X3, MATH_BF16 = 0, 1, 2
 CONV_MATH = MATH_F32
@@ -291,8 +292,9 @@ def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws
     ws = workspace(x.device, need, ws_tag)
     dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)
     db = torch.empty(weight_shape[0], dtype=torch.float32, device=x.device) if want_bias else None
-    _C.check(_C.lib().up_conv2d_bwd_weight(C.byref(dd), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db),
-                                           ws.data_ptr(), ws.numel(), _stream(x)), "conv2d_bwd_weight")
+    fn = _C.lib().up_conv2d_bwd_weight_bf16 if CONV_MATH == MATH_BF16 else _C.lib().up_conv2d_bwd_weight
+    _C.check(fn(C.byref(dd), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel(),
+                _stream(x)), "conv2d_bwd_weight")
     return dw, db
 
 
