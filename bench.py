@@ -179,26 +179,28 @@ def other_config_leg(dev, name):
     from unipose_amd import _C, ops
     lib = _C.lib()
     if name == "lstm":        # configs[3]: UniPose-LSTM, K=13, 8 clips x 5 frames per GPU, BPTT
-        lstm, K, B, S, T, math, steps = True, 13, 8, 368, 5, "f32", 3
+        lstm, K, B, S, T, math, steps = True, 13, 8, 368, 5, "f32", 5
         work = (f"UniPose-LSTM ResNet-101 (K={K}) train step: {T}-frame unroll, summed MSE, one backward (BPTT) + Adam, "
                 f"synthetic {S}x{S}, batch {B} clips/GPU (BASELINE.json configs[3])")
         flop_img = FLOP_PER_IMAGE_FWD_BWD + 3 * 2 * 8.93e9
     else:                     # configs[4]: 736x736, B=16/GPU, bf16 MFMA arithmetic
-        lstm, K, B, S, T, math, steps = False, 16, 16, 736, 1, "bf16", 3
+        lstm, K, B, S, T, math, steps = False, 16, 16, 736, 1, "bf16", 5
         work = (f"UniPose ResNet-101 (K={K}) train step: fwd + MSE + bwd + Adam, synthetic {S}x{S}, batch {B}/GPU, "
                 f"bf16 MFMA arithmetic (BASELINE.json configs[4])")
         flop_img = FLOP_PER_IMAGE_FWD_BWD * 4.0
     ops.set_conv_math(math)
     try:
         model, opt, step = make_workload(dev, lstm, K, B, S, T, seed=7)
-        for _ in range(2):
+        for _ in range(3):          # the first steps of a new shape set allocate, build tap-order / rectangle tables, pack
             step()
         torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(steps):
+        times = []
+        for _ in range(steps):      # every step fenced; the MEDIAN is reported (a leg is only a handful of steps long, and
+            t0 = time.perf_counter()          # the caching allocator may still grow during the first of them)
             step()
-        torch.cuda.synchronize(dev)
-        dt = (time.perf_counter() - t0) / steps
+            torch.cuda.synchronize(dev)
+            times.append(time.perf_counter() - t0)
+        dt = sorted(times)[len(times) // 2]
         lib.up_profile_begin()
         step()
         torch.cuda.synchronize(dev)
@@ -208,7 +210,8 @@ def other_config_leg(dev, name):
     ips = B * T / dt
     out = {"config": {"workload": work, "per_gpu_batch": B, "input": [3, S, S], "frames": T},
            "metric": "images/sec fwd+bwd" + (" (frames)" if lstm else ""), "value": round(ips, 2), "unit": "images/sec",
-           "ms_per_step": round(1e3 * dt, 3), "steps": steps, "warmup": 2,
+           "ms_per_step": round(1e3 * dt, 3), "steps": steps, "warmup": 3, "timing": "median of individually fenced steps",
+           "ms_all_steps": [round(1e3 * v, 2) for v in times],
            "dtype": {"f32": "f32", "bf16": "bf16 (storage per DESIGN 3.3)"}[math],
            "step_tflops": round(ips * flop_img / 1e12, 2)}
     if rows:
@@ -221,7 +224,6 @@ def other_config_leg(dev, name):
                            "by_kernel": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}
                                          for r in rows[:6]]}
     del model, opt, step
-    torch.cuda.empty_cache()
     return out
 
 
