@@ -184,9 +184,10 @@ def other_config_leg(dev, name):
                 f"synthetic {S}x{S}, batch {B} clips/GPU (BASELINE.json configs[3])")
         flop_img = FLOP_PER_IMAGE_FWD_BWD + 3 * 2 * 8.93e9
     else:                     # configs[4]: 736x736, B=16/GPU, bf16 MFMA arithmetic
-        lstm, K, B, S, T, math, steps = False, 16, 16, 736, 1, "bf16", 5
-        work = (f"UniPose ResNet-101 (K={K}) train step: fwd + MSE + bwd + Adam, synthetic {S}x{S}, batch {B}/GPU, "
-                f"bf16 MFMA arithmetic (BASELINE.json configs[4])")
+        lstm, K, B, S, T, math, steps = False, 16, 16, 736, 1, "bf16s", 5
+        work = (f"UniPose ResNet-101 (K={K}) train step: fwd + MSE + bwd + Adam, synthetic {S}x{S}, batch {B}/GPU, bf16 "
+                f"storage (activations and their gradients bf16 in HBM behind the fp32 stem) + bf16 MFMA with fp32 "
+                f"accumulation; fp32 BatchNorm statistics, weights, weight gradients, Adam (BASELINE.json configs[4])")
         flop_img = FLOP_PER_IMAGE_FWD_BWD * 4.0
     ops.set_conv_math(math)
     try:
@@ -212,7 +213,7 @@ def other_config_leg(dev, name):
            "metric": "images/sec fwd+bwd" + (" (frames)" if lstm else ""), "value": round(ips, 2), "unit": "images/sec",
            "ms_per_step": round(1e3 * dt, 3), "steps": steps, "warmup": 3, "timing": "median of individually fenced steps",
            "ms_all_steps": [round(1e3 * v, 2) for v in times],
-           "dtype": {"f32": "f32", "bf16": "bf16 (storage per DESIGN 3.3)"}[math],
+           "dtype": {"f32": "f32", "bf16": "bf16 operands, fp32 storage", "bf16s": "bf16"}[math],
            "step_tflops": round(ips * flop_img / 1e12, 2)}
     if rows:
         top = rows[0]
@@ -237,7 +238,7 @@ def main():
     ap.add_argument("--num-classes", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch hipEvent timing")
-    ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "bf16"],
+    ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "bf16", "bf16s"],
                     help="arithmetic of the forward/data-gradient convolutions: exact fp32 MFMA (default, the parity "
                          "configuration), split-bf16 fp32-equivalent, or plain bf16 operands")
     ap.add_argument("--model", default="unipose", choices=["unipose", "lstm"],
@@ -443,7 +444,8 @@ def main():
             "value": round(ips, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16x3": "f32 (split-bf16 MFMA, fp32-equivalent)", "bf16": "bf16"}[args.math],
+            "dtype": {"f32": "f32", "bf16x3": "f32 (split-bf16 MFMA, fp32-equivalent)", "bf16": "bf16 operands, fp32 storage",
+                      "bf16s": "bf16"}[args.math],
             "data": "synthetic",
             "config": {"workload": (f"UniPose-LSTM ResNet-101 (K={K}) train step: {T}-frame unroll, summed MSE, one "
                                     f"backward (BPTT) + Adam, synthetic {S}x{S}, batch {B} clips/GPU (BASELINE.json "
@@ -454,7 +456,8 @@ def main():
                        "parallelism": f"dp{world}", "optimizer": "torch.optim.Adam(lr=1e-4, fused=True)",
                        "arithmetic": {"f32": "fp32 MFMA 32x32x2 everywhere",
                                       "bf16x3": "fwd/dgrad: 3x bf16 MFMA 32x32x16 on (hi,lo) split operands; wgrad: fp32 MFMA",
-                                      "bf16": "fwd/dgrad: bf16 MFMA 32x32x16; wgrad: fp32 MFMA"}[args.math]},
+                                      "bf16": "bf16 MFMA 32x32x16 (fwd, dgrad, wgrad), operands rounded from fp32 tensors",
+                                      "bf16s": "bf16 MFMA 32x32x16 (fwd, dgrad, wgrad) on bf16 tensors; fp32 stem"}[args.math]},
             "step_tflops_per_gpu": round(ips / world * (FLOP_PER_IMAGE_FWD_BWD + (3 * 2 * 8.93e9 if lstm else 0.0))
                                          * (S / 368.0) ** 2 / 1e12, 2),
             "loss": loss_val,

@@ -133,7 +133,7 @@ int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const float* w_dg
  * operands (BASELINE config 5 arithmetic).  Weights come as bf16 planes made by up_pack_weights_bf16 in the
  * [rows][R*S][padded channels] order of up_pack_weights.  Requires the padded reduction channel count (Cp forward,
  * Kp backward) to be a multiple of 32; otherwise UP_ERR_UNSUPPORTED (use the fp32 entry points). */
-typedef enum { UP_MATH_F32 = 0, UP_MATH_BF16X3 = 1, UP_MATH_BF16 = 2 } up_math;
+typedef enum { UP_MATH_F32 = 0, UP_MATH_BF16X3 = 1, UP_MATH_BF16 = 2, UP_MATH_BF16S = 3 } up_math;
 int up_pack_weights_bf16(const up_conv_desc* d, const float* w_oihw, uint16_t* fwd_hi, uint16_t* fwd_lo,
                          uint16_t* dgrad_hi, uint16_t* dgrad_lo, void* stream);
 int up_conv2d_fwd_bf16(const up_conv_desc* d, const float* x, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
@@ -151,6 +151,20 @@ int up_conv2d_bwd_weight(const up_conv_desc* d, const float* x, const float* dy,
  * than 2^31 elements. */
 int up_conv2d_bwd_weight_bf16(const up_conv_desc* d, const float* x, const float* dy, float* dw_oihw,
                               float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- bf16 STORAGE (BASELINE configs[4]: "bf16, 736x736, batch 16/GPU") -------------------------------------------------
+ * Activations and activation gradients live in HBM as bf16 (raw 16-bit patterns, NHWC, channel counts and pixel strides
+ * multiples of 8 = 16-byte channel groups; convolution outputs are padded to multiples of 32 channels so that every
+ * reduction is a whole number of 32-wide K slices); all arithmetic is fp32 (BatchNorm statistics, accumulators) or
+ * bf16 MFMA with fp32 accumulation; weights, weight gradients, BatchNorm parameters and the optimizer stay fp32.
+ *   - convolutions: up_conv2d_fwd_bf16 / up_conv2d_bwd_data_bf16 with math = UP_MATH_BF16S — x / y / residual / add are
+ *     then bf16 tensors passed through the same pointer arguments; up_conv2d_bwd_weight_bf16s below;
+ *   - every streaming operator has a `_t` twin taking the element type of its activation tensors (UP_DT_F32 / UP_DT_BF16);
+ *     the fp32 entry points above are the `_t` forms with UP_DT_F32.  The max-pool takes two types: it is where the
+ *     network leaves the fp32 stem (fp32 in, bf16 out; its backward bf16 in, fp32 out). */
+enum { UP_DT_F32 = 0, UP_DT_BF16 = 1 };
+int up_conv2d_bwd_weight_bf16s(const up_conv_desc* d, const void* x_bf16, const void* dy_bf16, float* dw_oihw,
+                               float* dbias, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- BatchNorm (nn.BatchNorm2d, K7; every bnX site, e.g. resnet.py:11,14,16; wasp.py:11,53,61) ---- */
 /* eval: scale = g/sqrt(rv+eps), shift = b - rm*scale */
@@ -176,6 +190,12 @@ int up_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const uint32_t
               float* dy, int lddy, float* dres, int lddres, float* dgamma, float* dbeta,
               float* workspace, size_t workspace_bytes, int64_t rows, int C, void* stream);
 size_t up_bn_bwd_workspace(int64_t rows, int C);
+int up_bn_apply_t(const void* y, int ldy, const float* scale, const float* shift, const void* residual, int ldr,
+                  int relu, void* z, int ldz, uint32_t* relu_bits, int64_t rows, int C, int dtype, void* stream);
+int up_bn_bwd_t(const void* dz, int lddz, const void* z, int ldz, const uint32_t* relu_bits, const void* y, int ldy,
+                const float* gamma, const float* mean, const float* invstd, int relu, int use_batch_stats,
+                void* dy, int lddy, void* dres, int lddres, float* dgamma, float* dbeta,
+                float* workspace, size_t workspace_bytes, int64_t rows, int C, int dtype, void* stream);
 
 /* ---- pointwise / data movement ---- */
 int up_relu_bwd(const float* dz, const float* z, float* dx, int64_t n, void* stream);              /* K8 */
@@ -202,6 +222,22 @@ int up_avgpool9s8_fwd(const float* x, float* y, int ldy, int coff, int N, int H,
 int up_dropout_fwd(const float* x, float* y, uint8_t* mask, const float* ext_mask, int64_t n,
                    float p, uint64_t seed, void* stream);
 int up_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, void* stream);
+/* `_t` twins of the data-movement operators (see "bf16 STORAGE" above) */
+int up_nchw_to_nhwc_t(const float* x, void* y, int N, int C, int H, int W, int ldy, int dt_out, void* stream);
+int up_nhwc_to_nchw_t(const void* x, int ldx, float* y, int N, int C, int H, int W, int dt_in, void* stream);
+int up_maxpool3s2_fwd_t(const void* x, int ldx, void* y, int ldy, uint8_t* idx, int N, int H, int W, int C, int P, int Q,
+                        int dt_in, int dt_out, void* stream);
+int up_maxpool3s2_bwd_t(const void* dy, int lddy, const uint8_t* idx, void* dx, int lddx, int N, int H, int W, int C, int P,
+                        int Q, int dt_in, int dt_out, void* stream);
+int up_bilinear_fwd_t(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, int P, int Q, int dtype,
+                      void* stream);
+int up_bilinear_bwd_t(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int C, int P, int Q, int dtype,
+                      void* stream);
+int up_gap_fwd_t(const void* x, int ldx, void* y, int N, int HW, int C, int dtype, void* stream);
+int up_gap_bwd_t(const void* dy, void* dx, int lddx, int N, int HW, int C, int dtype, void* stream);
+int up_dropout_fwd_t(const void* x, void* y, uint8_t* mask, const float* ext_mask, int64_t n, float p, uint64_t seed,
+                     int dtype, void* stream);
+int up_dropout_bwd_t(const void* dy, const uint8_t* mask, void* dx, int64_t n, float p, int dtype, void* stream);
 /* nn.MSELoss() mean reduction (unipose.py:70,117): loss[0] = mean((y-t)^2); bwd: dy = 2(y-t)/n * dloss[0] */
 int up_mse_fwd(const float* y, const float* t, float* loss, float* workspace, int64_t n, void* stream);
 int up_mse_bwd(const float* y, const float* t, const float* dloss, float* dy, int64_t n, void* stream);

@@ -1,0 +1,44 @@
+"""bf16 STORAGE (BASELINE configs[4]) on the CPU emulator: the same kernel sources, bf16 tensors in "HBM"."""
+import pytest
+
+import bf16s_cases as bc
+
+CONVS = [
+    # n, c,  h,  w,  k, r, stride, pad, dil, bias
+    (2, 64, 6, 5, 32, 1, 1, 0, 1, False),        # 1x1
+    (1, 64, 7, 7, 72, 3, 1, 1, 1, False),        # 3x3, K = 72 -> 96 physical channels, ragged N tile
+    (1, 64, 7, 7, 64, 3, 1, 3, 3, False),        # dilated, taps in the padding
+    (2, 64, 9, 9, 64, 3, 2, 1, 1, False),        # stride 2 (data gradient through the parity gather)
+    (1, 128, 5, 5, 64, 1, 1, 0, 1, False),       # several K slices per tap
+    (2, 256, 6, 6, 17, 1, 1, 0, 1, True),        # the network's last layer: K = 17 -> 32, bias
+    (3, 32, 23, 23, 48, 3, 1, 18, 18, False),    # WASP geometry; K = 48 -> 64 (decoder.conv1's width)
+    (2, 160, 7, 7, 136, 3, 1, 1, 1, False),      # two row tiles x several column tiles in the weight gradient
+]
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_bf16_storage(emu_backend, cfg):
+    bc.conv_case(emu_backend, *cfg)
+
+
+@pytest.mark.parametrize("cfg", [
+    (3, 32, 9, 9, 48, 3, 1, 1, 1, True, False, True),       # pad channels of y / z / dy stay zero (K = 48 -> 64)
+    (3, 64, 9, 9, 64, 3, 2, 1, 1, True, True, True),        # residual + ReLU
+    (4, 64, 5, 5, 96, 1, 1, 0, 1, False, True, True),       # downsample-like: no ReLU, residual
+    (2, 32, 7, 7, 32, 3, 1, 2, 2, True, False, False),      # eval: BatchNorm folded into the convolution epilogue
+])
+def test_conv_bn_bf16_storage(emu_backend, cfg):
+    n, c, h, w, k, r, s, p, d, relu, residual, train = cfg
+    bc.conv_bn_case(emu_backend, n, c, h, w, k, r, s, p, d, relu=relu, residual=residual, train=train)
+
+
+def test_small_ops_bf16_storage(emu_backend):
+    bc.small_ops_case(emu_backend)
+
+
+def test_model_eval_bf16_storage(emu_backend):
+    bc.model_eval_case(emu_backend)
+
+
+def test_model_train_bf16_storage(emu_backend):
+    bc.model_train_case(emu_backend)

@@ -51,11 +51,14 @@ SIGNATURES = {
     "up_conv2d_bwd_weight_workspace": (_sz, [_D]),
     "up_conv2d_bwd_weight": (_i, [_D, _p, _p, _p, _p, _p, _sz, _p]),
     "up_conv2d_bwd_weight_bf16": (_i, [_D, _p, _p, _p, _p, _p, _sz, _p]),
+    "up_conv2d_bwd_weight_bf16s": (_i, [_D, _p, _p, _p, _p, _p, _sz, _p]),
     "up_bn_eval_coeffs": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
     "up_bn_finalize": (_i, [_p, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "up_bn_apply": (_i, [_p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i64, _i, _p]),
     "up_bn_bwd": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _sz, _i64, _i, _p]),
     "up_bn_bwd_workspace": (_sz, [_i64, _i]),
+    "up_bn_apply_t": (_i, [_p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i64, _i, _i, _p]),
+    "up_bn_bwd_t": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _sz, _i64, _i, _i, _p]),
     "up_relu_bwd": (_i, [_p, _p, _p, _i64, _p]),
     "up_copy2d": (_i, [_p, _i, _p, _i, _i64, _i, _p]),
     "up_add2d": (_i, [_p, _i, _p, _i, _p, _i, _i64, _i, _p]),
@@ -70,6 +73,16 @@ SIGNATURES = {
     "up_avgpool9s8_fwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "up_dropout_fwd": (_i, [_p, _p, _p, _p, _i64, _f, _u64, _p]),
     "up_dropout_bwd": (_i, [_p, _p, _p, _i64, _f, _p]),
+    "up_nchw_to_nhwc_t": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "up_nhwc_to_nchw_t": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "up_maxpool3s2_fwd_t": (_i, [_p, _i, _p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "up_maxpool3s2_bwd_t": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "up_bilinear_fwd_t": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "up_bilinear_bwd_t": (_i, [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "up_gap_fwd_t": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
+    "up_gap_bwd_t": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    "up_dropout_fwd_t": (_i, [_p, _p, _p, _p, _i64, _f, _u64, _i, _p]),
+    "up_dropout_bwd_t": (_i, [_p, _p, _p, _i64, _f, _i, _p]),
     "up_mse_fwd": (_i, [_p, _p, _p, _p, _i64, _p]),
     "up_mse_bwd": (_i, [_p, _p, _p, _p, _i64, _p]),
     "up_mse_workspace": (_sz, [_i64]),

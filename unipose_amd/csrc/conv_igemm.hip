@@ -208,10 +208,12 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int BM, int BN, bool RES, bool CHECK, bool OMAP = false, bool PMAP = false>
+template <int BM, int BN, bool RES, bool CHECK, bool OMAP = false, bool PMAP = false, typename TO = float>
 __device__ __forceinline__ void igemm_store(const IgemmArgs& a, f32x16 (&acc)[BM / 64][BN / 64], int mrow0, int ncol0) {
     constexpr int TM = BM / 64, TN = BN / 64;
     const bool relu = a.relu != 0;
+    TO* const yo = reinterpret_cast<TO*>(a.y);                       // TO = bf16_t: bf16 storage (output and residual)
+    const TO* const rs = reinterpret_cast<const TO*>(a.residual);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = ncol0 + j * 32;
@@ -227,7 +229,7 @@ __device__ __forceinline__ void igemm_store(const IgemmArgs& a, f32x16 (&acc)[BM
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mb + (r & 3) + 8 * (r >> 2);
-                    res[r] = a.residual[(size_t)(!CHECK || m < a.M ? m : a.M - 1) * a.ldr + n];
+                    res[r] = ld1(rs + (size_t)(!CHECK || m < a.M ? m : a.M - 1) * a.ldr + n);
                 }
             }
 #pragma unroll
@@ -245,7 +247,7 @@ __device__ __forceinline__ void igemm_store(const IgemmArgs& a, f32x16 (&acc)[BM
                     pix = (size_t)(img * a.o_H + 2 * hc + a.o_ph) * a.o_W + 2 * wc + a.o_pw;
                 }
                 if (PMAP) pix = (size_t)a.perm[!CHECK || m < a.M ? m : a.M - 1];   // tap-sorted rows: scatter to the pixel
-                if (!CHECK || m < a.M) a.y[pix * a.ldy + n] = v;
+                if (!CHECK || m < a.M) st1(yo + pix * a.ldy + n, v);
             }
         }
     }
@@ -257,7 +259,7 @@ __device__ __forceinline__ void igemm_store(const IgemmArgs& a, f32x16 (&acc)[BM
 // Shared epilogue of the fp32 and bf16-operand kernels.  C/D map of the 32x32 MFMA (dtype independent):
 // column = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  `smem` must be free (all waves past their last
 // LDS read) and hold >= 2*(BN/64)*32*3 floats.
-template <int BM, int BN, bool PERM = false>
+template <int BM, int BN, bool PERM = false, typename TO = float>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[BM / 64][BN / 64], float* smem,
                                                int mt, int m0, int n0, int wm, int wn, int l31, int lh) {
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -343,14 +345,14 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
         return;
     }
     if (a.residual) {
-        if (full) igemm_store<BM, BN, true, false>(a, acc, mrow0, ncol0);
-        else igemm_store<BM, BN, true, true>(a, acc, mrow0, ncol0);
+        if (full) igemm_store<BM, BN, true, false, false, false, TO>(a, acc, mrow0, ncol0);
+        else igemm_store<BM, BN, true, true, false, false, TO>(a, acc, mrow0, ncol0);
     } else if (a.o_mode) {
-        if (full) igemm_store<BM, BN, false, false, true>(a, acc, mrow0, ncol0);
-        else igemm_store<BM, BN, false, true, true>(a, acc, mrow0, ncol0);
+        if (full) igemm_store<BM, BN, false, false, true, false, TO>(a, acc, mrow0, ncol0);
+        else igemm_store<BM, BN, false, true, true, false, TO>(a, acc, mrow0, ncol0);
     } else {
-        if (full) igemm_store<BM, BN, false, false>(a, acc, mrow0, ncol0);
-        else igemm_store<BM, BN, false, true>(a, acc, mrow0, ncol0);
+        if (full) igemm_store<BM, BN, false, false, false, false, TO>(a, acc, mrow0, ncol0);
+        else igemm_store<BM, BN, false, true, false, false, TO>(a, acc, mrow0, ncol0);
     }
 }
 
@@ -912,13 +914,6 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
 // ------------------------------------------------------------------------------------------
 #ifndef UP_EMU
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo_elem, float hi_elem) {   // RNE, v_cvt_pk_bf16_f32
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    bf16x2 v;
-    v[0] = (__bf16)lo_elem;
-    v[1] = (__bf16)hi_elem;
-    return __builtin_bit_cast(uint32_t, v);
-}
 #endif
 // (HIP's native uint2 / uint4 vector types: hand-made structs moved through reinterpret_cast stayed in scratch)
 // (hi, lo) bf16 pairs of two floats; element 0 in the low half-word
@@ -934,16 +929,20 @@ __device__ __forceinline__ void split_bf16x2(float a0, float a1, uint32_t& hi, u
 // the blocks sharing the SIMD) to land — the bf16 MFMA phase alone (768 cycles) is shorter than the memory
 // latency, which made the first single-stage version of this kernel latency-bound.  One barrier per slice.
 // Slice indices past the end are clamped (harmless reloads): the loop body is branch-free.
-template <int BM, int BN, int MODE, bool SPLIT, int KT = 32>
+// HS: bf16 STORAGE (BASELINE configs[4]): the activation operand, the residual / addend and the output are bf16 in HBM.  A
+// thread stages 16 bytes = 8 channels per row with no conversion at all (the fp32 form: 4 channels + two packs).
+template <int BM, int BN, int MODE, bool SPLIT, int KT = 32, bool HS = false>
 __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
     static_assert(MODE == 1 || MODE == 2, "bf16 kernels need channel counts that are multiples of the K slice");
+    static_assert(!(HS && SPLIT), "split-bf16 is an fp32-storage arithmetic");
     constexpr bool FAST = MODE == 2;
+    constexpr int EA = HS ? 8 : 4;                   // activation elements per 16-byte staging access
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int NP = SPLIT ? 2 : 1;
     constexpr int RS = KT * 2 + 16;                 // LDS row stride in bytes: 80 / 144, (RS/16) odd -> conflict-free
     constexpr int A_PLANE = BM * RS, B_PLANE = BN * RS;
     constexpr int BUF = NP * (A_PLANE + B_PLANE);
-    constexpr int Q4 = KT / 4, RPA = 256 / Q4;      // A staging: RPA rows x Q4 float4 per pass
+    constexpr int Q4 = KT / EA, RPA = 256 / Q4;     // A staging: RPA rows x Q4 16-byte chunks per pass
     constexpr int C8 = KT / 8, RPB = 256 / C8;      // B staging: RPB rows x C8 chunks (8 bf16) per pass and plane
     constexpr int PA = BM / RPA;
     constexpr int PB = BN / RPB;
@@ -1001,8 +1000,8 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
     const int spt = a.Cp / KT;                      // K slices per filter tap
     const FastDiv fspt = a.fSpt;
 
-    // two register staging sets
-    float4 raX[PA], raY[PA];
+    // two register staging sets (16 bytes per row and thread: four fp32 or eight bf16 channels)
+    uint4 raX[PA], raY[PA];
     // B staging registers are named scalars (PB <= 2): as uint4 arrays one set stayed in scratch memory
     static_assert(PB <= 2, "two weight rows per thread at most");
     uint4 rbhX0, rbhX1, rblX0, rblX1, rbhY0, rbhY1, rblY0, rblY1;
@@ -1015,7 +1014,7 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
     auto gload##SFX = [&](int kt_req) {                                                                              \
         const int kt = kt_req < nk ? kt_req : nk - 1;                                                                \
         const int tap = fdiv(kt, fspt);                                                                              \
-        const int ci = (kt - tap * spt) * KT + kq * 4;                                                               \
+        const int ci = (kt - tap * spt) * KT + kq * EA;                                                              \
         int r = fdiv(tap, a.fS);                                                                                     \
         int sx = tap - r * a.S;                                                                                      \
         int dh = r * a.tapstep, dw = sx * a.tapstep;                                                                 \
@@ -1025,7 +1024,8 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
             _Pragma("unroll") for (int i = 0; i < PA; ++i) {                                                         \
                 const bool ok = (tmask[i] >> tap) & 1u;                                                              \
                 const int off = ok ? roff[i] + delta : 0;                                                            \
-                ra##SFX[i] = *reinterpret_cast<const float4*>(a.x + off);                                            \
+                ra##SFX[i] = HS ? *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.x) + off)        \
+                                : *reinterpret_cast<const uint4*>(a.x + off);                                        \
                 msk |= ok ? (1u << i) : 0u;                                                                          \
             }                                                                                                        \
         } else {                                                                                                     \
@@ -1036,7 +1036,8 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
                 w >>= a.divshift;                                                                                    \
                 ok = ok && h < a.H && w < a.W;                                                                       \
                 size_t off = ok ? (size_t)(ib[i] + h * a.W + w) * a.ldx + ci : (size_t)0;                            \
-                ra##SFX[i] = *reinterpret_cast<const float4*>(a.x + off);                                            \
+                ra##SFX[i] = HS ? *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.x) + off)        \
+                                : *reinterpret_cast<const uint4*>(a.x + off);                                        \
                 msk |= ok ? (1u << i) : 0u;                                                                          \
             }                                                                                                        \
         }                                                                                                            \
@@ -1053,18 +1054,26 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
         unsigned char* As = smem + buf * BUF;                                                                        \
         unsigned char* Bs = As + NP * A_PLANE;                                                                       \
         _Pragma("unroll") for (int i = 0; i < PA; ++i) {                                                             \
-            const float4 v = keep_or_zero((ok##SFX >> i) & 1u, ra##SFX[i]);                                          \
-            uint2 hi, lo;                                                                                            \
-            if (SPLIT) {                                                                                             \
-                split_bf16x2(v.x, v.y, hi.x, lo.x);                                                                  \
-                split_bf16x2(v.z, v.w, hi.y, lo.y);                                                                  \
+            const bool keep = (ok##SFX >> i) & 1u;                                                                   \
+            const uint4 u = ra##SFX[i];                                                                              \
+            if constexpr (HS) {                                                                                      \
+                *reinterpret_cast<uint4*>(As + (i * RPA + lrow) * RS + kq * 16) =                                    \
+                    make_uint4(keep ? u.x : 0u, keep ? u.y : 0u, keep ? u.z : 0u, keep ? u.w : 0u);                  \
             } else {                                                                                                 \
-                hi.x = pack_bf16x2(v.x, v.y);                                                                        \
-                hi.y = pack_bf16x2(v.z, v.w);                                                                        \
+                const float4 v = keep_or_zero(keep, make_float4(__uint_as_float(u.x), __uint_as_float(u.y),          \
+                                                                __uint_as_float(u.z), __uint_as_float(u.w)));        \
+                uint2 hi, lo;                                                                                        \
+                if (SPLIT) {                                                                                         \
+                    split_bf16x2(v.x, v.y, hi.x, lo.x);                                                              \
+                    split_bf16x2(v.z, v.w, hi.y, lo.y);                                                              \
+                } else {                                                                                             \
+                    hi.x = pack_bf16x2(v.x, v.y);                                                                    \
+                    hi.y = pack_bf16x2(v.z, v.w);                                                                    \
+                }                                                                                                    \
+                unsigned char* d = As + (i * RPA + lrow) * RS + kq * 8;                                              \
+                *reinterpret_cast<uint2*>(d) = hi;                                                                   \
+                if (SPLIT) *reinterpret_cast<uint2*>(d + A_PLANE) = lo;                                              \
             }                                                                                                        \
-            unsigned char* d = As + (i * RPA + lrow) * RS + kq * 8;                                                  \
-            *reinterpret_cast<uint2*>(d) = hi;                                                                       \
-            if (SPLIT) *reinterpret_cast<uint2*>(d + A_PLANE) = lo;                                                  \
         }                                                                                                            \
         {                                                                                                            \
             unsigned char* d = Bs + brow * RS + bch * 16;                                                            \
@@ -1134,7 +1143,8 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
         bodyX(kt);
         if (kt + 1 < nk) bodyY(kt + 1);
     }
-    igemm_epilogue<BM, BN>(a, acc, reinterpret_cast<float*>(smem), mt, m0, n0, wm, wn, l31, lh);
+    igemm_epilogue<BM, BN, false, std::conditional_t<HS, bf16_t, float>>(a, acc, reinterpret_cast<float*>(smem), mt, m0, n0,
+                                                                         wm, wn, l31, lh);
 }
 
 // OIHW fp32 -> bf16 hi / lo planes in the [rows][tap][channel] order of pack_fwd / pack_dgrad
@@ -1455,15 +1465,24 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) wgrad_k
 // tile's filter taps; both are walked as (image, row, column) with an incremental carry, two FastDivs per slice.
 // Output: fp32 split-K slabs, summed by wgrad_reduce_kernel (unchanged).
 // ------------------------------------------------------------------------------------------
-constexpr int WB_KS = 32;           // pixels per slice
-constexpr int WB_RS = WB_KS * 2 + 16;   // LDS row stride in bytes
+// HS = bf16 storage (activations are bf16 in HBM): a staging unit is 8 channels x 8 pixels (eight 16-byte loads again),
+// the 8x8 transpose of 16-bit elements is 32 v_perm-class operations (low / high half-word merges of two registers), a
+// slice is 64 pixels so that every thread still owns exactly one unit, and tile row R holds channel
+// (R % (BM/8)) * 8 + R / (BM/8).
+template <bool HS>
+struct WbGeom {
+    static constexpr int E = HS ? 8 : 4;        // channels per staging unit
+    static constexpr int KS = HS ? 64 : 32;     // pixels per slice
+    static constexpr int RS = KS * 2 + 16;      // LDS row stride in bytes: 80 / 144, (RS/16) odd
+};
 
-template <int BM, int BN>
+template <int BM, int BN, bool HS = false>
 __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradArgs a) {
     static_assert(BM % 64 == 0 && BN % 64 == 0 && BM + BN <= 256, "one staging unit per thread, wave-uniform roles");
+    constexpr int E = WbGeom<HS>::E, WB_KS = WbGeom<HS>::KS, WB_RS = WbGeom<HS>::RS;
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int A_BYTES = BM * WB_RS, BUF = (BM + BN) * WB_RS;
-    constexpr int QA = BM / 4, QB = BN / 4;   // channel quads per tile side
+    constexpr int QA = BM / E, QB = BN / E;   // channel groups per tile side
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
 
     const int tid = threadIdx.x;
@@ -1497,16 +1516,16 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradArgs a) {
     const int r_hw = r_h * r_w;
     const int nslices = mbeg < mend ? (mend - mbeg + WB_KS - 1) / WB_KS : 0;
 
-    // staging role of this thread: one unit = 4 channels (columns) x 8 consecutive pixels of the slice
+    // staging role of this thread: one unit = E channels (columns) x 8 consecutive pixels of the slice
     const bool isA = tid < BM, isB = !isA && tid < BM + BN;
     const int u = isA ? tid : tid - BM;
-    const int q4 = isA ? u % QA : u % QB;          // channel quad within the tile side
-    const int pg = isA ? u / QA : u / QB;          // pixel group 0..3
+    const int qg = isA ? u % QA : u % QB;          // channel group within the tile side
+    const int pg = isA ? u / QA : u / QB;          // pixel group of the slice
     int ch_off = 0, b_dh = 0, b_dw = 0;
     if (isA) {
-        ch_off = (co0 + q4 * 4 < a.ldy) ? co0 + q4 * 4 : 0;      // channels >= K are never stored: any valid address
+        ch_off = (co0 + qg * E < a.ldy) ? co0 + qg * E : 0;      // channels >= K are never stored: any valid address
     } else {
-        const int col = (col0 + q4 * 4 < a.Ncols) ? col0 + q4 * 4 : 0;
+        const int col = (col0 + qg * E < a.Ncols) ? col0 + qg * E : 0;
         const int tap = fdiv(col, a.fCp);
         ch_off = col - tap * a.Cp;
         const int r = fdiv(tap, a.fS);
@@ -1514,11 +1533,11 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradArgs a) {
         b_dw = (tap - r * a.S) * a.dil - a.pad;
     }
     const float* src = isA ? a.dy : a.x;
-    // LDS destination of channel e of the quad: row e * Q + q4 of the side, pixel group pg
-    const int lds_dst = (isA ? 0 : A_BYTES) + q4 * WB_RS + pg * 16;
+    // LDS destination of channel e of the group: row e * Q + qg of the side, pixel group pg
+    const int lds_dst = (isA ? 0 : A_BYTES) + qg * WB_RS + pg * 16;
     const int lds_estride = (isA ? QA : QB) * WB_RS;
 
-    float4 stX[8], stY[8];
+    uint4 stX[8], stY[8];
     unsigned okX = 0, okY = 0;
 #define UP_WB_STAGE(SFX)                                                                                          \
     auto gload##SFX = [&](int slice_req) {                                                                        \
@@ -1540,7 +1559,9 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradArgs a) {
                 ok = ok && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;                            \
                 off = ((img * a.H + h) * a.W + w) * a.ldx;                                                        \
             }                                                                                                     \
-            st##SFX[j] = *reinterpret_cast<const float4*>(src + (ok ? off : 0) + ch_off);                         \
+            off = (ok ? off : 0) + ch_off;                                                                        \
+            st##SFX[j] = HS ? *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(src) + off)         \
+                            : *reinterpret_cast<const uint4*>(src + off);                                         \
             msk |= ok ? (1u << j) : 0u;                                                                           \
             if (++qi == r_w) {                                                                                    \
                 qi = 0;                                                                                           \
@@ -1554,20 +1575,37 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradArgs a) {
     };                                                                                                            \
     auto lstore##SFX = [&](int buf) {                                                                             \
         if (!(isA || isB)) return;                                                                                \
-        float4 v[8];                                                                                              \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) v[j] = keep_or_zero((ok##SFX >> j) & 1u, st##SFX[j]);      \
+        uint32_t v[8][4];                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                           \
+            const bool k = (ok##SFX >> j) & 1u;                                                                   \
+            v[j][0] = k ? st##SFX[j].x : 0u;                                                                      \
+            v[j][1] = k ? st##SFX[j].y : 0u;                                                                      \
+            v[j][2] = k ? st##SFX[j].z : 0u;                                                                      \
+            v[j][3] = k ? st##SFX[j].w : 0u;                                                                      \
+        }                                                                                                         \
         unsigned char* d = smem + buf * BUF + lds_dst;                                                            \
-        *reinterpret_cast<uint4*>(d) = make_uint4(pack_bf16x2(v[0].x, v[1].x), pack_bf16x2(v[2].x, v[3].x),      \
-                                                  pack_bf16x2(v[4].x, v[5].x), pack_bf16x2(v[6].x, v[7].x));      \
-        *reinterpret_cast<uint4*>(d + lds_estride) =                                                              \
-            make_uint4(pack_bf16x2(v[0].y, v[1].y), pack_bf16x2(v[2].y, v[3].y), pack_bf16x2(v[4].y, v[5].y),    \
-                       pack_bf16x2(v[6].y, v[7].y));                                                              \
-        *reinterpret_cast<uint4*>(d + 2 * lds_estride) =                                                          \
-            make_uint4(pack_bf16x2(v[0].z, v[1].z), pack_bf16x2(v[2].z, v[3].z), pack_bf16x2(v[4].z, v[5].z),    \
-                       pack_bf16x2(v[6].z, v[7].z));                                                              \
-        *reinterpret_cast<uint4*>(d + 3 * lds_estride) =                                                          \
-            make_uint4(pack_bf16x2(v[0].w, v[1].w), pack_bf16x2(v[2].w, v[3].w), pack_bf16x2(v[4].w, v[5].w),    \
-                       pack_bf16x2(v[6].w, v[7].w));                                                              \
+        if constexpr (HS) { /* 8 pixels x 8 channels of bf16: word w of pixel j = channels 2w, 2w+1 */           \
+            _Pragma("unroll") for (int w = 0; w < 4; ++w) {                                                       \
+                uint4 lo, hi;                                                                                     \
+                lo.x = (v[0][w] & 0xffffu) | (v[1][w] << 16);                                                     \
+                lo.y = (v[2][w] & 0xffffu) | (v[3][w] << 16);                                                     \
+                lo.z = (v[4][w] & 0xffffu) | (v[5][w] << 16);                                                     \
+                lo.w = (v[6][w] & 0xffffu) | (v[7][w] << 16);                                                     \
+                hi.x = (v[0][w] >> 16) | (v[1][w] & 0xffff0000u);                                                 \
+                hi.y = (v[2][w] >> 16) | (v[3][w] & 0xffff0000u);                                                 \
+                hi.z = (v[4][w] >> 16) | (v[5][w] & 0xffff0000u);                                                 \
+                hi.w = (v[6][w] >> 16) | (v[7][w] & 0xffff0000u);                                                 \
+                *reinterpret_cast<uint4*>(d + (2 * w) * lds_estride) = lo;                                        \
+                *reinterpret_cast<uint4*>(d + (2 * w + 1) * lds_estride) = hi;                                    \
+            }                                                                                                     \
+        } else { /* 8 pixels x 4 channels of fp32: the conversion pack does the transpose */                      \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                         \
+                *reinterpret_cast<uint4*>(d + e * lds_estride) =                                                  \
+                    make_uint4(pack_bf16x2(__uint_as_float(v[0][e]), __uint_as_float(v[1][e])),                   \
+                               pack_bf16x2(__uint_as_float(v[2][e]), __uint_as_float(v[3][e])),                   \
+                               pack_bf16x2(__uint_as_float(v[4][e]), __uint_as_float(v[5][e])),                   \
+                               pack_bf16x2(__uint_as_float(v[6][e]), __uint_as_float(v[7][e])));                  \
+        }                                                                                                         \
     };
     UP_WB_STAGE(X)
     UP_WB_STAGE(Y)
@@ -1619,14 +1657,14 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int cc = wn * (BN / 2) + j * 32 + l31;            // tile column -> GEMM column (see the LDS row order)
-        const int col = col0 + (cc % QB) * 4 + cc / QB;
+        const int col = col0 + (cc % QB) * E + cc / QB;
         if (col >= a.Ncols) continue;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int co = co0 + (rr % QA) * 4 + rr / QA;
+                const int co = co0 + (rr % QA) * E + rr / QA;
                 if (co < a.K) out[(size_t)co * a.Ncols + col] = acc[i][j][r];
             }
     }
@@ -1770,7 +1808,8 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const up_pack_job* jo
 }
 
 // column sums of a [rows][ld] matrix (bias gradient): partial per block, atomically combined
-__global__ void __launch_bounds__(256) colsum_kernel(const float* x, int ld, long long rows, int C, float* out,
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_kernel(const T* x, int ld, long long rows, int C, float* out,
                                                      int rows_per_block) {
     // blockDim = 256 = 4 row-lanes x 64 columns
     __shared__ float red[256];
@@ -1780,7 +1819,7 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* x, int ld, lon
     long long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     float s = 0.f;
     if (c < C)
-        for (long long r = r0 + rl; r < r1; r += 4) s += x[r * ld + c];
+        for (long long r = r0 + rl; r < r1; r += 4) s += ld1(x + r * ld + c);
     red[threadIdx.x] = s;
     __syncthreads();
     if (rl == 0 && c < C) {
@@ -2327,6 +2366,14 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
     const bool split = math == UP_MATH_BF16X3;
     // K slice: 64 on the 64x64 tile (6 -> 12 MFMAs per wave and barrier) measured no faster than 32 (141.7 vs 145.1 TF)
     constexpr int KT = 32;
+    if (math == UP_MATH_BF16S) {   // bf16 storage
+        a.fSpt = make_fastdiv(a.Cp / KT);
+        if (fast)
+            hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 2, false, KT, true>), dim3(a.nwg), dim3(256), 0, st, a);
+        else
+            hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 1, false, KT, true>), dim3(a.nwg), dim3(256), 0, st, a);
+        return;
+    }
     if (a.Cp % KT != 0) {   // e.g. Cp = 32: fall back to the 32-wide slice
         a.fSpt = make_fastdiv(a.Cp / 32);
         if (fast && split)
@@ -2350,7 +2397,10 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
         hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 1, false, KT>), dim3(a.nwg), dim3(256), 0, st, a);
 }
 static int run_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
-    UP_REQUIRE(math == UP_MATH_BF16X3 || math == UP_MATH_BF16, UP_ERR_INVALID, "bf16 convolution: math mode %d", math);
+    UP_REQUIRE(math == UP_MATH_BF16X3 || math == UP_MATH_BF16 || math == UP_MATH_BF16S, UP_ERR_INVALID,
+               "bf16 convolution: math mode %d", math);
+    UP_REQUIRE(math != UP_MATH_BF16S || (a.ldx % 8 == 0 && a.ldy % 2 == 0), UP_ERR_INVALID,
+               "bf16-storage convolution: ldx=%d must be a multiple of 8 (16-byte rows)", a.ldx);
     UP_REQUIRE(a.Cp % 32 == 0, UP_ERR_UNSUPPORTED, "bf16 convolution: padded channel count %d is not a multiple of 32",
                a.Cp);
     TileChoice t = choose_tile(a.M, a.Ng, a.Ktot);
@@ -2465,7 +2515,7 @@ extern "C" int up_pack_weights_bf16(const up_conv_desc* d, const float* w, uint1
 extern "C" int up_conv2d_fwd_bf16(const up_conv_desc* d, const float* x, const uint16_t* w_hi, const uint16_t* w_lo,
                                   float* y, const up_conv_epilogue* ep, int math, void* stream) {
     if (int e = check_desc(d)) return e;
-    UP_REQUIRE(x && w_hi && y && (w_lo || math == UP_MATH_BF16), UP_ERR_INVALID, "conv2d_fwd_bf16: null pointer");
+    UP_REQUIRE(x && w_hi && y && (w_lo || math != UP_MATH_BF16X3), UP_ERR_INVALID, "conv2d_fwd_bf16: null pointer");
     IgemmArgs a;
     if (int e = fill_fwd_args(a, d, x, nullptr, y, ep)) return e;
     a.w_hi = w_hi;
@@ -2478,7 +2528,7 @@ extern "C" int up_conv2d_bwd_data_bf16(const up_conv_desc* d, const float* dy, c
                                        const uint16_t* w_lo, float* dx, const float* add, int ld_add, int math,
                                        void* stream) {
     if (int e = check_desc(d)) return e;
-    UP_REQUIRE(dy && w_hi && dx && (w_lo || math == UP_MATH_BF16), UP_ERR_INVALID, "conv2d_bwd_data_bf16: null pointer");
+    UP_REQUIRE(dy && w_hi && dx && (w_lo || math != UP_MATH_BF16X3), UP_ERR_INVALID, "conv2d_bwd_data_bf16: null pointer");
     UP_REQUIRE(!add || ld_add >= d->C, UP_ERR_INVALID, "conv2d_bwd_data_bf16: ld_add=%d < C=%d", ld_add, d->C);
     IgemmArgs a;
     if (int e = fill_dgrad_args(a, d, dy, nullptr, dx)) return e;
@@ -2499,7 +2549,7 @@ static bool g_wgrad_single = false;
 struct WgradPlan {
     int bm, bn, ntm, ntn, splits, rows_per_split;
 };
-static WgradPlan plan_wgrad(const up_conv_desc* d) {
+static WgradPlan plan_wgrad(const up_conv_desc* d, int slice = BK) {
     WgradPlan p;
     int ncols = d->R * d->S * d->Cp;
     p.bm = d->K <= 64 ? 64 : 128;
@@ -2528,7 +2578,7 @@ static WgradPlan plan_wgrad(const up_conv_desc* d) {
         if (util >= 0.95) break;
     }
     int64_t rps = (M + splits - 1) / splits;
-    rps = (rps + BK - 1) / BK * BK;
+    rps = (rps + slice - 1) / slice * slice;
     p.rows_per_split = (int)rps;
     p.splits = (int)((M + rps - 1) / rps);
     return p;
@@ -2648,12 +2698,21 @@ extern "C" int up_conv2d_bwd_weight_bf16(const up_conv_desc* d, const float* x, 
                                          void* workspace, size_t workspace_bytes, void* stream) {
     return conv2d_bwd_weight_impl(d, x, dy, dw, dbias, workspace, workspace_bytes, 1, stream);
 }
+extern "C" int up_conv2d_bwd_weight_bf16s(const up_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    UP_REQUIRE(d && d->Cp % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0, UP_ERR_INVALID,
+               "conv2d_bwd_weight_bf16s: Cp, ldx and ldy must be multiples of 8 (16-byte channel groups)");
+    UP_REQUIRE((int64_t)d->N * d->H * d->W * d->ldx < (1ll << 31) && (int64_t)d->N * d->P * d->Q * d->ldy < (1ll << 31),
+               UP_ERR_UNSUPPORTED, "conv2d_bwd_weight_bf16s: more than 2^31 elements");
+    return conv2d_bwd_weight_impl(d, static_cast<const float*>(x), static_cast<const float*>(dy), dw, dbias, workspace,
+                                  workspace_bytes, 2, stream);
+}
 static int up::conv2d_bwd_weight_impl(const up_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
                                       void* workspace, size_t workspace_bytes, int bf16, void* stream) {
     if (int e = check_desc(d)) return e;
     UP_REQUIRE(x && dy && dw && workspace, UP_ERR_INVALID, "conv2d_bwd_weight: null pointer");
     UP_REQUIRE(d->ldy % 4 == 0, UP_ERR_INVALID, "conv2d_bwd_weight: ldy=%d must be a multiple of 4", d->ldy);
-    WgradPlan p = plan_wgrad(d);
+    WgradPlan p = plan_wgrad(d, bf16 == 2 ? 64 : BK);
     size_t need = (size_t)p.splits * d->K * d->R * d->S * d->Cp * sizeof(float);
     UP_REQUIRE(workspace_bytes >= need, UP_ERR_WORKSPACE, "conv2d_bwd_weight: workspace %zu < %zu", workspace_bytes,
                need);
@@ -2695,7 +2754,16 @@ static int up::conv2d_bwd_weight_impl(const up_conv_desc* d, const float* x, con
         ProfScope prof(v, 2.0 * (double)a.M * (double)d->K * (double)d->R * d->S * d->C, st, d->K, a.Ncols, a.M,
                        a.nwg);
         a.rect = (g_wgrad_rect && (int64_t)d->N * d->P * d->Q < (1ll << 30)) ? wgrad_rect_device(d, p) : nullptr;
-        if (p.bm == 128 && p.bn == 128)
+        if (bf16 == 2) {
+            if (p.bm == 128 && p.bn == 128)
+                hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128, true>), grid, dim3(256), 0, st, a);
+            else if (p.bm == 128 && p.bn == 64)
+                hipLaunchKernelGGL((wgrad_bf16_kernel<128, 64, true>), grid, dim3(256), 0, st, a);
+            else if (p.bm == 64 && p.bn == 128)
+                hipLaunchKernelGGL((wgrad_bf16_kernel<64, 128, true>), grid, dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL((wgrad_bf16_kernel<64, 64, true>), grid, dim3(256), 0, st, a);
+        } else if (p.bm == 128 && p.bn == 128)
             hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128>), grid, dim3(256), 0, st, a);
         else if (p.bm == 128 && p.bn == 64)
             hipLaunchKernelGGL((wgrad_bf16_kernel<128, 64>), grid, dim3(256), 0, st, a);
@@ -2777,7 +2845,11 @@ static int up::conv2d_bwd_weight_impl(const up_conv_desc* d, const float* x, con
         if (hipMemsetAsync(dbias, 0, sizeof(float) * d->K, st) != hipSuccess) return check_launch("dbias memset");
         int rpb = 1024;
         dim3 g(cdiv(a.M, rpb), cdiv(d->K, 64));
-        hipLaunchKernelGGL(colsum_kernel, g, dim3(256), 0, st, dy, d->ldy, (long long)a.M, d->K, dbias, rpb);
+        if (bf16 == 2)
+            hipLaunchKernelGGL(colsum_kernel<bf16_t>, g, dim3(256), 0, st, reinterpret_cast<const bf16_t*>(dy), d->ldy,
+                               (long long)a.M, d->K, dbias, rpb);
+        else
+            hipLaunchKernelGGL(colsum_kernel<float>, g, dim3(256), 0, st, dy, d->ldy, (long long)a.M, d->K, dbias, rpb);
     }
     return check_launch("conv2d_bwd_weight");
 }

@@ -95,9 +95,10 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* stats, in
 
 // relu_bits (optional): bit (row*C + c) of a dense bit array = (z > 0).  The backward passes read this instead of z:
 // 1/32 of the bytes.  One thread produces 4 bits; 8 neighbouring lanes are merged into one 32-bit word.
-__global__ void __launch_bounds__(256) bn_apply_kernel(const float* y, int ldy, const float* scale,
-                                                       const float* shift, const float* res, int ldr, int relu,
-                                                       float* z, int ldz, uint32_t* relu_bits, int64_t total, int C4,
+template <typename T>
+__global__ void __launch_bounds__(256) bn_apply_kernel(const T* y, int ldy, const float* scale,
+                                                       const float* shift, const T* res, int ldr, int relu,
+                                                       T* z, int ldz, uint32_t* relu_bits, int64_t total, int C4,
                                                        FastDiv fC4) {
     const int lane = threadIdx.x & 63;
     for (int64_t i0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63); i0 < total; i0 += (int64_t)gridDim.x * 256) {
@@ -106,7 +107,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* y, int ldy, 
         if (i < total) {
             uint32_t row = fdiv((uint32_t)i, fC4);
             int c = ((int)i - (int)row * C4) * 4;
-            float4 v = *reinterpret_cast<const float4*>(y + (size_t)row * ldy + c);
+            float4 v = ld4<T>(y + (size_t)row * ldy + c);
             float4 s = *reinterpret_cast<const float4*>(scale + c);
             float4 h = *reinterpret_cast<const float4*>(shift + c);
             v.x = v.x * s.x + h.x;
@@ -114,7 +115,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* y, int ldy, 
             v.z = v.z * s.z + h.z;
             v.w = v.w * s.w + h.w;
             if (res) {
-                float4 r = *reinterpret_cast<const float4*>(res + (size_t)row * ldr + c);
+                float4 r = ld4<T>(res + (size_t)row * ldr + c);
                 v.x += r.x;
                 v.y += r.y;
                 v.z += r.z;
@@ -126,7 +127,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* y, int ldy, 
                 v.z = fmaxf(v.z, 0.f);
                 v.w = fmaxf(v.w, 0.f);
             }
-            *reinterpret_cast<float4*>(z + (size_t)row * ldz + c) = v;
+            st4(z + (size_t)row * ldz + c, v);
             nib = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
         }
         if (relu_bits) {   // wave-uniform
@@ -145,16 +146,18 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const float* y, int ldy, 
 // consecutive channels, rows strided by 16 and unrolled x2 so 6 loads are in flight per thread.
 // the ReLU mask of 4 consecutive channels: from the bit array written by bn_apply_kernel when there is one
 // (relu_bits: 1/32 of the bytes of z), else from z itself
-__device__ __forceinline__ float4 relu_mask4(const uint32_t* bits, int64_t quad, const float* z, size_t zoff) {
+template <typename T>
+__device__ __forceinline__ float4 relu_mask4(const uint32_t* bits, int64_t quad, const T* z, size_t zoff) {
     if (bits) {
         const uint32_t nib = bits[quad >> 3] >> (4 * (int)(quad & 7));
         return make_float4((nib & 1u) ? 1.f : 0.f, (nib & 2u) ? 1.f : 0.f, (nib & 4u) ? 1.f : 0.f, (nib & 8u) ? 1.f : 0.f);
     }
-    return *reinterpret_cast<const float4*>(z + zoff);
+    return ld4<T>(z + zoff);
 }
 
-__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* dz, int lddz, const float* z, int ldz,
-                                                            const uint32_t* bits, const float* y, int ldy,
+template <typename T>
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* dz, int lddz, const T* z, int ldz,
+                                                            const uint32_t* bits, const T* y, int ldy,
                                                             const float* mean, const float* invstd, int relu,
                                                             float* partial, int64_t rows, int C, int rows_per_chunk) {
     __shared__ float red[16][64][2];
@@ -186,8 +189,8 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* dz, int
             float4 g[4], yv[4], zv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                g[u] = *reinterpret_cast<const float4*>(dz + (r + 16 * u) * lddz + c);
-                yv[u] = *reinterpret_cast<const float4*>(y + (r + 16 * u) * ldy + c);
+                g[u] = ld4<T>(dz + (r + 16 * u) * lddz + c);
+                yv[u] = ld4<T>(y + (r + 16 * u) * ldy + c);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
@@ -196,8 +199,8 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const float* dz, int
             for (int u = 0; u < 4; ++u) acc(g[u], zv[u], yv[u]);
         }
         for (; r < r1; r += 16) {
-            float4 ga = *reinterpret_cast<const float4*>(dz + r * lddz + c);
-            float4 ya = *reinterpret_cast<const float4*>(y + r * ldy + c);
+            float4 ga = ld4<T>(dz + r * lddz + c);
+            float4 ya = ld4<T>(y + r * ldy + c);
             float4 za = relu ? relu_mask4(bits, r * (C >> 2) + (c >> 2), z, r * ldz + c) : ga;
             acc(ga, za, ya);
         }
@@ -244,18 +247,19 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* parti
     }
 }
 // pass 3: dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M);  dres = g
-__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* dz, int lddz, const float* z, int ldz,
-                                                           const uint32_t* bits, const float* y, int ldy,
+template <typename T>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* dz, int lddz, const T* z, int ldz,
+                                                           const uint32_t* bits, const T* y, int ldy,
                                                            const float* gamma,
                                                            const float* mean, const float* invstd,
                                                            const float* dgamma, const float* dbeta, int relu,
-                                                           int use_batch, float inv_m, float* dy, int lddy,
-                                                           float* dres, int lddres, int64_t total, int C4,
+                                                           int use_batch, float inv_m, T* dy, int lddy,
+                                                           T* dres, int lddres, int64_t total, int C4,
                                                            FastDiv fC4) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         uint32_t row = fdiv((uint32_t)i, fC4);
         int c = ((int)i - (int)row * C4) * 4;
-        float4 g4 = *reinterpret_cast<const float4*>(dz + (size_t)row * lddz + c);
+        float4 g4 = ld4<T>(dz + (size_t)row * lddz + c);
         float g[4] = {g4.x, g4.y, g4.z, g4.w};
         if (relu) {
             float4 z4 = relu_mask4(bits, i, z, (size_t)row * ldz + c);
@@ -264,8 +268,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* dz, int 
             if (!(z4.z > 0.f)) g[2] = 0.f;
             if (!(z4.w > 0.f)) g[3] = 0.f;
         }
-        if (dres) *reinterpret_cast<float4*>(dres + (size_t)row * lddres + c) = make_float4(g[0], g[1], g[2], g[3]);
-        float4 y4 = *reinterpret_cast<const float4*>(y + (size_t)row * ldy + c);
+        if (dres) st4(dres + (size_t)row * lddres + c, make_float4(g[0], g[1], g[2], g[3]));
+        float4 y4 = ld4<T>(y + (size_t)row * ldy + c);
         float yv[4] = {y4.x, y4.y, y4.z, y4.w};
         float o[4];
         const float4 is4 = *reinterpret_cast<const float4*>(invstd + c), ga4 = *reinterpret_cast<const float4*>(gamma + c);
@@ -284,7 +288,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const float* dz, int 
                 o[e] = k * g[e];
             }
         }
-        *reinterpret_cast<float4*>(dy + (size_t)row * lddy + c) = make_float4(o[0], o[1], o[2], o[3]);
+        st4(dy + (size_t)row * lddy + c, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 
@@ -303,7 +307,8 @@ __device__ __forceinline__ uint32_t mix_hash(uint64_t seed, uint64_t idx) {
     v ^= v >> 31;
     return (uint32_t)(v >> 40);  // 24 random bits
 }
-__global__ void __launch_bounds__(256) dropout_fwd_kernel(const float* x, float* y, uint8_t* mask,
+template <typename T>
+__global__ void __launch_bounds__(256) dropout_fwd_kernel(const T* x, T* y, uint8_t* mask,
                                                           const float* ext, int64_t n, float p, float inv_keep,
                                                           uint64_t seed) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -313,13 +318,14 @@ __global__ void __launch_bounds__(256) dropout_fwd_kernel(const float* x, float*
         else
             keep = (float)mix_hash(seed, (uint64_t)i) * (1.0f / 16777216.0f) >= p;
         mask[i] = keep ? 1 : 0;
-        y[i] = keep ? x[i] * inv_keep : 0.f;
+        st1(y + i, keep ? ld1(x + i) * inv_keep : 0.f);
     }
 }
-__global__ void __launch_bounds__(256) dropout_bwd_kernel(const float* dy, const uint8_t* mask, float* dx, int64_t n,
+template <typename T>
+__global__ void __launch_bounds__(256) dropout_bwd_kernel(const T* dy, const uint8_t* mask, T* dx, int64_t n,
                                                           float inv_keep) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-        dx[i] = mask[i] ? dy[i] * inv_keep : 0.f;
+        st1(dx + i, mask[i] ? ld1(dy + i) * inv_keep : 0.f);
 }
 
 // ---- MSE ---------------------------------------------------------------------------------
@@ -384,28 +390,57 @@ extern "C" int up_bn_finalize(const float* stats, int tiles, int C, float eps, f
     return check_launch("bn_finalize");
 }
 
-extern "C" int up_bn_apply(const float* y, int ldy, const float* scale, const float* shift, const float* res,
-                           int ldr, int relu, float* z, int ldz, uint32_t* relu_bits, int64_t rows, int C,
-                           void* stream) {
+extern "C" int up_bn_apply_t(const void* y, int ldy, const float* scale, const float* shift, const void* res,
+                             int ldr, int relu, void* z, int ldz, uint32_t* relu_bits, int64_t rows, int C, int dtype,
+                             void* stream) {
     UP_REQUIRE(y && scale && shift && z && rows > 0 && C > 0, UP_ERR_INVALID, "bn_apply: bad argument");
     UP_REQUIRE(C % 4 == 0 && ldy % 4 == 0 && ldz % 4 == 0 && (!res || ldr % 4 == 0), UP_ERR_INVALID,
                "bn_apply: C and strides must be multiples of 4");
     UP_REQUIRE(rows * (C / 4) < (1ll << 31), UP_ERR_UNSUPPORTED, "bn_apply: tensor too large");
+    UP_REQUIRE(dtype == UP_DT_F32 || dtype == UP_DT_BF16, UP_ERR_INVALID, "bn_apply: dtype %d", dtype);
     int64_t total = rows * (C / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), y, ldy, scale, shift,
-                       res, ldr, relu, z, ldz, relu_bits, total, C / 4, make_fastdiv(C / 4));
+    if (dtype == UP_DT_BF16)
+        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                           (const bf16_t*)y, ldy, scale, shift, (const bf16_t*)res, ldr, relu, (bf16_t*)z, ldz, relu_bits,
+                           total, C / 4, make_fastdiv(C / 4));
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)y,
+                           ldy, scale, shift, (const float*)res, ldr, relu, (float*)z, ldz, relu_bits, total, C / 4,
+                           make_fastdiv(C / 4));
     return check_launch("bn_apply");
+}
+extern "C" int up_bn_apply(const float* y, int ldy, const float* scale, const float* shift, const float* res,
+                           int ldr, int relu, float* z, int ldz, uint32_t* relu_bits, int64_t rows, int C,
+                           void* stream) {
+    return up_bn_apply_t(y, ldy, scale, shift, res, ldr, relu, z, ldz, relu_bits, rows, C, UP_DT_F32, stream);
 }
 
 extern "C" size_t up_bn_bwd_workspace(int64_t rows, int C) {
     return (size_t)cdiv(rows, BNB_ROWS) * C * 2 * sizeof(float);
 }
 
-extern "C" int up_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const uint32_t* relu_bits,
-                         const float* y, int ldy,
-                         const float* gamma, const float* mean, const float* invstd, int relu, int use_batch_stats,
-                         float* dy, int lddy, float* dres, int lddres, float* dgamma, float* dbeta,
-                         float* workspace, size_t workspace_bytes, int64_t rows, int C, void* stream) {
+namespace up {
+template <typename T>
+static void launch_bn_bwd(const T* dz, int lddz, const T* z, int ldz, const uint32_t* relu_bits, const T* y, int ldy,
+                          const float* gamma, const float* mean, const float* invstd, int relu, int use_batch_stats, T* dy,
+                          int lddy, T* dres, int lddres, float* dgamma, float* dbeta, float* workspace, int64_t rows, int C,
+                          hipStream_t st) {
+    int chunks = cdiv(rows, BNB_ROWS);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(chunks, cdiv(C, 64)), dim3(256), 0, st, dz, lddz, z, ldz, relu_bits,
+                       y, ldy, mean, invstd, relu, workspace, rows, C, BNB_ROWS);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, (const float*)workspace, chunks, C,
+                       dgamma, dbeta);
+    int64_t total = rows * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(total)), dim3(256), 0, st, dz, lddz, z, ldz, relu_bits, y,
+                       ldy, gamma, mean, invstd, (const float*)dgamma, (const float*)dbeta, relu, use_batch_stats,
+                       1.0f / (float)rows, dy, lddy, dres, lddres, total, C / 4, make_fastdiv(C / 4));
+}
+}  // namespace up
+
+extern "C" int up_bn_bwd_t(const void* dz, int lddz, const void* z, int ldz, const uint32_t* relu_bits, const void* y,
+                           int ldy, const float* gamma, const float* mean, const float* invstd, int relu,
+                           int use_batch_stats, void* dy, int lddy, void* dres, int lddres, float* dgamma, float* dbeta,
+                           float* workspace, size_t workspace_bytes, int64_t rows, int C, int dtype, void* stream) {
     UP_REQUIRE(dz && y && gamma && mean && invstd && dy && dgamma && dbeta && workspace, UP_ERR_INVALID,
                "bn_bwd: null pointer");
     UP_REQUIRE(!relu || z || relu_bits, UP_ERR_INVALID, "bn_bwd: relu needs the forward output z or its sign bits");
@@ -414,17 +449,25 @@ extern "C" int up_bn_bwd(const float* dz, int lddz, const float* z, int ldz, con
                UP_ERR_INVALID, "bn_bwd: C and strides must be multiples of 4");
     UP_REQUIRE(rows * (C / 4) < (1ll << 31), UP_ERR_UNSUPPORTED, "bn_bwd: tensor too large");
     UP_REQUIRE(workspace_bytes >= up_bn_bwd_workspace(rows, C), UP_ERR_WORKSPACE, "bn_bwd: workspace too small");
+    UP_REQUIRE(dtype == UP_DT_F32 || dtype == UP_DT_BF16, UP_ERR_INVALID, "bn_bwd: dtype %d", dtype);
     hipStream_t st = as_stream(stream);
-    int chunks = cdiv(rows, BNB_ROWS);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(chunks, cdiv(C, 64)), dim3(256), 0, st, dz, lddz, z, ldz, relu_bits, y,
-                       ldy, mean, invstd, relu, workspace, rows, C, BNB_ROWS);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, (const float*)workspace, chunks, C,
-                       dgamma, dbeta);
-    int64_t total = rows * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, st, dz, lddz, z, ldz, relu_bits, y, ldy,
-                       gamma, mean, invstd, (const float*)dgamma, (const float*)dbeta, relu, use_batch_stats,
-                       1.0f / (float)rows, dy, lddy, dres, lddres, total, C / 4, make_fastdiv(C / 4));
+    if (dtype == UP_DT_BF16)
+        launch_bn_bwd<bf16_t>((const bf16_t*)dz, lddz, (const bf16_t*)z, ldz, relu_bits, (const bf16_t*)y, ldy, gamma, mean,
+                              invstd, relu, use_batch_stats, (bf16_t*)dy, lddy, (bf16_t*)dres, lddres, dgamma, dbeta,
+                              workspace, rows, C, st);
+    else
+        launch_bn_bwd<float>((const float*)dz, lddz, (const float*)z, ldz, relu_bits, (const float*)y, ldy, gamma, mean,
+                             invstd, relu, use_batch_stats, (float*)dy, lddy, (float*)dres, lddres, dgamma, dbeta,
+                             workspace, rows, C, st);
     return check_launch("bn_bwd");
+}
+extern "C" int up_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const uint32_t* relu_bits,
+                         const float* y, int ldy,
+                         const float* gamma, const float* mean, const float* invstd, int relu, int use_batch_stats,
+                         float* dy, int lddy, float* dres, int lddres, float* dgamma, float* dbeta,
+                         float* workspace, size_t workspace_bytes, int64_t rows, int C, void* stream) {
+    return up_bn_bwd_t(dz, lddz, z, ldz, relu_bits, y, ldy, gamma, mean, invstd, relu, use_batch_stats, dy, lddy, dres,
+                       lddres, dgamma, dbeta, workspace, workspace_bytes, rows, C, UP_DT_F32, stream);
 }
 
 extern "C" int up_relu_bwd(const float* dz, const float* z, float* dx, int64_t n, void* stream) {
@@ -433,18 +476,36 @@ extern "C" int up_relu_bwd(const float* dz, const float* z, float* dx, int64_t n
     return check_launch("relu_bwd");
 }
 
-extern "C" int up_dropout_fwd(const float* x, float* y, uint8_t* mask, const float* ext_mask, int64_t n, float p,
-                              uint64_t seed, void* stream) {
+extern "C" int up_dropout_fwd_t(const void* x, void* y, uint8_t* mask, const float* ext_mask, int64_t n, float p,
+                                uint64_t seed, int dtype, void* stream) {
     UP_REQUIRE(x && y && mask && n > 0 && p >= 0.f && p < 1.f, UP_ERR_INVALID, "dropout_fwd: bad argument");
-    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, y, mask, ext_mask,
-                       n, p, 1.0f / (1.0f - p), seed);
+    UP_REQUIRE(dtype == UP_DT_F32 || dtype == UP_DT_BF16, UP_ERR_INVALID, "dropout_fwd: dtype %d", dtype);
+    if (dtype == UP_DT_BF16)
+        hipLaunchKernelGGL(dropout_fwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), (const bf16_t*)x,
+                           (bf16_t*)y, mask, ext_mask, n, p, 1.0f / (1.0f - p), seed);
+    else
+        hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), (const float*)x,
+                           (float*)y, mask, ext_mask, n, p, 1.0f / (1.0f - p), seed);
     return check_launch("dropout_fwd");
 }
-extern "C" int up_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, void* stream) {
+extern "C" int up_dropout_fwd(const float* x, float* y, uint8_t* mask, const float* ext_mask, int64_t n, float p,
+                              uint64_t seed, void* stream) {
+    return up_dropout_fwd_t(x, y, mask, ext_mask, n, p, seed, UP_DT_F32, stream);
+}
+extern "C" int up_dropout_bwd_t(const void* dy, const uint8_t* mask, void* dx, int64_t n, float p, int dtype,
+                                void* stream) {
     UP_REQUIRE(dy && mask && dx && n > 0 && p >= 0.f && p < 1.f, UP_ERR_INVALID, "dropout_bwd: bad argument");
-    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), dy, mask, dx, n,
-                       1.0f / (1.0f - p));
+    UP_REQUIRE(dtype == UP_DT_F32 || dtype == UP_DT_BF16, UP_ERR_INVALID, "dropout_bwd: dtype %d", dtype);
+    if (dtype == UP_DT_BF16)
+        hipLaunchKernelGGL(dropout_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), (const bf16_t*)dy,
+                           mask, (bf16_t*)dx, n, 1.0f / (1.0f - p));
+    else
+        hipLaunchKernelGGL(dropout_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), (const float*)dy,
+                           mask, (float*)dx, n, 1.0f / (1.0f - p));
     return check_launch("dropout_bwd");
+}
+extern "C" int up_dropout_bwd(const float* dy, const uint8_t* mask, float* dx, int64_t n, float p, void* stream) {
+    return up_dropout_bwd_t(dy, mask, dx, n, p, UP_DT_F32, stream);
 }
 
 extern "C" size_t up_mse_workspace(int64_t) { return MSE_PARTS * sizeof(float); }

@@ -16,24 +16,26 @@ static inline int grid_cap(int64_t work_items, int cap = 8192) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (total); i += (int64_t)gridDim.x * 256)
 
 // ---- layout ------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* x, float* y, int C, int HW, int ld,
+template <typename TO>
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* x, TO* y, int C, int HW, int ld,
                                                            int64_t npix) {
     UP_GRID_STRIDE(i, npix) {
         int64_t n = i / HW;
         int hw = (int)(i - n * HW);
         const float* src = x + n * C * HW + hw;
-        float* dst = y + i * ld;
-        for (int c = 0; c < ld; ++c) dst[c] = c < C ? src[(int64_t)c * HW] : 0.f;
+        TO* dst = y + i * ld;
+        for (int c = 0; c < ld; ++c) st1(dst + c, c < C ? src[(int64_t)c * HW] : 0.f);
     }
 }
-__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float* x, int ld, float* y, int C, int HW,
+template <typename TI>
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const TI* x, int ld, float* y, int C, int HW,
                                                            int64_t npix) {
     UP_GRID_STRIDE(i, npix) {
         int64_t n = i / HW;
         int hw = (int)(i - n * HW);
-        const float* src = x + i * ld;
+        const TI* src = x + i * ld;
         float* dst = y + n * C * HW + hw;
-        for (int c = 0; c < C; ++c) dst[(int64_t)c * HW] = src[c];
+        for (int c = 0; c < C; ++c) dst[(int64_t)c * HW] = ld1(src + c);
     }
 }
 
@@ -64,7 +66,8 @@ __global__ void __launch_bounds__(256) add2d_kernel(const float* a, int lda, con
 }
 
 // ---- max-pool 3x3 / stride 2 / pad 1 --------------------------------------------------------
-__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* x, int ldx, float* y, int ldy, uint8_t* idx,
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const TI* x, int ldx, TO* y, int ldy, uint8_t* idx,
                                                           int H, int W, int C4, int P, int Q, int64_t total,
                                                           FastDiv fC4, FastDiv fQ, FastDiv fP) {
     UP_GRID_STRIDE(i, total) {
@@ -83,7 +86,7 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* x, int ld
             for (int s = 0; s < 3; ++s) {
                 int w = 2 * q - 1 + s;
                 if (w < 0 || w >= W) continue;
-                float4 v4 = *reinterpret_cast<const float4*>(x + ((size_t)(n * H + h) * W + w) * ldx + c);
+                float4 v4 = ld4<TI>(x + ((size_t)(n * H + h) * W + w) * ldx + c);
                 float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -94,7 +97,7 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* x, int ld
                 first = false;
             }
         }
-        *reinterpret_cast<float4*>(y + (size_t)pix * ldy + c) = make_float4(best[0], best[1], best[2], best[3]);
+        st4(y + (size_t)pix * ldy + c, make_float4(best[0], best[1], best[2], best[3]));
         uint8_t* ip = idx + (size_t)pix * (C4 * 4) + c;
         ip[0] = (uint8_t)bi[0];
         ip[1] = (uint8_t)bi[1];
@@ -102,7 +105,8 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const float* x, int ld
         ip[3] = (uint8_t)bi[3];
     }
 }
-__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* dy, int lddy, const uint8_t* idx, float* dx,
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const TI* dy, int lddy, const uint8_t* idx, TO* dx,
                                                           int lddx, int H, int W, int C4, int P, int Q,
                                                           int64_t total, FastDiv fC4, FastDiv fW, FastDiv fH) {
     UP_GRID_STRIDE(i, total) {
@@ -123,7 +127,7 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* dy, int l
                 int q = tq >> 1;
                 size_t op = (size_t)(n * P + p) * Q + q;
                 const uint8_t* ip = idx + op * (C4 * 4) + c;
-                float4 g = *reinterpret_cast<const float4*>(dy + op * lddy + c);
+                float4 g = ld4<TI>(dy + op * lddy + c);
                 int code = r * 3 + s;
                 if (ip[0] == code) acc[0] += g.x;
                 if (ip[1] == code) acc[1] += g.y;
@@ -131,12 +135,13 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float* dy, int l
                 if (ip[3] == code) acc[3] += g.w;
             }
         }
-        *reinterpret_cast<float4*>(dx + (size_t)pix * lddx + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        st4(dx + (size_t)pix * lddx + c, make_float4(acc[0], acc[1], acc[2], acc[3]));
     }
 }
 
 // ---- bilinear, align_corners=True ----------------------------------------------------------
-__global__ void __launch_bounds__(256) bilinear_fwd_kernel(const float* x, int ldx, float* y, int ldy, int H, int W,
+template <typename T>
+__global__ void __launch_bounds__(256) bilinear_fwd_kernel(const T* x, int ldx, T* y, int ldy, int H, int W,
                                                            int C4, int P, int Q, float sh, float sw, int64_t total,
                                                            FastDiv fC4, FastDiv fQ, FastDiv fP) {
     UP_GRID_STRIDE(i, total) {
@@ -150,17 +155,17 @@ __global__ void __launch_bounds__(256) bilinear_fwd_kernel(const float* x, int l
         int h0 = (int)fh, w0 = (int)fw;
         int h1 = h0 < H - 1 ? h0 + 1 : h0, w1 = w0 < W - 1 ? w0 + 1 : w0;
         float lh1 = fh - h0, lw1 = fw - w0, lh0 = 1.f - lh1, lw0 = 1.f - lw1;
-        const float* b = x + (size_t)n * H * W * ldx + c;
-        float4 a00 = *reinterpret_cast<const float4*>(b + (size_t)(h0 * W + w0) * ldx);
-        float4 a01 = *reinterpret_cast<const float4*>(b + (size_t)(h0 * W + w1) * ldx);
-        float4 a10 = *reinterpret_cast<const float4*>(b + (size_t)(h1 * W + w0) * ldx);
-        float4 a11 = *reinterpret_cast<const float4*>(b + (size_t)(h1 * W + w1) * ldx);
+        const T* b = x + (size_t)n * H * W * ldx + c;
+        float4 a00 = ld4<T>(b + (size_t)(h0 * W + w0) * ldx);
+        float4 a01 = ld4<T>(b + (size_t)(h0 * W + w1) * ldx);
+        float4 a10 = ld4<T>(b + (size_t)(h1 * W + w0) * ldx);
+        float4 a11 = ld4<T>(b + (size_t)(h1 * W + w1) * ldx);
         float4 o;
         o.x = lh0 * (lw0 * a00.x + lw1 * a01.x) + lh1 * (lw0 * a10.x + lw1 * a11.x);
         o.y = lh0 * (lw0 * a00.y + lw1 * a01.y) + lh1 * (lw0 * a10.y + lw1 * a11.y);
         o.z = lh0 * (lw0 * a00.z + lw1 * a01.z) + lh1 * (lw0 * a10.z + lw1 * a11.z);
         o.w = lh0 * (lw0 * a00.w + lw1 * a01.w) + lh1 * (lw0 * a10.w + lw1 * a11.w);
-        *reinterpret_cast<float4*>(y + (size_t)pix * ldy + c) = o;
+        st4(y + (size_t)pix * ldy + c, o);
     }
 }
 // weight with which output coordinate o (of `out` samples, scale s) reads input sample `in_i`
@@ -174,7 +179,8 @@ __device__ __forceinline__ float bil_weight(int o, int in_i, int in_n, float s) 
     if (i1 == in_i) w += l1;
     return w;
 }
-__global__ void __launch_bounds__(256) bilinear_bwd_kernel(const float* dy, int lddy, float* dx, int lddx, int H,
+template <typename T>
+__global__ void __launch_bounds__(256) bilinear_bwd_kernel(const T* dy, int lddy, T* dx, int lddx, int H,
                                                            int W, int C4, int P, int Q, float sh, float sw,
                                                            int64_t total, FastDiv fC4, FastDiv fW, FastDiv fH) {
     UP_GRID_STRIDE(i, total) {
@@ -200,7 +206,7 @@ __global__ void __launch_bounds__(256) bilinear_bwd_kernel(const float* dy, int 
             for (int q = q_lo; q <= q_hi; ++q) {
                 float ww = bil_weight(q, w, W, sw);
                 if (ww == 0.f) continue;
-                float4 g = *reinterpret_cast<const float4*>(dy + ((size_t)(n * P + p) * Q + q) * lddy + c);
+                float4 g = ld4<T>(dy + ((size_t)(n * P + p) * Q + q) * lddy + c);
                 float k = wh * ww;
                 acc[0] += k * g.x;
                 acc[1] += k * g.y;
@@ -208,34 +214,36 @@ __global__ void __launch_bounds__(256) bilinear_bwd_kernel(const float* dy, int 
                 acc[3] += k * g.w;
             }
         }
-        *reinterpret_cast<float4*>(dx + (size_t)pix * lddx + c) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        st4(dx + (size_t)pix * lddx + c, make_float4(acc[0], acc[1], acc[2], acc[3]));
     }
 }
 
 // ---- global average pool ---------------------------------------------------------------------
-__global__ void __launch_bounds__(256) gap_fwd_kernel(const float* x, int ldx, float* y, int HW, int C) {
+template <typename T>
+__global__ void __launch_bounds__(256) gap_fwd_kernel(const T* x, int ldx, T* y, int HW, int C) {
     __shared__ float red[256];
     int n = blockIdx.x;
     int c = blockIdx.y * 64 + (threadIdx.x & 63);
     int rl = threadIdx.x >> 6;
     float s = 0.f;
     if (c < C)
-        for (int r = rl; r < HW; r += 4) s += x[((size_t)n * HW + r) * ldx + c];
+        for (int r = rl; r < HW; r += 4) s += ld1(x + ((size_t)n * HW + r) * ldx + c);
     red[threadIdx.x] = s;
     __syncthreads();
     if (rl == 0 && c < C) {
         int t = threadIdx.x;
-        y[(size_t)n * C + c] = (red[t] + red[t + 64] + red[t + 128] + red[t + 192]) / (float)HW;
+        st1(y + (size_t)n * C + c, (red[t] + red[t + 64] + red[t + 128] + red[t + 192]) / (float)HW);
     }
 }
-__global__ void __launch_bounds__(256) gap_bwd_kernel(const float* dy, float* dx, int lddx, int HW, int C4,
+template <typename T>
+__global__ void __launch_bounds__(256) gap_bwd_kernel(const T* dy, T* dx, int lddx, int HW, int C4,
                                                       float inv, int64_t total, FastDiv fC4, FastDiv fHW) {
     UP_GRID_STRIDE(i, total) {
         uint32_t pix = fdiv((uint32_t)i, fC4);
         int c = ((int)i - (int)pix * C4) * 4;
         uint32_t n = fdiv(pix, fHW);
-        float4 g = *reinterpret_cast<const float4*>(dy + (size_t)n * (C4 * 4) + c);
-        *reinterpret_cast<float4*>(dx + (size_t)pix * lddx + c) = make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
+        float4 g = ld4<T>(dy + (size_t)n * (C4 * 4) + c);
+        st4(dx + (size_t)pix * lddx + c, make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv));
     }
 }
 
@@ -577,17 +585,32 @@ using namespace up;
 #define UP_LAUNCH_1D(kernel, total, st, ...) \
     hipLaunchKernelGGL(kernel, dim3(grid_cap(total)), dim3(256), 0, st, __VA_ARGS__)
 
-extern "C" int up_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int ldy, void* stream) {
-    UP_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && ldy >= C, UP_ERR_INVALID, "nchw_to_nhwc: bad argument");
+#define UP_DT_OK(dt) ((dt) == UP_DT_F32 || (dt) == UP_DT_BF16)
+extern "C" int up_nchw_to_nhwc_t(const float* x, void* y, int N, int C, int H, int W, int ldy, int dt_out, void* stream) {
+    UP_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && ldy >= C && UP_DT_OK(dt_out), UP_ERR_INVALID,
+               "nchw_to_nhwc: bad argument");
     int64_t npix = (int64_t)N * H * W;
-    UP_LAUNCH_1D(nchw_to_nhwc_kernel, npix, as_stream(stream), x, y, C, H * W, ldy, npix);
+    if (dt_out == UP_DT_BF16)
+        UP_LAUNCH_1D(nchw_to_nhwc_kernel<bf16_t>, npix, as_stream(stream), x, (bf16_t*)y, C, H * W, ldy, npix);
+    else
+        UP_LAUNCH_1D(nchw_to_nhwc_kernel<float>, npix, as_stream(stream), x, (float*)y, C, H * W, ldy, npix);
     return check_launch("nchw_to_nhwc");
 }
-extern "C" int up_nhwc_to_nchw(const float* x, int ldx, float* y, int N, int C, int H, int W, void* stream) {
-    UP_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && ldx >= C, UP_ERR_INVALID, "nhwc_to_nchw: bad argument");
+extern "C" int up_nchw_to_nhwc(const float* x, float* y, int N, int C, int H, int W, int ldy, void* stream) {
+    return up_nchw_to_nhwc_t(x, y, N, C, H, W, ldy, UP_DT_F32, stream);
+}
+extern "C" int up_nhwc_to_nchw_t(const void* x, int ldx, float* y, int N, int C, int H, int W, int dt_in, void* stream) {
+    UP_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && ldx >= C && UP_DT_OK(dt_in), UP_ERR_INVALID,
+               "nhwc_to_nchw: bad argument");
     int64_t npix = (int64_t)N * H * W;
-    UP_LAUNCH_1D(nhwc_to_nchw_kernel, npix, as_stream(stream), x, ldx, y, C, H * W, npix);
+    if (dt_in == UP_DT_BF16)
+        UP_LAUNCH_1D(nhwc_to_nchw_kernel<bf16_t>, npix, as_stream(stream), (const bf16_t*)x, ldx, y, C, H * W, npix);
+    else
+        UP_LAUNCH_1D(nhwc_to_nchw_kernel<float>, npix, as_stream(stream), (const float*)x, ldx, y, C, H * W, npix);
     return check_launch("nhwc_to_nchw");
+}
+extern "C" int up_nhwc_to_nchw(const float* x, int ldx, float* y, int N, int C, int H, int W, void* stream) {
+    return up_nhwc_to_nchw_t(x, ldx, y, N, C, H, W, UP_DT_F32, stream);
 }
 
 extern "C" int up_copy2d(const float* s, int lds, float* d, int ldd, int64_t rows, int C, void* stream) {
@@ -621,60 +644,125 @@ static int pool_args_ok(int N, int H, int W, int C, int P, int Q, int lda, int l
     return UP_OK;
 }
 
-extern "C" int up_maxpool3s2_fwd(const float* x, int ldx, float* y, int ldy, uint8_t* idx, int N, int H, int W, int C,
-                                 int P, int Q, void* stream) {
+// (dt_in, dt_out): the max-pool after the stem is where the bf16-storage network leaves fp32 (fp32 in, bf16 out; its
+// backward bf16 in, fp32 out); all other uses have equal types
+namespace up {
+template <typename TI, typename TO>
+static void launch_maxpool_fwd(const void* x, int ldx, void* y, int ldy, uint8_t* idx, int H, int W, int C, int P, int Q,
+                               int64_t total, hipStream_t st) {
+    UP_LAUNCH_1D((maxpool_fwd_kernel<TI, TO>), total, st, (const TI*)x, ldx, (TO*)y, ldy, idx, H, W, C / 4, P, Q, total,
+                 make_fastdiv(C / 4), make_fastdiv(Q), make_fastdiv(P));
+}
+template <typename TI, typename TO>
+static void launch_maxpool_bwd(const void* dy, int lddy, const uint8_t* idx, void* dx, int lddx, int H, int W, int C, int P,
+                               int Q, int64_t total, hipStream_t st) {
+    UP_LAUNCH_1D((maxpool_bwd_kernel<TI, TO>), total, st, (const TI*)dy, lddy, idx, (TO*)dx, lddx, H, W, C / 4, P, Q, total,
+                 make_fastdiv(C / 4), make_fastdiv(W), make_fastdiv(H));
+}
+}  // namespace up
+extern "C" int up_maxpool3s2_fwd_t(const void* x, int ldx, void* y, int ldy, uint8_t* idx, int N, int H, int W, int C,
+                                   int P, int Q, int dt_in, int dt_out, void* stream) {
     if (int e = pool_args_ok(N, H, W, C, P, Q, ldx, ldy)) return e;
-    UP_REQUIRE(x && y && idx, UP_ERR_INVALID, "maxpool_fwd: null pointer");
+    UP_REQUIRE(x && y && idx && UP_DT_OK(dt_in) && UP_DT_OK(dt_out), UP_ERR_INVALID, "maxpool_fwd: bad argument");
     UP_REQUIRE(P == (H - 1) / 2 + 1 && Q == (W - 1) / 2 + 1, UP_ERR_INVALID, "maxpool_fwd: P,Q mismatch");
     int64_t total = (int64_t)N * P * Q * (C / 4);
-    UP_LAUNCH_1D(maxpool_fwd_kernel, total, as_stream(stream), x, ldx, y, ldy, idx, H, W, C / 4, P, Q, total,
-                 make_fastdiv(C / 4), make_fastdiv(Q), make_fastdiv(P));
+    hipStream_t st = as_stream(stream);
+    if (dt_in == UP_DT_F32 && dt_out == UP_DT_F32) launch_maxpool_fwd<float, float>(x, ldx, y, ldy, idx, H, W, C, P, Q, total, st);
+    else if (dt_in == UP_DT_F32) launch_maxpool_fwd<float, bf16_t>(x, ldx, y, ldy, idx, H, W, C, P, Q, total, st);
+    else if (dt_out == UP_DT_F32) launch_maxpool_fwd<bf16_t, float>(x, ldx, y, ldy, idx, H, W, C, P, Q, total, st);
+    else launch_maxpool_fwd<bf16_t, bf16_t>(x, ldx, y, ldy, idx, H, W, C, P, Q, total, st);
     return check_launch("maxpool_fwd");
+}
+extern "C" int up_maxpool3s2_fwd(const float* x, int ldx, float* y, int ldy, uint8_t* idx, int N, int H, int W, int C,
+                                 int P, int Q, void* stream) {
+    return up_maxpool3s2_fwd_t(x, ldx, y, ldy, idx, N, H, W, C, P, Q, UP_DT_F32, UP_DT_F32, stream);
+}
+extern "C" int up_maxpool3s2_bwd_t(const void* dy, int lddy, const uint8_t* idx, void* dx, int lddx, int N, int H,
+                                   int W, int C, int P, int Q, int dt_in, int dt_out, void* stream) {
+    if (int e = pool_args_ok(N, H, W, C, P, Q, lddx, lddy)) return e;
+    UP_REQUIRE(dy && idx && dx && UP_DT_OK(dt_in) && UP_DT_OK(dt_out), UP_ERR_INVALID, "maxpool_bwd: bad argument");
+    int64_t total = (int64_t)N * H * W * (C / 4);
+    hipStream_t st = as_stream(stream);
+    if (dt_in == UP_DT_F32 && dt_out == UP_DT_F32) launch_maxpool_bwd<float, float>(dy, lddy, idx, dx, lddx, H, W, C, P, Q, total, st);
+    else if (dt_in == UP_DT_F32) launch_maxpool_bwd<float, bf16_t>(dy, lddy, idx, dx, lddx, H, W, C, P, Q, total, st);
+    else if (dt_out == UP_DT_F32) launch_maxpool_bwd<bf16_t, float>(dy, lddy, idx, dx, lddx, H, W, C, P, Q, total, st);
+    else launch_maxpool_bwd<bf16_t, bf16_t>(dy, lddy, idx, dx, lddx, H, W, C, P, Q, total, st);
+    return check_launch("maxpool_bwd");
 }
 extern "C" int up_maxpool3s2_bwd(const float* dy, int lddy, const uint8_t* idx, float* dx, int lddx, int N, int H,
                                  int W, int C, int P, int Q, void* stream) {
-    if (int e = pool_args_ok(N, H, W, C, P, Q, lddx, lddy)) return e;
-    UP_REQUIRE(dy && idx && dx, UP_ERR_INVALID, "maxpool_bwd: null pointer");
-    int64_t total = (int64_t)N * H * W * (C / 4);
-    UP_LAUNCH_1D(maxpool_bwd_kernel, total, as_stream(stream), dy, lddy, idx, dx, lddx, H, W, C / 4, P, Q, total,
-                 make_fastdiv(C / 4), make_fastdiv(W), make_fastdiv(H));
-    return check_launch("maxpool_bwd");
+    return up_maxpool3s2_bwd_t(dy, lddy, idx, dx, lddx, N, H, W, C, P, Q, UP_DT_F32, UP_DT_F32, stream);
 }
 
 static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 
+extern "C" int up_bilinear_fwd_t(const void* x, int ldx, void* y, int ldy, int N, int H, int W, int C, int P, int Q,
+                                 int dtype, void* stream) {
+    if (int e = pool_args_ok(N, H, W, C, P, Q, ldx, ldy)) return e;
+    UP_REQUIRE(x && y && UP_DT_OK(dtype), UP_ERR_INVALID, "bilinear_fwd: bad argument");
+    int64_t total = (int64_t)N * P * Q * (C / 4);
+    if (dtype == UP_DT_BF16)
+        UP_LAUNCH_1D(bilinear_fwd_kernel<bf16_t>, total, as_stream(stream), (const bf16_t*)x, ldx, (bf16_t*)y, ldy, H, W,
+                     C / 4, P, Q, ac_scale(H, P), ac_scale(W, Q), total, make_fastdiv(C / 4), make_fastdiv(Q),
+                     make_fastdiv(P));
+    else
+        UP_LAUNCH_1D(bilinear_fwd_kernel<float>, total, as_stream(stream), (const float*)x, ldx, (float*)y, ldy, H, W,
+                     C / 4, P, Q, ac_scale(H, P), ac_scale(W, Q), total, make_fastdiv(C / 4), make_fastdiv(Q),
+                     make_fastdiv(P));
+    return check_launch("bilinear_fwd");
+}
 extern "C" int up_bilinear_fwd(const float* x, int ldx, float* y, int ldy, int N, int H, int W, int C, int P, int Q,
                                void* stream) {
-    if (int e = pool_args_ok(N, H, W, C, P, Q, ldx, ldy)) return e;
-    UP_REQUIRE(x && y, UP_ERR_INVALID, "bilinear_fwd: null pointer");
-    int64_t total = (int64_t)N * P * Q * (C / 4);
-    UP_LAUNCH_1D(bilinear_fwd_kernel, total, as_stream(stream), x, ldx, y, ldy, H, W, C / 4, P, Q, ac_scale(H, P),
-                 ac_scale(W, Q), total, make_fastdiv(C / 4), make_fastdiv(Q), make_fastdiv(P));
-    return check_launch("bilinear_fwd");
+    return up_bilinear_fwd_t(x, ldx, y, ldy, N, H, W, C, P, Q, UP_DT_F32, stream);
+}
+extern "C" int up_bilinear_bwd_t(const void* dy, int lddy, void* dx, int lddx, int N, int H, int W, int C, int P,
+                                 int Q, int dtype, void* stream) {
+    if (int e = pool_args_ok(N, H, W, C, P, Q, lddx, lddy)) return e;
+    UP_REQUIRE(dy && dx && UP_DT_OK(dtype), UP_ERR_INVALID, "bilinear_bwd: bad argument");
+    int64_t total = (int64_t)N * H * W * (C / 4);
+    if (dtype == UP_DT_BF16)
+        UP_LAUNCH_1D(bilinear_bwd_kernel<bf16_t>, total, as_stream(stream), (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, H,
+                     W, C / 4, P, Q, ac_scale(H, P), ac_scale(W, Q), total, make_fastdiv(C / 4), make_fastdiv(W),
+                     make_fastdiv(H));
+    else
+        UP_LAUNCH_1D(bilinear_bwd_kernel<float>, total, as_stream(stream), (const float*)dy, lddy, (float*)dx, lddx, H, W,
+                     C / 4, P, Q, ac_scale(H, P), ac_scale(W, Q), total, make_fastdiv(C / 4), make_fastdiv(W),
+                     make_fastdiv(H));
+    return check_launch("bilinear_bwd");
 }
 extern "C" int up_bilinear_bwd(const float* dy, int lddy, float* dx, int lddx, int N, int H, int W, int C, int P,
                                int Q, void* stream) {
-    if (int e = pool_args_ok(N, H, W, C, P, Q, lddx, lddy)) return e;
-    UP_REQUIRE(dy && dx, UP_ERR_INVALID, "bilinear_bwd: null pointer");
-    int64_t total = (int64_t)N * H * W * (C / 4);
-    UP_LAUNCH_1D(bilinear_bwd_kernel, total, as_stream(stream), dy, lddy, dx, lddx, H, W, C / 4, P, Q, ac_scale(H, P),
-                 ac_scale(W, Q), total, make_fastdiv(C / 4), make_fastdiv(W), make_fastdiv(H));
-    return check_launch("bilinear_bwd");
+    return up_bilinear_bwd_t(dy, lddy, dx, lddx, N, H, W, C, P, Q, UP_DT_F32, stream);
 }
 
-extern "C" int up_gap_fwd(const float* x, int ldx, float* y, int N, int HW, int C, void* stream) {
-    UP_REQUIRE(x && y && N > 0 && HW > 0 && C > 0 && ldx >= C, UP_ERR_INVALID, "gap_fwd: bad argument");
-    hipLaunchKernelGGL(gap_fwd_kernel, dim3(N, cdiv(C, 64)), dim3(256), 0, as_stream(stream), x, ldx, y, HW, C);
+extern "C" int up_gap_fwd_t(const void* x, int ldx, void* y, int N, int HW, int C, int dtype, void* stream) {
+    UP_REQUIRE(x && y && N > 0 && HW > 0 && C > 0 && ldx >= C && UP_DT_OK(dtype), UP_ERR_INVALID, "gap_fwd: bad argument");
+    if (dtype == UP_DT_BF16)
+        hipLaunchKernelGGL(gap_fwd_kernel<bf16_t>, dim3(N, cdiv(C, 64)), dim3(256), 0, as_stream(stream), (const bf16_t*)x,
+                           ldx, (bf16_t*)y, HW, C);
+    else
+        hipLaunchKernelGGL(gap_fwd_kernel<float>, dim3(N, cdiv(C, 64)), dim3(256), 0, as_stream(stream), (const float*)x,
+                           ldx, (float*)y, HW, C);
     return check_launch("gap_fwd");
 }
-extern "C" int up_gap_bwd(const float* dy, float* dx, int lddx, int N, int HW, int C, void* stream) {
-    UP_REQUIRE(dy && dx && N > 0 && HW > 0 && C > 0 && C % 4 == 0 && lddx % 4 == 0 && lddx >= C, UP_ERR_INVALID,
-               "gap_bwd: bad argument");
+extern "C" int up_gap_fwd(const float* x, int ldx, float* y, int N, int HW, int C, void* stream) {
+    return up_gap_fwd_t(x, ldx, y, N, HW, C, UP_DT_F32, stream);
+}
+extern "C" int up_gap_bwd_t(const void* dy, void* dx, int lddx, int N, int HW, int C, int dtype, void* stream) {
+    UP_REQUIRE(dy && dx && N > 0 && HW > 0 && C > 0 && C % 4 == 0 && lddx % 4 == 0 && lddx >= C && UP_DT_OK(dtype),
+               UP_ERR_INVALID, "gap_bwd: bad argument");
     int64_t total = (int64_t)N * HW * (C / 4);
     UP_REQUIRE(total < (1ll << 31), UP_ERR_UNSUPPORTED, "gap_bwd: tensor too large");
-    UP_LAUNCH_1D(gap_bwd_kernel, total, as_stream(stream), dy, dx, lddx, HW, C / 4, 1.0f / (float)HW, total,
-                 make_fastdiv(C / 4), make_fastdiv(HW));
+    if (dtype == UP_DT_BF16)
+        UP_LAUNCH_1D(gap_bwd_kernel<bf16_t>, total, as_stream(stream), (const bf16_t*)dy, (bf16_t*)dx, lddx, HW, C / 4,
+                     1.0f / (float)HW, total, make_fastdiv(C / 4), make_fastdiv(HW));
+    else
+        UP_LAUNCH_1D(gap_bwd_kernel<float>, total, as_stream(stream), (const float*)dy, (float*)dx, lddx, HW, C / 4,
+                     1.0f / (float)HW, total, make_fastdiv(C / 4), make_fastdiv(HW));
     return check_launch("gap_bwd");
+}
+extern "C" int up_gap_bwd(const float* dy, float* dx, int lddx, int N, int HW, int C, void* stream) {
+    return up_gap_bwd_t(dy, dx, lddx, N, HW, C, UP_DT_F32, stream);
 }
 
 extern "C" int up_avgpool9s8_fwd(const float* x, float* y, int ldy, int coff, int N, int H, int W, int P, int Q,

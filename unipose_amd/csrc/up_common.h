@@ -56,4 +56,42 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// ---- bf16 storage (BASELINE configs[4]): activations as raw bf16 bit patterns in HBM, arithmetic in fp32 -------------
+typedef uint16_t bf16_t;          // (element-type codes UP_DT_F32 / UP_DT_BF16: include/unipose_hip.h)
+#ifndef UP_EMU
+// round-to-nearest-even pair conversion (v_cvt_pk_bf16_f32); element 0 in the low half-word
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo_elem, float hi_elem) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t v;
+    v[0] = (__bf16)lo_elem;
+    v[1] = (__bf16)hi_elem;
+    return __builtin_bit_cast(uint32_t, v);
+}
+#endif
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+// four consecutive elements <-> float4 (fp32: one 16-byte access; bf16: one 8-byte access)
+template <typename T>
+__device__ __forceinline__ float4 ld4(const T* p);
+template <>
+__device__ __forceinline__ float4 ld4<float>(const float* p) {
+    return *reinterpret_cast<const float4*>(p);
+}
+template <>
+__device__ __forceinline__ float4 ld4<bf16_t>(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y));
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+    uint2 u;
+    u.x = pack_bf16x2(v.x, v.y);
+    u.y = pack_bf16x2(v.z, v.w);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return __uint_as_float((uint32_t)*p << 16); }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16_t* p, float v) { *p = (bf16_t)(pack_bf16x2(v, 0.f) & 0xffffu); }
+
 }  // namespace up

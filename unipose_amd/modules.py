@@ -108,8 +108,8 @@ class ResNet(nn.Module):
         self.load_state_dict(own)
 
     def forward(self, x_nhwc):
-        x = ops.conv_bn_act(x_nhwc, self.conv1, self.bn1, relu=True)
-        x = ops.MaxPool3s2.apply(x)
+        x = ops.conv_bn_act(x_nhwc, self.conv1, self.bn1, relu=True)      # the 3-channel stem stays fp32 in every mode
+        x = ops.MaxPool3s2.apply(x, ops.storage_dtype())                 # bf16 storage starts here (ops.set_conv_math)
         x = self.layer1(x)
         low = x
         x = self.layer4(self.layer3(self.layer2(x)))

@@ -25,6 +25,21 @@ def rup4(c: int) -> int:
     return (c + 3) // 4 * 4
 
 
+def rup32(c: int) -> int:
+    return (c + 31) // 32 * 32
+
+
+def _dt(t: torch.Tensor) -> int:
+    """Element-type code of an activation tensor for the `_t` entry points (UP_DT_F32 / UP_DT_BF16)."""
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
+def _padk(k: int, like: torch.Tensor) -> int:
+    """Physical channel count of a convolution output: multiples of 4 (fp32), of 32 in bf16 storage — there every
+    reduction (also the data gradient's, over the OUTPUT channels) must be a whole number of 32-wide K slices."""
+    return rup32(k) if like.dtype == torch.bfloat16 else rup4(k)
+
+
 def _stream(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
 
@@ -39,16 +54,17 @@ def _dev_ok(*ts):
             continue
         if not t.is_cuda and not _C._ALLOW_HOST_POINTERS:
             raise _C.UniPoseHipError("unipose_amd kernels need CUDA(HIP) tensors; there is no CPU fallback")
-        if t.dtype != torch.float32 and t.dtype != torch.uint8 and t.dtype != torch.int32:
+        if t.dtype not in (torch.float32, torch.bfloat16, torch.uint8, torch.int32):
             raise TypeError(f"unsupported dtype {t.dtype}")
 
 
 def _nhwc_ok(t: torch.Tensor):
     n, h, w, c = t.shape
-    if t.is_contiguous() and c % 4 == 0 and t.data_ptr() % 16 == 0:     # the common case, without four stride() calls
+    q = 8 if t.dtype == torch.bfloat16 else 4                           # elements per 16 bytes
+    if t.is_contiguous() and c % q == 0 and t.data_ptr() % 16 == 0:     # the common case, without four stride() calls
         return c
     ld = t.stride(2)
-    if t.stride(3) != 1 or t.stride(1) != w * ld or (n > 1 and t.stride(0) != h * w * ld) or ld % 4 or \
+    if t.stride(3) != 1 or t.stride(1) != w * ld or (n > 1 and t.stride(0) != h * w * ld) or ld % q or \
             t.data_ptr() % 16:
         raise ValueError(f"tensor is not a pixel-contiguous NHWC view: shape {tuple(t.shape)} strides {t.stride()}")
     return ld
@@ -95,8 +111,8 @@ def make_desc(x: torch.Tensor, weight: torch.Tensor, cfg: ConvCfg, ldy: Optional
     d.K, d.R, d.S = k, r, s
     d.stride, d.pad, d.dil = cfg.stride, cfg.pad, cfg.dil
     d.P, d.Q = p, q
-    d.Kp = rup4(k)
-    d.ldy = ldy if ldy is not None else rup4(k)
+    d.Kp = _padk(k, x)
+    d.ldy = ldy if ldy is not None else _padk(k, x)
     return d
 
 
@@ -176,16 +192,25 @@ def _packed(weight: torch.Tensor, d: _C.ConvDesc):
 #      stay on the exact fp32 MFMA
 #   2  plain bf16 operands, fp32 accumulation (BASELINE config 5): forward, data gradient AND weight gradient
 # Layers whose padded channel count is not a multiple of 32 (stem, 15-channel ConvLSTM convs) stay exact.
-MATH_F32, MATH_BF16X3, MATH_BF16 = 0, 1, 2
+#   3  "bf16s": as 2 with bf16 STORAGE — every activation and activation gradient behind the stem's max-pool is a bf16
+#      tensor in HBM (half the bytes of every streaming pass and of every operand gather); BatchNorm statistics,
+#      accumulators, weights, weight gradients and the optimizer stay fp32.  The kernels dispatch on the tensor dtype,
+#      the switch only tells the model where to change the element type (modules.ResNet.forward, unipose.forward).
+MATH_F32, MATH_BF16X3, MATH_BF16, MATH_BF16S = 0, 1, 2, 3
 CONV_MATH = MATH_F32
-_MATH_NAMES = {"f32": 0, "fp32": 0, "bf16x3": 1, "split": 1, "bf16": 2}
+_MATH_NAMES = {"f32": 0, "fp32": 0, "bf16x3": 1, "split": 1, "bf16": 2, "bf16s": 3, "bf16_storage": 3}
 
 
 def set_conv_math(mode):
     global CONV_MATH
     CONV_MATH = _MATH_NAMES.get(mode, mode)
-    if CONV_MATH not in (0, 1, 2):
+    if CONV_MATH not in (0, 1, 2, 3):
         raise ValueError(f"unknown conv math {mode!r}")
+
+
+def storage_dtype():
+    """Element type of the activations behind the stem (torch.bfloat16 in the bf16-storage configuration)."""
+    return torch.bfloat16 if CONV_MATH == MATH_BF16S else torch.float32
 
 
 if os.environ.get("UNIPOSE_CONV_MATH"):           # e.g. UNIPOSE_CONV_MATH=bf16x3 python -m pytest tests -m gpu
@@ -228,7 +253,7 @@ def conv_fwd_raw(x, weight, cfg, *, scale=None, shift=None, bias=None, residual=
     d = make_desc(x, weight, cfg, None if out is None else _nhwc_ok(out))
     if out is None:
         alloc = torch.zeros if d.ldy != d.K else torch.empty      # pad channels must read as zeros
-        out = alloc((d.N, d.P, d.Q, d.ldy), dtype=torch.float32, device=x.device)
+        out = alloc((d.N, d.P, d.Q, d.ldy), dtype=x.dtype, device=x.device)
     ep = _C.ConvEpilogue()
     ep.scale, ep.shift, ep.bias = _ptr(scale), _ptr(shift), _ptr(bias)
     ep.residual = _ptr(residual)
@@ -239,10 +264,18 @@ def conv_fwd_raw(x, weight, cfg, *, scale=None, shift=None, bias=None, residual=
         tiles = _C.lib().up_conv_stats_tiles(C.byref(d))
         st = torch.empty((tiles, d.K, 3), dtype=torch.float32, device=x.device)
         ep.stats = st.data_ptr()
-    if CONV_MATH != MATH_F32 and d.Cp % 32 == 0:
+    if x.dtype == torch.bfloat16:                                  # bf16 storage: the kernels follow the tensor
+        if d.Cp % 32 or (residual is not None and residual.dtype != x.dtype) or out.dtype != x.dtype:
+            raise NotImplementedError(f"bf16-storage convolution needs 32-aligned input channels (got {d.Cp}) and bf16 "
+                                      "residual / output tensors")
         wf, _ = _packed_bf16(weight, d)
         _C.check(_C.lib().up_conv2d_fwd_bf16(C.byref(d), x.data_ptr(), wf[0].data_ptr(), wf[1].data_ptr(),
-                                             out.data_ptr(), C.byref(ep), CONV_MATH, _stream(x)), "conv2d_fwd_bf16")
+                                             out.data_ptr(), C.byref(ep), MATH_BF16S, _stream(x)), "conv2d_fwd_bf16s")
+    elif CONV_MATH in (MATH_BF16X3, MATH_BF16, MATH_BF16S) and d.Cp % 32 == 0:
+        wf, _ = _packed_bf16(weight, d)
+        _C.check(_C.lib().up_conv2d_fwd_bf16(C.byref(d), x.data_ptr(), wf[0].data_ptr(), wf[1].data_ptr(),
+                                             out.data_ptr(), C.byref(ep), min(CONV_MATH, MATH_BF16), _stream(x)),
+                 "conv2d_fwd_bf16")
     else:
         wp = packed_fwd(weight, d)
         _C.check(_C.lib().up_conv2d_fwd(C.byref(d), x.data_ptr(), wp.data_ptr(), out.data_ptr(), C.byref(ep),
@@ -254,16 +287,23 @@ def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev, add=None):
     """dx = dgrad(dy) (+ add: another gradient of the same input, summed in the kernel epilogue)."""
     n, h, w, cp = x_shape
     alloc = torch.zeros if cp != d.C else torch.empty
-    dx = alloc((n, h, w, cp), dtype=torch.float32, device=dev)
+    dx = alloc((n, h, w, cp), dtype=dy.dtype, device=dev)
     dd = _C.ConvDesc.from_buffer_copy(d)
     dd.ldx = cp
     dd.ldy = _nhwc_ok(dy)
     ld_add = _nhwc_ok(add) if add is not None else 0
-    if CONV_MATH != MATH_F32 and d.Kp % 32 == 0:
+    if dy.dtype == torch.bfloat16:
+        if d.Kp % 32 or (add is not None and add.dtype != dy.dtype):
+            raise NotImplementedError("bf16-storage data gradient needs 32-aligned output channels and a bf16 addend")
         _, wd16 = _packed_bf16(weight, d)
         _C.check(_C.lib().up_conv2d_bwd_data_bf16(C.byref(dd), dy.data_ptr(), wd16[0].data_ptr(), wd16[1].data_ptr(),
-                                                  dx.data_ptr(), _ptr(add), ld_add, CONV_MATH, _stream(dy)),
-                 "conv2d_bwd_data_bf16")
+                                                  dx.data_ptr(), _ptr(add), ld_add, MATH_BF16S, _stream(dy)),
+                 "conv2d_bwd_data_bf16s")
+    elif CONV_MATH in (MATH_BF16X3, MATH_BF16, MATH_BF16S) and d.Kp % 32 == 0:
+        _, wd16 = _packed_bf16(weight, d)
+        _C.check(_C.lib().up_conv2d_bwd_data_bf16(C.byref(dd), dy.data_ptr(), wd16[0].data_ptr(), wd16[1].data_ptr(),
+                                                  dx.data_ptr(), _ptr(add), ld_add, min(CONV_MATH, MATH_BF16),
+                                                  _stream(dy)), "conv2d_bwd_data_bf16")
     else:
         wd = packed_dgrad(weight, d)
         _C.check(_C.lib().up_conv2d_bwd_data(C.byref(dd), dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), _ptr(add),
@@ -292,7 +332,12 @@ def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws
     ws = workspace(x.device, need, ws_tag)
     dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)
     db = torch.empty(weight_shape[0], dtype=torch.float32, device=x.device) if want_bias else None
-    fn = _C.lib().up_conv2d_bwd_weight_bf16 if CONV_MATH == MATH_BF16 else _C.lib().up_conv2d_bwd_weight
+    if x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16:
+        fn = _C.lib().up_conv2d_bwd_weight_bf16s
+    elif x.dtype != torch.float32 or dy.dtype != torch.float32:
+        raise TypeError(f"weight gradient of mixed element types {x.dtype} / {dy.dtype}")
+    else:
+        fn = _C.lib().up_conv2d_bwd_weight_bf16 if CONV_MATH in (MATH_BF16, MATH_BF16S) else _C.lib().up_conv2d_bwd_weight
     _C.check(fn(C.byref(dd), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel(),
                 _stream(x)), "conv2d_bwd_weight")
     return dw, db
@@ -404,6 +449,8 @@ class ConvBias(Function):
         x, weight, y = ctx.saved_tensors
         dy = _dense(dy)
         if ctx.relu:
+            if dy.dtype != torch.float32:
+                raise NotImplementedError("conv + bias + ReLU (the ConvLSTM head) has no bf16-storage backward")
             g = torch.empty_like(dy)
             _C.check(_C.lib().up_relu_bwd(dy.data_ptr(), y.data_ptr(), g.data_ptr(), dy.numel(), _stream(dy)),
                      "relu_bwd")
@@ -448,13 +495,15 @@ class ConvBnAct(Function):
             torch.rsqrt(rv + eps, out=coef[1])
             _C.check(L.up_bn_eval_coeffs(gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(), eps, k,
                                          coef[2].data_ptr(), coef[3].data_ptr(), _stream(x)), "bn_eval_coeffs")
-        z = torch.empty_like(y)
+        z = torch.empty_like(y) if d.ldy == k else torch.zeros_like(y)     # pad channels must read as zeros
         # sign bits of z for the backward passes (1/32 of re-reading z there); only when a backward can follow
         bits = torch.empty(((rows * k + 31) // 32,), dtype=torch.int32, device=dev) \
             if relu and any(ctx.needs_input_grad[:5]) else None
-        _C.check(L.up_bn_apply(y.data_ptr(), d.ldy, coef[2].data_ptr(), coef[3].data_ptr(), _ptr(residual),
-                               _nhwc_ok(residual) if residual is not None else 0, int(relu), z.data_ptr(), d.ldy,
-                               _ptr(bits), rows, k, _stream(x)), "bn_apply")
+        if residual is not None and residual.dtype != y.dtype:
+            raise TypeError(f"residual {residual.dtype} vs convolution output {y.dtype}")
+        _C.check(L.up_bn_apply_t(y.data_ptr(), d.ldy, coef[2].data_ptr(), coef[3].data_ptr(), _ptr(residual),
+                                 _nhwc_ok(residual) if residual is not None else 0, int(relu), z.data_ptr(), d.ldy,
+                                 _ptr(bits), rows, k, _dt(y), _stream(x)), "bn_apply")
         if relu and _RELU_TRACE is not None:
             _RELU_TRACE.append(z.detach())
         ctx.d, ctx.relu, ctx.train, ctx.has_res = d, relu, train, residual is not None
@@ -472,15 +521,18 @@ class ConvBnAct(Function):
         dz = _dense(dz)
         k = weight.shape[0]
         rows = d.N * d.P * d.Q
-        dy = torch.empty_like(y)
-        dres = torch.empty_like(y) if ctx.has_res else None
+        fresh = torch.empty_like if d.ldy == k else torch.zeros_like         # pad channels meet zero weights: keep them finite
+        dy = fresh(y)
+        dres = fresh(y) if ctx.has_res else None
         dgb = torch.empty((2, k), dtype=torch.float32, device=x.device)
         need = L.up_bn_bwd_workspace(rows, k)
         ws = workspace(x.device, need)
-        _C.check(L.up_bn_bwd(dz.data_ptr(), d.ldy, None, 0, _ptr(bits), y.data_ptr(), d.ldy, gamma.data_ptr(),
-                             coef[0].data_ptr(), coef[1].data_ptr(), int(ctx.relu), int(ctx.train), dy.data_ptr(),
-                             d.ldy, _ptr(dres), d.ldy, dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(),
-                             ws.numel(), rows, k, _stream(x)), "bn_bwd")
+        if dz.dtype != y.dtype:
+            raise TypeError(f"gradient {dz.dtype} vs saved convolution output {y.dtype}")
+        _C.check(L.up_bn_bwd_t(dz.data_ptr(), d.ldy, None, 0, _ptr(bits), y.data_ptr(), d.ldy, gamma.data_ptr(),
+                               coef[0].data_ptr(), coef[1].data_ptr(), int(ctx.relu), int(ctx.train), dy.data_ptr(),
+                               d.ldy, _ptr(dres), d.ldy, dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(),
+                               ws.numel(), rows, k, _dt(y), _stream(x)), "bn_bwd")
         add = None
         if ctx.link_in is not None:
             add, ctx.link_in.grad, ctx.link_in.armed = ctx.link_in.grad, None, False
@@ -607,9 +659,10 @@ class ToNCHW(Function):
         _dev_ok(x)
         n, h, w, _ = x.shape
         ld = _nhwc_ok(x)
-        y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
-        _C.check(_C.lib().up_nhwc_to_nchw(x.data_ptr(), ld, y.data_ptr(), n, c, h, w, _stream(x)), "nhwc_to_nchw")
-        ctx.ld = x.shape[3]
+        y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)      # the network's output is always fp32
+        _C.check(_C.lib().up_nhwc_to_nchw_t(x.data_ptr(), ld, y.data_ptr(), n, c, h, w, _dt(x), _stream(x)),
+                 "nhwc_to_nchw")
+        ctx.ld, ctx.dtype = x.shape[3], x.dtype
         return y
 
     @staticmethod
@@ -617,8 +670,9 @@ class ToNCHW(Function):
     def backward(ctx, dy):
         dy = _dense(dy)
         n, c, h, w = dy.shape
-        dx = torch.empty((n, h, w, ctx.ld), dtype=torch.float32, device=dy.device)
-        _C.check(_C.lib().up_nchw_to_nhwc(dy.data_ptr(), dx.data_ptr(), n, c, h, w, ctx.ld, _stream(dy)), "nchw_to_nhwc")
+        dx = torch.empty((n, h, w, ctx.ld), dtype=ctx.dtype, device=dy.device)
+        _C.check(_C.lib().up_nchw_to_nhwc_t(dy.data_ptr(), dx.data_ptr(), n, c, h, w, ctx.ld, _dt(dx), _stream(dy)),
+                 "nchw_to_nhwc")
         return dx, None
 
 
@@ -626,16 +680,20 @@ class MaxPool3s2(Function):
     """nn.MaxPool2d(3, 2, 1): resnet.py:65,117; decoder.py:33,47."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, out_dtype=None):
+        """`out_dtype`: element type of the result (default: that of x) — the pool behind the fp32 stem is where the
+        bf16-storage network changes its element type."""
         _dev_ok(x)
         n, h, w, c = x.shape
         p, q = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-        y = torch.empty((n, p, q, c), dtype=torch.float32, device=x.device)
+        y = torch.empty((n, p, q, c), dtype=out_dtype or x.dtype, device=x.device)
+        if y.dtype == torch.bfloat16 and c % 8:
+            raise ValueError(f"bf16 tensors need channel counts that are multiples of 8, got {c}")
         idx = torch.empty((n, p, q, c), dtype=torch.uint8, device=x.device)
-        _C.check(_C.lib().up_maxpool3s2_fwd(x.data_ptr(), _nhwc_ok(x), y.data_ptr(), c, idx.data_ptr(), n, h, w, c,
-                                            p, q, _stream(x)), "maxpool_fwd")
+        _C.check(_C.lib().up_maxpool3s2_fwd_t(x.data_ptr(), _nhwc_ok(x), y.data_ptr(), c, idx.data_ptr(), n, h, w, c,
+                                              p, q, _dt(x), _dt(y), _stream(x)), "maxpool_fwd")
         ctx.save_for_backward(idx)
-        ctx.hw = (h, w)
+        ctx.hw, ctx.in_dtype = (h, w), x.dtype
         return y
 
     @staticmethod
@@ -645,10 +703,10 @@ class MaxPool3s2(Function):
         dy = _dense(dy)
         n, p, q, c = dy.shape
         h, w = ctx.hw
-        dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device)
-        _C.check(_C.lib().up_maxpool3s2_bwd(dy.data_ptr(), c, idx.data_ptr(), dx.data_ptr(), c, n, h, w, c, p, q,
-                                            _stream(dy)), "maxpool_bwd")
-        return dx
+        dx = torch.empty((n, h, w, c), dtype=ctx.in_dtype, device=dy.device)
+        _C.check(_C.lib().up_maxpool3s2_bwd_t(dy.data_ptr(), c, idx.data_ptr(), dx.data_ptr(), c, n, h, w, c, p, q,
+                                              _dt(dy), _dt(dx), _stream(dy)), "maxpool_bwd")
+        return dx, None
 
 
 class Bilinear(Function):
@@ -658,9 +716,9 @@ class Bilinear(Function):
     def forward(ctx, x, p: int, q: int):
         _dev_ok(x)
         n, h, w, c = x.shape
-        y = torch.empty((n, p, q, c), dtype=torch.float32, device=x.device)
-        _C.check(_C.lib().up_bilinear_fwd(x.data_ptr(), _nhwc_ok(x), y.data_ptr(), c, n, h, w, c, p, q, _stream(x)),
-                 "bilinear_fwd")
+        y = torch.empty((n, p, q, c), dtype=x.dtype, device=x.device)
+        _C.check(_C.lib().up_bilinear_fwd_t(x.data_ptr(), _nhwc_ok(x), y.data_ptr(), c, n, h, w, c, p, q, _dt(x),
+                                            _stream(x)), "bilinear_fwd")
         ctx.hw = (h, w)
         return y
 
@@ -670,8 +728,8 @@ class Bilinear(Function):
         dy = _dense(dy)
         n, p, q, c = dy.shape
         h, w = ctx.hw
-        dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device)
-        _C.check(_C.lib().up_bilinear_bwd(dy.data_ptr(), c, dx.data_ptr(), c, n, h, w, c, p, q, _stream(dy)),
+        dx = torch.empty((n, h, w, c), dtype=dy.dtype, device=dy.device)
+        _C.check(_C.lib().up_bilinear_bwd_t(dy.data_ptr(), c, dx.data_ptr(), c, n, h, w, c, p, q, _dt(dy), _stream(dy)),
                  "bilinear_bwd")
         return dx, None, None
 
@@ -683,8 +741,9 @@ class GlobalAvgPool(Function):
     def forward(ctx, x):
         _dev_ok(x)
         n, h, w, c = x.shape
-        y = torch.empty((n, 1, 1, c), dtype=torch.float32, device=x.device)
-        _C.check(_C.lib().up_gap_fwd(x.data_ptr(), _nhwc_ok(x), y.data_ptr(), n, h * w, c, _stream(x)), "gap_fwd")
+        y = torch.empty((n, 1, 1, c), dtype=x.dtype, device=x.device)
+        _C.check(_C.lib().up_gap_fwd_t(x.data_ptr(), _nhwc_ok(x), y.data_ptr(), n, h * w, c, _dt(x), _stream(x)),
+                 "gap_fwd")
         ctx.hw = (h, w)
         return y
 
@@ -694,9 +753,22 @@ class GlobalAvgPool(Function):
         dy = _dense(dy)
         n, _, _, c = dy.shape
         h, w = ctx.hw
-        dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device)
-        _C.check(_C.lib().up_gap_bwd(dy.data_ptr(), dx.data_ptr(), c, n, h * w, c, _stream(dy)), "gap_bwd")
+        dx = torch.empty((n, h, w, c), dtype=dy.dtype, device=dy.device)
+        _C.check(_C.lib().up_gap_bwd_t(dy.data_ptr(), dx.data_ptr(), c, n, h * w, c, _dt(dy), _stream(dy)), "gap_bwd")
         return dx
+
+
+def _copy2d(src, lds, soff, dst, ldd, doff, rows, c):
+    """Strided copy of `c` channels per pixel row (element offsets soff / doff).  The kernel moves 4-byte words: a bf16
+    tensor is copied as c/2 words per row (channel counts and offsets of bf16 tensors are multiples of 8)."""
+    if src.dtype != dst.dtype:
+        raise TypeError(f"copy2d: {src.dtype} -> {dst.dtype}")
+    es = src.element_size()
+    w = 4 // es                       # elements per 4-byte word
+    if c % w or lds % w or ldd % w or soff % w or doff % w:
+        raise ValueError("copy2d: bf16 rows must be whole 4-byte words")
+    _C.check(_C.lib().up_copy2d(src.data_ptr() + es * soff, lds // w, dst.data_ptr() + es * doff, ldd // w, rows, c // w,
+                                _stream(src)), "copy2d")
 
 
 class ConcatC(Function):
@@ -710,11 +782,10 @@ class ConcatC(Function):
         widths = [t.shape[3] for t in xs]
         tot = sum(widths)
         alloc = torch.zeros if ld_out > tot else torch.empty
-        y = alloc((n, h, w, max(ld_out, tot)), dtype=torch.float32, device=xs[0].device)
+        y = alloc((n, h, w, max(ld_out, tot)), dtype=xs[0].dtype, device=xs[0].device)
         off = 0
         for t, c in zip(xs, widths):
-            _C.check(_C.lib().up_copy2d(t.data_ptr(), _nhwc_ok(t), y.data_ptr() + 4 * off, y.shape[3], n * h * w, c,
-                                        _stream(t)), "copy2d")
+            _copy2d(t, _nhwc_ok(t), 0, y, y.shape[3], off, n * h * w, c)
             off += c
         ctx.widths = widths
         return y
@@ -727,9 +798,8 @@ class ConcatC(Function):
         outs, off = [], 0
         for i, c in enumerate(ctx.widths):
             if ctx.needs_input_grad[i + 1]:
-                g = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device)
-                _C.check(_C.lib().up_copy2d(dy.data_ptr() + 4 * off, ld, g.data_ptr(), c, n * h * w, c, _stream(dy)),
-                         "copy2d")
+                g = torch.empty((n, h, w, c), dtype=dy.dtype, device=dy.device)
+                _copy2d(dy, ld, off, g, c, 0, n * h * w, c)
                 outs.append(g)
             else:
                 outs.append(None)
@@ -747,8 +817,8 @@ class Dropout(Function):
         x = _dense(x)
         y = torch.empty_like(x)
         mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
-        _C.check(_C.lib().up_dropout_fwd(x.data_ptr(), y.data_ptr(), mask.data_ptr(), _ptr(ext_mask), x.numel(),
-                                         float(p), int(seed) & (2 ** 64 - 1), _stream(x)), "dropout_fwd")
+        _C.check(_C.lib().up_dropout_fwd_t(x.data_ptr(), y.data_ptr(), mask.data_ptr(), _ptr(ext_mask), x.numel(),
+                                           float(p), int(seed) & (2 ** 64 - 1), _dt(x), _stream(x)), "dropout_fwd")
         ctx.p = float(p)
         ctx.save_for_backward(mask)
         return y
@@ -759,8 +829,8 @@ class Dropout(Function):
         (mask,) = ctx.saved_tensors
         dy = _dense(dy)
         dx = torch.empty_like(dy)
-        _C.check(_C.lib().up_dropout_bwd(dy.data_ptr(), mask.data_ptr(), dx.data_ptr(), dy.numel(), ctx.p,
-                                         _stream(dy)), "dropout_bwd")
+        _C.check(_C.lib().up_dropout_bwd_t(dy.data_ptr(), mask.data_ptr(), dx.data_ptr(), dy.numel(), ctx.p, _dt(dy),
+                                           _stream(dy)), "dropout_bwd")
         return dx, None, None, None
 
 

@@ -57,6 +57,9 @@ class unipose(nn.Module):
 
     def forward(self, input, centermap, iter, previous, previousHide, previousCell):
         b = input.shape[0]
+        if ops.storage_dtype() != torch.float32:
+            raise NotImplementedError("bf16 storage (BASELINE configs[4]) is an image-model configuration: the ConvLSTM "
+                                      "head (15-channel state, configs[3]) runs in fp32")
         with ops.bn_counters(self):
             x = ops.ToNHWC.apply(input[:, iter])
             x, low = self.backbone(x)
