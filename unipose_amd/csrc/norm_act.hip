@@ -59,25 +59,42 @@ __global__ void __launch_bounds__(256) bn_eval_coeffs_kernel(const float* g, con
     shift[c] = b[c] - rm[c] * sc;
 }
 
-// one wavefront per channel: lanes stride over the row-tile partials, then a shuffle tree
+// One workgroup per channel: thread t merges the partials of row tiles t, t+256, ... (one or two independent loads for
+// the layer shapes of this network: 265 tiles at 23x23 / B = 32), then an 8-level merge tree over LDS.  These few-hundred-
+// byte kernels sit on the critical path of the forward pass between every convolution and its apply pass, and their
+// time is the number of DEPENDENT load rounds (the partials were written by other XCDs: ~2 us per round): one wavefront
+// per channel (5 rounds) took 10.5 us per layer, 16 lanes per channel with coalesced 192-byte rows (17 rounds) 23 us.
 __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* stats, int tiles, int C, float eps, float mom,
                                                           float* rm, float* rv, const float* gamma,
                                                           const float* beta, float* mean_o, float* invstd_o,
                                                           float* scale, float* shift) {
-    int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
-    if (c >= C) return;  // whole wave exits together
+    __shared__ float red[256][3];
+    const int c = blockIdx.x, t0 = threadIdx.x;
     float n = 0.f, m = 0.f, q = 0.f;
-    for (int t = lane; t < tiles; t += 64) {
+    for (int t = t0; t < tiles; t += 512) {      // two loads in flight per round
         const float* s = stats + ((size_t)t * C + c) * 3;
-        wf_merge3(n, m, q, s[0], s[1], s[2]);
+        const int t2 = t + 256;
+        const float* s2 = stats + ((size_t)(t2 < tiles ? t2 : t) * C + c) * 3;
+        const float a0 = s[0], a1 = s[1], a2 = s[2];
+        const float b0 = t2 < tiles ? s2[0] : 0.f, b1 = s2[1], b2 = s2[2];
+        wf_merge3(n, m, q, a0, a1, a2);
+        wf_merge3(n, m, q, b0, b1, b2);
     }
+    red[t0][0] = n;
+    red[t0][1] = m;
+    red[t0][2] = q;
+    __syncthreads();
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        float n2 = __shfl_down(n, off), m2 = __shfl_down(m, off), q2 = __shfl_down(q, off);
-        wf_merge3(n, m, q, n2, m2, q2);
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (t0 < off) {
+            wf_merge3(n, m, q, red[t0 + off][0], red[t0 + off][1], red[t0 + off][2]);
+            red[t0][0] = n;
+            red[t0][1] = m;
+            red[t0][2] = q;
+        }
+        __syncthreads();
     }
-    if (lane == 0) {
+    if (t0 == 0) {
         float var = q / n;
         float is = 1.0f / sqrtf(var + eps);
         mean_o[c] = m;
@@ -225,23 +242,42 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* dz, int ldd
         if (cc < C) partial[((size_t)blockIdx.x * C + cc) * 2 + which] = t;
     }
 }
-// pass 2: one wave per channel sums the chunk partials
+// pass 2: one workgroup per channel, thread t sums chunks t, t+256, ... (four independent loads per round), LDS tree;
+// fixed order: deterministic.  (Same reasoning as bn_finalize_kernel: the time is the number of dependent load rounds.)
 __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* partial, int chunks, int C, float* dgamma,
                                                               float* dbeta) {
-    int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    int lane = threadIdx.x & 63;
-    if (c >= C) return;
+    __shared__ float red[256][2];
+    const int c = blockIdx.x, t0 = threadIdx.x;
     float a = 0.f, b = 0.f;
-    for (int t = lane; t < chunks; t += 64) {
-        a += partial[((size_t)t * C + c) * 2];
-        b += partial[((size_t)t * C + c) * 2 + 1];
-    }
+    for (int t = t0; t < chunks; t += 1024) {
+        float va[4], vb[4];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        a += __shfl_down(a, off);
-        b += __shfl_down(b, off);
+        for (int u = 0; u < 4; ++u) {
+            const int tt = t + 256 * u;
+            const float* v = partial + ((size_t)(tt < chunks ? tt : t) * C + c) * 2;
+            va[u] = tt < chunks ? v[0] : 0.f;
+            vb[u] = tt < chunks ? v[1] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a += va[u];
+            b += vb[u];
+        }
     }
-    if (lane == 0) {
+    red[t0][0] = a;
+    red[t0][1] = b;
+    __syncthreads();
+#pragma unroll
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (t0 < off) {
+            a += red[t0 + off][0];
+            b += red[t0 + off][1];
+            red[t0][0] = a;
+            red[t0][1] = b;
+        }
+        __syncthreads();
+    }
+    if (t0 == 0) {
         dbeta[c] = a;
         dgamma[c] = b;
     }
@@ -385,7 +421,7 @@ extern "C" int up_bn_finalize(const float* stats, int tiles, int C, float eps, f
     UP_REQUIRE(stats && gamma && beta && mean && invstd && scale && shift && tiles > 0 && C > 0, UP_ERR_INVALID,
                "bn_finalize: bad argument");
     UP_REQUIRE((rm == nullptr) == (rv == nullptr), UP_ERR_INVALID, "bn_finalize: running stats must come in pairs");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, as_stream(stream), stats, tiles, C, eps,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, as_stream(stream), stats, tiles, C, eps,
                        momentum, rm, rv, gamma, beta, mean, invstd, scale, shift);
     return check_launch("bn_finalize");
 }
@@ -428,7 +464,7 @@ static void launch_bn_bwd(const T* dz, int lddz, const T* z, int ldz, const uint
     int chunks = cdiv(rows, BNB_ROWS);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(chunks, cdiv(C, 64)), dim3(256), 0, st, dz, lddz, z, ldz, relu_bits,
                        y, ldy, mean, invstd, relu, workspace, rows, C, BNB_ROWS);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, (const float*)workspace, chunks, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (const float*)workspace, chunks, C,
                        dgamma, dbeta);
     int64_t total = rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(total)), dim3(256), 0, st, dz, lddz, z, ldz, relu_bits, y,

@@ -77,32 +77,33 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const TI* x, int ldx, 
         int q = (int)pix - (int)t * Q;
         uint32_t n = fdiv(t, fP);
         int p = (int)t - (int)n * P;
+        // The first in-bounds window element is (r0, s0); starting every channel from its code with best = -inf makes the
+        // scan branch-free ("first" flag gone): a later element replaces it iff it is larger or NaN, exactly F.max_pool2d's
+        // rule (first maximum in scan order wins).  (With a `first` flag in the loop hipcc 7.2 mis-compiled the
+        // <bf16, bf16> instantiation — stale code for element 0, values right — tools/gpu/dbg_maxpool.py.)
+        const int r0 = 2 * p - 1 < 0 ? 1 : 0, s0 = 2 * q - 1 < 0 ? 1 : 0;
         float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        int bi[4] = {0, 0, 0, 0};
-        bool first = true;
-        for (int r = 0; r < 3; ++r) {
+        int bi[4] = {r0 * 3 + s0, r0 * 3 + s0, r0 * 3 + s0, r0 * 3 + s0};
+        for (int r = r0; r < 3; ++r) {
             int h = 2 * p - 1 + r;
-            if (h < 0 || h >= H) continue;
-            for (int s = 0; s < 3; ++s) {
+            if (h >= H) break;
+            for (int s = s0; s < 3; ++s) {
                 int w = 2 * q - 1 + s;
-                if (w < 0 || w >= W) continue;
+                if (w >= W) break;
                 float4 v4 = ld4<TI>(x + ((size_t)(n * H + h) * W + w) * ldx + c);
                 float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (first || v[e] > best[e] || v[e] != v[e]) {
+                    if (v[e] > best[e] || v[e] != v[e]) {
                         best[e] = v[e];
                         bi[e] = r * 3 + s;
                     }
-                first = false;
             }
         }
         st4(y + (size_t)pix * ldy + c, make_float4(best[0], best[1], best[2], best[3]));
-        uint8_t* ip = idx + (size_t)pix * (C4 * 4) + c;
-        ip[0] = (uint8_t)bi[0];
-        ip[1] = (uint8_t)bi[1];
-        ip[2] = (uint8_t)bi[2];
-        ip[3] = (uint8_t)bi[3];
+        // one 32-bit store of the four window codes
+        *reinterpret_cast<uint32_t*>(idx + (size_t)pix * (C4 * 4) + c) =
+            (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
     }
 }
 template <typename TI, typename TO>
