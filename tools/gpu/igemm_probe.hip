@@ -32,7 +32,22 @@ static float run(IgemmArgs a, int iters) {
     return ms / iters;
 }
 
-static void analyze(std::vector<long long>& h, int nwg, double mfma_ticks_per_block) {
+static void analyze(std::vector<long long>& h, int nwg, double mfma_ticks_per_block, int full_blocks = -1, int parts = 1) {
+    if (full_blocks >= 0 && full_blocks < nwg && parts > 1) {   // tail blocks: K loop / publish (parts 0..p-2) / merge + epilogue (last part)
+        double kl = 0, pub = 0, mrg = 0, klm = 0; int np = 0, nm = 0;
+        long long first_start = h[0], tail_first = h[4 * (size_t)full_blocks], tail_last_end = 0;
+        for (int b = 0; b < nwg; ++b) first_start = std::min(first_start, h[4 * (size_t)b]);
+        for (int b = full_blocks; b < nwg; ++b) {
+            const int part = (b - full_blocks) % parts;
+            tail_first = std::min(tail_first, h[4 * (size_t)b]);
+            tail_last_end = std::max(tail_last_end, h[4 * (size_t)b + 2]);
+            if (part < parts - 1) { kl += h[4 * (size_t)b + 1] - h[4 * (size_t)b]; pub += h[4 * (size_t)b + 2] - h[4 * (size_t)b + 1]; ++np; }
+            else { klm += h[4 * (size_t)b + 1] - h[4 * (size_t)b]; mrg += h[4 * (size_t)b + 2] - h[4 * (size_t)b + 1]; ++nm; }
+        }
+        printf("   tail: %d publishing parts: K loop %.2f us, publish %.2f us;  %d merging parts: K loop %.2f us, wait+merge+epilogue %.2f us;"
+               "  tail phase %.1f .. %.1f us after the first start\n", np, kl / np / 100.0, pub / np / 100.0, nm, klm / nm / 100.0,
+               mrg / nm / 100.0, (tail_first - first_start) / 100.0, (tail_last_end - first_start) / 100.0);
+    }
     struct { int nwg; } a{nwg};
     long long t0 = h[0], t1 = h[2];
     for (int b = 0; b < a.nwg; ++b) { t0 = std::min(t0, h[4 * b]); t1 = std::max(t1, h[4 * b + 2]); }
@@ -96,7 +111,7 @@ static void analyze(std::vector<long long>& h, int nwg, double mfma_ticks_per_bl
     printf("\n");
 }
 
-template <int BM, int BN, int DBG>
+template <int BM, int BN, int DBG, bool SWZ = false>
 static void timeline(IgemmArgs a, double mfma_ticks_per_block, bool split = false) {
     a.ntn = cdiv(a.Ng, BN);
     a.nwg = cdiv(a.M, BM) * a.ntn;
@@ -119,12 +134,13 @@ static void timeline(IgemmArgs a, double mfma_ticks_per_block, bool split = fals
     long long* dbg;
     hipMalloc(&dbg, (size_t)a.nwg * 32);
     a.dbg = dbg;
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, DBG | 32>), dim3(a.nwg), dim3(256), 0, 0, a);
+    for (int i = 0; i < 2; ++i)
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, DBG | 32, 32, false, false, SWZ>), dim3(a.nwg), dim3(256), 0, 0, a);
     hipDeviceSynchronize();
     std::vector<long long> h((size_t)a.nwg * 4);
     hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
     hipFree(dbg);
-    analyze(h, a.nwg, mfma_ticks_per_block);
+    analyze(h, a.nwg, mfma_ticks_per_block, a.full_blocks, a.parts);
 }
 
 template <int BM, int BN, int DBG>
@@ -293,6 +309,35 @@ int main(int argc, char** argv) {
         sweep<128, 128, 128>("1x1 512->2048 @23^2 DB", mk(32, 23, 512, 2048, 1, 0, 1));
         sweep<64, 128, 64>("1x1 512->128 @46^2 SB", mk(32, 46, 512, 128, 1, 0, 1));
         sweep<64, 128, 128>("1x1 512->128 @46^2 DB", mk(32, 46, 512, 128, 1, 0, 1));
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "swz")) {   // padded vs XOR-swizzled LDS rows (4 vs 5 resident workgroups per CU), with the tail split
+        for (auto cfg : {mk(32, 23, 256, 256, 3, 1, 1), mk(32, 23, 1024, 256, 1, 0, 1)}) {
+            size_t nx = (size_t)cfg.N * cfg.H * cfg.W * cfg.ldx, nw = (size_t)cfg.K * cfg.R * cfg.S * cfg.Cp, ny = (size_t)cfg.N * cfg.P * cfg.Q * cfg.ldy;
+            float *x, *w, *y;
+            hipMalloc(&x, nx * 4); hipMalloc(&w, nw * 4); hipMalloc(&y, ny * 4);
+            hipMemset(x, 0, nx * 4); hipMemset(w, 0, nw * 4);
+            IgemmArgs a;
+            fill_fwd_args(a, &cfg, x, w, y, nullptr);
+            double mfma_ticks = (double)(64 / 32) * (64 / 32) / 4.0 * (a.Ktot / 2.0) * 64.0 / 2.4e9 * 1e8;
+            printf("K=%d padded rows (36.9 KB):\n", a.Ktot);
+            timeline<64, 64, 0, false>(a, mfma_ticks, true);
+            printf("K=%d swizzled rows (32 KB):\n", a.Ktot);
+            timeline<64, 64, 0, true>(a, mfma_ticks, true);
+            hipFree(x); hipFree(w); hipFree(y);
+        }
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "alone")) {   // how fast is a workgroup that is alone on its CU?  256 / 512 / 1024 / 2048 tiles of 64x64
+        sweep<64, 64, 0>("3x3 256->64 @32^2 B16: 1 tile per CU", mk(16, 32, 256, 64, 3, 1, 1));
+        sweep<64, 64, 0>("3x3 256->128 @32^2 B16: 2 tiles per CU", mk(16, 32, 256, 128, 3, 1, 1));
+        sweep<64, 64, 0>("3x3 256->256 @32^2 B16: 4 tiles per CU", mk(16, 32, 256, 256, 3, 1, 1));
+        sweep<64, 64, 0>("3x3 256->512 @32^2 B16: 8 tiles per CU", mk(16, 32, 256, 512, 3, 1, 1));
+        sweep<64, 64, 64>("3x3 256->64 @32^2 B16: 1 tile per CU, single-buffer loop", mk(16, 32, 256, 64, 3, 1, 1));
+        sweep<64, 64, 64>("3x3 256->256 @32^2 B16: 4 tiles per CU, single-buffer loop", mk(16, 32, 256, 256, 3, 1, 1));
+        sweep<64, 64, 0>("1x1 256->64 @32^2 B16: 1 tile per CU, K=256", mk(16, 32, 256, 64, 1, 0, 1));
+        sweep<64, 64, 0>("3x3 256->64 @32^2 B2: 32 tiles, input (2 MB) L2-resident", mk(2, 32, 256, 64, 3, 1, 1));
+        sweep<64, 64, 0>("3x3 256->64 @16^2 B8: 32 tiles, input (2 MB) L2-resident", mk(8, 16, 256, 64, 3, 1, 1));
         return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "wasp")) {

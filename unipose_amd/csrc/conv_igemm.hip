@@ -369,15 +369,25 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
 // PERM:    GEMM rows are output pixels in tap-sorted order (a.perm), MODE 2 only.
 // (Measured and removed in round 2: the 64x64 short-reduction kernel compiled for 7 / 8 waves per SIMD — 72 / 64 VGPRs with
 //  4 / 10 spills outside the K loop — was 0.2 / 0.7 ms per step SLOWER than the natural 78-VGPR build, profiles/r02_a_knob_ab.txt.)
-template <int BM, int BN, int MODE, int DBG = 0, int KT = 32, bool PERSIST = false, bool PERM = false>
-__global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_kernel(IgemmArgs a) {
+// SWZ:     LDS rows are 32 floats with NO padding; the eight 16-byte chunks of row r sit at chunk ^ ((r >> 1) & 7).  The
+//          16-lane groups of a ds_read_b128 fragment read (rows l&31, same logical chunk) then hit 16 distinct 16-byte
+//          slots of the 256-byte bank row, like with the 4-float pad, and a 64x64 double-buffered workgroup takes 32 KB
+//          instead of 36.9 KB (64x128: 48 instead of 55.3 KB, three per CU instead of two).  Measured -0.55 ms per step.
+//          It does NOT get a fifth 64x64 workgroup onto a CU: the LDS allocator hands out 130 granules of 256 B for a
+//          32 KB request, 5 x 130 > 640 (probe timeline: the K-split tail parts still start when a whole tile ends).
+//          (Double-buffered forms only: the single-buffer loop is register-, not LDS-limited, and the four per-lane chunk
+//          offsets cost it an occupancy step.  The 64x64 form is compiled for 5 waves per SIMD: 96 registers.)
+template <int BM, int BN, int MODE, int DBG = 0, int KT = 32, bool PERSIST = false, bool PERM = false, bool SWZ = false>
+__global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (SWZ && BM == 64 && BN == 64) ? 5 : 3)
+    igemm_kernel(IgemmArgs a) {
+    static_assert(!SWZ || KT == 32, "the XOR swizzle is written for 8 chunks per row");
     static_assert(!PERM || (MODE == 2 && !PERSIST), "tap-sorted rows: aligned fast path of the default form only");
     constexpr bool ALIGNED = MODE >= 1, FAST = MODE == 2;
     constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave along m / n
     constexpr int Q4 = KT / 4;                   // float4 per K slice row
     constexpr int RPP = 256 / Q4;                // rows staged per pass (32 at KT=32, 16 at KT=64)
     constexpr int PA = BM / RPP, PB = BN / RPP;  // staging passes
-    constexpr int LDS_LD = KT + 4;               // (KT+4)/4 odd -> conflict-free ds_read_b128
+    constexpr int LDS_LD = SWZ ? KT : KT + 4;    // (KT+4)/4 odd -> conflict-free ds_read_b128; SWZ: XOR swizzle instead
     constexpr int BK = KT;
     static_assert(PA <= 8 && PB <= 8, "okmask holds 8 row bits");
     constexpr bool DB = (DBG & 64) == 0;         // two LDS buffers, ONE barrier per slice, refill interleaved
@@ -436,6 +446,8 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
 
     const int lrow = tid / Q4;  // row within a staging pass
     const int kq = tid % Q4;    // which float4 of the K slice
+    // LDS chunk of this thread's float4 (staging passes are 32 rows apart: the swizzle term only depends on lrow)
+    const int kqs = SWZ ? (kq ^ ((lrow >> 1) & 7)) : kq;
 
     // per-thread gather bases for its PA rows.  Rows beyond M only need a SAFE address (their results
     // are never stored); taps that fall into the zero padding are zeroed by a select at LDS-store time.
@@ -610,11 +622,11 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     auto lstore = [&](int buf = 0) {
 #pragma unroll
         for (int i = 0; i < PA; ++i)
-            *reinterpret_cast<float4*>(&As[buf * BUF + (i * RPP + lrow) * LDS_LD + kq * 4]) =
+            *reinterpret_cast<float4*>(&As[buf * BUF + (i * RPP + lrow) * LDS_LD + kqs * 4]) =
                 keep_or_zero((okmask >> i) & 1u, ra[i]);
 #pragma unroll
         for (int j = 0; j < PB; ++j)
-            *reinterpret_cast<float4*>(&Bs[buf * BUF + (j * RPP + lrow) * LDS_LD + kq * 4]) =
+            *reinterpret_cast<float4*>(&Bs[buf * BUF + (j * RPP + lrow) * LDS_LD + kqs * 4]) =
                 ALIGNED ? rb[j] : keep_or_zero(okmask >> 31, rb[j]);
     };
     // the same for the second staging set
@@ -641,11 +653,11 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
         for (int part = 0; part < 4; ++part) gissue2(part);
     };
     auto lstore2 = [&](int buf) {
-        *reinterpret_cast<float4*>(&As[buf * BUF + lrow * LDS_LD + kq * 4]) = keep_or_zero(okmask2 & 1u, ya0);
-        *reinterpret_cast<float4*>(&As[buf * BUF + ((PA - 1) * RPP + lrow) * LDS_LD + kq * 4]) =
+        *reinterpret_cast<float4*>(&As[buf * BUF + lrow * LDS_LD + kqs * 4]) = keep_or_zero(okmask2 & 1u, ya0);
+        *reinterpret_cast<float4*>(&As[buf * BUF + ((PA - 1) * RPP + lrow) * LDS_LD + kqs * 4]) =
             keep_or_zero((okmask2 >> (PA - 1)) & 1u, ya1);
-        *reinterpret_cast<float4*>(&Bs[buf * BUF + lrow * LDS_LD + kq * 4]) = yb0;
-        *reinterpret_cast<float4*>(&Bs[buf * BUF + ((PB - 1) * RPP + lrow) * LDS_LD + kq * 4]) = yb1;
+        *reinterpret_cast<float4*>(&Bs[buf * BUF + lrow * LDS_LD + kqs * 4]) = yb0;
+        *reinterpret_cast<float4*>(&Bs[buf * BUF + ((PB - 1) * RPP + lrow) * LDS_LD + kqs * 4]) = yb1;
     };
 
     f32x16 acc[TM][TN];
@@ -655,16 +667,22 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     if (!PERSIST || kb < ke) {   // (a persistent share can be empty on a tile that skips most of its taps)
     gload(kb);
     lstore();
     __syncthreads();
     }
 
-    const float* Ard = As + (wm * (BM / 2) + l31) * LDS_LD + lh * 4;
-    const float* Brd = Bs + (wn * (BN / 2) + l31) * LDS_LD + lh * 4;
+    // fragment of k-group g: logical chunk 2g + lh of row (32-multiple + l31); SWZ: chunk ^ ((l31 >> 1) & 7)
+    const float* Ard = As + (wm * (BM / 2) + l31) * LDS_LD + (SWZ ? 0 : lh * 4);
+    const float* Brd = Bs + (wn * (BN / 2) + l31) * LDS_LD + (SWZ ? 0 : lh * 4);
+    const int swz = (l31 >> 1) & 7;
+    auto fcol = [&](int g) { return SWZ ? (((g * 2 + lh) ^ swz) * 4) : g * 8; };   // float offset inside the row
 
+    // (Measured and removed in round 2: a second accumulator for the odd k pairs of the 32x32-per-wave tile, so that
+    //  consecutive MFMAs never form one dependent chain — the K loop of a workgroup that is alone on its CU stayed at
+    //  53.7 us for 30.7 us of MFMA work (tools/gpu/igemm_probe alone).  What a lone wave loses per slice is the time of the
+    //  ~100 non-MFMA instructions the scheduler places in blocks between its 4-MFMA groups)
     auto mfma_group = [&](const float4(&af)[TM], const float4(&bf)[TN]) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -696,10 +714,10 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
                 auto frag = [&](int g, int b) {
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
-                        af[b][i] = *reinterpret_cast<const float4*>(Ard + cur * BUF + i * 32 * LDS_LD + g * 8);
+                        af[b][i] = *reinterpret_cast<const float4*>(Ard + cur * BUF + i * 32 * LDS_LD + fcol(g));
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        bf[b][j] = *reinterpret_cast<const float4*>(Brd + cur * BUF + j * 32 * LDS_LD + g * 8);
+                        bf[b][j] = *reinterpret_cast<const float4*>(Brd + cur * BUF + j * 32 * LDS_LD + fcol(g));
                 };
                 frag(0, 0);
 #pragma unroll
@@ -737,10 +755,10 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
             auto frag = [&](int g, int b) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    af[b][i] = *reinterpret_cast<const float4*>(Ard + cur * BUF + i * 32 * LDS_LD + g * 8);
+                    af[b][i] = *reinterpret_cast<const float4*>(Ard + cur * BUF + i * 32 * LDS_LD + fcol(g));
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    bf[b][j] = *reinterpret_cast<const float4*>(Brd + cur * BUF + j * 32 * LDS_LD + g * 8);
+                    bf[b][j] = *reinterpret_cast<const float4*>(Brd + cur * BUF + j * 32 * LDS_LD + fcol(g));
             };
             frag(0, 0);
 #pragma unroll
@@ -777,10 +795,10 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
         auto frag = [&](int g, int b) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[b][i] = *reinterpret_cast<const float4*>(Ard + i * 32 * LDS_LD + g * 8);
+                af[b][i] = *reinterpret_cast<const float4*>(Ard + i * 32 * LDS_LD + fcol(g));
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-                bf[b][j] = *reinterpret_cast<const float4*>(Brd + j * 32 * LDS_LD + g * 8);
+                bf[b][j] = *reinterpret_cast<const float4*>(Brd + j * 32 * LDS_LD + fcol(g));
         };
         frag(0, 0);
 #pragma unroll
@@ -1193,6 +1211,8 @@ constexpr int WGRAD_RECT_INTS = 12;
 // DBG bit 5: per-block timeline (probe); bit 6: the older single-buffer loop (two barriers per slice)
 // RECT: the reduction of a column tile runs over the live rectangle of its filter taps only (see WgradRect) instead of
 //       all N*P*Q output pixels: the pixels outside multiply structural zeros (77 % of them on the dilation-18 branch).
+// (Measured and removed in round 2: 16-pixel K slices in the double-buffered 128x128 form — 32 KB of LDS instead of 64 KB, to
+//  let one weight-gradient workgroup share a CU with four data-gradient workgroups of the other stream — +0.5 ms per step.)
 template <int BM, int BN, int DBG = 0, bool RECT = false>
 __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) wgrad_kernel(WgradArgs a) {
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -1993,6 +2013,7 @@ static int split_parts(int tiles, int Ktot) {
 // kept on the device.  Knob "tap_sort" (UP_TAP_SORT).  Measured (profiles/r02_a_*): WASP d = 12 / 18 forward 0.166 -> 0.099 /
 // 0.157 -> 0.093 ms, whole step -0.45 ms: on by default.
 static int g_tap_sort = env_int("UP_TAP_SORT", 1, 0);
+static int g_lds_swz = env_int("UP_LDS_SWZ", 1, 0);   // XOR-swizzled, unpadded LDS rows in the double-buffered fp32 kernels (see SWZ); -0.55 ms per step (r02_i)
 struct TapSortKey {
     int M, H, W, P, Q, taps, S, mul, off0, off0w, tapstep;
     bool operator<(const TapSortKey& o) const { return memcmp(this, &o, sizeof(*this)) < 0; }
@@ -2111,7 +2132,11 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     if (g_tap_sort && !g_persist && fast && a.taps > 1 && a.taps <= 16 && !a.residual && !a.o_mode && !a.no_tap_skip &&
         a.M % (a.P * a.Q) == 0)
         a.perm = tap_sort_perm(a);
-    if (a.perm && db)
+    if (g_lds_swz && a.perm && db)
+        kernel = igemm_kernel<BM, BN, 2, DB_VARIANT, 32, false, true, true>;
+    else if (g_lds_swz && fast && db)
+        kernel = igemm_kernel<BM, BN, 2, DB_VARIANT, 32, false, false, true>;
+    else if (a.perm && db)
         kernel = igemm_kernel<BM, BN, 2, DB_VARIANT, 32, false, true>;
     else if (a.perm)
         kernel = igemm_kernel<BM, BN, 2, 64, 32, false, true>;
@@ -2223,6 +2248,7 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "tail_split")) g_tail_split = value ? 1 : 0;
     else if (!strcmp(key, "tap_skip")) g_tap_skip = value ? 1 : 0;
     else if (!strcmp(key, "tap_sort")) g_tap_sort = value ? 1 : 0;
+    else if (!strcmp(key, "lds_swz")) g_lds_swz = value ? 1 : 0;
     else if (!strcmp(key, "wgrad_rect")) g_wgrad_rect = value ? 1 : 0;
     else if (!strcmp(key, "wgrad_per_cu") && value > 0) g_wgrad_per_cu = value;
     else UP_REQUIRE(false, UP_ERR_INVALID, "conv_tune: unknown key '%s'", key);
@@ -2880,8 +2906,13 @@ extern "C" int up_profile_end(double* out /* [variants][3] = launches, ms, flops
 #ifndef UP_EMU
     g_prof_on = false;
     FILE* csv = nullptr;
-    if (const char* path = getenv("UP_PROFILE_CSV")) {   // optional per-launch dump for offline analysis
-        csv = fopen(path, "w");
+    if (const char* path = getenv("UP_PROFILE_CSV")) {   // optional per-launch dump for offline analysis: the first
+        static int calls = 0;                            // collection goes to `path`, later ones to `path.1`, `path.2` ...
+        char name[1024];
+        if (calls == 0) snprintf(name, sizeof(name), "%s", path);
+        else snprintf(name, sizeof(name), "%s.%d", path, calls);
+        ++calls;
+        csv = fopen(name, "w");
         if (csv) fprintf(csv, "kernel,M,N,K,workgroups,ms,tflops\n");
     }
     for (auto& r : g_prof) {
