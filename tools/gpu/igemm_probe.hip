@@ -336,8 +336,10 @@ int main(int argc, char** argv) {
         sweep<64, 64, 64>("3x3 256->64 @32^2 B16: 1 tile per CU, single-buffer loop", mk(16, 32, 256, 64, 3, 1, 1));
         sweep<64, 64, 64>("3x3 256->256 @32^2 B16: 4 tiles per CU, single-buffer loop", mk(16, 32, 256, 256, 3, 1, 1));
         sweep<64, 64, 0>("1x1 256->64 @32^2 B16: 1 tile per CU, K=256", mk(16, 32, 256, 64, 1, 0, 1));
-        sweep<64, 64, 0>("3x3 256->64 @32^2 B2: 32 tiles, input (2 MB) L2-resident", mk(2, 32, 256, 64, 3, 1, 1));
-        sweep<64, 64, 0>("3x3 256->64 @16^2 B8: 32 tiles, input (2 MB) L2-resident", mk(8, 16, 256, 64, 3, 1, 1));
+        sweep<64, 64, 256>("3x3 256->64 @32^2 B16: 1 tile per CU, EARLY BARRIER", mk(16, 32, 256, 64, 3, 1, 1));
+        sweep<64, 64, 256>("3x3 256->128 @32^2 B16: 2 tiles per CU, EARLY BARRIER", mk(16, 32, 256, 128, 3, 1, 1));
+        sweep<64, 64, 256>("3x3 256->256 @32^2 B16: 4 tiles per CU, EARLY BARRIER", mk(16, 32, 256, 256, 3, 1, 1));
+        sweep<64, 64, 256>("3x3 256->512 @32^2 B16: 8 tiles per CU, EARLY BARRIER", mk(16, 32, 256, 512, 3, 1, 1));
         return 0;
     }
     if (argc > 1 && !strcmp(argv[1], "wasp")) {

@@ -376,10 +376,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
 //          It does NOT get a fifth 64x64 workgroup onto a CU: the LDS allocator hands out 130 granules of 256 B for a
 //          32 KB request, 5 x 130 > 640 (probe timeline: the K-split tail parts still start when a whole tile ends).
 //          (Double-buffered forms only: the single-buffer loop is register-, not LDS-limited, and the four per-lane chunk
-//          offsets cost it an occupancy step.  The 64x64 form is compiled for 5 waves per SIMD: 96 registers.)
+//          offsets cost it an occupancy step.)
 template <int BM, int BN, int MODE, int DBG = 0, int KT = 32, bool PERSIST = false, bool PERM = false, bool SWZ = false>
-__global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (SWZ && BM == 64 && BN == 64) ? 5 : 3)
-    igemm_kernel(IgemmArgs a) {
+__global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_kernel(IgemmArgs a) {
     static_assert(!SWZ || KT == 32, "the XOR swizzle is written for 8 chunks per row");
     static_assert(!PERM || (MODE == 2 && !PERSIST), "tap-sorted rows: aligned fast path of the default form only");
     constexpr bool ALIGNED = MODE >= 1, FAST = MODE == 2;
@@ -747,24 +746,31 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (SWZ && BM
         // refilled with slice kt+3, so a load has two full slices to land instead of one (FAST path only).
         static_assert(PA == 2 && PB == 2, "the two-set loop is written for the 64x64 tile");
         if (ke - kb > 2) gload2(kb + 2);
+        // EARLYBAR (DBG bit 8, probe only): the slice's barrier sits BEFORE its last MFMA group and is followed at once by the
+        // fragment reads of the NEXT slice's first group, so a wave never starts a slice by waiting for LDS.  A workgroup
+        // alone on its CU gains 10 % (K loop 53.9 -> 48.4 us, tools/gpu/igemm_probe alone), a 1024-tile launch 5 % in the
+        // probe — and the network LOSES 1.2-1.4 ms per step with it in both stream modes, forward alone +3.4 % (r02_j):
+        // kept out of the library, kept here as the record of the experiment.
+        constexpr bool EARLYBAR = (DBG & 256) != 0;
+        float4 af[2][TM], bf[2][TN];
+        auto fragc = [&](int cur, int g, int b) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[b][i] = *reinterpret_cast<const float4*>(Ard + cur * BUF + i * 32 * LDS_LD + fcol(g));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[b][j] = *reinterpret_cast<const float4*>(Brd + cur * BUF + j * 32 * LDS_LD + fcol(g));
+        };
+        if constexpr (EARLYBAR) fragc(0, 0, 0);
         auto slice = [&](int kt, auto cur_c, auto use_x_c) {   // compile-time buffer / staging-set choice
             constexpr int cur = decltype(cur_c)::value;
             constexpr bool useX = decltype(use_x_c)::value;
             const bool has1 = kt + 1 < ke, has3 = kt + 3 < ke;
-            float4 af[2][TM], bf[2][TN];
-            auto frag = [&](int g, int b) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-                    af[b][i] = *reinterpret_cast<const float4*>(Ard + cur * BUF + i * 32 * LDS_LD + fcol(g));
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    bf[b][j] = *reinterpret_cast<const float4*>(Brd + cur * BUF + j * 32 * LDS_LD + fcol(g));
-            };
-            frag(0, 0);
+            if constexpr (!EARLYBAR) fragc(cur, 0, 0);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 const int b = g & 1;
-                if (g + 1 < G) frag(g + 1, b ^ 1);
+                if (g + 1 < G) fragc(cur, g + 1, b ^ 1);
                 if (g == G / 2 - 1 && has1) {
                     if constexpr (useX) lstore(cur ^ 1);
                     else lstore2(cur ^ 1);
@@ -777,9 +783,15 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : (SWZ && BM
                         else gissue2((g - G / 2) * (8 / G) + q);
                     }
                 }
+                if constexpr (EARLYBAR) {
+                    if (g == G - 1) {
+                        __syncthreads();
+                        fragc(cur ^ 1, 0, b ^ 1);   // (the last slice reads a buffer nobody stored: the values are never used)
+                    }
+                }
                 mfma_group(af[b], bf[b]);
             }
-            __syncthreads();
+            if constexpr (!EARLYBAR) __syncthreads();
         };
         for (int kt = kb; kt < ke; kt += 2) {
             slice(kt, std::integral_constant<int, 0>{}, std::true_type{});
