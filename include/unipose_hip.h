@@ -92,23 +92,15 @@ int up_conv2d_fwd(const up_conv_desc* d, const float* x, const float* w_fwd, flo
 int up_conv_stats_tiles(const up_conv_desc* d);   /* row tiles the forward kernel will use */
 /* Load balance: when the tile count leaves a short tail (tiles % CUs small), the forward / data-gradient launch splits
  * each tail tile along K into this many parts (1 = no split), one per CU, and merges them in a fixed order through a
- * per-stream scratch the library allocates on first use (32 MB + flags).  UP_TAIL_SPLIT=0 disables it.  Informational. */
+ * per-stream scratch the library allocates on first use (one 128x128 fp32 partial per CU: 16 MB + flags).  UP_TAIL_SPLIT=0 disables it.  Informational. */
 int up_conv_split_parts(const up_conv_desc* d);
-/* Tuning hook: route the fp32 forward / data-gradient launches through the persistent stream-K form of the kernel (one
- * wave of workgroups, each walking a contiguous range of (tile, K-slice) work units; tiles cut by a range boundary are
- * merged through the same per-stream scratch, 32 MB + flags).  `grid` = 0 lets the library size the wave (CUs x
- * occupancy); a positive value overrides it.  Default off; UP_PERSISTENT=1 / UP_PERSIST_GRID set the same at load time.
- * Results agree with the default form to fp32 round-off (the K split changes the summation order). */
-int up_conv_set_persistent(int on, int grid);
-int up_conv_get_persistent(void);
 /* Development knobs (A/B runs inside one process; each also has an environment variable read at load time):
  * "tile_want" (UP_TILE_WANT) workgroups a launch should at least have when the tile size is chosen ("short_k" /
  * "short_k_mult": reductions shorter than short_k want short_k_mult / 2 times as many), "db_min_k"
  * (UP_DB_MIN_K) shortest reduction that uses the double-buffered K loop, "tail_split" (UP_TAIL_SPLIT), "tap_skip"
  * (UP_TAP_SKIP), "tap_sort" (UP_TAP_SORT: GEMM rows ordered by their set of live filter taps so that the tile-level tap
  * skipping becomes near exact; default on since the round-2 A/B), "wgrad_per_cu" (UP_WGRAD_PER_CU), "wgrad_rect" (UP_WGRAD_RECT, see
- * up_conv_wgrad_visits; default on since the round-2 A/B); persistent form: "persist_tpw" = tiles x100 a workgroup should own
- * when the tile size is chosen (0 = the default form's tile rule), "persist_xcd" = XCD-aware workgroup numbering.
+ * up_conv_wgrad_visits; default on since the round-2 A/B), "lds_swz" (UP_LDS_SWZ: XOR-swizzled unpadded LDS rows).
  * Change them only between steps: workspace sizes and the BatchNorm partial-row count follow the tile choice. */
 int up_conv_tune(const char* key, int value);
 /* Analysis (host only, no launch): share of (row tile, filter tap) pairs the K loop of the forward (data_gradient = 0) or

@@ -1,4 +1,4 @@
-"""Compare two per-launch CSVs written through UP_PROFILE_CSV (tools/gpu/persist_ab.py --csv): launches grouped by
+"""Compare two per-launch CSVs written through UP_PROFILE_CSV (tools/gpu/csv.sh): launches grouped by
 kernel family and GEMM shape.   python tools/gpu/csv_compare.py a.csv b.csv [min_ms]"""
 import collections
 import csv

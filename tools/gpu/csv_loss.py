@@ -1,4 +1,4 @@
-"""Rank the GEMM shapes of a per-launch CSV (UP_PROFILE_CSV, see persist_ab.py --csv / csv.sh) by the time they lose against
+"""Rank the GEMM shapes of a per-launch CSV (UP_PROFILE_CSV, see csv.sh) by the time they lose against
 the fp32 MFMA peak: which layers to look at first.   python tools/gpu/csv_loss.py launches.csv [peak_tflops] [rows]"""
 import collections
 import csv

@@ -135,7 +135,7 @@ static void timeline(IgemmArgs a, double mfma_ticks_per_block, bool split = fals
     hipMalloc(&dbg, (size_t)a.nwg * 32);
     a.dbg = dbg;
     for (int i = 0; i < 2; ++i)
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, DBG | 32, 32, false, false, SWZ>), dim3(a.nwg), dim3(256), 0, 0, a);
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, 2, DBG | 32, 32, false, SWZ>), dim3(a.nwg), dim3(256), 0, 0, a);
     hipDeviceSynchronize();
     std::vector<long long> h((size_t)a.nwg * 4);
     hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);

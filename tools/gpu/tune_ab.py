@@ -1,4 +1,4 @@
-"""In-process A/B of run-time knobs (up_conv_tune / up_conv_set_persistent) on the BASELINE configs[1] training step:
+"""In-process A/B of run-time knobs (up_conv_tune) on the BASELINE configs[1] training step:
 the model is built once, variants are timed interleaved.  A variant is 'name=value+name=value' ('base' = defaults).
     python tools/gpu/tune_ab.py --rounds 3 --steps 5 base db_min_k=100000+tail_split=0 tile_want=1000"""
 import argparse
@@ -13,7 +13,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch  # noqa: E402
 
 DEFAULTS = {"short_k": 512, "short_k_mult": 4, "tile_want": 1500, "db_min_k": 1024, "tail_split": 1, "tap_skip": 1, "tap_sort": 1,
-            "wgrad_rect": 1, "wgrad_per_cu": 2, "lds_swz": 1, "persist_tpw": 100, "persist_xcd": 0, "persistent": 0, "persist_grid": 0}
+            "wgrad_rect": 1, "wgrad_per_cu": 2, "lds_swz": 1}
 # (round 2, profiles/r02_a_knob_ab.txt: occ64, wgrad_single and the high-priority main stream measured no gain and were removed)
 
 
@@ -43,7 +43,6 @@ def main():
             for item in spec.split("+"):
                 k, v = item.split("=")
                 kv[k] = int(v)
-        _C.check(lib.up_conv_set_persistent(kv.pop("persistent"), kv.pop("persist_grid")), "set_persistent")
         for k, v in kv.items():
             _C.check(lib.up_conv_tune(k.encode(), v), "tune " + k)
 

@@ -8,7 +8,8 @@ kernels are ISA-identical to the profiled build" are checked with this, not asse
 Each side's three .hip files are compiled device-only to AMDGCN assembly with the flags of unipose_amd/build.py
 (hipcc --offload-arch=gfx950 -O3 -std=c++17); the text is cut into one body per kernel symbol, labels and comments are
 normalised away, and bodies are compared by hash.  Output: one line per kernel that is new / gone / changed (with the
-instruction-count delta and the VGPR/SGPR/LDS/scratch figures of both sides) and the number of identical kernels.
+instruction-count delta and the VGPR/SGPR/LDS/scratch figures of both sides) and the number of identical kernels; a kernel whose
+symbol changed (template parameter list) but whose body did not is reported as RENAMED, not as a change.
 Exit code 0 if nothing in the selection changed, 1 otherwise.  Runs without a GPU (hipcc cross-compiles)."""
 import argparse
 import hashlib
@@ -32,8 +33,8 @@ def hipcc():
 
 
 def demangle(names):
-    filt = shutil.which("llvm-cxxfilt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
-    if not os.path.exists(filt):
+    filt = shutil.which("llvm-cxxfilt") or shutil.which("c++filt")
+    if not filt:
         return {n: n for n in names}
     out = subprocess.run([filt], input="\n".join(names), capture_output=True, text=True, check=True).stdout.split("\n")
     return dict(zip(names, out))
@@ -118,10 +119,26 @@ def main():
         b = build_side(args.new, tmp, "new")
     names = demangle(sorted(set(a) | set(b)))
     sel = re.compile(args.only) if args.only else None
-    same = changed = 0
+    same = changed = renamed = 0
+    # a kernel whose template parameter list changed has a new symbol: pair GONE / NEW symbols with identical bodies
+    gone = {}
+    for sym in set(a) - set(b):
+        gone.setdefault(hashlib.sha1(a[sym][0].encode()).digest(), []).append(sym)
+    moved = {}
+    for sym in sorted(set(b) - set(a)):
+        cands = gone.get(hashlib.sha1(b[sym][0].encode()).digest())
+        if cands:
+            moved[sym] = cands.pop()
+    moved_old = set(moved.values())
     for sym in sorted(names, key=lambda s: names[s]):
         nm = names[sym]
         if sel and not sel.search(nm):
+            continue
+        if sym in moved_old:
+            continue
+        if sym in moved:
+            print(f"RENAMED  {names[moved[sym]]}  ->  {nm}  (identical body)")
+            renamed += 1
             continue
         if sym not in a:
             print(f"NEW      {nm}  [{fmt_meta(b[sym][2])}, {b[sym][1]} instr]")
@@ -134,7 +151,8 @@ def main():
             changed += 1
         else:
             same += 1
-    print(f"# {args.ref} vs {args.new or 'working tree'}: {same} kernels identical, {changed} new/gone/changed"
+    print(f"# {args.ref} vs {args.new or 'working tree'}: {same} kernels identical, {renamed} renamed with identical bodies, "
+          f"{changed} new/gone/changed"
           + (f" (selection /{args.only}/)" if args.only else ""))
     return 1 if changed else 0
 

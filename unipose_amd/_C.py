@@ -39,8 +39,6 @@ SIGNATURES = {
     "up_pack_weights_batched": (_i, [_p, _i, _p]),
     "up_conv_stats_tiles": (_i, [_D]),
     "up_conv_split_parts": (_i, [_D]),
-    "up_conv_set_persistent": (_i, [_i, _i]),
-    "up_conv_get_persistent": (_i, []),
     "up_conv_tune": (_i, [C.c_char_p, _i]),
     "up_conv_wgrad_visits": (_i, [_D, C.POINTER(C.c_double)]),
     "up_conv_tap_visits": (_i, [_D, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

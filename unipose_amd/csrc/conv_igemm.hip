@@ -124,26 +124,10 @@ struct IgemmArgs {
     int no_tap_skip;   // UP_TAP_SKIP=0 (A/B runs): visit every filter tap
     float* partials;
     int* flags;
-    // persistent stream-K form (igemm_kernel<..., PERSIST = true>, see launch_igemm): the launch is p_U = tiles * p_R
-    // work units (p_R units per tile = its nominal K-slice count); workgroup w of G computes units
-    // [bound(w), bound(w+1)), bound(w) = w * p_U / G snapped to a tile boundary when closer than p_snap units to one
-    int p_R, p_snap;
-    int p_share, p_rem;   // p_U = G * p_share + p_rem: 32-bit, division-free bounds on the device
-    int p_xcd;            // workgroup index = xcd_remap(block index) (hardware only; the emulator keeps the identity)
     // tap-sorted row order (igemm_kernel<..., PERM = true>, see TapSort): GEMM row m is output pixel perm[m]; pixels
     // with the same set of live filter taps are contiguous, so the tile-level tap skipping drops (nearly) every dead tap
     const int* perm;
-    FastDiv fR;
 };
-
-// first work unit of persistent workgroup w (of G); bound(G) = p_U
-__device__ __forceinline__ int persist_bound(const IgemmArgs& a, int w) {
-    int u = w * a.p_share + (w < a.p_rem ? w : a.p_rem);
-    const int r = u - fdiv(u, a.fR) * a.p_R;
-    if (r < a.p_snap) u -= r;
-    else if (a.p_R - r < a.p_snap) u += a.p_R - r;
-    return u;
-}
 
 __device__ __forceinline__ void wf_merge(float& n1, float& m1, float& s1, float n2, float m2, float s2) {
     if (n2 == 0.f) return;
@@ -360,13 +344,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
 // MODE 1: aligned (Cp % 32 == 0), per-slice bounds arithmetic (strided data gradient, > 32 taps)
 // MODE 2: aligned + precomputed per-row offset and per-row tap-validity bit mask: one add + one bit test
 //         per gathered row and K slice (the address arithmetic of MODE 1 was ~20 % of the kernel time)
-// PERSIST: persistent stream-K form.  The grid is one wave of workgroups (CUs x occupancy); each walks its contiguous
-//         range of (tile, K slice) work units from the LAST tile of the range down to the first.  A tile cut by a range
-//         boundary is finished by the workgroup that holds its last K slices (the owner): it handles that tile at the
-//         END of its walk, while the workgroups holding the earlier slices (lower block index) handle theirs FIRST and
-//         publish raw accumulators, so the owner normally finds them ready.  Writers always have a lower block index
-//         than their reader and publish before they ever wait: no dependence on co-residency or dispatch gaps.
 // PERM:    GEMM rows are output pixels in tap-sorted order (a.perm), MODE 2 only.
+// (Measured and removed in round 2: a persistent stream-K form of this kernel — one wave of workgroups, each walking a
+//  contiguous range of (tile, K slice) units and merging cut tiles through agent-scope partials — was 1-3 % SLOWER per step
+//  than the tail-split form in every configuration tried, profiles/r01_j_persistent_vs_default_per_shape.txt.)
 // (Measured and removed in round 2: the 64x64 short-reduction kernel compiled for 7 / 8 waves per SIMD — 72 / 64 VGPRs with
 //  4 / 10 spills outside the K loop — was 0.2 / 0.7 ms per step SLOWER than the natural 78-VGPR build, profiles/r02_a_knob_ab.txt.)
 // SWZ:     LDS rows are 32 floats with NO padding; the eight 16-byte chunks of row r sit at chunk ^ ((r >> 1) & 7).  The
@@ -377,10 +358,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
 //          32 KB request, 5 x 130 > 640 (probe timeline: the K-split tail parts still start when a whole tile ends).
 //          (Double-buffered forms only: the single-buffer loop is register-, not LDS-limited, and the four per-lane chunk
 //          offsets cost it an occupancy step.)
-template <int BM, int BN, int MODE, int DBG = 0, int KT = 32, bool PERSIST = false, bool PERM = false, bool SWZ = false>
+template <int BM, int BN, int MODE, int DBG = 0, int KT = 32, bool PERM = false, bool SWZ = false>
 __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_kernel(IgemmArgs a) {
     static_assert(!SWZ || KT == 32, "the XOR swizzle is written for 8 chunks per row");
-    static_assert(!PERM || (MODE == 2 && !PERSIST), "tap-sorted rows: aligned fast path of the default form only");
+    static_assert(!PERM || MODE == 2, "tap-sorted rows: aligned fast path only");
     constexpr bool ALIGNED = MODE >= 1, FAST = MODE == 2;
     constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave along m / n
     constexpr int Q4 = KT / 4;                   // float4 per K slice row
@@ -396,42 +377,15 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     float* As = smem;
     float* Bs = smem + BM * LDS_LD;
 
-    int tid_opaque = threadIdx.x;
-
     long long dbg_w0 = 0;   // probe bit 5: per-block timeline (start / end of K loop / stores drained, 100 MHz ticks + HW ids)
     if ((DBG & 32) && threadIdx.x == 0) dbg_w0 = wall_clock64();
-    int p_ub = 0, p_ue = 0;   // PERSIST: work-unit range of this workgroup, tile being walked
-    int p_tile = 0, p_w = 0;
-    if constexpr (PERSIST) {
-        p_w = (int)blockIdx.x;
-#ifndef UP_EMU
-        if (a.p_xcd) p_w = xcd_remap(p_w, (int)gridDim.x);
-#endif
-        p_ub = persist_bound(a, p_w);
-        p_ue = persist_bound(a, p_w + 1);
-        if (p_ub >= p_ue) return;   // (uniform) nothing left for this workgroup after snapping
-        p_tile = fdiv(p_ue - 1, a.fR);
-    }
-    for (;;) {   // PERSIST: one pass per tile of the range (non-persistent: exactly one pass)
-#ifndef UP_EMU
-    // every per-thread quantity below derives from this value: making it opaque per pass keeps the compiler from
-    // hoisting the whole address set-up of a tile out of the tile loop (it then stayed live across the K loop:
-    // 92 -> 166 VGPRs on the 64x64 tile, scratch spills on the 128-wide ones)
-    if constexpr (PERSIST) asm volatile("" : "+v"(tid_opaque));
-#endif
-    const int tid = tid_opaque;
+    const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
     int logical, part = 0, tail = 0;
-    int p_lo = 0, p_hi = 0;         // PERSIST: this pass covers units [p_lo, p_hi) of the p_R units of tile p_tile
-    const bool split = !PERSIST && (int)blockIdx.x >= a.full_blocks;
-    if constexpr (PERSIST) {
-        const int t0 = p_tile * a.p_R;
-        p_lo = (p_ub > t0 ? p_ub : t0) - t0;
-        p_hi = (p_ue < t0 + a.p_R ? p_ue : t0 + a.p_R) - t0;
-        logical = p_tile;
-    } else if (!split) {
+    const bool split = (int)blockIdx.x >= a.full_blocks;
+    if (!split) {
         logical = xcd_remap(blockIdx.x, a.full_blocks);
     } else {   // K-split tail tile: a 1/parts share of the K slices of tile full_blocks + tail
         const int j = (int)blockIdx.x - a.full_blocks;
@@ -512,10 +466,6 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     if (split) {
         kb = (int)((long long)nk * part / a.parts);
         ke = (int)((long long)nk * (part + 1) / a.parts);
-    }
-    if constexpr (PERSIST) {   // the unit range scales onto the slices this tile really visits (tap skipping)
-        kb = fdiv(nk * p_lo, a.fR);
-        ke = fdiv(nk * p_hi, a.fR);
     }
 
     const float* wrow[PB];
@@ -666,11 +616,9 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if (!PERSIST || kb < ke) {   // (a persistent share can be empty on a tile that skips most of its taps)
     gload(kb);
     lstore();
     __syncthreads();
-    }
 
     // fragment of k-group g: logical chunk 2g + lh of row (32-multiple + l31); SWZ: chunk ^ ((l31 >> 1) & 7)
     const float* Ard = As + (wm * (BM / 2) + l31) * LDS_LD + (SWZ ? 0 : lh * 4);
@@ -695,7 +643,6 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     };
     constexpr int G = BK / 8;   // MFMA groups (8 k each) per slice
 
-    if (!PERSIST || kb < ke) {
     if constexpr (DB) {
         // slice kt is in LDS buffer kt&1; slice kt+1 sits in the staging registers (loaded during slice kt-1)
         // and is written to the OTHER buffer in the middle of this slice's MFMAs; the registers are then
@@ -827,7 +774,6 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
         }
     }
     }
-    }
 
     long long dbg_w1 = 0;
     auto dbg_record = [&]() {   // probe bit 5
@@ -845,50 +791,6 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
 #endif
     };
     if (DBG & 32) dbg_w1 = wall_clock64();
-    if constexpr (PERSIST) {
-        // one partial slot + flag per workgroup: a range has at most one tile it does not finish (its last one)
-        const int w = p_w;
-        if (p_hi < a.p_R) {   // the tile's last slices belong to a later workgroup: publish and move on
-            float* o = a.partials + (size_t)w * (BM * BN) + tid;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) st_agent(o + ((i * TN + j) * 16 + r) * 256, acc[i][j][r]);
-            wait_stores();
-            __syncthreads();
-            if (tid == 0) st_agent_flag(a.flags + w, 1);
-        } else {
-            if (p_lo > 0) {   // earlier slices of this tile were computed by the workgroups below: fixed merge order
-                const int t0 = p_tile * a.p_R;
-                int ub_next = p_ub;
-                for (int v = w - 1; v >= 0 && ub_next > t0; --v) {
-                    const int ub_v = persist_bound(a, v);
-                    if (ub_v < ub_next) {   // (a workgroup whose range snapped to nothing published nothing)
-                        if (tid == 0) {
-                            spin_until_set(a.flags + v);
-                            st_agent_flag(a.flags + v, 0);   // consumed: ready for the next launch on this stream
-                        }
-                        __syncthreads();
-                        const float* o = a.partials + (size_t)v * (BM * BN) + tid;
-#pragma unroll
-                        for (int i = 0; i < TM; ++i)
-#pragma unroll
-                            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                                for (int r = 0; r < 16; ++r) acc[i][j][r] += ld_agent(o + ((i * TN + j) * 16 + r) * 256);
-                    }
-                    ub_next = ub_v;
-                }
-            }
-            igemm_epilogue<BM, BN>(a, acc, smem, mt, m0, n0, wm, wn, l31, lh);
-        }
-        if (p_tile * a.p_R <= p_ub) break;   // that was the first tile of the range
-        --p_tile;
-        __syncthreads();   // the epilogue's statistics exchange read smem; the next tile's prologue writes it
-        continue;
-    } else {
     if (split) {
         // Partials are [part][(i*TN+j)*16 + r][256 threads] floats: every access is one coalesced 256-B row per wave.
         // They are written and read with agent-scope accesses (write-through / cache-bypassing on gfx950), so the
@@ -926,9 +828,6 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
 
     igemm_epilogue<BM, BN, PERM>(a, acc, smem, mt, m0, n0, wm, wn, l31, lh);
     if (DBG & 32) dbg_record();
-    break;
-    }
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1703,6 +1602,11 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradArgs a) {
 }
 
 // sum the split-K slabs and scatter into PyTorch OIHW
+// (Measured and removed in round 2: the merge folded into the weight-gradient kernels — every split publishes its slab with
+//  write-through stores and bumps a per-tile arrival counter, the last arriver adds the slabs in split order and scatters the
+//  tile.  Parity held, the step went from 67.4 to 144 ms (736^2 bf16 storage: 52 to 114 ms): the layers with few weight tiles
+//  run 32-256 splits per tile, and ONE workgroup per tile then reads all of them, ~1.5 us per 64 KB slab tile, while this pass
+//  spreads the same bytes over the whole chip.  profiles/r02_i_knob_ab.txt, r02_m.)
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* slab, float* dw, int splits, int K, int C,
                                                           int Cp, int taps, long long total4 /* K*taps*Cp / 4 */) {
     // one thread = 4 consecutive input channels (Cp % 4 == 0): 16-byte slab reads, two splits in flight per step
@@ -1883,26 +1787,6 @@ static int check_desc(const up_conv_desc* d) {
 struct TileChoice {
     int bm, bn;
 };
-// ---- persistent stream-K launches (igemm_kernel<..., PERSIST>) ---------------------------------------
-// Off by default: UP_PERSISTENT=1 (or up_conv_set_persistent) routes every fp32 forward / data-gradient launch
-// through the persistent form.  UP_PERSIST_TPW = tiles (x100) a workgroup should at least own when the tile size is
-// chosen (default 100), UP_PERSIST_GRID / the setter's second argument overrides the grid (tests shrink the "chip").
-static int g_persist = [] {
-    const char* e = getenv("UP_PERSISTENT");
-    return e && atoi(e) > 0 ? 1 : 0;
-}();
-static int g_persist_grid = [] {
-    const char* e = getenv("UP_PERSIST_GRID");
-    return e && atoi(e) > 0 ? atoi(e) : 0;
-}();
-static int g_persist_tpw = [] {   // 0: keep the tile rule of the default form
-    const char* e = getenv("UP_PERSIST_TPW");
-    return e && atoi(e) >= 0 ? atoi(e) : 100;
-}();
-static int g_persist_xcd = [] {   // 1: workgroup index = XCD-aware remap of the block index (neighbouring ranges share an L2)
-    const char* e = getenv("UP_PERSIST_XCD");
-    return e && atoi(e) > 0 ? 1 : 0;
-}();
 // knobs of the default form (environment at load time, up_conv_tune at run time)
 static int env_int(const char* name, int dflt, int min_ok) {
     const char* e = getenv(name);
@@ -1917,23 +1801,12 @@ static int g_tap_skip = env_int("UP_TAP_SKIP", 1, 0);
 static int g_wgrad_per_cu = env_int("UP_WGRAD_PER_CU", 2, 1);   // workgroups per CU a weight-gradient launch aims for
 static int g_wgrad_rect = env_int("UP_WGRAD_RECT", 1, 0);      // weight-gradient reduction over live rectangles (see WgradRectKey); on since r02_a (-0.65 ms per step)
 static int cu_count();
-static int persist_occupancy(int bm, int bn) { return (bm == 128 && bn == 128) ? 2 : 3; }   // = __launch_bounds__
 // Largest tile that still yields ~6 workgroups per CU (the tail split evens out the remainder).  Short reductions
 // are epilogue-heavy and run better on twice as many, smaller tiles (1x1 256->1024 at 23x23: 64x128 91 TF,
 // 128x128 85 TF).
 static TileChoice choose_tile(int64_t M, int Ng, int Ktot) {
     const int cands[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
     const int base_want = g_tile_want;   // tuning knob (A/B runs): workgroups a launch should at least have
-    if (g_persist && g_persist_tpw > 0) {   // stream-K balances any tile count: the largest tile that still gives every
-        const int tpw = g_persist_tpw;      // workgroup its share
-        for (auto& c : cands) {
-            if (Ng <= 64 && c[1] == 128) continue;
-            const int64_t wgs = (int64_t)cdiv(M, c[0]) * cdiv(Ng, c[1]);
-            const int64_t grid = g_persist_grid ? g_persist_grid : (int64_t)cu_count() * persist_occupancy(c[0], c[1]);
-            if (wgs * 100 >= grid * tpw) return {c[0], c[1]};
-        }
-        return {64, 64};
-    }
     const int64_t want = Ktot < g_short_k ? (int64_t)g_short_k_mult * base_want / 2 : base_want;
     for (auto& c : cands) {
         if (Ng <= 64 && c[1] == 128) continue;
@@ -1979,10 +1852,9 @@ static SplitScratch* split_scratch(hipStream_t st) {
     std::lock_guard<std::mutex> lock(mu);
     SplitScratch& s = table[st];
     if (!s.partials) {
-        // tail split: one 128x128 partial per CU; persistent form: one partial + flag per workgroup of the largest grid
-        // (2 x CUs of 128x128, 3 x CUs of the smaller tiles) or of the overriding grid
-        const size_t slots = (size_t)std::max(2 * cu_count(), g_persist_grid);
-        const size_t nflags = (size_t)std::max(3 * cu_count(), g_persist_grid);
+        // tail split: at most one 128x128 partial and one flag per CU and launch
+        const size_t slots = (size_t)cu_count();
+        const size_t nflags = (size_t)cu_count();
         const size_t pbytes = slots * 128 * 128 * sizeof(float), fbytes = nflags * sizeof(int);
 #ifdef UP_EMU
         s.partials = static_cast<float*>(malloc(pbytes));
@@ -2141,17 +2013,17 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     void (*kernel)(IgemmArgs);
     a.no_tap_skip = g_tap_skip ? 0 : 1;
     a.perm = nullptr;
-    if (g_tap_sort && !g_persist && fast && a.taps > 1 && a.taps <= 16 && !a.residual && !a.o_mode && !a.no_tap_skip &&
+    if (g_tap_sort && fast && a.taps > 1 && a.taps <= 16 && !a.residual && !a.o_mode && !a.no_tap_skip &&
         a.M % (a.P * a.Q) == 0)
         a.perm = tap_sort_perm(a);
     if (g_lds_swz && a.perm && db)
-        kernel = igemm_kernel<BM, BN, 2, DB_VARIANT, 32, false, true, true>;
+        kernel = igemm_kernel<BM, BN, 2, DB_VARIANT, 32, true, true>;
     else if (g_lds_swz && fast && db)
-        kernel = igemm_kernel<BM, BN, 2, DB_VARIANT, 32, false, false, true>;
-    else if (a.perm && db)
         kernel = igemm_kernel<BM, BN, 2, DB_VARIANT, 32, false, true>;
+    else if (a.perm && db)
+        kernel = igemm_kernel<BM, BN, 2, DB_VARIANT, 32, true>;
     else if (a.perm)
-        kernel = igemm_kernel<BM, BN, 2, 64, 32, false, true>;
+        kernel = igemm_kernel<BM, BN, 2, 64, 32, true>;
     else if (fast && db)
         kernel = igemm_kernel<BM, BN, 2, DB_VARIANT>;
     else if (fast)
@@ -2161,42 +2033,6 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     else
         kernel = igemm_kernel<BM, BN, 0, 64>;
 
-    if (g_persist) {
-        // Work units: p_R per tile (its nominal K-slice count), dealt out evenly over one wave of workgroups.  A share
-        // never drops below min_part units (>= 2 K slices, >= 1/8 tile), and a range boundary closer than that to a
-        // tile boundary snaps onto it, so no workgroup publishes or merges for a sliver of a tile.
-        const int R = std::max(1, cdiv(a.Ktot, KT_DEFAULT));
-        const int min_part = std::max(2, R / 8);
-        const long long U = (long long)a.nwg * R;
-        long long G = g_persist_grid ? g_persist_grid : (long long)cu_count() * persist_occupancy(BM, BN);
-        G = std::max(1ll, std::min(G, U / min_part));
-        SplitScratch* sc = U < (1ll << 30) ? split_scratch(st) : nullptr;   // 32-bit unit arithmetic on the device
-        if (sc) {
-            G = std::min(G, (long long)std::min(sc->pfloats / (size_t)(BM * BN), sc->nflags));   // one slot per workgroup
-            a.p_R = R;
-            a.p_snap = min_part;
-            a.p_share = (int)(U / G);
-            a.p_rem = (int)(U % G);
-            a.fR = make_fastdiv(R);
-            a.p_xcd = g_persist_xcd;
-            a.partials = sc->partials;
-            a.flags = sc->flags;
-            a.full_blocks = a.nwg;
-            a.parts = 1;
-            a.no_tap_skip = g_tap_skip ? 0 : 1;
-            void (*pk)(IgemmArgs);
-            if (fast && db)
-                pk = igemm_kernel<BM, BN, 2, DB_VARIANT, 32, true>;
-            else if (fast)
-                pk = igemm_kernel<BM, BN, 2, 64, 32, true>;
-            else if (aligned)
-                pk = igemm_kernel<BM, BN, 1, 64, 32, true>;
-            else
-                pk = igemm_kernel<BM, BN, 0, 64, 32, true>;
-            hipLaunchKernelGGL(pk, dim3((unsigned)G), dim3(256), 0, st, a);
-            return;
-        }
-    }
     a.full_blocks = a.nwg;
     a.parts = 1;
     a.no_tap_skip = g_tap_skip ? 0 : 1;
@@ -2242,18 +2078,9 @@ extern "C" int up_pack_weights_batched(const up_pack_job* jobs_device, int njobs
     return check_launch("pack_weights_batched");
 }
 
-extern "C" int up_conv_set_persistent(int on, int grid) {
-    UP_REQUIRE(grid >= 0, UP_ERR_INVALID, "conv_set_persistent: grid %d", grid);
-    g_persist = on ? 1 : 0;
-    g_persist_grid = grid;
-    return UP_OK;
-}
-extern "C" int up_conv_get_persistent(void) { return g_persist; }
 extern "C" int up_conv_tune(const char* key, int value) {
     UP_REQUIRE(key, UP_ERR_INVALID, "conv_tune: null key");
-    if (!strcmp(key, "persist_tpw")) g_persist_tpw = value < 0 ? 0 : value;
-    else if (!strcmp(key, "persist_xcd")) g_persist_xcd = value ? 1 : 0;
-    else if (!strcmp(key, "tile_want") && value > 0) g_tile_want = value;
+    if (!strcmp(key, "tile_want") && value > 0) g_tile_want = value;
     else if (!strcmp(key, "db_min_k") && value > 0) g_db_min_k = value;
     else if (!strcmp(key, "short_k") && value > 0) g_short_k = value;
     else if (!strcmp(key, "short_k_mult") && value > 0) g_short_k_mult = value;
