@@ -1917,8 +1917,8 @@ static std::vector<unsigned> tap_masks(const IgemmArgs& a) {
         }
     return mask;
 }
-// rows in tap-sorted order: classes with more live taps first (the longest tiles start first), then by mask value;
-// image order inside a class.  Empty when every pixel has the same mask (nothing to gain).
+// rows in tap-sorted order: classes with more live taps first, then by mask value; image order inside a class; then the
+// 128-row blocks of that order are dealt out over the XCDs (below).  Empty when every pixel has the same mask.
 static std::vector<int> tap_sort_order(const IgemmArgs& a, const std::vector<unsigned>& mask) {
     std::vector<unsigned> classes;
     for (unsigned mk : mask) {
@@ -1938,6 +1938,25 @@ static std::vector<int> tap_sort_order(const IgemmArgs& a, const std::vector<uns
         for (int img = 0; img < imgs; ++img)
             for (int e = 0; e < PQ; ++e)
                 if (mask[e] == c) perm.push_back(img * PQ + e);
+    // Sorted like this, every XCD (a contiguous run of logical tiles, xcd_remap) would hold ONE class: the XCD with the
+    // nine-tap rows of the dilation-6 WASP branch ran as long as the dense convolution while the others idled (0.190 vs
+    // 0.194 ms, r02_n).  Deal the 128-row blocks of the sorted order out over the eight runs instead, heaviest first, so
+    // that every XCD — and, dispatched in order, every CU of it — gets the same mix of long and short tiles.
+    constexpr int BLK = 128, XCDS = 8;
+    const int nb = a.M / BLK;   // (rows past the last full block keep their place at the end)
+    if (nb >= 2 * XCDS) {
+        int lo[XCDS + 1];
+        for (int x = 0; x <= XCDS; ++x) lo[x] = (int)((long long)x * nb / XCDS);
+        std::vector<int> dealt(perm);
+        int r = 0;
+        for (int slot = 0; r < nb; ++slot)
+            for (int x = 0; x < XCDS && r < nb; ++x)
+                if (lo[x] + slot < lo[x + 1]) {
+                    memcpy(&dealt[(size_t)(lo[x] + slot) * BLK], &perm[(size_t)r * BLK], sizeof(int) * BLK);
+                    ++r;
+                }
+        perm.swap(dealt);
+    }
     return perm;
 }
 static const int* tap_sort_perm(const IgemmArgs& a) {
