@@ -13,7 +13,8 @@ the reference's Trainer.training (unipose.py:100-131) with synthetic inputs alre
 Rank 0 prints ONE JSON line.  `roofline` is measured live: on every 4th step of the timed region each
 MFMA convolution launch is bracketed by hipEvents on its stream (up_profile_begin/enable/end in the C ABI).
 `cpu_baseline` times the CPU oracle (a torch-CPU restatement of the reference graph, pinned to the
-reference by tests/golden) on this box's host cores on a bounded sample; baseline only.
+reference by tests/golden) on this box's host cores on a bounded sample; `stock_gpu_baseline` times the same graph on
+this GPU through PyTorch-ROCm eager (MIOpen) — the reference's own way of running; baselines only.
 """
 import argparse
 import ctypes
@@ -68,6 +69,54 @@ def cpu_baseline(num_classes, size, batch, steps, threads):
             "kind": "port",
             "sample": f"{steps} train steps (fwd+MSE+bwd, no optimizer) of batch {batch} at {size}x{size}, "
                       f"torch {torch.__version__} CPU, after 1 warm-up step"}
+
+
+def stock_gpu_baseline(dev, num_classes, size, batch, steps=5, warmup=3, benchmark=True):
+    """The SAME train step on the SAME GPU through the platform's stock path: the oracle's functional restatement of the
+    reference graph executed by PyTorch-ROCm eager (MIOpen / hipBLASLt / ATen kernels, fp32) with torch's fused Adam and
+    `cudnn.benchmark = True` like the reference sets it (unipose.py:56) — what a user of the reference gets on an MI355X
+    without this library.  A reported baseline like `cpu_baseline`, never `value`."""
+    from oracle import unipose_oracle as O
+    old = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = benchmark
+    try:
+        sd = {k: v.to(dev) for k, v in O.synth_state_dict(num_classes, 0).items()}
+        params = []
+        for k, v in sd.items():
+            if v.is_floating_point() and "running_" not in k:
+                v.requires_grad_(True)
+                params.append(v)
+        opt = torch.optim.Adam(params, lr=1e-4, fused=True)
+        x = O.synth_input((batch, 3, size, size), 1).to(dev)
+        t = O.synth_input((batch, num_classes + 1, size // 8, size // 8), 2, "rand").to(dev)
+
+        def one():
+            opt.zero_grad(set_to_none=True)
+            loss = torch.nn.functional.mse_loss(O.unipose_forward(sd, x, train=True), t)
+            loss.backward()
+            opt.step()
+            return loss
+
+        t0 = time.perf_counter()
+        for _ in range(warmup):
+            one()
+        torch.cuda.synchronize(dev)
+        t_warm = time.perf_counter() - t0
+        ts = []
+        for _ in range(steps):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            one()
+            torch.cuda.synchronize(dev)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        ms = sorted(ts)[len(ts) // 2]
+        return {"value": round(batch * 1e3 / ms, 2), "unit": "images/sec", "ms_per_step": round(ms, 3),
+                "kind": "port on the stock GPU path",
+                "sample": f"median of {steps} fenced train steps (fwd+MSE+bwd+fused Adam) of batch {batch} at {size}x{size}, "
+                          f"oracle graph on torch {torch.__version__} eager (MIOpen, cudnn.benchmark={benchmark}), fp32, "
+                          f"after {warmup} warm-up steps ({t_warm:.1f} s incl. MIOpen's search)"}
+    finally:
+        torch.backends.cudnn.benchmark = old
 
 
 def wasp_dilated_leg(dev, batch=32, hw=23, iters=20):
@@ -237,6 +286,8 @@ def main():
     ap.add_argument("--size", type=int, default=368)
     ap.add_argument("--num-classes", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stock-baseline", action="store_true",
+                    help="skip the leg that times the same step through PyTorch-ROCm eager (MIOpen) on this GPU")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-launch hipEvent timing")
     ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "bf16", "bf16s"],
                     help="arithmetic of the forward/data-gradient convolutions: exact fp32 MFMA (default, the parity "
@@ -477,6 +528,13 @@ def main():
                     out["other_configs"].append(other_config_leg(dev, name))
                 except Exception as e:      # a reporting extra must never cost the bench line
                     log(f"other config {name} skipped: {type(e).__name__}: {e}")
+        if world == 1 and not emu and not args.no_stock_baseline and not lstm and args.math == "f32":
+            try:
+                log("stock GPU baseline (oracle graph on PyTorch-ROCm eager)")
+                out["stock_gpu_baseline"] = stock_gpu_baseline(dev, K, S, B)
+                out["vs_stock_gpu"] = round(out["value"] / out["stock_gpu_baseline"]["value"], 3)
+            except Exception as e:          # a reporting extra must never cost the bench line
+                log(f"stock GPU baseline skipped: {type(e).__name__}: {e}")
         if world == 1 and not args.no_cpu_baseline and not lstm:
             log("cpu baseline (oracle on host cores)")
             out["cpu_baseline"] = cpu_baseline(K, S, args.cpu_batch, args.cpu_steps, args.cpu_threads)
