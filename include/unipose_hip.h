@@ -89,13 +89,14 @@ int up_pack_weights_batched(const up_pack_job* jobs_device, int njobs, void* str
 /* Forward convolution, implicit GEMM on v_mfma_f32_32x32x2_f32 (replaces aten::convolution, K1-K6,K17). */
 int up_conv2d_fwd(const up_conv_desc* d, const float* x, const float* w_fwd, float* y,
                   const up_conv_epilogue* ep, void* stream);
-int up_conv_stats_tiles(const up_conv_desc* d);   /* row tiles the forward kernel will use */
+int up_conv_stats_tiles(const up_conv_desc* d);   /* row tiles the fp32 forward kernel will use */
+int up_conv_stats_tiles_math(const up_conv_desc* d, int math);   /* ... the forward kernel of arithmetic `math` (up_math) */
 /* Load balance: when the tile count leaves a short tail (tiles % CUs small), the forward / data-gradient launch splits
  * each tail tile along K into this many parts (1 = no split), one per CU, and merges them in a fixed order through a
  * per-stream scratch the library allocates on first use (one 128x128 fp32 partial per CU: 16 MB + flags).  UP_TAIL_SPLIT=0 disables it.  Informational. */
 int up_conv_split_parts(const up_conv_desc* d);
 /* Development knobs (A/B runs inside one process; each also has an environment variable read at load time):
- * "tile_want" (UP_TILE_WANT) workgroups a launch should at least have when the tile size is chosen ("short_k" /
+ * "tile_want" (UP_TILE_WANT; "tile_want_bf16" for the plain-bf16 kernels) workgroups a launch should at least have when the tile size is chosen ("short_k" /
  * "short_k_mult": reductions shorter than short_k want short_k_mult / 2 times as many), "db_min_k"
  * (UP_DB_MIN_K) shortest reduction that uses the double-buffered K loop, "tail_split" (UP_TAIL_SPLIT), "tap_skip"
  * (UP_TAP_SKIP), "tap_sort" (UP_TAP_SORT: GEMM rows ordered by their set of live filter taps so that the tile-level tap

@@ -42,3 +42,21 @@ def test_model_eval_bf16_storage(emu_backend):
 
 def test_model_train_bf16_storage(emu_backend):
     bc.model_train_case(emu_backend)
+
+
+def test_tile_rule_of_the_bf16_kernels_and_statistics_rows(emu_backend):
+    """The plain-bf16 kernels choose their tile with their own threshold ("tile_want_bf16"), so the BatchNorm partial rows
+    the convolution epilogue writes follow up_conv_stats_tiles_math, not the fp32 rule: force the two rules apart (fp32:
+    the largest tile, bf16: the smallest) and run a training conv+BN in bf16 storage over several row tiles."""
+    from unipose_amd import _C
+    lib = _C.lib()
+    try:
+        _C.check(lib.up_conv_tune(b"tile_want", 1), "tile_want")
+        _C.check(lib.up_conv_tune(b"tile_want_bf16", 100000), "tile_want_bf16")
+        bc.conv_bn_case(emu_backend, 3, 32, 9, 9, 48, 3, 1, 1, 1, relu=True, residual=False, train=True)   # 243 rows: 2 vs 4 tiles
+        _C.check(lib.up_conv_tune(b"tile_want", 100000), "tile_want")
+        _C.check(lib.up_conv_tune(b"tile_want_bf16", 1), "tile_want_bf16")
+        bc.conv_bn_case(emu_backend, 3, 32, 9, 9, 48, 3, 1, 1, 1, relu=True, residual=False, train=True)
+    finally:
+        lib.up_conv_tune(b"tile_want", 1500)
+        lib.up_conv_tune(b"tile_want_bf16", 500)

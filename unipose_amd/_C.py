@@ -38,6 +38,7 @@ SIGNATURES = {
     "up_conv2d_fwd": (_i, [_D, _p, _p, _p, _E, _p]),
     "up_pack_weights_batched": (_i, [_p, _i, _p]),
     "up_conv_stats_tiles": (_i, [_D]),
+    "up_conv_stats_tiles_math": (_i, [_D, _i]),
     "up_conv_split_parts": (_i, [_D]),
     "up_conv_tune": (_i, [C.c_char_p, _i]),
     "up_conv_wgrad_visits": (_i, [_D, C.POINTER(C.c_double)]),

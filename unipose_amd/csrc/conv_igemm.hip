@@ -1793,6 +1793,7 @@ static int env_int(const char* name, int dflt, int min_ok) {
     return e && atoi(e) >= min_ok ? atoi(e) : dflt;
 }
 static int g_tile_want = env_int("UP_TILE_WANT", 1500, 1);   // A/B in the network: 700 / 1000 / 1500 / 2200 / 4300 -> 70.1 / 69.9 / 69.6 / 69.9 / 69.8 ms
+static int g_tile_want_bf16 = env_int("UP_TILE_WANT_BF16", 500, 1);
 static int g_db_min_k = env_int("UP_DB_MIN_K", 1024, 1);
 static int g_short_k = env_int("UP_SHORT_K", 512, 1);             // reductions shorter than this are epilogue-heavy:
 static int g_short_k_mult = env_int("UP_SHORT_K_MULT", 4, 1);     // they want g_short_k_mult / 2 times as many workgroups
@@ -1804,9 +1805,11 @@ static int cu_count();
 // Largest tile that still yields ~6 workgroups per CU (the tail split evens out the remainder).  Short reductions
 // are epilogue-heavy and run better on twice as many, smaller tiles (1x1 256->1024 at 23x23: 64x128 91 TF,
 // 128x128 85 TF).
-static TileChoice choose_tile(int64_t M, int Ng, int Ktot) {
+// (math >= UP_MATH_BF16: the plain-bf16 kernels do 16x the MFMA work per cycle and live on operand reuse, they want
+//  larger tiles: 736^2 B=16 step in bf16 storage 52.0 ms at 1500, 49.0-49.5 ms anywhere in 300..1000, profiles/r02_t)
+static TileChoice choose_tile(int64_t M, int Ng, int Ktot, int math = 0) {
     const int cands[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
-    const int base_want = g_tile_want;   // tuning knob (A/B runs): workgroups a launch should at least have
+    const int base_want = math >= UP_MATH_BF16 ? g_tile_want_bf16 : g_tile_want;   // workgroups a launch should at least have
     const int64_t want = Ktot < g_short_k ? (int64_t)g_short_k_mult * base_want / 2 : base_want;
     for (auto& c : cands) {
         if (Ng <= 64 && c[1] == 128) continue;
@@ -2085,10 +2088,11 @@ static void run_igemm(IgemmArgs& a, TileChoice t, hipStream_t st) {
 
 using namespace up;
 
-extern "C" int up_conv_stats_tiles(const up_conv_desc* d) {
-    if (!d) return UP_ERR_INVALID;
+extern "C" int up_conv_stats_tiles(const up_conv_desc* d) { return up_conv_stats_tiles_math(d, UP_MATH_F32); }
+extern "C" int up_conv_stats_tiles_math(const up_conv_desc* d, int math) {
+    if (!d || math < UP_MATH_F32 || math > UP_MATH_BF16S) return UP_ERR_INVALID;
     int64_t M = (int64_t)d->N * d->P * d->Q;
-    return cdiv(M, choose_tile(M, d->K, d->R * d->S * d->Cp).bm);
+    return cdiv(M, choose_tile(M, d->K, d->R * d->S * d->Cp, math).bm);
 }
 
 extern "C" int up_pack_weights_batched(const up_pack_job* jobs_device, int njobs, void* stream) {
@@ -2100,6 +2104,7 @@ extern "C" int up_pack_weights_batched(const up_pack_job* jobs_device, int njobs
 extern "C" int up_conv_tune(const char* key, int value) {
     UP_REQUIRE(key, UP_ERR_INVALID, "conv_tune: null key");
     if (!strcmp(key, "tile_want") && value > 0) g_tile_want = value;
+    else if (!strcmp(key, "tile_want_bf16") && value > 0) g_tile_want_bf16 = value;
     else if (!strcmp(key, "db_min_k") && value > 0) g_db_min_k = value;
     else if (!strcmp(key, "short_k") && value > 0) g_short_k = value;
     else if (!strcmp(key, "short_k_mult") && value > 0) g_short_k_mult = value;
@@ -2287,7 +2292,7 @@ static int run_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
                "bf16-storage convolution: ldx=%d must be a multiple of 8 (16-byte rows)", a.ldx);
     UP_REQUIRE(a.Cp % 32 == 0, UP_ERR_UNSUPPORTED, "bf16 convolution: padded channel count %d is not a multiple of 32",
                a.Cp);
-    TileChoice t = choose_tile(a.M, a.Ng, a.Ktot);
+    TileChoice t = choose_tile(a.M, a.Ng, a.Ktot, math);
     if (t.bm == 128 && t.bn == 128)
         launch_igemm_bf16<128, 128>(a, math, st);
     else if (t.bm == 64 && t.bn == 128)

@@ -260,8 +260,14 @@ def conv_fwd_raw(x, weight, cfg, *, scale=None, shift=None, bias=None, residual=
     ep.ldr = _nhwc_ok(residual) if residual is not None else 0
     ep.relu = int(relu)
     st = None
+    if x.dtype == torch.bfloat16:
+        math = MATH_BF16S
+    elif CONV_MATH in (MATH_BF16X3, MATH_BF16, MATH_BF16S) and d.Cp % 32 == 0:
+        math = min(CONV_MATH, MATH_BF16)
+    else:
+        math = MATH_F32
     if stats:
-        tiles = _C.lib().up_conv_stats_tiles(C.byref(d))
+        tiles = _C.lib().up_conv_stats_tiles_math(C.byref(d), math)   # the tile rule depends on the arithmetic
         st = torch.empty((tiles, d.K, 3), dtype=torch.float32, device=x.device)
         ep.stats = st.data_ptr()
     if x.dtype == torch.bfloat16:                                  # bf16 storage: the kernels follow the tensor
