@@ -99,7 +99,8 @@ int up_conv_split_parts(const up_conv_desc* d);
  * "tile_want" (UP_TILE_WANT; "tile_want_bf16" for the plain-bf16 kernels) workgroups a launch should at least have when the tile size is chosen ("short_k" /
  * "short_k_mult": reductions shorter than short_k want short_k_mult / 2 times as many), "db_min_k"
  * (UP_DB_MIN_K) shortest reduction that uses the double-buffered K loop, "tail_split" (UP_TAIL_SPLIT), "tap_skip"
- * (UP_TAP_SKIP), "tap_sort" (UP_TAP_SORT: GEMM rows ordered by their set of live filter taps so that the tile-level tap
+ * (UP_TAP_SKIP), "split_per_cu" (UP_SPLIT_PER_CU: launches with fewer tiles than CUs split every tile along K up to this many
+ * workgroups per CU), "tap_sort" (UP_TAP_SORT: GEMM rows ordered by their set of live filter taps so that the tile-level tap
  * skipping becomes near exact; default on since the round-2 A/B), "wgrad_per_cu" (UP_WGRAD_PER_CU), "wgrad_rect" (UP_WGRAD_RECT, see
  * up_conv_wgrad_visits; default on since the round-2 A/B), "lds_swz" (UP_LDS_SWZ: XOR-swizzled unpadded LDS rows).
  * Change them only between steps: workspace sizes and the BatchNorm partial-row count follow the tile choice. */

@@ -254,3 +254,20 @@ def test_small_ops_no_out_of_bounds(guard_pages, golden_dir):
     oc.avgpool_case(dev, 37, 41)
     oc.lstm_case(dev)
     oc.argmax_case(dev, golden_dir)
+
+
+@pytest.mark.parametrize("per_cu", [2, 4])
+def test_conv_all_tiles_split(emu_backend, per_cu):
+    """Launches with fewer than two tiles per CU split EVERY tile along K (knob "split_per_cu"): forward, data gradient
+    (incl. the addend that joins after the merge) and BatchNorm statistics from the merged accumulators."""
+    from unipose_amd import _C
+    lib = _C.lib()
+    try:
+        _C.check(lib.up_conv_tune(b"split_per_cu", per_cu), "split_per_cu")
+        oc.conv_case(emu_backend, 2, 256, 9, 9, 80, 3, 1, 1, 1, bias=True, relu=True)        # 3 row tiles x 2 column tiles, 72 slices
+        oc.conv_case(emu_backend, 1, 512, 7, 7, 64, 1, 1, 0, 1)                              # 1x1, 16 slices
+        oc.conv_case(emu_backend, 3, 64, 23, 23, 32, 3, 1, 6, 6)                             # tap-sorted rows + split
+        oc.dgrad_add_case(emu_backend, 1, 128, 6, 6, 64, 3, 1, 1, 1)
+        oc.conv_bn_case(emu_backend, 2, 128, 5, 5, 48, 3, 1, 1, 1, relu=True, residual=True, train=True)
+    finally:
+        lib.up_conv_tune(b"split_per_cu", 2)

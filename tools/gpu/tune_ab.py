@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch  # noqa: E402
 
-DEFAULTS = {"short_k": 512, "short_k_mult": 4, "tile_want": 1500, "tile_want_bf16": 500, "db_min_k": 1024, "tail_split": 1, "tap_skip": 1, "tap_sort": 1,
+DEFAULTS = {"short_k": 512, "short_k_mult": 4, "tile_want": 1500, "tile_want_bf16": 500, "db_min_k": 1024, "tail_split": 1, "split_per_cu": 2, "tap_skip": 1, "tap_sort": 1,
             "wgrad_rect": 1, "wgrad_per_cu": 2, "lds_swz": 1}
 # (round 2, profiles/r02_a_knob_ab.txt: occ64, wgrad_single and the high-priority main stream measured no gain and were removed)
 

@@ -1855,9 +1855,10 @@ static SplitScratch* split_scratch(hipStream_t st) {
     std::lock_guard<std::mutex> lock(mu);
     SplitScratch& s = table[st];
     if (!s.partials) {
-        // tail split: at most one 128x128 partial and one flag per CU and launch
+        // tail split: at most one 128x128 partial per CU and launch; the all-tiles split of small launches cuts the same
+        // bytes into up to four 64x64 partials per CU, one flag each
         const size_t slots = (size_t)cu_count();
-        const size_t nflags = (size_t)cu_count();
+        const size_t nflags = 4 * (size_t)cu_count();
         const size_t pbytes = slots * 128 * 128 * sizeof(float), fbytes = nflags * sizeof(int);
 #ifdef UP_EMU
         s.partials = static_cast<float*>(malloc(pbytes));
@@ -1879,14 +1880,34 @@ static SplitScratch* split_scratch(hipStream_t st) {
 static bool tail_split_enabled() { return g_tail_split != 0; }
 
 // parts each tail tile is split into (1 = no split) for a launch of `tiles` tiles reducing over Ktot
-static int split_parts(int tiles, int Ktot) {
+// *all_tiles: every tile is split, not only the tail of the launch
+static int g_split_per_cu = env_int("UP_SPLIT_PER_CU", 2, 1);
+static int split_parts(int tiles, int Ktot, size_t slots, bool* all_tiles = nullptr) {
+    if (all_tiles) *all_tiles = false;
     if (!tail_split_enabled()) return 1;
     const int cus = cu_count(), q = tiles / cus, r = tiles % cus, nk = Ktot / BK;
     // A/B over the whole step: r <= 25 % of the CUs 70.9 ms, 50 % 70.1, 75 % 70.1;  >= 2 / 4 / 8 slices per part 70.1 / 70.1 / 70.3
-    if (r == 0 || r > cus / 2 || q > 12) return 1;
-    int p = cus / r;              // one part per CU (finer cuts measured slower: the merge chain grows)
-    if (p > nk / 2) p = nk / 2;   // a part keeps >= 2 K slices
-    return p >= 2 ? p : 1;
+    int p = 1;
+    if (!(r == 0 || r > cus / 2 || q > 12)) {
+        p = cus / r;                  // one part per CU (finer cuts of a TAIL measured slower: the merge chain grows)
+        if (p > nk / 2) p = nk / 2;   // a part keeps >= 2 K slices
+        if (p < 2) p = 1;
+    }
+    // Small batches (inference at B <= 4): with fewer tiles than CUs every workgroup is alone on its CU, where the K loop
+    // runs at 57 % of what four co-resident workgroups reach.  Split EVERY tile so that the launch has g_split_per_cu
+    // workgroups per CU (>= 4 K slices per part) when that is a finer cut than the tail rule's.  Measured (tools/gpu/
+    // small_batch.py, 368^2 inference forward): B = 1 3.44 -> 3.14 ms, B = 4 4.42 -> 3.79 ms with 2 per CU (3 and 4: the
+    // same); launches with one to two tiles per CU (B = 8: 268 tiles) gain nothing from it and keep the tail rule.
+    if (g_split_per_cu > 1 && q == 0 && all_tiles) {
+        int pn = g_split_per_cu * cus / tiles;
+        if (pn > nk / 4) pn = nk / 4;
+        if (pn > 16) pn = 16;
+        if (pn >= 2 && pn > p && (size_t)tiles * (pn - 1) <= slots) {
+            *all_tiles = true;
+            return pn;
+        }
+    }
+    return p;
 }
 
 // ---- tap-sorted row order -----------------------------------------------------------------------------
@@ -2059,10 +2080,13 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     a.parts = 1;
     a.no_tap_skip = g_tap_skip ? 0 : 1;
     int grid = a.nwg;
-    const int p = aligned ? split_parts(a.nwg, a.Ktot) : 1;
+    SplitScratch* sc0 = aligned && tail_split_enabled() ? split_scratch(st) : nullptr;
+    bool all_tiles = false;
+    const size_t slots = sc0 ? std::min(sc0->pfloats / (size_t)(BM * BN), sc0->nflags) : 0;
+    const int p = aligned ? split_parts(a.nwg, a.Ktot, slots, &all_tiles) : 1;
     if (p >= 2) {
-        if (SplitScratch* sc = split_scratch(st)) {
-            a.full_blocks = a.nwg / cu_count() * cu_count();
+        if (SplitScratch* sc = sc0) {
+            a.full_blocks = all_tiles ? 0 : a.nwg / cu_count() * cu_count();
             a.parts = p;
             a.partials = sc->partials;
             a.flags = sc->flags;
@@ -2109,6 +2133,7 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "short_k") && value > 0) g_short_k = value;
     else if (!strcmp(key, "short_k_mult") && value > 0) g_short_k_mult = value;
     else if (!strcmp(key, "tail_split")) g_tail_split = value ? 1 : 0;
+    else if (!strcmp(key, "split_per_cu") && value > 0) g_split_per_cu = value;
     else if (!strcmp(key, "tap_skip")) g_tap_skip = value ? 1 : 0;
     else if (!strcmp(key, "tap_sort")) g_tap_sort = value ? 1 : 0;
     else if (!strcmp(key, "lds_swz")) g_lds_swz = value ? 1 : 0;
@@ -2123,7 +2148,9 @@ extern "C" int up_conv_split_parts(const up_conv_desc* d) {
     if (d->Cp % BK) return 1;
     int64_t M = (int64_t)d->N * d->P * d->Q;
     TileChoice t = choose_tile(M, d->K, d->R * d->S * d->Cp);
-    return split_parts(cdiv(M, t.bm) * cdiv(d->K, t.bn), d->R * d->S * d->Cp);
+    bool all_tiles = false;
+    return split_parts(cdiv(M, t.bm) * cdiv(d->K, t.bn), d->R * d->S * d->Cp,
+                       (size_t)cu_count() * (128 * 128) / (size_t)(t.bm * t.bn), &all_tiles);
 }
 
 extern "C" int up_pack_weights(const up_conv_desc* d, const float* w, float* w_fwd, float* w_dgrad, void* stream) {
