@@ -1,27 +1,40 @@
-# Round-end measurement set: default bench line (with cpu_baseline + alt_math), rocprofv3 kernel stats of the
-# default command and of the exclusive (single-stream) variant, smoke, full gpu test suite.
+# Round-end measurement set: smoke, default bench line (cpu_baseline, stock_gpu_baseline, alt_math, other_configs), rocprofv3 kernel
+# stats of the bench command in both stream modes, PMC passes; with TESTS=1 also the full -m gpu suite (default + bf16x3 arithmetic).
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r01_f}
+TAG=${1:-r02_z}
 mkdir -p gpurun_out/$TAG
-python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/$TAG/smoke.log 2>&1; echo "smoke exit $?"
-timeout 900 python bench.py > gpurun_out/$TAG/bench.log 2>&1; echo "bench exit $?"
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/$TAG/smoke.log 2>&1; echo "smoke exit $?"; tail -1 gpurun_out/$TAG/smoke.log
+timeout 900 python bench.py > gpurun_out/$TAG/bench.log 2> gpurun_out/$TAG/bench.err; echo "bench exit $?"
 tail -1 gpurun_out/$TAG/bench.log > gpurun_out/$TAG/bench.json
 python - <<PY
 import json
 d=json.load(open("gpurun_out/$TAG/bench.json"))
-print(d["value"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["achieved"], d["roofline"]["frac"], d["roofline"].get("exclusive",{}).get("achieved"), d.get("alt_math",{}).get("value"), d.get("cpu_baseline",{}).get("value"))
+r=d["roofline"]
+print("value", d["value"], "ms", d["ms_per_step"], r["kernel"], r["achieved"], r["frac"], "excl", r.get("exclusive",{}).get("frac"),
+      "alt", d.get("alt_math",{}).get("value"), "cpu", d.get("cpu_baseline",{}).get("value"), "stock", d.get("stock_gpu_baseline",{}).get("value"))
+for o in d.get("other_configs", []): print("other", o["value"], o["ms_per_step"], o["roofline"]["kernel"], o["roofline"]["achieved"])
+for w in r.get("wasp_dilated", []): print("wasp", w["dilation"], w["ms"], w["effective_mfma_frac"])
 PY
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-alt-math > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof.log 2>&1
-UNIPOSE_SYNC_WGRAD=1 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_sync -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-alt-math > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_sync.log 2>&1
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-stock-baseline --no-profile --no-alt-math --no-other-configs"
+timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof.log 2>&1
+UNIPOSE_SYNC_WGRAD=1 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_sync -o bench -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_sync.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_736 -o bench -- python $GRAFT_REPO_ROOT/bench.py --size 736 --batch 16 --math bf16s $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_736.log 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof -name "*.db" | head -1) 4 > gpurun_out/$TAG/kernel_stats.txt 2>&1
 python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof_sync -name "*.db" | head -1) 4 > gpurun_out/$TAG/kernel_stats_exclusive.txt 2>&1
+python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof_736 -name "*.db" | head -1) 4 > gpurun_out/$TAG/kernel_stats_736_bf16s.txt 2>&1
 find gpurun_out/$TAG -name "*.db" -delete
-head -12 gpurun_out/$TAG/kernel_stats.txt
-head -12 gpurun_out/$TAG/kernel_stats_exclusive.txt
-[ -n "$SKIP_TESTS" ] && exit 0
-timeout 900 python -m pytest tests -m gpu -q --timeout 600 > gpurun_out/$TAG/pytest_gpu.log 2>&1; echo "pytest exit $?"
+head -8 gpurun_out/$TAG/kernel_stats.txt
+head -8 gpurun_out/$TAG/kernel_stats_exclusive.txt
+head -8 gpurun_out/$TAG/kernel_stats_736_bf16s.txt
+UNIPOSE_SYNC_WGRAD=1 UP_PROFILE_CSV=$GRAFT_REPO_ROOT/gpurun_out/$TAG/launches.csv timeout 300 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-stock-baseline --no-alt-math --no-other-configs > gpurun_out/$TAG/bench_csv.log 2>&1
+python tools/gpu/csv_loss.py gpurun_out/$TAG/launches.csv.1 157.3 20 > gpurun_out/$TAG/lost_time_by_shape.txt 2>&1 || python tools/gpu/csv_loss.py gpurun_out/$TAG/launches.csv 157.3 20 > gpurun_out/$TAG/lost_time_by_shape.txt 2>&1
+head -4 gpurun_out/$TAG/lost_time_by_shape.txt
+bash tools/gpu/pmc.sh $TAG
+if [ -n "$TESTS" ]; then
+timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > gpurun_out/$TAG/pytest_gpu.log 2>&1; echo "pytest exit $?"
 tail -2 gpurun_out/$TAG/pytest_gpu.log
 UNIPOSE_CONV_MATH=bf16x3 timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -m gpu -q --timeout 600 > gpurun_out/$TAG/pytest_gpu_bf16x3.log 2>&1; echo "pytest(bf16x3 default) exit $?"
 tail -2 gpurun_out/$TAG/pytest_gpu_bf16x3.log
+fi
