@@ -868,7 +868,14 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
     constexpr int EA = HS ? 8 : 4;                   // activation elements per 16-byte staging access
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int NP = SPLIT ? 2 : 1;
-    constexpr int RS = KT * 2 + 16;                 // LDS row stride in bytes: 80 / 144, (RS/16) odd -> conflict-free
+    // LDS row stride in bytes: 80 / 144 = slice + 16 B pad, (RS/16) odd -> the ds_read_b128 of 16 consecutive rows are conflict-free.
+    // bf16 storage stages whole 16-byte chunks (4 lanes per 64-byte row), and with the pad its ds_write_b128 hit a 2-way
+    // conflict on 3 of every 16 lanes (SQ_LDS_BANK_CONFLICT = 0.34 of the LDS-active cycles, profiles/r02_ac_*) in a kernel
+    // whose LDS time exceeds its MFMA time.  SWZB: unpadded 64-byte rows, chunk c of row r at c ^ ((r >> 2) & 3): reads of
+    // 16 consecutive rows and writes of 4 rows x 4 chunks both touch 16 distinct 16-byte slots of the 256-byte bank row,
+    // and the tile takes 32 KB instead of 40.
+    constexpr bool SWZB = HS && KT == 32;
+    constexpr int RS = SWZB ? KT * 2 : KT * 2 + 16;
     constexpr int A_PLANE = BM * RS, B_PLANE = BN * RS;
     constexpr int BUF = NP * (A_PLANE + B_PLANE);
     constexpr int Q4 = KT / EA, RPA = 256 / Q4;     // A staging: RPA rows x Q4 16-byte chunks per pass
@@ -986,7 +993,7 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
             const bool keep = (ok##SFX >> i) & 1u;                                                                   \
             const uint4 u = ra##SFX[i];                                                                              \
             if constexpr (HS) {                                                                                      \
-                *reinterpret_cast<uint4*>(As + (i * RPA + lrow) * RS + kq * 16) =                                    \
+                *reinterpret_cast<uint4*>(As + (i * RPA + lrow) * RS + (SWZB ? (kq ^ ((lrow >> 2) & 3)) : kq) * 16) =       \
                     make_uint4(keep ? u.x : 0u, keep ? u.y : 0u, keep ? u.z : 0u, keep ? u.w : 0u);                  \
             } else {                                                                                                 \
                 const float4 v = keep_or_zero(keep, make_float4(__uint_as_float(u.x), __uint_as_float(u.y),          \
@@ -1005,7 +1012,7 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
             }                                                                                                        \
         }                                                                                                            \
         {                                                                                                            \
-            unsigned char* d = Bs + brow * RS + bch * 16;                                                            \
+            unsigned char* d = Bs + brow * RS + (SWZB ? (bch ^ ((brow >> 2) & 3)) : bch) * 16;                       \
             *reinterpret_cast<uint4*>(d) = rbh##SFX##0;                                                              \
             if (SPLIT) *reinterpret_cast<uint4*>(d + B_PLANE) = rbl##SFX##0;                                         \
             if (PB > 1) {                                                                                            \
@@ -1026,8 +1033,11 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int a_rd = (wm * (BM / 2) + l31) * RS + lh * 16;
-    const int b_rd = NP * A_PLANE + (wn * (BN / 2) + l31) * RS + lh * 16;
+    // fragment of 16-wide k step s: logical chunk lh + 2s of row (32-multiple + l31); SWZB: chunk ^ ((l31 >> 2) & 3)
+    const int frag_c0 = SWZB ? ((lh ^ ((l31 >> 2) & 3)) * 16) : lh * 16;
+    const int a_rd = (wm * (BM / 2) + l31) * RS;
+    const int b_rd = NP * A_PLANE + (wn * (BN / 2) + l31) * RS;
+    auto fcol = [&](int s) { return SWZB ? (frag_c0 ^ (s * 32)) : frag_c0 + s * 32; };   // byte offset inside the row
 
     // one K slice: MFMAs from LDS buffer kt&1; in between, slice kt+1 (register set S) goes to the other buffer
     // and S is refilled with slice kt+3
@@ -1040,12 +1050,12 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
         _Pragma("unroll") for (int s = 0; s < KT / 16; ++s) {                                                         \
             bf16x8 ah[TM], al[TM], bh[TN], bl[TN];                                                                    \
             _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                          \
-                ah[i] = *reinterpret_cast<const bf16x8*>(base + a_rd + i * 32 * RS + s * 32);                         \
-                if (SPLIT) al[i] = *reinterpret_cast<const bf16x8*>(base + a_rd + A_PLANE + i * 32 * RS + s * 32);    \
+                ah[i] = *reinterpret_cast<const bf16x8*>(base + a_rd + i * 32 * RS + fcol(s));                        \
+                if (SPLIT) al[i] = *reinterpret_cast<const bf16x8*>(base + a_rd + A_PLANE + i * 32 * RS + fcol(s));   \
             }                                                                                                         \
             _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                          \
-                bh[j] = *reinterpret_cast<const bf16x8*>(base + b_rd + j * 32 * RS + s * 32);                         \
-                if (SPLIT) bl[j] = *reinterpret_cast<const bf16x8*>(base + b_rd + B_PLANE + j * 32 * RS + s * 32);    \
+                bh[j] = *reinterpret_cast<const bf16x8*>(base + b_rd + j * 32 * RS + fcol(s));                        \
+                if (SPLIT) bl[j] = *reinterpret_cast<const bf16x8*>(base + b_rd + B_PLANE + j * 32 * RS + fcol(s));   \
             }                                                                                                         \
             if (s == 0) lstore##SFX((kt & 1) ^ 1);                                                                    \
             if (s == KT / 16 - 1) gload##SFX(kt + 3);                                                                 \
