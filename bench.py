@@ -199,7 +199,11 @@ def make_workload(dev, lstm, K, B, S, T, seed, emu=False):
                 loss = loss + ops.mse_loss(heat, t[:, j])
         else:
             loss = ops.mse_loss(model(x), t)
-        loss.backward()
+        if lstm:
+            with ops.deferred_wgrad():                         # every weight is used T times: see ops.deferred_wgrad
+                loss.backward()
+        else:
+            loss.backward()
         if reducer is not None:
             reducer.finish()
         opt.step()

@@ -314,3 +314,55 @@ def test_one_rank_rccl_gradient_exchange():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_deferred_wgrad_matches_autograd_accumulation():
+    """ops.deferred_wgrad (weight gradients of a re-used weight summed on the side stream and installed as .grad at the end of
+    the backward pass) against the engine's own accumulation on the UniPose-LSTM unroll: same gradients for every
+    parameter, with and without a gradient already present (zero_grad(set_to_none=False))."""
+    from model.uniposeLSTM import unipose_lstm
+    from unipose_amd import ops
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    K, B, T, S = 13, 2, 3, 128
+    model = unipose_lstm(num_classes=K).to(dev).train()
+    x = torch.randn(B, T, 3, S, S, device=dev)
+    cm = torch.rand(B, T, 1, S, S, device=dev)
+    t = torch.rand(B, T, K + 1, S // 8, S // 8, device=dev)
+
+    def run(deferred, keep_grads):
+        ops.manual_seed(9)
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        if keep_grads:
+            model.zero_grad(set_to_none=False)
+            for p in model.parameters():
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                p.grad.fill_(0.25)
+        else:
+            model.zero_grad(set_to_none=True)
+        hs = S // 8
+        heat = torch.zeros(K + 1, hs, hs, device=dev)
+        cell = torch.zeros(K + 2, hs, hs, device=dev)
+        hide = torch.zeros(K + 2, hs, hs, device=dev)
+        loss = 0.0
+        for j in range(T):
+            heat, cell, hide = model(x, cm, j, heat, hide, cell)
+            loss = loss + ops.mse_loss(heat, t[:, j])
+        if deferred:
+            with ops.deferred_wgrad():
+                loss.backward()
+        else:
+            loss.backward()
+        torch.cuda.synchronize()
+        g = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+        model.load_state_dict(sd)                    # running statistics back to where they were
+        return g
+
+    for keep in (False, True):
+        ref, got = run(False, keep), run(True, keep)
+        assert ref.keys() == got.keys() and len(ref) > 300
+        worst = max(float((got[n] - ref[n]).abs().max() / (ref[n].abs().max() + 1e-30)) for n in ref)
+        print(f"deferred vs engine accumulation (grads kept: {keep}): worst max-rel difference {worst:.2e}")
+        assert worst < 1e-5

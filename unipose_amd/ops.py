@@ -360,6 +360,39 @@ def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws
 ASYNC_WGRAD = os.environ.get("UNIPOSE_SYNC_WGRAD", "") == ""   # development switch: weight gradients on the main stream
 _SIDE = {}
 _PASS = {"seen": set(), "task": None}      # task: id of the autograd graph task whose end-of-backward callback is queued
+_DEFER = {"on": False, "acc": {}}          # see deferred_wgrad
+
+
+class deferred_wgrad:
+    """``with ops.deferred_wgrad(): loss.backward()`` — for graphs that use a weight more than once (the five-frame unroll of
+    the video model, uniposeLSTM.py:116-133).
+
+    The autograd engine sums the gradients of a re-used leaf in its input buffer on the MAIN stream, so without this
+    context `conv_bwd_weight` must make the main stream wait for the side stream at every such weight: 4 of the 5 frames
+    then run their weight gradients synchronously, followed by one small add per weight and frame.  Inside the context a
+    weight-gradient node hands autograd NOTHING: the first gradient of a weight becomes a buffer, later ones are added
+    to it on the side stream behind the kernel that produced them, and on exit (the end-of-backward callback has made the
+    main stream wait for the side stream by then) every buffer is installed as / added to ``weight.grad``.
+    Opt-in because it changes what autograd sees: ``torch.autograd.grad`` w.r.t. such a weight and gradient hooks on it get
+    no gradient inside the context (weights with post-accumulate hooks keep the normal path).  Convolutions with a bias
+    and non-leaf weights keep the normal path too."""
+
+    def __enter__(self):
+        if _DEFER["on"]:
+            raise RuntimeError("ops.deferred_wgrad() does not nest")
+        _DEFER["on"], _DEFER["acc"] = True, {}
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        acc, _DEFER["acc"], _DEFER["on"] = _DEFER["acc"], {}, False
+        if exc_type is None:
+            wgrad_fence()                     # (no-op after a completed backward; covers a backward that never ran the callback)
+            for weight, buf in acc.values():
+                if weight.grad is None:
+                    weight.grad = buf
+                else:
+                    weight.grad.add_(buf)
+        return False
 
 
 def _side_stream(dev):
@@ -414,6 +447,16 @@ def conv_bwd_weight(x, dy, weight, d, want_bias):
     side.wait_stream(main)
     with torch.cuda.stream(side):
         dw, db = conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias, ws_tag="side")
+        if _DEFER["on"] and db is None and not getattr(weight, "_post_accumulate_grad_hooks", None):
+            entry = _DEFER["acc"].get(id(weight))
+            if entry is None:
+                _DEFER["acc"][id(weight)] = (weight, dw)
+            else:
+                entry[1].add_(dw)             # on the side stream, ordered behind both weight-gradient kernels
+            for t in (x, dy):
+                t.record_stream(side)
+            dw.record_stream(main)
+            return None, None
     for t in (x, dy):
         t.record_stream(side)
     for t in (dw, db):

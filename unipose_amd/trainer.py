@@ -367,7 +367,8 @@ class VideoTrainer(_TrainerBase):
             self.optimizer.zero_grad()
             loss = self._unroll(input_var, heatmap_var, centermap_var)
             train_loss += loss.item()
-            loss.backward()                                            # one backward through all frames
+            with ops.deferred_wgrad():                                 # every weight is used once per frame
+                loss.backward()                                        # one backward through all frames
             self._optim_step()
             if hasattr(bar, "set_description"):
                 bar.set_description("Train loss: %.6f" % (train_loss / ((i + 1) * self.batch_size)))
