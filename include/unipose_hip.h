@@ -190,6 +190,12 @@ int up_bn_bwd_t(const void* dz, int lddz, const void* z, int ldz, const uint32_t
                 const float* gamma, const float* mean, const float* invstd, int relu, int use_batch_stats,
                 void* dy, int lddy, void* dres, int lddres, float* dgamma, float* dbeta,
                 float* workspace, size_t workspace_bytes, int64_t rows, int C, int dtype, void* stream);
+/* ... and with running sums over several calls: acc_dgamma[c] += this call's dgamma[c] (likewise dbeta), for a BatchNorm that
+ * runs once per frame of the video unroll (uniposeLSTM.py:116-133); dgamma / dbeta still receive this call's sums. */
+int up_bn_bwd_acc_t(const void* dz, int lddz, const void* z, int ldz, const uint32_t* relu_bits, const void* y, int ldy,
+                const float* gamma, const float* mean, const float* invstd, int relu, int use_batch_stats,
+                void* dy, int lddy, void* dres, int lddres, float* dgamma, float* dbeta, float* acc_dgamma, float* acc_dbeta,
+                float* workspace, size_t workspace_bytes, int64_t rows, int C, int dtype, void* stream);
 
 /* ---- pointwise / data movement ---- */
 int up_relu_bwd(const float* dz, const float* z, float* dx, int64_t n, void* stream);              /* K8 */

@@ -137,7 +137,7 @@ def train_case(dev, K=16, B=2, size=32, wseed=3, dropout_masks=False):
             assert int(msd[k]) == int(v) == 1, k
 
 
-def lstm_case(dev, K=13, B=1, size=32, T=3, wseed=4, tol=1e-3, train=False):
+def lstm_case(dev, K=13, B=1, size=32, T=3, wseed=4, tol=1e-3, train=False, deferred=False):
     """T-frame unroll with the reference driver's call pattern (uniposeLSTM.py:116-133).  eval: strict
     tolerance per frame.  train: summed MSE, ONE backward through all frames (BPTT), fp64 yardstick."""
     from model.uniposeLSTM import unipose_lstm
@@ -205,7 +205,11 @@ def lstm_case(dev, K=13, B=1, size=32, T=3, wseed=4, tol=1e-3, train=False):
                 else:
                     assert O.max_rel(got.cpu(), o32[j][i]) < tol, (j, i)
     if train:
-        loss.backward()
+        if deferred:                       # gradients of the re-used weights summed by the library (ops.deferred_wgrad)
+            with ops.deferred_wgrad():
+                loss.backward()
+        else:
+            loss.backward()
         l32.backward()
         l64.backward()
         worst = {}

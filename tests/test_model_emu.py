@@ -25,3 +25,8 @@ def test_lstm_eval_emu(emu_backend):
 
 def test_lstm_train_bptt_emu(emu_backend):
     mc.lstm_case(emu_backend, size=32, T=2, B=2, train=True)
+
+
+def test_lstm_train_bptt_deferred_wgrad_emu(emu_backend):
+    # three frames: every weight and every BatchNorm affine pair is summed over three uses by the library
+    mc.lstm_case(emu_backend, size=32, T=3, B=2, train=True, deferred=True)

@@ -1,6 +1,6 @@
 # rocprofv3 kernel stats of the UniPose-LSTM step (K=13, B=8, T=5) — where do the 11x11 head convolutions stand?
 cd $GRAFT_REPO_ROOT
-TAG=r02_k
+TAG=${1:-r02_k}
 mkdir -p gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --model lstm --num-classes 13 --batch 8 --frames 5 --steps 3 --warmup 1 --no-cpu-baseline --no-profile --no-alt-math --no-other-configs > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof.log 2>&1

@@ -58,6 +58,7 @@ SIGNATURES = {
     "up_bn_bwd_workspace": (_sz, [_i64, _i]),
     "up_bn_apply_t": (_i, [_p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i64, _i, _i, _p]),
     "up_bn_bwd_t": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _sz, _i64, _i, _i, _p]),
+    "up_bn_bwd_acc_t": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _sz, _i64, _i, _i, _p]),
     "up_relu_bwd": (_i, [_p, _p, _p, _i64, _p]),
     "up_copy2d": (_i, [_p, _i, _p, _i, _i64, _i, _p]),
     "up_add2d": (_i, [_p, _i, _p, _i, _p, _i, _i64, _i, _p]),

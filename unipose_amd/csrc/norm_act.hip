@@ -307,8 +307,10 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* dz, int ldd
 }
 // pass 2: one workgroup per channel, thread t sums chunks t, t+256, ... (four independent loads per round), LDS tree;
 // fixed order: deterministic.  (Same reasoning as bn_finalize_kernel: the time is the number of dependent load rounds.)
+// acc_dgamma / acc_dbeta (optional): running sums over several calls (a BatchNorm used once per frame of the video unroll):
+// the per-call sums still go to dgamma / dbeta, pass 3 needs them.
 __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* partial, int chunks, int C, float* dgamma,
-                                                              float* dbeta) {
+                                                              float* dbeta, float* acc_dgamma, float* acc_dbeta) {
     __shared__ float red[256][2];
     const int c = blockIdx.x, t0 = threadIdx.x;
     float a = 0.f, b = 0.f;
@@ -343,6 +345,10 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* parti
     if (t0 == 0) {
         dbeta[c] = a;
         dgamma[c] = b;
+        if (acc_dgamma) {
+            acc_dbeta[c] += a;
+            acc_dgamma[c] += b;
+        }
     }
 }
 // pass 3: dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M);  dres = g
@@ -568,13 +574,13 @@ namespace up {
 template <typename T>
 static void launch_bn_bwd(const T* dz, int lddz, const T* z, int ldz, const uint32_t* relu_bits, const T* y, int ldy,
                           const float* gamma, const float* mean, const float* invstd, int relu, int use_batch_stats, T* dy,
-                          int lddy, T* dres, int lddres, float* dgamma, float* dbeta, float* workspace, int64_t rows, int C,
-                          hipStream_t st) {
+                          int lddy, T* dres, int lddres, float* dgamma, float* dbeta, float* acc_dgamma, float* acc_dbeta,
+                          float* workspace, int64_t rows, int C, hipStream_t st) {
     int chunks = cdiv(rows, BNB_ROWS);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(chunks, cdiv(C, 64)), dim3(256), 0, st, dz, lddz, z, ldz, relu_bits,
                        y, ldy, mean, invstd, relu, workspace, rows, C, BNB_ROWS);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (const float*)workspace, chunks, C,
-                       dgamma, dbeta);
+                       dgamma, dbeta, acc_dgamma, acc_dbeta);
     int64_t total = rows * (C / 4);
     if constexpr (sizeof(T) == 2) {
         if (C % 8 == 0 && lddz % 8 == 0 && ldy % 8 == 0 && lddy % 8 == 0 && (!relu || relu_bits || ldz % 8 == 0) &&
@@ -595,6 +601,15 @@ extern "C" int up_bn_bwd_t(const void* dz, int lddz, const void* z, int ldz, con
                            int ldy, const float* gamma, const float* mean, const float* invstd, int relu,
                            int use_batch_stats, void* dy, int lddy, void* dres, int lddres, float* dgamma, float* dbeta,
                            float* workspace, size_t workspace_bytes, int64_t rows, int C, int dtype, void* stream) {
+    return up_bn_bwd_acc_t(dz, lddz, z, ldz, relu_bits, y, ldy, gamma, mean, invstd, relu, use_batch_stats, dy, lddy, dres,
+                           lddres, dgamma, dbeta, nullptr, nullptr, workspace, workspace_bytes, rows, C, dtype, stream);
+}
+extern "C" int up_bn_bwd_acc_t(const void* dz, int lddz, const void* z, int ldz, const uint32_t* relu_bits, const void* y,
+                               int ldy, const float* gamma, const float* mean, const float* invstd, int relu,
+                               int use_batch_stats, void* dy, int lddy, void* dres, int lddres, float* dgamma,
+                               float* dbeta, float* acc_dgamma, float* acc_dbeta, float* workspace, size_t workspace_bytes,
+                               int64_t rows, int C, int dtype, void* stream) {
+    UP_REQUIRE(!acc_dgamma == !acc_dbeta, UP_ERR_INVALID, "bn_bwd: acc_dgamma and acc_dbeta come together");
     UP_REQUIRE(dz && y && gamma && mean && invstd && dy && dgamma && dbeta && workspace, UP_ERR_INVALID,
                "bn_bwd: null pointer");
     UP_REQUIRE(!relu || z || relu_bits, UP_ERR_INVALID, "bn_bwd: relu needs the forward output z or its sign bits");
@@ -608,11 +623,11 @@ extern "C" int up_bn_bwd_t(const void* dz, int lddz, const void* z, int ldz, con
     if (dtype == UP_DT_BF16)
         launch_bn_bwd<bf16_t>((const bf16_t*)dz, lddz, (const bf16_t*)z, ldz, relu_bits, (const bf16_t*)y, ldy, gamma, mean,
                               invstd, relu, use_batch_stats, (bf16_t*)dy, lddy, (bf16_t*)dres, lddres, dgamma, dbeta,
-                              workspace, rows, C, st);
+                              acc_dgamma, acc_dbeta, workspace, rows, C, st);
     else
         launch_bn_bwd<float>((const float*)dz, lddz, (const float*)z, ldz, relu_bits, (const float*)y, ldy, gamma, mean,
                              invstd, relu, use_batch_stats, (float*)dy, lddy, (float*)dres, lddres, dgamma, dbeta,
-                             workspace, rows, C, st);
+                             acc_dgamma, acc_dbeta, workspace, rows, C, st);
     return check_launch("bn_bwd");
 }
 extern "C" int up_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const uint32_t* relu_bits,

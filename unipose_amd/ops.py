@@ -360,7 +360,7 @@ def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws
 ASYNC_WGRAD = os.environ.get("UNIPOSE_SYNC_WGRAD", "") == ""   # development switch: weight gradients on the main stream
 _SIDE = {}
 _PASS = {"seen": set(), "task": None}      # task: id of the autograd graph task whose end-of-backward callback is queued
-_DEFER = {"on": False, "acc": {}}          # see deferred_wgrad
+_DEFER = {"on": False, "acc": {}, "bn": {}}          # see deferred_wgrad
 
 
 class deferred_wgrad:
@@ -380,18 +380,22 @@ class deferred_wgrad:
     def __enter__(self):
         if _DEFER["on"]:
             raise RuntimeError("ops.deferred_wgrad() does not nest")
-        _DEFER["on"], _DEFER["acc"] = True, {}
+        _DEFER["on"], _DEFER["acc"], _DEFER["bn"] = True, {}, {}
         return self
 
     def __exit__(self, exc_type, exc, tb):
-        acc, _DEFER["acc"], _DEFER["on"] = _DEFER["acc"], {}, False
+        acc, bn = _DEFER["acc"], _DEFER["bn"]
+        _DEFER["acc"], _DEFER["bn"], _DEFER["on"] = {}, {}, False
         if exc_type is None:
             wgrad_fence()                     # (no-op after a completed backward; covers a backward that never ran the callback)
-            for weight, buf in acc.values():
-                if weight.grad is None:
-                    weight.grad = buf
+            pairs = [(w, buf) for w, buf in acc.values()]
+            for gamma, beta, dgb in bn.values():       # BatchNorm affine parameters: sums kept by up_bn_bwd_acc_t
+                pairs += [(gamma, dgb[0]), (beta, dgb[1])]
+            for p, buf in pairs:
+                if p.grad is None:
+                    p.grad = buf
                 else:
-                    weight.grad.add_(buf)
+                    p.grad.add_(buf)
         return False
 
 
@@ -556,6 +560,7 @@ class ConvBnAct(Function):
         if relu and _RELU_TRACE is not None:
             _RELU_TRACE.append(z.detach())
         ctx.d, ctx.relu, ctx.train, ctx.has_res = d, relu, train, residual is not None
+        ctx.beta = beta                       # (the parameter object: deferred_wgrad installs its gradient)
         ctx.link_in, ctx.link_out = link_in, link_out
         if link_in is not None:
             link_in.armed = True       # this node will compute a data gradient: the producer may hand over
@@ -578,10 +583,23 @@ class ConvBnAct(Function):
         ws = workspace(x.device, need)
         if dz.dtype != y.dtype:
             raise TypeError(f"gradient {dz.dtype} vs saved convolution output {y.dtype}")
-        _C.check(L.up_bn_bwd_t(dz.data_ptr(), d.ldy, None, 0, _ptr(bits), y.data_ptr(), d.ldy, gamma.data_ptr(),
-                               coef[0].data_ptr(), coef[1].data_ptr(), int(ctx.relu), int(ctx.train), dy.data_ptr(),
-                               d.ldy, _ptr(dres), d.ldy, dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(),
-                               ws.numel(), rows, k, _dt(y), _stream(x)), "bn_bwd")
+        beta = ctx.beta
+        hand_over = True                      # autograd gets dgamma / dbeta
+        acc = None
+        if _DEFER["on"] and gamma.is_leaf and beta.is_leaf and ctx.needs_input_grad[2] and ctx.needs_input_grad[3] and \
+                not getattr(gamma, "_post_accumulate_grad_hooks", None) and not getattr(beta, "_post_accumulate_grad_hooks", None):
+            hand_over = False                 # ops.deferred_wgrad: the sums over all uses live in ONE buffer per layer
+            entry = _DEFER["bn"].get(id(gamma))
+            if entry is None:
+                _DEFER["bn"][id(gamma)] = (gamma, beta, dgb)
+            else:
+                acc = entry[2]
+        _C.check(L.up_bn_bwd_acc_t(dz.data_ptr(), d.ldy, None, 0, _ptr(bits), y.data_ptr(), d.ldy, gamma.data_ptr(),
+                                   coef[0].data_ptr(), coef[1].data_ptr(), int(ctx.relu), int(ctx.train), dy.data_ptr(),
+                                   d.ldy, _ptr(dres), d.ldy, dgb[0].data_ptr(), dgb[1].data_ptr(),
+                                   acc[0].data_ptr() if acc is not None else None,
+                                   acc[1].data_ptr() if acc is not None else None, ws.data_ptr(),
+                                   ws.numel(), rows, k, _dt(y), _stream(x)), "bn_bwd")
         add = None
         if ctx.link_in is not None:
             add, ctx.link_in.grad, ctx.link_in.armed = ctx.link_in.grad, None, False
@@ -589,7 +607,8 @@ class ConvBnAct(Function):
         if ctx.link_out is not None and ctx.link_out.armed and dres is not None:
             ctx.link_out.grad, dres = dres, None          # the block's first convolution adds it to ITS dx
         dw = conv_bwd_weight(x, dy, weight, d, False)[0] if ctx.needs_input_grad[1] else None   # frozen weight: no launch
-        return dx, dw, dgb[0], dgb[1], dres, None, None, None, None, None, None, None, None, None
+        return dx, dw, (dgb[0] if hand_over else None), (dgb[1] if hand_over else None), dres, None, None, None, None, None, \
+            None, None, None, None
 
 
 def conv_bn_act_eval_fused(x, weight, gamma, beta, rm, rv, cfg, relu, residual=None, eps=BN_EPS_DEFAULT):
