@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--math", default="f32")
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--sync-wgrad", action="store_true")
+    ap.add_argument("--lstm", action="store_true", help="UniPose-LSTM (K=13, --frames frames) instead of the image model")
+    ap.add_argument("--frames", type=int, default=5)
     args = ap.parse_args()
     import bench
     from unipose_amd import ops
@@ -26,7 +28,8 @@ def main():
     ops.set_conv_math(args.math)
     if args.sync_wgrad:
         ops.ASYNC_WGRAD = False
-    model, opt, step = bench.make_workload(dev, False, 16, args.batch, args.size, 1, seed=0)
+    model, opt, step = bench.make_workload(dev, args.lstm, 13 if args.lstm else 16, args.batch, args.size,
+                                           args.frames if args.lstm else 1, seed=0)
     ts = []
     for i in range(args.steps):
         torch.cuda.synchronize()
