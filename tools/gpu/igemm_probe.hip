@@ -121,10 +121,11 @@ static void timeline(IgemmArgs a, double mfma_ticks_per_block, bool split = fals
     a.parts = 1;
     const int tiles = a.nwg;
     if (split) {   // the production tail split (launch_igemm)
-        const int p = split_parts(a.nwg, a.Ktot);
+        SplitScratch* sc = split_scratch(0);
+        bool all_tiles = false;
+        const int p = split_parts(a.nwg, a.Ktot, std::min(sc->pfloats / (size_t)(BM * BN), sc->nflags), &all_tiles);
         if (p >= 2) {
-            SplitScratch* sc = split_scratch(0);
-            a.full_blocks = a.nwg / cu_count() * cu_count();
+            a.full_blocks = all_tiles ? 0 : a.nwg / cu_count() * cu_count();
             a.parts = p;
             a.partials = sc->partials;
             a.flags = sc->flags;
