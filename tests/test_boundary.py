@@ -111,3 +111,21 @@ def test_conv_desc_validation_without_gpu():
     assert lib.up_conv2d_bwd_weight_workspace(ctypes.byref(d)) % (256 * 9 * 256 * 4) == 0
     d.P = 22                                                                           # inconsistent geometry
     assert lib.up_conv2d_bwd_weight_workspace(ctypes.byref(d)) == 0
+
+
+def test_deferred_wgrad_context_state():
+    """ops.deferred_wgrad is a plain context: no nesting, and an exception inside leaves no state (and no half-summed
+    gradients) behind."""
+    from unipose_amd import ops
+    with pytest.raises(RuntimeError):
+        with ops.deferred_wgrad():
+            with ops.deferred_wgrad():
+                pass
+    assert not ops._DEFER["on"] and not ops._DEFER["acc"] and not ops._DEFER["bn"]
+    with pytest.raises(ZeroDivisionError):
+        with ops.deferred_wgrad():
+            ops._DEFER["acc"][1] = (None, None)
+            1 / 0
+    assert not ops._DEFER["on"] and not ops._DEFER["acc"] and not ops._DEFER["bn"]
+    with ops.deferred_wgrad():
+        pass
