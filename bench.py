@@ -71,7 +71,7 @@ def cpu_baseline(num_classes, size, batch, steps, threads):
                       f"torch {torch.__version__} CPU, after 1 warm-up step"}
 
 
-def stock_gpu_baseline(dev, num_classes, size, batch, steps=5, warmup=3, benchmark=False):
+def stock_gpu_baseline(dev, num_classes, size, batch, steps=5, warmup=3, benchmark=False, lstm_frames=0):
     """The SAME train step on the SAME GPU through the platform's stock path: the oracle's functional restatement of the
     reference graph executed by PyTorch-ROCm eager (MIOpen / hipBLASLt / ATen kernels, fp32) with torch's fused Adam —
     what a user of the reference gets on an MI355X without this library.  A reported baseline like `cpu_baseline`, never
@@ -82,19 +82,33 @@ def stock_gpu_baseline(dev, num_classes, size, batch, steps=5, warmup=3, benchma
     old = torch.backends.cudnn.benchmark
     torch.backends.cudnn.benchmark = benchmark
     try:
-        sd = {k: v.to(dev) for k, v in O.synth_state_dict(num_classes, 0).items()}
+        sd = {k: v.to(dev) for k, v in O.synth_state_dict(num_classes, 0, lstm=lstm_frames > 0).items()}
         params = []
         for k, v in sd.items():
             if v.is_floating_point() and "running_" not in k:
                 v.requires_grad_(True)
                 params.append(v)
         opt = torch.optim.Adam(params, lr=1e-4, fused=True)
-        x = O.synth_input((batch, 3, size, size), 1).to(dev)
-        t = O.synth_input((batch, num_classes + 1, size // 8, size // 8), 2, "rand").to(dev)
+        T, hs = lstm_frames, size // 8
+        if T:
+            x = O.synth_input((batch, T, 3, size, size), 1).to(dev)
+            cm = O.synth_input((batch, T, 1, size, size), 3, "rand").to(dev)
+            t = O.synth_input((batch, T, num_classes + 1, hs, hs), 2, "rand").to(dev)
+        else:
+            x = O.synth_input((batch, 3, size, size), 1).to(dev)
+            t = O.synth_input((batch, num_classes + 1, hs, hs), 2, "rand").to(dev)
 
         def one():
             opt.zero_grad(set_to_none=True)
-            loss = torch.nn.functional.mse_loss(O.unipose_forward(sd, x, train=True), t)
+            if T:                                      # uniposeLSTM.py:116-133: T frames, summed MSE, one backward
+                h = torch.zeros(batch, num_classes + 2, hs, hs, device=dev)
+                c = torch.zeros(batch, num_classes + 2, hs, hs, device=dev)
+                loss = 0.0
+                for j in range(T):
+                    heat, c, h = O.unipose_lstm_forward(sd, x, cm, j, h, c, train=True)
+                    loss = loss + torch.nn.functional.mse_loss(heat, t[:, j])
+            else:
+                loss = torch.nn.functional.mse_loss(O.unipose_forward(sd, x, train=True), t)
             loss.backward()
             opt.step()
             return loss
@@ -112,9 +126,10 @@ def stock_gpu_baseline(dev, num_classes, size, batch, steps=5, warmup=3, benchma
             torch.cuda.synchronize(dev)
             ts.append((time.perf_counter() - t0) * 1e3)
         ms = sorted(ts)[len(ts) // 2]
-        return {"value": round(batch * 1e3 / ms, 2), "unit": "images/sec", "ms_per_step": round(ms, 3),
+        return {"value": round(batch * max(T, 1) * 1e3 / ms, 2), "unit": "images/sec", "ms_per_step": round(ms, 3),
                 "kind": "port on the stock GPU path",
-                "sample": f"median of {steps} fenced train steps (fwd+MSE+bwd+fused Adam) of batch {batch} at {size}x{size}, "
+                "sample": f"median of {steps} fenced train steps (fwd+MSE+bwd+fused Adam) of batch {batch}"
+                          f"{' x %d frames' % T if T else ''} at {size}x{size}, "
                           f"oracle graph on torch {torch.__version__} eager (MIOpen, cudnn.benchmark={benchmark}), fp32, "
                           f"after {warmup} warm-up steps ({t_warm:.1f} s incl. MIOpen's search)"}
     finally:
@@ -363,8 +378,10 @@ def main():
         print(json.dumps({"wasp_dilated": wasp_dilated_leg(dev)}), flush=True)
         return
     if args.stock_baseline_only:
-        print(json.dumps(stock_gpu_baseline(dev, args.num_classes, args.size, args.batch, benchmark=args.stock_benchmark)),
-              flush=True)
+        video = args.model == "lstm"
+        print(json.dumps(stock_gpu_baseline(dev, 13 if video and args.num_classes == 16 else args.num_classes, args.size,
+                                            8 if video and args.batch == 32 else args.batch, benchmark=args.stock_benchmark,
+                                            lstm_frames=args.frames if video else 0)), flush=True)
         return
 
     K, B, S = args.num_classes, args.batch, args.size
