@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-TAG=r02_z3; mkdir -p gpurun_out/$TAG
+TAG=${1:-r02_z3}; mkdir -p gpurun_out/$TAG
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/$TAG/smoke.log 2>&1; echo "smoke exit $?"; tail -1 gpurun_out/$TAG/smoke.log
 SECONDS=0; timeout 900 python bench.py > gpurun_out/$TAG/bench.log 2> gpurun_out/$TAG/bench.err; echo "bench exit $? wall ${SECONDS}s"
 tail -1 gpurun_out/$TAG/bench.log > gpurun_out/$TAG/bench.json
