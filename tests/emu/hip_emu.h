@@ -291,6 +291,7 @@ static inline float atomicAdd(float* p, float v) {
     } while (!__atomic_compare_exchange_n(ip, &old, nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
     return f;
 }
+static inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 // ---- bf16 (round-to-nearest-even like v_cvt_pk_bf16_f32) and v_mfma_f32_32x32x16_bf16 ----
 struct bf16x8 {
     uint16_t v[8];

@@ -60,3 +60,13 @@ def test_tile_rule_of_the_bf16_kernels_and_statistics_rows(emu_backend):
     finally:
         lib.up_conv_tune(b"tile_want", 1500)
         lib.up_conv_tune(b"tile_want_bf16", 500)
+
+
+import glds_cases as gc
+
+
+@pytest.mark.parametrize("case", gc.SMALL, ids=lambda c: "c%d_%dx%d_k%d_r%d_d%d_t%d" % (c["c"], c["h"], c["w"], c["k"], c["r"], c["dil"], c["tile_want"]))
+def test_glds_kernel_matches_register_staged_kernel(emu_backend, case):
+    """second-generation bf16-storage kernel (direct-to-LDS loads, tap skipping, tap-sorted rows, 16-byte stores) == the
+    register-staged kernel, element for element: outputs, BatchNorm partials, data gradients"""
+    gc.conv_ab(emu_backend, **case)

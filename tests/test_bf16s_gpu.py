@@ -7,6 +7,7 @@ import pytest
 import torch
 
 import bf16s_cases as bc
+import glds_cases as gc
 import model_cases as mc
 from oracle import unipose_oracle as O
 
@@ -48,6 +49,14 @@ def test_conv_bn_bf16_storage(cfg):
 
 def test_small_ops_bf16_storage():
     bc.small_ops_case(DEV)
+
+
+@pytest.mark.parametrize("case", gc.SMALL + gc.FULL,
+                         ids=lambda c: "n%d_c%d_%dx%d_k%d_r%d_d%d_t%d" % (c["n"], c["c"], c["h"], c["w"], c["k"], c["r"], c["dil"], c["tile_want"]))
+def test_glds_kernel_matches_register_staged_kernel(case):
+    """second-generation bf16-storage kernel (direct-to-LDS loads, tap skipping, tap-sorted rows, 16-byte stores) == the
+    register-staged kernel, element for element, at small sizes and at the geometries of BASELINE configs[4]"""
+    gc.conv_ab(DEV, **case)
 
 
 def _golden_eval(golden_dir, name, size, B):

@@ -1,0 +1,34 @@
+# One parametrised runner for the GPU box:  bash tools/gpu/run.sh <tag> <action> [<action> ...]
+# Outputs land in gpurun_out/<tag>/.  Actions:
+#   tr16         lane map of ds_read_b64_tr_b16 (tools/gpu/tr16_probe)
+#   tests_bf16s  tests/test_bf16s_gpu.py           tests_all   the whole -m gpu suite
+#   ab736        736^2 B=16 bf16-storage step, UP_GLDS=1 vs 0 (two alternations)
+#   csv736       per-launch CSV (exclusive stream mode) of the same step for UP_GLDS=1 and 0, grouped by GEMM shape
+#   ab368        default fp32 step, two runs (box sanity)
+#   lstm         UniPose-LSTM leg with host / wall split (tools/gpu/steps.py)
+cd $GRAFT_REPO_ROOT
+TAG=$1; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+B736="--size 736 --batch 16 --math bf16s --no-cpu-baseline --no-stock-baseline --no-alt-math --no-other-configs"
+line() { tail -1 $1 | python -c "
+import sys, json
+try:
+    d = json.loads(sys.stdin.read()); print('$2', d['value'], d['ms_per_step'])
+except Exception as e: print('$2', 'no json line', e)"; }
+for act in "$@"; do
+case $act in
+tr16) ./tools/gpu/tr16_probe > $OUT/tr16.txt 2>&1; echo "tr16 exit $?"; head -20 $OUT/tr16.txt ;;
+tests_bf16s) timeout 900 python -m pytest tests/test_bf16s_gpu.py -m gpu -q --timeout 600 > $OUT/pytest_bf16s.log 2>&1; echo "pytest exit $?"; tail -15 $OUT/pytest_bf16s.log ;;
+tests_all) timeout 1500 python -m pytest tests -m gpu -q --timeout 600 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -15 $OUT/pytest_gpu.log ;;
+ab736) for rep in 1 2; do for g in 1 0; do
+  UP_GLDS=$g timeout 300 python bench.py $B736 --steps 8 --warmup 3 --no-profile > $OUT/ab736_$g.log 2>&1; line $OUT/ab736_$g.log "glds=$g"; done; done ;;
+csv736) for g in 1 0; do
+  UP_GLDS=$g UNIPOSE_SYNC_WGRAD=1 UP_PROFILE_CSV=$GRAFT_REPO_ROOT/$OUT/launches736_g$g.csv timeout 300 python bench.py $B736 --steps 3 --warmup 2 > $OUT/csv736_$g.log 2>&1; line $OUT/csv736_$g.log "csv glds=$g"; done
+  ls $OUT/*.csv*; A=$(ls $OUT/launches736_g1.csv* | tail -1); B=$(ls $OUT/launches736_g0.csv* | tail -1)
+  python tools/gpu/csv_compare.py $A $B > $OUT/csv736_compare.txt 2>&1; head -60 $OUT/csv736_compare.txt ;;
+ab368) for rep in 1 2; do timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-stock-baseline --no-alt-math --no-other-configs --no-profile > $OUT/ab368.log 2>&1; line $OUT/ab368.log "fp32"; done ;;
+lstm) timeout 300 python tools/gpu/steps.py --model lstm --batch 8 > $OUT/lstm_steps.log 2>&1; tail -5 $OUT/lstm_steps.log ;;
+*) echo "unknown action $act" ;;
+esac
+done

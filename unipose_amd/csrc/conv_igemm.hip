@@ -127,6 +127,7 @@ struct IgemmArgs {
     // tap-sorted row order (igemm_kernel<..., PERM = true>, see TapSort): GEMM row m is output pixel perm[m]; pixels
     // with the same set of live filter taps are contiguous, so the tile-level tap skipping drops (nearly) every dead tap
     const int* perm;
+    uint32_t x_bytes;   // bf16s_glds.h: bytes of the activation tensor behind x (num_records of its buffer descriptor)
 };
 
 __device__ __forceinline__ void wf_merge(float& n1, float& m1, float& s1, float n2, float m2, float s2) {
@@ -1107,6 +1108,8 @@ __global__ void __launch_bounds__(256) pack_split_kernel(const float* w, uint16_
     lo[e] = (uint16_t)(l & 0xffffu);
 }
 
+#include "bf16s_glds.h"
+
 // ------------------------------------------------------------------------------------------
 // weight gradient
 // ------------------------------------------------------------------------------------------
@@ -1804,6 +1807,7 @@ static int env_int(const char* name, int dflt, int min_ok) {
 }
 static int g_tile_want = env_int("UP_TILE_WANT", 1500, 1);   // A/B in the network: 700 / 1000 / 1500 / 2200 / 4300 -> 70.1 / 69.9 / 69.6 / 69.9 / 69.8 ms
 static int g_tile_want_bf16 = env_int("UP_TILE_WANT_BF16", 500, 1);
+static int g_glds = env_int("UP_GLDS", 1, 0);   // bf16 storage: direct-to-LDS kernels of bf16s_glds.h (0 = the register-staged round-2 kernels)
 static int g_db_min_k = env_int("UP_DB_MIN_K", 1024, 1);
 static int g_short_k = env_int("UP_SHORT_K", 512, 1);             // reductions shorter than this are epilogue-heavy:
 static int g_short_k_mult = env_int("UP_SHORT_K_MULT", 4, 1);     // they want g_short_k_mult / 2 times as many workgroups
@@ -2139,6 +2143,7 @@ extern "C" int up_conv_tune(const char* key, int value) {
     UP_REQUIRE(key, UP_ERR_INVALID, "conv_tune: null key");
     if (!strcmp(key, "tile_want") && value > 0) g_tile_want = value;
     else if (!strcmp(key, "tile_want_bf16") && value > 0) g_tile_want_bf16 = value;
+    else if (!strcmp(key, "glds")) g_glds = value ? 1 : 0;
     else if (!strcmp(key, "db_min_k") && value > 0) g_db_min_k = value;
     else if (!strcmp(key, "short_k") && value > 0) g_short_k = value;
     else if (!strcmp(key, "short_k_mult") && value > 0) g_short_k_mult = value;
@@ -2293,6 +2298,24 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
     // K slice: 64 on the 64x64 tile (6 -> 12 MFMAs per wave and barrier) measured no faster than 32 (141.7 vs 145.1 TF)
     constexpr int KT = 32;
     if (math == UP_MATH_BF16S) {   // bf16 storage
+        // second-generation kernel (bf16s_glds.h): operands HBM -> LDS directly, 64-channel slices, 16-byte epilogue stores.
+        // Needs 64-channel alignment, 8-channel (16-byte) output rows, 31-bit byte offsets and no strided gather.
+        const long long a_bytes = (long long)(a.M / (a.P * a.Q)) * a.H * a.W * a.ldx * 2;
+        const uintptr_t ptrs = reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.y) |
+                               reinterpret_cast<uintptr_t>(a.w_hi) | reinterpret_cast<uintptr_t>(a.residual);
+        if (g_glds && fast && a.M % (a.P * a.Q) == 0 && a.Cp % glds::KT == 0 && a.Ng % 8 == 0 && a.ldy % 8 == 0 &&
+            a.ldx % 8 == 0 && (!a.residual || a.ldr % 8 == 0) && !a.o_mode && a_bytes < (1ll << 31) &&
+            (long long)a.Ng * a.Ktot * 2 < (1ll << 31) && (ptrs & 15) == 0) {
+            a.no_tap_skip = g_tap_skip ? 0 : 1;
+            a.perm = nullptr;
+            a.x_bytes = (uint32_t)a_bytes;
+            if (g_tap_sort && a.taps > 1 && a.taps <= 16 && !a.residual && !a.no_tap_skip) a.perm = tap_sort_perm(a);
+            if (a.perm)
+                hipLaunchKernelGGL((glds::igemm_glds_kernel<BM, BN, true>), dim3(a.nwg), dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL((glds::igemm_glds_kernel<BM, BN, false>), dim3(a.nwg), dim3(256), 0, st, a);
+            return;
+        }
         a.fSpt = make_fastdiv(a.Cp / KT);
         if (fast)
             hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 2, false, KT, true>), dim3(a.nwg), dim3(256), 0, st, a);
