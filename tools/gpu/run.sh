@@ -4,6 +4,7 @@
 #   tests_bf16s  tests/test_bf16s_gpu.py           tests_all   the whole -m gpu suite
 #   ab736        736^2 B=16 bf16-storage step, UP_GLDS=1 vs 0 (two alternations)
 #   csv736       per-launch CSV (exclusive stream mode) of the same step for UP_GLDS=1 and 0, grouped by GEMM shape
+#   abenv/csvenv VARIANTS="A=1;A=2 B=3": the 736^2 step / its per-launch CSV under each environment
 #   ab368        default fp32 step, two runs (box sanity)
 #   lstm         UniPose-LSTM leg with host / wall split (tools/gpu/steps.py)
 cd $GRAFT_REPO_ROOT
@@ -27,6 +28,16 @@ csv736) for g in 1 0; do
   UP_GLDS=$g UNIPOSE_SYNC_WGRAD=1 UP_PROFILE_CSV=$GRAFT_REPO_ROOT/$OUT/launches736_g$g.csv timeout 300 python bench.py $B736 --steps 3 --warmup 2 > $OUT/csv736_$g.log 2>&1; line $OUT/csv736_$g.log "csv glds=$g"; done
   ls $OUT/*.csv*; A=$(ls $OUT/launches736_g1.csv* | tail -1); B=$(ls $OUT/launches736_g0.csv* | tail -1)
   python tools/gpu/csv_compare.py $A $B > $OUT/csv736_compare.txt 2>&1; head -60 $OUT/csv736_compare.txt ;;
+abenv) # VARIANTS="UP_GLDS=0;UP_GLDS=1 UP_GLDS_KT=32;..."  (736^2 bf16-storage step per variant, REPS alternations, default 2)
+  IFS=';' read -ra VS <<< "$VARIANTS"
+  for rep in $(seq 1 ${REPS:-2}); do for v in "${VS[@]}"; do
+  env $v timeout 300 python bench.py $B736 --steps 8 --warmup 3 --no-profile > $OUT/abenv.log 2>&1; line $OUT/abenv.log "$v"; done; done ;;
+csvenv) # per-launch CSVs (exclusive stream mode) for each of VARIANTS, each compared with the first
+  IFS=';' read -ra VS <<< "$VARIANTS"; i=0
+  for v in "${VS[@]}"; do
+  env $v UNIPOSE_SYNC_WGRAD=1 UP_PROFILE_CSV=$GRAFT_REPO_ROOT/$OUT/launches_v$i.csv timeout 300 python bench.py $B736 --steps 3 --warmup 2 > $OUT/csvenv_$i.log 2>&1; line $OUT/csvenv_$i.log "csv $v"
+  if [ $i -gt 0 ]; then echo "== variant $i ($v) vs variant 0 (${VS[0]})"; python tools/gpu/csv_compare.py $(ls $OUT/launches_v$i.csv* | tail -1) $(ls $OUT/launches_v0.csv* | tail -1) > $OUT/csv_compare_$i.txt 2>&1; head -${HEAD:-25} $OUT/csv_compare_$i.txt; fi
+  i=$((i+1)); done ;;
 ab368) for rep in 1 2; do timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-stock-baseline --no-alt-math --no-other-configs --no-profile > $OUT/ab368.log 2>&1; line $OUT/ab368.log "fp32"; done ;;
 lstm) timeout 300 python tools/gpu/steps.py --model lstm --batch 8 > $OUT/lstm_steps.log 2>&1; tail -5 $OUT/lstm_steps.log ;;
 *) echo "unknown action $act" ;;

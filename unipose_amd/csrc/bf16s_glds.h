@@ -1,5 +1,5 @@
 // bf16-STORAGE implicit GEMM, second generation (BASELINE configs[4]: 736x736, B = 16, bf16 activations in HBM).
-// Included by conv_igemm.hip inside namespace up, after IgemmArgs / xcd_remap / wf_merge.
+// Included by conv_igemm.hip inside namespace up, after IgemmArgs / WgradArgs / xcd_remap / wf_merge.
 //
 // What differs from igemm_bf16_kernel<..., HS = true> (the round-1/2 register-staged kernel, kept as the fallback):
 //  * operands go HBM -> LDS directly (`buffer_load_dwordx4 ... lds`, 1 KiB per wave-instruction): no staging registers,
@@ -20,8 +20,6 @@
 
 namespace glds {
 
-constexpr int KT = 64;            // channels per K slice
-constexpr int ROWB = KT * 2;      // bytes per LDS row
 constexpr uint32_t OOB = 0x80000000u;   // byte offset beyond every descriptor's num_records (< 2^31, checked at launch)
 
 #ifdef UP_EMU
@@ -44,7 +42,9 @@ __device__ __forceinline__ uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t
     for (int b = 0; b < 4; ++b) r |= (uint32_t)((src >> (8 * ((sel >> (8 * b)) & 7))) & 0xff) << (8 * b);
     return r;
 }
-__device__ __forceinline__ void lds_or(unsigned* p, unsigned v) { *p |= v; }   // fibers of a block run on one OS thread
+template <int N>
+__device__ __forceinline__ void wait_dma_but() {}
+__device__ __forceinline__ void raw_barrier() { __syncthreads(); }
 #else
 typedef __amdgpu_buffer_rsrc_t Rsrc;
 __device__ __forceinline__ Rsrc make_rsrc(const void* p, uint32_t bytes) {
@@ -57,28 +57,38 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 // the LDS-DMA writes count on vmcnt; __syncthreads() drains them too, the explicit wait keeps that independent of the compiler
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
-__device__ __forceinline__ void lds_or(unsigned* p, unsigned v) { atomicOr(p, v); }
+// all but the N youngest vector-memory operations of this wave have completed
+template <int N>
+__device__ __forceinline__ void wait_dma_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// s_barrier without the fence of __syncthreads() (which would wait for every LDS-DMA in flight); LDS reads of this wave are
+// complete (their MFMAs consumed them), LDS-DMA writes are ordered by the counted wait in front
+__device__ __forceinline__ void raw_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
 #endif
 
-struct RowRec {
-    int roff;        // byte offset of filter tap (0,0), channel 0 of this GEMM row in the activation tensor (may be negative)
-    unsigned mask;   // bit t: tap t reads a real pixel (0 for rows >= M)
-    int opix;        // destination pixel of the row, -1 for rows >= M
-    int pad;
+// geometry of a K slice of KT channels: LDS rows of KT*2 bytes, CH 16-byte chunks per row, RPI rows per LDS-DMA instruction;
+// chunk c of row r sits at slot c ^ swz(r): 128-byte rows (r >> 1) & 7, 64-byte rows (r >> 2) & 3 — in both cases the 16 rows of a
+// ds_read_b128 lane group land on 16 different 16-byte slots of the 256-byte bank row.
+template <int KT>
+struct Slice {
+    static_assert(KT == 64 || KT == 32, "K slice of 64 or 32 channels");
+    static constexpr int ROWB = KT * 2, CH = KT / 8, RPI = 1024 / ROWB;
+    __host__ __device__ static constexpr int swz(int r) { return KT == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); }
 };
 
-template <int BM, int BN>
+template <int BM, int BN, int KT, int ST>
 struct Geom {
-    static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
-    static constexpr int IMG_BYTES = BM * BN * 4;                        // fp32 epilogue image (addend / residual path)
-    static constexpr int MAIN = 2 * STAGE > IMG_BYTES ? 2 * STAGE : IMG_BYTES;
-    static constexpr int TAB_OFF = MAIN;                                 // RowRec[BM]
-    static constexpr int MASK_OFF = TAB_OFF + BM * (int)sizeof(RowRec);  // tile tap mask (16 bytes reserved)
-    static constexpr int STAT_OFF = MASK_OFF + 16;                       // BatchNorm exchange between the two M-waves
-    static constexpr int TOTAL = STAT_OFF + BN * 12;
+    static constexpr int A_BYTES = BM * Slice<KT>::ROWB, B_BYTES = BN * Slice<KT>::ROWB, STAGE = A_BYTES + B_BYTES;
+    static constexpr int IMG_BYTES = BM * BN * 2;                        // epilogue image: bf16 row pairs, or fp32 for half the rows
+    static constexpr int MAIN = ST * STAGE > IMG_BYTES ? ST * STAGE : IMG_BYTES;
+    static constexpr int STAT_OFF = MAIN;                                // BatchNorm exchange between the two M-waves
+    static constexpr int MASK_OFF = STAT_OFF + BN * 12;                  // tap masks of the four waves
+    static constexpr int TOTAL = MASK_OFF + 16;
 };
 
-// BatchNorm partials of the wave's columns (count, mean, M2 over the tile's rows), exactly the arithmetic of igemm_epilogue;
+// BatchNorm partials of the wave's columns (count, mean, M2 over the tile's rows), the arithmetic of igemm_epilogue;
 // FULL: every row of the tile is a real row, so counts are literals and the per-element predicate disappears.
 template <int BM, int BN, bool FULL>
 __device__ __forceinline__ void tile_stats(const IgemmArgs& a, f32x16 (&acc)[BM / 64][BN / 64], float* xch, int mt, int m0, int n0,
@@ -155,18 +165,144 @@ __device__ __forceinline__ void tile_stats(const IgemmArgs& a, f32x16 (&acc)[BM 
     }
 }
 
-// PERM: GEMM row m is output pixel a.perm[m] (tap-sorted order, see tap_sort_order).
+// Epilogue of the bf16-storage kernels: BatchNorm partials, optional folded scale / shift / bias / ReLU, then the tile leaves
+// through LDS as 16-byte stores of 8 consecutive channels.  `img` (>= BM*BN*2 bytes, 16-byte aligned) must be free: every
+// wave is past its last fragment read.  Row r of the tile is output pixel perm[m0 + r] (PERM) or m0 + r.
+//   no residual: image word [row pair][column] = bf16 (row 2rp, row 2rp + 1) of one channel (registers r, r + 1 of an accumulator
+//                hold consecutive rows); a thread reads 8 words = 8 channels x 2 rows, two byte-permutes per output word
+//   residual / addend: fp32 image of half the rows at a time; the addend is added before the single rounding to bf16
 template <int BM, int BN, bool PERM>
-__global__ void __launch_bounds__(256, 2) igemm_glds_kernel(IgemmArgs a) {
-    using G = Geom<BM, BN>;
+__device__ __forceinline__ void store_tile(const IgemmArgs& a, f32x16 (&acc)[BM / 64][BN / 64], unsigned char* img_mem, float* xch,
+                                           int mt, int m0, int n0, int tid, int wm, int wn, int l31, int lh) {
     constexpr int TM = BM / 64, TN = BN / 64;
-    constexpr int NA = BM / 32, NB = BN / 32;   // LDS-DMA instructions per wave, slice and operand (8 rows x 128 bytes each)
-    __shared__ __attribute__((aligned(16))) unsigned char smem[G::TOTAL];
-    RowRec* const tab = reinterpret_cast<RowRec*>(smem + G::TAB_OFF);
-    unsigned* const tmask_s = reinterpret_cast<unsigned*>(smem + G::MASK_OFF);
-    float* const xch = reinterpret_cast<float*>(smem + G::STAT_OFF);
+    const bool full = m0 + BM <= a.M;   // uniform
+    if (a.stats) {
+        if (full) tile_stats<BM, BN, true>(a, acc, xch, mt, m0, n0, wm, wn, l31, lh);
+        else tile_stats<BM, BN, false>(a, acc, xch, mt, m0, n0, wm, wn, l31, lh);
+    }
+    const bool relu = a.relu != 0;
+    const bool affine = a.scale != nullptr || a.bias != nullptr;
+    float esc[TN], esh[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+        const int nn = n < a.Ng ? n : a.Ng - 1;
+        esc[j] = a.scale ? a.scale[nn] : 1.f;
+        esh[j] = a.scale ? a.shift[nn] : 0.f;
+        if (a.bias) esh[j] += a.bias[nn];
+    }
+    auto opix = [&](int row) {   // destination pixel of tile row `row`, -1 past the end
+        const int m = m0 + row;
+        if (m >= a.M) return -1;
+        if constexpr (PERM) return a.perm[m];
+        return m;
+    };
+    bf16_t* const yo = reinterpret_cast<bf16_t*>(a.y);
+    constexpr int CQ = BN / 8;   // 16-byte chunks (8 channels) per row
+    if (!a.residual) {
+        uint32_t* const img = reinterpret_cast<uint32_t*>(img_mem);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    float v0 = acc[i][j][r], v1 = acc[i][j][r + 1];
+                    if (affine) {
+                        v0 = v0 * esc[j] + esh[j];
+                        v1 = v1 * esc[j] + esh[j];
+                    }
+                    if (relu) {
+                        v0 = fmaxf(v0, 0.f);
+                        v1 = fmaxf(v1, 0.f);
+                    }
+                    const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    img[(row >> 1) * BN + wn * (BN / 2) + j * 32 + l31] = pack_bf16x2(v0, v1);
+                }
+        __syncthreads();
+        constexpr int UNITS = (BM / 2) * CQ / 256;   // (row pair, chunk) units per thread
+#pragma unroll
+        for (int k = 0; k < UNITS; ++k) {
+            const int u = k * 256 + tid;
+            const int rp = u / CQ, cq = u - rp * CQ;
+            const uint4 w0 = *reinterpret_cast<const uint4*>(img + rp * BN + cq * 8);
+            const uint4 w1 = *reinterpret_cast<const uint4*>(img + rp * BN + cq * 8 + 4);
+            const int n = n0 + cq * 8;
+            if (n >= a.Ng) continue;
+            const int p0 = opix(2 * rp), p1 = opix(2 * rp + 1);
+            if (p0 >= 0)
+                *reinterpret_cast<uint4*>(yo + (size_t)p0 * a.ldy + n) =
+                    make_uint4(byte_perm(w0.y, w0.x, 0x05040100u), byte_perm(w0.w, w0.z, 0x05040100u),
+                               byte_perm(w1.y, w1.x, 0x05040100u), byte_perm(w1.w, w1.z, 0x05040100u));
+            if (p1 >= 0)
+                *reinterpret_cast<uint4*>(yo + (size_t)p1 * a.ldy + n) =
+                    make_uint4(byte_perm(w0.y, w0.x, 0x07060302u), byte_perm(w0.w, w0.z, 0x07060302u),
+                               byte_perm(w1.y, w1.x, 0x07060302u), byte_perm(w1.w, w1.z, 0x07060302u));
+        }
+    } else {
+        float* const img = reinterpret_cast<float*>(img_mem);
+        const bf16_t* const rs = reinterpret_cast<const bf16_t*>(a.residual);
+        constexpr int UNITS = (BM / 2) * CQ / 256;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (half) __syncthreads();   // the first half has been read
+            if (wm == half) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float v = acc[i][j][r];
+                            if (affine) v = v * esc[j] + esh[j];
+                            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;   // inside this half
+                            img[row * BN + wn * (BN / 2) + j * 32 + l31] = v;
+                        }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < UNITS; ++k) {
+                const int u = k * 256 + tid;
+                const int row = u / CQ, cq = u - row * CQ;
+                const int n = n0 + cq * 8;
+                const int px = opix(half * (BM / 2) + row);
+                if (n >= a.Ng || px < 0) continue;
+                const float4 f0 = *reinterpret_cast<const float4*>(img + row * BN + cq * 8);
+                const float4 f1 = *reinterpret_cast<const float4*>(img + row * BN + cq * 8 + 4);
+                const uint4 rr = *reinterpret_cast<const uint4*>(rs + (size_t)px * a.ldr + n);
+                float v[8] = {f0.x + bf_lo(rr.x), f0.y + bf_hi(rr.x), f0.z + bf_lo(rr.y), f0.w + bf_hi(rr.y),
+                              f1.x + bf_lo(rr.z), f1.y + bf_hi(rr.z), f1.z + bf_lo(rr.w), f1.w + bf_hi(rr.w)};
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                *reinterpret_cast<uint4*>(yo + (size_t)px * a.ldy + n) = make_uint4(
+                    pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+            }
+        }
+    }
+}
 
+// PERM: GEMM row m is output pixel a.perm[m] (tap-sorted order, see tap_sort_order).
+// KT:   channels per K slice (64: 16 MFMAs per wave and barrier, 32 KB per stage of a 128x128 tile; 32: half of both).
+// ST:   LDS stages.  2: one barrier per slice, the next slice in flight during the MFMAs.  3: two slices in flight, counted
+//       vmcnt + raw s_barrier (a __syncthreads() would drain the LDS-DMA queue).
+// EPI:  0 = store_tile (LDS transpose, 16-byte stores), 1 = igemm_epilogue (the register-staged kernel's 2-byte stores; probe).
+// DBG:  probe only (tools/gpu/glds_probe.hip): eight 100 MHz time stamps per workgroup.
+template <int BM, int BN, bool PERM, int KT = 64, int ST = 2, int OCC = 2, int EPI = 0, int DBG = 0>
+__global__ void __launch_bounds__(256, OCC) igemm_glds_kernel(IgemmArgs a) {
+    using SL = Slice<KT>;
+    using G = Geom<BM, BN, KT, ST>;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int NA = BM / (4 * SL::RPI), NB = BN / (4 * SL::RPI);   // LDS-DMA instructions per wave, slice and operand
+    static_assert(NA >= 1 && NB >= 1, "a wave issues at least one LDS-DMA instruction per operand");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::TOTAL];
+    float* const xch = reinterpret_cast<float*>(smem + G::STAT_OFF);
+    unsigned* const wmask = reinterpret_cast<unsigned*>(smem + G::MASK_OFF);
+
+    long long stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int tid = threadIdx.x;
+    if (DBG && tid == 0) stamp[0] = wall_clock64();
     const int lane = tid & 63, wave = uniform(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -175,78 +311,79 @@ __global__ void __launch_bounds__(256, 2) igemm_glds_kernel(IgemmArgs a) {
     const int mt = fdiv(logical, a.fNtn);
     const int nt = logical - mt * a.ntn;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int R = a.taps / a.S;
 
-    if (tid == 0) *tmask_s = 0u;
-    __syncthreads();
-    if (tid < BM) {   // one thread per GEMM row of the tile
-        const int m = m0 + tid;
-        const bool in = m < a.M;
-        int pix = in ? m : a.M - 1;
+    // this lane's rows of the operand tiles: row (wave + 4 i) * RPI + lane / CH, 16-byte slot lane % CH
+    const int rsub = lane / SL::CH, slot = lane % SL::CH;
+    const int R = a.taps / a.S;
+    int roffA[NA];        // byte offset of (filter tap (0,0), this lane's chunk) of the row in the activation tensor
+    unsigned tmA[NA];     // bit t: tap t of the row reads a real pixel (0 for rows >= M)
+    unsigned tile_taps = 0;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int row = (wave + 4 * i) * SL::RPI + rsub;
+        const int m = m0 + row;
+        int pix = m < a.M ? m : a.M - 1;
         if constexpr (PERM) pix = a.perm[pix];
         const int img = fdiv(pix, a.fPQ);
         const int rem = pix - img * (a.P * a.Q);
         const int p = fdiv(rem, a.fQ);
         const int q = rem - p * a.Q;
         const int hb = p * a.mul + a.off0, wb = q * a.mul + a.off0w;
-        unsigned hm = 0, wmk = 0;
-        for (int r = 0; r < R; ++r) {
-            const int h = hb + r * a.tapstep;
-            hm |= (h >= 0 && h < a.H) ? (1u << r) : 0u;
+        unsigned mk = 1u;
+        if (a.taps > 1) {   // separable test: R + S comparisons instead of R * S
+            unsigned hm = 0, wmk = 0;
+            for (int r = 0; r < R; ++r) {
+                const int h = hb + r * a.tapstep;
+                hm |= (h >= 0 && h < a.H) ? (1u << r) : 0u;
+            }
+            for (int s = 0; s < a.S; ++s) {
+                const int w = wb + s * a.tapstep;
+                wmk |= (w >= 0 && w < a.W) ? (1u << s) : 0u;
+            }
+            mk = 0u;
+            for (int r = 0; r < R; ++r) mk |= ((hm >> r) & 1u) ? (wmk << (r * a.S)) : 0u;
+        } else {
+            mk = (hb >= 0 && hb < a.H && wb >= 0 && wb < a.W) ? 1u : 0u;
         }
-        for (int s = 0; s < a.S; ++s) {
-            const int w = wb + s * a.tapstep;
-            wmk |= (w >= 0 && w < a.W) ? (1u << s) : 0u;
-        }
-        unsigned mk = 0;
-        for (int r = 0; r < R; ++r) mk |= ((hm >> r) & 1u) ? (wmk << (r * a.S)) : 0u;
-        if (!in) mk = 0u;
-        RowRec rec;
-        rec.roff = ((img * a.H + hb) * a.W + wb) * a.ldx * 2;
-        rec.mask = mk;
-        rec.opix = in ? pix : -1;
-        rec.pad = 0;
-        tab[tid] = rec;
-        if (mk) lds_or(tmask_s, mk);
-    }
-    __syncthreads();
-
-    // operand descriptors: the bounds check of the buffer load zero-fills padding rows (offset OOB) and weight rows >= N
-    const Rsrc rsA = make_rsrc(a.x, a.x_bytes);
-    const Rsrc rsB = make_rsrc(a.w_hi, (uint32_t)a.Ng * (uint32_t)a.Ktot * 2u);
-
-    const int rsub = lane >> 3, slot = lane & 7;
-    int roffA[NA];
-    unsigned tmA[NA];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int row = (wave + 4 * i) * 8 + rsub;
-        roffA[i] = tab[row].roff + ((slot ^ ((row >> 1) & 7)) << 4);
-        tmA[i] = tab[row].mask;
+        if (m >= a.M) mk = 0u;
+        roffA[i] = ((img * a.H + hb) * a.W + wb) * a.ldx * 2 + ((slot ^ SL::swz(row)) << 4);
+        tmA[i] = mk;
+        tile_taps |= mk;
     }
     uint32_t woffB[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const int row = (wave + 4 * j) * 8 + rsub;
+        const int row = (wave + 4 * j) * SL::RPI + rsub;
         const int n = n0 + row;
-        woffB[j] = n < a.Ng ? (uint32_t)n * (uint32_t)a.Ktot * 2u + (uint32_t)((slot ^ ((row >> 1) & 7)) << 4) : OOB;
+        woffB[j] = n < a.Ng ? (uint32_t)n * (uint32_t)a.Ktot * 2u + (uint32_t)((slot ^ SL::swz(row)) << 4) : OOB;
     }
 
     // the K loop visits the slices of the filter taps that are live for at least one row of the tile
     const unsigned all_taps = a.taps >= 32 ? 0xffffffffu : ((1u << a.taps) - 1u);
-    unsigned live = (unsigned)uniform((int)*tmask_s);
-    if (a.no_tap_skip || live == 0u) live = all_taps;
+    unsigned live = all_taps;
+    if (a.taps > 1 && !a.no_tap_skip) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) tile_taps |= __shfl_xor(tile_taps, off);
+        if (lane == 0) wmask[wave] = tile_taps;
+        __syncthreads();
+        live = (unsigned)uniform((int)(wmask[0] | wmask[1] | wmask[2] | wmask[3]));
+        if (live == 0u) live = all_taps;
+    }
     const int spt = a.Cp / KT;
     const int nsl = __builtin_popcount(live) * spt;
     unsigned rest = live;
     int tap = __builtin_ctz(rest), cs = 0;
+
+    // operand descriptors: the bounds check of the buffer load zero-fills padding rows (offset OOB) and weight rows >= N
+    const Rsrc rsA = make_rsrc(a.x, a.x_bytes);
+    const Rsrc rsB = make_rsrc(a.w_hi, (uint32_t)a.Ng * (uint32_t)a.Ktot * 2u);
 
     auto issue = [&](int stage) {
         unsigned char* const As = smem + stage * G::STAGE;
         unsigned char* const Bs = As + G::A_BYTES;
         const int r = fdiv(tap, a.fS);
         const int sx = tap - r * a.S;
-        const int delta = ((r * a.tapstep) * a.W + sx * a.tapstep) * a.ldx * 2 + cs * ROWB;
+        const int delta = ((r * a.tapstep) * a.W + sx * a.tapstep) * a.ldx * 2 + cs * SL::ROWB;
         const uint32_t kb = (uint32_t)(tap * a.Cp + cs * KT) * 2u;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -271,130 +408,291 @@ __global__ void __launch_bounds__(256, 2) igemm_glds_kernel(IgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int swz = ((l31 >> 1) & 7) << 4;
-    const int a_rd = (wm * (BM / 2) + l31) * ROWB;
-    const int b_rd = G::A_BYTES + (wn * (BN / 2) + l31) * ROWB;
-
-    issue(0);
-    for (int it = 0; it < nsl; ++it) {
-        wait_dma();
-        __syncthreads();   // slice `it` has landed for every wave, and every wave is done with the other stage
-        if (it + 1 < nsl) issue((it + 1) & 1);
-        const unsigned char* base = smem + (it & 1) * G::STAGE;
+    const int swz = SL::swz(l31) << 4;
+    const int a_rd = (wm * (BM / 2) + l31) * SL::ROWB;
+    const int b_rd = G::A_BYTES + (wn * (BN / 2) + l31) * SL::ROWB;
+    auto mfmas = [&](const unsigned char* base) {
 #pragma unroll
         for (int s = 0; s < KT / 16; ++s) {
             const int col = (((2 * s + lh) << 4) ^ swz);
             bf16x8 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + a_rd + i * 32 * ROWB + col);
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + a_rd + i * 32 * SL::ROWB + col);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(base + b_rd + j * 32 * ROWB + col);
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(base + b_rd + j * 32 * SL::ROWB + col);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-    }
-    __syncthreads();   // every wave is past its last fragment read: the stages become the epilogue image
+    };
 
-    // ---- epilogue ----
-    const bool full = m0 + BM <= a.M;   // uniform
-    if (a.stats) {
-        if (full) tile_stats<BM, BN, true>(a, acc, xch, mt, m0, n0, wm, wn, l31, lh);
-        else tile_stats<BM, BN, false>(a, acc, xch, mt, m0, n0, wm, wn, l31, lh);
-    }
-    const bool relu = a.relu != 0;
-    const bool affine = a.scale != nullptr || a.bias != nullptr;
-    float esc[TN], esh[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + l31;
-        const int nn = n < a.Ng ? n : a.Ng - 1;
-        esc[j] = a.scale ? a.scale[nn] : 1.f;
-        esh[j] = a.scale ? a.shift[nn] : 0.f;
-        if (a.bias) esh[j] += a.bias[nn];
-    }
-    bf16_t* const yo = reinterpret_cast<bf16_t*>(a.y);
-    if (!a.residual) {
-        // image word [row pair][column] = (row 2rp, row 2rp + 1) of one channel: registers r, r+1 of the accumulator
-        uint32_t* const img = reinterpret_cast<uint32_t*>(smem);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    float v0 = acc[i][j][r], v1 = acc[i][j][r + 1];
-                    if (affine) {
-                        v0 = v0 * esc[j] + esh[j];
-                        v1 = v1 * esc[j] + esh[j];
-                    }
-                    if (relu) {
-                        v0 = fmaxf(v0, 0.f);
-                        v1 = fmaxf(v1, 0.f);
-                    }
-                    const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    img[(row >> 1) * BN + wn * (BN / 2) + j * 32 + l31] = pack_bf16x2(v0, v1);
-                }
-        __syncthreads();
-        constexpr int CQ = BN / 8;                       // 16-byte chunks (8 channels) per row
-        constexpr int UNITS = (BM / 2) * CQ / 256;       // (row pair, chunk) units per thread
-#pragma unroll
-        for (int k = 0; k < UNITS; ++k) {
-            const int u = k * 256 + tid;
-            const int rp = u / CQ, cq = u - rp * CQ;
-            const uint4 w0 = *reinterpret_cast<const uint4*>(img + rp * BN + cq * 8);
-            const uint4 w1 = *reinterpret_cast<const uint4*>(img + rp * BN + cq * 8 + 4);
-            const int n = n0 + cq * 8;
-            if (n >= a.Ng) continue;
-            const int p0 = tab[2 * rp].opix, p1 = tab[2 * rp + 1].opix;
-            if (p0 >= 0)
-                *reinterpret_cast<uint4*>(yo + (size_t)p0 * a.ldy + n) =
-                    make_uint4(byte_perm(w0.y, w0.x, 0x05040100u), byte_perm(w0.w, w0.z, 0x05040100u),
-                               byte_perm(w1.y, w1.x, 0x05040100u), byte_perm(w1.w, w1.z, 0x05040100u));
-            if (p1 >= 0)
-                *reinterpret_cast<uint4*>(yo + (size_t)p1 * a.ldy + n) =
-                    make_uint4(byte_perm(w0.y, w0.x, 0x07060302u), byte_perm(w0.w, w0.z, 0x07060302u),
-                               byte_perm(w1.y, w1.x, 0x07060302u), byte_perm(w1.w, w1.z, 0x07060302u));
+    if (DBG && tid == 0) stamp[1] = wall_clock64();
+    if constexpr (ST == 2) {
+        issue(0);
+        for (int it = 0; it < nsl; ++it) {
+            wait_dma();
+            __syncthreads();   // slice `it` has landed for every wave, and every wave is done with the other stage
+            if (DBG && tid == 0 && it == 0) stamp[2] = wall_clock64();
+            if (it + 1 < nsl) issue((it + 1) & 1);
+            mfmas(smem + (it & 1) * G::STAGE);
         }
     } else {
-        // addend / residual: fp32 image [row][column]; the addend is added before the single rounding to bf16
-        float* const img = reinterpret_cast<float*>(smem);
+        static_assert(ST == 3, "two or three LDS stages");
+        issue(0);
+        if (nsl > 1) issue(1);
+        int cur = 0, nxt = 2;   // stage of slice `it`, stage slice it + 2 goes to
+        for (int it = 0; it < nsl; ++it) {
+            if (it + 1 < nsl) wait_dma_but<NA + NB>();   // slice `it` has landed, slice it + 1 may still be in flight
+            else wait_dma();
+            raw_barrier();
+            if (DBG && tid == 0 && it == 0) stamp[2] = wall_clock64();
+            if (it + 2 < nsl) issue(nxt);               // that stage was read during slice it - 1
+            mfmas(smem + cur * G::STAGE);
+            cur = cur == 2 ? 0 : cur + 1;
+            nxt = nxt == 2 ? 0 : nxt + 1;
+        }
+    }
+    __syncthreads();   // every wave is past its last fragment read: the stages become the epilogue image
+    if (DBG && tid == 0) stamp[3] = wall_clock64();
+
+    if constexpr (EPI == 1) {
+        igemm_epilogue<BM, BN, PERM, bf16_t>(a, acc, reinterpret_cast<float*>(smem), mt, m0, n0, wm, wn, l31, lh);
+    } else {
+        store_tile<BM, BN, PERM>(a, acc, smem, xch, mt, m0, n0, tid, wm, wn, l31, lh);
+    }
+    if (DBG && tid == 0) {
+        stamp[4] = wall_clock64();
+        wait_dma();   // stores of this wave acknowledged
+        stamp[5] = wall_clock64();
+        long long* o = reinterpret_cast<long long*>(a.dbg) + 8 * (size_t)blockIdx.x;
+        for (int k = 0; k < 8; ++k) o[k] = stamp[k];
+    }
+}
+
+// ======================================================================================================================
+// Weight gradient in bf16 storage, second generation.  dW[co][tap*Cp + ci] = sum over pixels of dY[pixel][co] * X[src(pixel, tap)][ci]:
+// the reduction index is the PIXEL while both operands are channel-contiguous in HBM.  wgrad_bf16_kernel<HS> transposed 8x8
+// half-word blocks in registers (22.8 VALU instructions per MFMA, profiles/r02_ae_sq_counters.txt).  Here both operand slices
+// go HBM -> LDS as they are ([pixel][channel] rows, plain 16-byte LDS-DMA copies, hardware zero fill for padding taps and for
+// pixels past the end of the split), and the MFMA fragments (8 consecutive pixels of one channel per lane) come out of
+// gfx950's transposing LDS read ds_read_b64_tr_b16: a 16-lane group reads a [4 pixels][16 channels] block, lane j' supplies the
+// 8-byte address of (pixel j' >> 2, channels 4 * (j' & 3) .. + 3) and receives channel j' & 15, pixels 0..3
+// (lane map measured with tools/gpu/tr16_probe.hip, profiles/r03_a_tr16_lane_map.txt).
+// LDS rows are BM*2 / BN*2 bytes; the 16-byte chunk c of pixel row p sits at slot c ^ swz(p) so that the four pixel rows of
+// a transposing read hit four different 64-byte bank quarters (256-byte rows: swz = 4 * (p & 3); 128-byte rows: 4 * ((p >> 1) & 1)).
+// A 64-entry table per slice (pixel -> byte offsets of its dY row and of filter tap (0,0) of its X row, + the tap-(0,0)
+// coordinates for the bounds test) is computed by wave 0 one slice ahead, so the other waves only add per-lane constants.
+// ======================================================================================================================
+constexpr int KP = 64;   // pixels per K slice
+
+struct PixRec {
+    uint32_t dyoff;   // byte offset of the pixel's dY row (OOB for pixels >= mend)
+    int xoff;         // byte offset of filter tap (0,0) of the pixel's X row (may be negative)
+    int h0, w0;       // input coordinates of filter tap (0,0); h0 = -(1 << 20) for pixels >= mend
+};
+
+#ifdef UP_EMU
+__device__ __forceinline__ bf16x8 lds_read_tr16x2(const unsigned char* lds, int addr0, int addr1) {
+    bf16x8 f;
+    const int l = threadIdx.x & 63, j = l & 15, g = l & 48;
+    for (int h = 0; h < 2; ++h)
+        for (int e = 0; e < 4; ++e) {
+            const int src = ::emu::shfl(h ? addr1 : addr0, g + 4 * e + (j >> 2));
+            memcpy(&f.v[4 * h + e], lds + src + 2 * (j & 3), 2);
+        }
+    return f;
+}
+#else
+__device__ __forceinline__ bf16x8 lds_read_tr16x2(const unsigned char* lds, int addr0, int addr1) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + addr0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + addr1));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+#endif
+
+template <int BM, int BN>
+struct WGeom {
+    static constexpr int ROWA = BM * 2, ROWB_ = BN * 2;                 // bytes per pixel row of the two slices
+    static constexpr int A_BYTES = KP * ROWA, B_BYTES = KP * ROWB_, STAGE = A_BYTES + B_BYTES;
+    static constexpr int TAB_OFF = 2 * STAGE;                            // PixRec[2][KP]
+    static constexpr int TOTAL = TAB_OFF + 2 * KP * (int)sizeof(PixRec);
+};
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(256, 2) wgrad_glds_kernel(WgradArgs a) {
+    using G = WGeom<BM, BN>;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int RPA = 1024 / G::ROWA, RPB = 1024 / G::ROWB_;    // pixel rows per LDS-DMA instruction (4 or 8)
+    constexpr int NIA = KP / (4 * RPA), NIB = KP / (4 * RPB);     // instructions per wave, slice and operand (4 or 2)
+    constexpr int CHA = G::ROWA / 16, CHB = G::ROWB_ / 16;         // 16-byte chunks per row (16 or 8)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::TOTAL];
+    PixRec* const tab = reinterpret_cast<PixRec*>(smem + G::TAB_OFF);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = uniform(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31;
+
+    const int logical = xcd_remap(blockIdx.x, a.nwg);
+    const int split = fdiv(logical, a.fTiles);
+    const int tile = logical - split * (int)a.fTiles.d;
+    const int mt = fdiv(tile, a.fNtn);
+    const int nt = tile - mt * a.ntn;
+    const int co0 = mt * BM, col0 = nt * BN;
+
+    // reduction domain of this workgroup: pixels [mbeg, mend) of an (images x rows x cols) box at (r_pl, r_ql)
+    int r_pl = 0, r_ql = 0, r_h = a.P, r_w = a.Q;
+    FastDiv r_fhw = a.fPQ, r_fw = a.fQ;
+    int mbeg = split * a.rows_per_split;
+    int mend = min(a.M, mbeg + a.rows_per_split);
+    if (a.rect) {
+        const int* rc = a.rect + WGRAD_RECT_INTS * nt;
+        r_pl = rc[0];
+        r_ql = rc[1];
+        r_h = rc[2];
+        r_w = rc[3];
+        r_fhw = FastDiv{(uint32_t)rc[4], (uint32_t)rc[5], (uint32_t)rc[6]};
+        r_fw = FastDiv{(uint32_t)rc[7], (uint32_t)rc[8], (uint32_t)rc[9]};
+        mbeg = split * rc[10];
+        mend = min(rc[11], mbeg + rc[10]);
+    }
+    const int r_hw = r_h * r_w;
+    const int nsl = mbeg < mend ? (mend - mbeg + KP - 1) / KP : 0;
+
+    const Rsrc rsA = make_rsrc(a.dy, a.dy_bytes);
+    const Rsrc rsB = make_rsrc(a.x, a.x_bytes);
+
+    // per-lane constants of the LDS-DMA: pixel row inside the instruction's group and 16-byte slot
+    const int prowA = lane / CHA, slotA = lane % CHA;
+    const int prowB = lane / CHB, slotB = lane % CHB;
+    const int swzA = CHA == 16 ? 4 * (prowA & 3) : 4 * ((prowA >> 1) & 1);
+    const int swzB = CHB == 16 ? 4 * (prowB & 3) : 4 * ((prowB >> 1) & 1);
+    // A: channels co0 + 8 * (slot ^ swz) .. + 7 of the dY row (channels beyond the row only feed rows of dW that are never stored)
+    const uint32_t coffA = (uint32_t)(co0 + 8 * (slotA ^ swzA)) * 2u;
+    // B: GEMM columns col0 + 8 * (slot ^ swz) .. + 7 = one filter tap, 8 input channels
+    const int colB = col0 + 8 * (slotB ^ swzB);
+    const bool colokB = colB < a.Ncols;
+    const int tapB = fdiv(colokB ? colB : 0, a.fCp);
+    const int ciB = (colokB ? colB : 0) - tapB * a.Cp;
+    const int rB = fdiv(tapB, a.fS);
+    const int dhB = rB * a.dil, dwB = (tapB - rB * a.S) * a.dil;
+    const int deltaB = (dhB * a.W + dwB) * a.ldx * 2 + ciB * 2;
+
+    auto fill_table = [&](int sl) {   // wave 0: one lane per pixel of slice sl
+        const int m = mbeg + sl * KP + lane;
+        const bool ok = m < mend;
+        const int mm = ok ? m : mbeg;
+        const int img = fdiv(mm, r_fhw);
+        const int rem = mm - img * r_hw;
+        const int pi = fdiv(rem, r_fw);
+        const int qi = rem - pi * r_w;
+        const int p = r_pl + pi, q = r_ql + qi;
+        PixRec rec;
+        rec.dyoff = ok ? (uint32_t)(((img * a.P + p) * a.Q + q) * a.ldy) * 2u : OOB;
+        rec.h0 = ok ? p * a.stride - a.pad : -(1 << 20);
+        rec.w0 = q * a.stride - a.pad;
+        rec.xoff = ok ? ((img * a.H + rec.h0) * a.W + rec.w0) * a.ldx * 2 : 0;
+        tab[(sl & 1) * KP + lane] = rec;
+    };
+    auto issue = [&](int sl) {
+        unsigned char* const As = smem + (sl & 1) * G::STAGE;
+        unsigned char* const Bs = As + G::A_BYTES;
+        const PixRec* const t = tab + (sl & 1) * KP;
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) {
+            const int grp = wave + 4 * i;
+            const PixRec r = t[grp * RPA + prowA];
+            load16_to_lds(rsA, r.dyoff == OOB ? OOB : r.dyoff + coffA, As + grp * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < NIB; ++i) {
+            const int grp = wave + 4 * i;
+            const PixRec r = t[grp * RPB + prowB];
+            const int h = r.h0 + dhB, w = r.w0 + dwB;
+            const bool ok = colokB && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+            load16_to_lds(rsB, ok ? (uint32_t)(r.xoff + deltaB) : OOB, Bs + grp * 1024);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposing fragment reads: lane -> (pixel within the 16-pixel step, channel) of the [4 pixels][16 channels] block
+    const int jq = lane & 15, grp16 = lane >> 4;
+    const int fpix = 8 * (grp16 >> 1) + (jq >> 2);           // + 4 * h + 16 * s
+    const int fch = 16 * (grp16 & 1) + 4 * (jq & 3);         // channel inside the 32-wide MFMA tile
+
+    if (nsl > 0) {
+        if (wave == 0) fill_table(0);
+        __syncthreads();
+        issue(0);
+        if (wave == 0 && nsl > 1) fill_table(1);
+        for (int it = 0; it < nsl; ++it) {
+            wait_dma();
+            __syncthreads();   // slice `it` has landed, table it+1 is written, everyone is done with the other stage
+            if (it + 1 < nsl) issue(it + 1);
+            if (wave == 0 && it + 2 < nsl) fill_table(it + 2);
+            const unsigned char* As = smem + (it & 1) * G::STAGE;
+            const unsigned char* Bs = As + G::A_BYTES;
+#pragma unroll
+            for (int s = 0; s < KP / 16; ++s) {
+                bf16x8 af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int ch = wm * (BM / 2) + i * 32 + fch;            // channel inside the tile (multiple of 4)
+                    int ad[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int p = 16 * s + 4 * h + fpix;
+                        const int sw = CHA == 16 ? 4 * (p & 3) : 4 * ((p >> 1) & 1);
+                        ad[h] = p * G::ROWA + (((ch >> 3) ^ sw) << 4) + (ch & 7) * 2;
+                    }
+                    af[i] = lds_read_tr16x2(As, ad[0], ad[1]);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int ch = wn * (BN / 2) + j * 32 + fch;
+                    int ad[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int p = 16 * s + 4 * h + fpix;
+                        const int sw = CHB == 16 ? 4 * (p & 3) : 4 * ((p >> 1) & 1);
+                        ad[h] = p * G::ROWB_ + (((ch >> 3) ^ sw) << 4) + (ch & 7) * 2;
+                    }
+                    bf[j] = lds_read_tr16x2(Bs, ad[0], ad[1]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    float* out = a.slab + (size_t)split * a.K * a.Ncols;
+    const int lh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col0 + wn * (BN / 2) + j * 32 + l31;
+        if (col >= a.Ncols) continue;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][j][r];
-                    if (affine) v = v * esc[j] + esh[j];
-                    const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    img[row * BN + wn * (BN / 2) + j * 32 + l31] = v;
-                }
-        __syncthreads();
-        const bf16_t* const rs = reinterpret_cast<const bf16_t*>(a.residual);
-        constexpr int CQ = BN / 8;
-        constexpr int UNITS = BM * CQ / 256;
-#pragma unroll
-        for (int k = 0; k < UNITS; ++k) {
-            const int u = k * 256 + tid;
-            const int row = u / CQ, cq = u - row * CQ;
-            const int n = n0 + cq * 8;
-            const int px = tab[row].opix;
-            if (n >= a.Ng || px < 0) continue;
-            const float4 f0 = *reinterpret_cast<const float4*>(img + row * BN + cq * 8);
-            const float4 f1 = *reinterpret_cast<const float4*>(img + row * BN + cq * 8 + 4);
-            const uint4 rr = *reinterpret_cast<const uint4*>(rs + (size_t)px * a.ldr + n);
-            float v[8] = {f0.x + bf_lo(rr.x), f0.y + bf_hi(rr.x), f0.z + bf_lo(rr.y), f0.w + bf_hi(rr.y),
-                          f1.x + bf_lo(rr.z), f1.y + bf_hi(rr.z), f1.z + bf_lo(rr.w), f1.w + bf_hi(rr.w)};
-            if (relu) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < a.K) out[(size_t)co * a.Ncols + col] = acc[i][j][r];
             }
-            *reinterpret_cast<uint4*>(yo + (size_t)px * a.ldy + n) =
-                make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-        }
     }
 }
 

@@ -1108,8 +1108,6 @@ __global__ void __launch_bounds__(256) pack_split_kernel(const float* w, uint16_
     lo[e] = (uint16_t)(l & 0xffffu);
 }
 
-#include "bf16s_glds.h"
-
 // ------------------------------------------------------------------------------------------
 // weight gradient
 // ------------------------------------------------------------------------------------------
@@ -1129,6 +1127,7 @@ struct WgradArgs {
     // RECT form: per column tile 12 ints {p_lo, q_lo, rows, cols, FastDiv(rows*cols), FastDiv(cols), rows per split,
     // pixels} — the rectangle of output pixels (per image) on which ANY filter tap of the tile reads a real input pixel
     const int* rect;
+    uint32_t x_bytes, dy_bytes;   // bf16s_glds.h: bytes behind x / dy (num_records of their buffer descriptors)
 };
 constexpr int WGRAD_RECT_INTS = 12;
 
@@ -1614,6 +1613,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradArgs a) {
     }
 }
 
+#include "bf16s_glds.h"
+
 // sum the split-K slabs and scatter into PyTorch OIHW
 // (Measured and removed in round 2: the merge folded into the weight-gradient kernels — every split publishes its slab with
 //  write-through stores and bumps a per-tile arrival counter, the last arriver adds the slabs in split order and scatters the
@@ -1807,6 +1808,8 @@ static int env_int(const char* name, int dflt, int min_ok) {
 }
 static int g_tile_want = env_int("UP_TILE_WANT", 1500, 1);   // A/B in the network: 700 / 1000 / 1500 / 2200 / 4300 -> 70.1 / 69.9 / 69.6 / 69.9 / 69.8 ms
 static int g_tile_want_bf16 = env_int("UP_TILE_WANT_BF16", 500, 1);
+static int g_glds_kt = env_int("UP_GLDS_KT", 32, 32);   // channels per K slice of the direct-to-LDS kernels (64 | 32); 736^2 step (r03_b): register-staged 46.6 ms, 64: 43.6, 32: 41.7, 32 with three stages 42.1
+static int g_glds_st = env_int("UP_GLDS_ST", 2, 2);    // LDS stages of the 32-channel form (2 | 3)
 static int g_glds = env_int("UP_GLDS", 1, 0);   // bf16 storage: direct-to-LDS kernels of bf16s_glds.h (0 = the register-staged round-2 kernels)
 static int g_db_min_k = env_int("UP_DB_MIN_K", 1024, 1);
 static int g_short_k = env_int("UP_SHORT_K", 512, 1);             // reductions shorter than this are epilogue-heavy:
@@ -2144,6 +2147,8 @@ extern "C" int up_conv_tune(const char* key, int value) {
     if (!strcmp(key, "tile_want") && value > 0) g_tile_want = value;
     else if (!strcmp(key, "tile_want_bf16") && value > 0) g_tile_want_bf16 = value;
     else if (!strcmp(key, "glds")) g_glds = value ? 1 : 0;
+    else if (!strcmp(key, "glds_st") && (value == 2 || value == 3)) g_glds_st = value;
+    else if (!strcmp(key, "glds_kt") && (value == 32 || value == 64)) g_glds_kt = value;
     else if (!strcmp(key, "db_min_k") && value > 0) g_db_min_k = value;
     else if (!strcmp(key, "short_k") && value > 0) g_short_k = value;
     else if (!strcmp(key, "short_k_mult") && value > 0) g_short_k_mult = value;
@@ -2303,17 +2308,22 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
         const long long a_bytes = (long long)(a.M / (a.P * a.Q)) * a.H * a.W * a.ldx * 2;
         const uintptr_t ptrs = reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.y) |
                                reinterpret_cast<uintptr_t>(a.w_hi) | reinterpret_cast<uintptr_t>(a.residual);
-        if (g_glds && fast && a.M % (a.P * a.Q) == 0 && a.Cp % glds::KT == 0 && a.Ng % 8 == 0 && a.ldy % 8 == 0 &&
+        const int kt = (g_glds_kt == 64 && a.Cp % 64 == 0) ? 64 : 32;
+        if (g_glds && fast && a.M % (a.P * a.Q) == 0 && a.Ng % 8 == 0 && a.ldy % 8 == 0 &&
             a.ldx % 8 == 0 && (!a.residual || a.ldr % 8 == 0) && !a.o_mode && a_bytes < (1ll << 31) &&
             (long long)a.Ng * a.Ktot * 2 < (1ll << 31) && (ptrs & 15) == 0) {
             a.no_tap_skip = g_tap_skip ? 0 : 1;
             a.perm = nullptr;
             a.x_bytes = (uint32_t)a_bytes;
             if (g_tap_sort && a.taps > 1 && a.taps <= 16 && !a.residual && !a.no_tap_skip) a.perm = tap_sort_perm(a);
-            if (a.perm)
-                hipLaunchKernelGGL((glds::igemm_glds_kernel<BM, BN, true>), dim3(a.nwg), dim3(256), 0, st, a);
+            void (*kernel)(IgemmArgs);
+            if (kt == 64)
+                kernel = a.perm ? glds::igemm_glds_kernel<BM, BN, true, 64, 2, 2> : glds::igemm_glds_kernel<BM, BN, false, 64, 2, 2>;
+            else if (g_glds_st == 3)
+                kernel = a.perm ? glds::igemm_glds_kernel<BM, BN, true, 32, 3, 3> : glds::igemm_glds_kernel<BM, BN, false, 32, 3, 3>;
             else
-                hipLaunchKernelGGL((glds::igemm_glds_kernel<BM, BN, false>), dim3(a.nwg), dim3(256), 0, st, a);
+                kernel = a.perm ? glds::igemm_glds_kernel<BM, BN, true, 32, 2, 3> : glds::igemm_glds_kernel<BM, BN, false, 32, 2, 3>;
+            hipLaunchKernelGGL(kernel, dim3(a.nwg), dim3(256), 0, st, a);
             return;
         }
         a.fSpt = make_fastdiv(a.Cp / KT);
@@ -2705,7 +2715,21 @@ static int up::conv2d_bwd_weight_impl(const up_conv_desc* d, const float* x, con
         ProfScope prof(v, 2.0 * (double)a.M * (double)d->K * (double)d->R * d->S * d->C, st, d->K, a.Ncols, a.M,
                        a.nwg);
         a.rect = (g_wgrad_rect && (int64_t)d->N * d->P * d->Q < (1ll << 30)) ? wgrad_rect_device(d, p) : nullptr;
-        if (bf16 == 2) {
+        const long long xb = (long long)d->N * d->H * d->W * d->ldx * 2, dyb = (long long)d->N * d->P * d->Q * d->ldy * 2;
+        if (bf16 == 2 && g_glds && xb < (1ll << 31) && dyb < (1ll << 31) &&
+            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
+            // second generation (bf16s_glds.h): [pixel][channel] slices HBM -> LDS directly, transposing fragment reads
+            a.x_bytes = (uint32_t)xb;
+            a.dy_bytes = (uint32_t)dyb;
+            if (p.bm == 128 && p.bn == 128)
+                hipLaunchKernelGGL((glds::wgrad_glds_kernel<128, 128>), grid, dim3(256), 0, st, a);
+            else if (p.bm == 128 && p.bn == 64)
+                hipLaunchKernelGGL((glds::wgrad_glds_kernel<128, 64>), grid, dim3(256), 0, st, a);
+            else if (p.bm == 64 && p.bn == 128)
+                hipLaunchKernelGGL((glds::wgrad_glds_kernel<64, 128>), grid, dim3(256), 0, st, a);
+            else
+                hipLaunchKernelGGL((glds::wgrad_glds_kernel<64, 64>), grid, dim3(256), 0, st, a);
+        } else if (bf16 == 2) {
             if (p.bm == 128 && p.bn == 128)
                 hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128, true>), grid, dim3(256), 0, st, a);
             else if (p.bm == 128 && p.bn == 64)
