@@ -351,3 +351,34 @@ def normalize_case(dev):
     got = ops.normalize_image(img.to(dev))
     ref = img.permute(0, 3, 1, 2).contiguous().sub(128.0).div(256.0)      # Mytransforms.to_tensor + normalize
     assert torch.equal(got.cpu(), ref)
+
+
+def bn_rows_ab_case(dev, n, c, h, w, k, relu=True, residual=True, dtype=torch.float32, seed=0):
+    """The row-strided BatchNorm passes (norm_act.hip: bn_apply_rows_kernel / bn_bwd_apply_rows_kernel, per-channel parameters
+    loaded once per thread) against the flat ones on a conv -> BN (-> +residual) (-> ReLU) train step: same arithmetic, same
+    relu_bits layout, so every result must be bitwise equal."""
+    import copy
+    from unipose_amd import _C
+    gen = torch.Generator().manual_seed(seed)
+    conv = torch.nn.Conv2d(c, k, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(k)
+    with torch.no_grad():
+        bn.weight.copy_(0.5 + torch.rand(k, generator=gen))
+        bn.bias.copy_(0.2 * torch.randn(k, generator=gen))
+    x0 = torch.randn(n, h, w, c, generator=gen)
+    r0 = torch.randn(n, h, w, k, generator=gen)
+    g0 = torch.randn(n, h, w, k, generator=gen)
+    out = []
+    try:
+        for mode in (1, 0):
+            _C.check(_C.lib().up_conv_tune(b"bn_rows", mode), "bn_rows")
+            cd, bd = copy.deepcopy(conv).to(dev).train(), copy.deepcopy(bn).to(dev).train()
+            x = x0.to(dtype).to(dev).requires_grad_(True)
+            res = r0.to(dtype).to(dev).requires_grad_(True) if residual else None
+            z = ops.conv_bn_act(x, cd, bd, relu=relu, residual=res)
+            z.backward(g0.to(dtype).to(dev))
+            out.append([z.detach(), x.grad, cd.weight.grad, bd.weight.grad, bd.bias.grad] + ([res.grad] if residual else []))
+    finally:
+        _C.lib().up_conv_tune(b"bn_rows", 1)
+    for a, b, what in zip(out[0], out[1], ["z", "dx", "dw", "dgamma", "dbeta", "dres"]):
+        assert torch.equal(a.float().cpu(), b.float().cpu()), what

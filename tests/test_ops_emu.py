@@ -271,3 +271,17 @@ def test_conv_all_tiles_split(emu_backend, per_cu):
         oc.conv_bn_case(emu_backend, 2, 128, 5, 5, 48, 3, 1, 1, 1, relu=True, residual=True, train=True)
     finally:
         lib.up_conv_tune(b"split_per_cu", 2)
+
+
+@pytest.mark.parametrize("cfg", [
+    (3, 32, 5, 7, 32, True, True, "f32"),       # 8 channel groups of 4: the smallest row-strided geometry
+    (2, 32, 9, 9, 128, True, False, "f32"),
+    (5, 32, 3, 3, 64, False, True, "f32"),      # more row lanes than rows
+    (3, 32, 5, 7, 64, True, True, "bf16"),      # 8 channel groups of 8
+    (2, 32, 6, 5, 128, True, False, "bf16"),
+])
+def test_bn_row_strided_passes_match_flat_passes(emu_backend, cfg):
+    import torch
+    n, c, h, w, k, relu, residual, dt = cfg
+    oc.bn_rows_ab_case(emu_backend, n, c, h, w, k, relu=relu, residual=residual,
+                       dtype=torch.float32 if dt == "f32" else torch.bfloat16)

@@ -163,3 +163,17 @@ def test_pck_accuracy(golden_dir):
 def test_targets(golden_dir):
     oc.targets_case(DEV, golden_dir)
     oc.normalize_case(DEV)
+
+
+@pytest.mark.parametrize("cfg", [
+    (4, 64, 23, 23, 256, True, False, "f32"),
+    (4, 64, 23, 23, 1024, True, True, "f32"),      # 256 channel groups: one lane per group
+    (2, 64, 23, 23, 2048, False, True, "f32"),     # 512 groups: two workgroup columns
+    (2, 64, 92, 92, 64, True, False, "f32"),
+    (4, 64, 46, 46, 1024, True, True, "bf16"),
+    (2, 64, 92, 92, 64, True, False, "bf16"),
+    (2, 64, 23, 23, 2048, False, True, "bf16"),
+])
+def test_bn_row_strided_passes_match_flat_passes(cfg):
+    n, c, h, w, k, relu, residual, dt = cfg
+    oc.bn_rows_ab_case(DEV, n, c, h, w, k, relu=relu, residual=residual, dtype=torch.float32 if dt == "f32" else torch.bfloat16)

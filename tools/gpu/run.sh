@@ -5,6 +5,7 @@
 #   ab736        736^2 B=16 bf16-storage step, UP_GLDS=1 vs 0 (two alternations)
 #   csv736       per-launch CSV (exclusive stream mode) of the same step for UP_GLDS=1 and 0, grouped by GEMM shape
 #   abenv/csvenv VARIANTS="A=1;A=2 B=3": the 736^2 step / its per-launch CSV under each environment
+#   prof736      rocprofv3 kernel stats of the 736^2 step, both stream modes
 #   ab368        default fp32 step, two runs (box sanity)
 #   lstm         UniPose-LSTM leg with host / wall split (tools/gpu/steps.py)
 cd $GRAFT_REPO_ROOT
@@ -38,6 +39,14 @@ csvenv) # per-launch CSVs (exclusive stream mode) for each of VARIANTS, each com
   env $v UNIPOSE_SYNC_WGRAD=1 UP_PROFILE_CSV=$GRAFT_REPO_ROOT/$OUT/launches_v$i.csv timeout 300 python bench.py $B736 --steps 3 --warmup 2 > $OUT/csvenv_$i.log 2>&1; line $OUT/csvenv_$i.log "csv $v"
   if [ $i -gt 0 ]; then echo "== variant $i ($v) vs variant 0 (${VS[0]})"; python tools/gpu/csv_compare.py $(ls $OUT/launches_v$i.csv* | tail -1) $(ls $OUT/launches_v0.csv* | tail -1) > $OUT/csv_compare_$i.txt 2>&1; head -${HEAD:-25} $OUT/csv_compare_$i.txt; fi
   i=$((i+1)); done ;;
+prof736) # rocprofv3 kernel stats of the 736^2 step: default (two streams) and exclusive (UNIPOSE_SYNC_WGRAD=1)
+  ARGS="$B736 --steps 3 --warmup 1 --no-profile"
+  ( cd /tmp && export TMPDIR=/tmp
+    timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof_736 -o bench -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $GRAFT_REPO_ROOT/$OUT/prof_736.log 2>&1
+    UNIPOSE_SYNC_WGRAD=1 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof_736x -o bench -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $GRAFT_REPO_ROOT/$OUT/prof_736x.log 2>&1 )
+  python tools/rocprof_summary.py $(find $OUT/prof_736 -name "*.db" | head -1) 4 > $OUT/kernel_stats_736_bf16s.txt 2>&1
+  python tools/rocprof_summary.py $(find $OUT/prof_736x -name "*.db" | head -1) 4 > $OUT/kernel_stats_736_bf16s_exclusive.txt 2>&1
+  find $OUT -name "*.db" -delete; head -${HEAD:-30} $OUT/kernel_stats_736_bf16s_exclusive.txt ;;
 ab368) for rep in 1 2; do timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-stock-baseline --no-alt-math --no-other-configs --no-profile > $OUT/ab368.log 2>&1; line $OUT/ab368.log "fp32"; done ;;
 lstm) timeout 300 python tools/gpu/steps.py --model lstm --batch 8 > $OUT/lstm_steps.log 2>&1; tail -5 $OUT/lstm_steps.log ;;
 *) echo "unknown action $act" ;;

@@ -68,6 +68,12 @@ __device__ __forceinline__ void raw_barrier() {
 }
 #endif
 
+#ifdef UP_EMU
+typedef float f32x2 __attribute__((vector_size(8)));
+#else
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#endif
+
 // geometry of a K slice of KT channels: LDS rows of KT*2 bytes, CH 16-byte chunks per row, RPI rows per LDS-DMA instruction;
 // chunk c of row r sits at slot c ^ swz(r): 128-byte rows (r >> 1) & 7, 64-byte rows (r >> 2) & 3 — in both cases the 16 rows of a
 // ds_read_b128 lane group land on 16 different 16-byte slots of the 256-byte bank row.
@@ -88,8 +94,9 @@ struct Geom {
     static constexpr int TOTAL = MASK_OFF + 16;
 };
 
-// BatchNorm partials of the wave's columns (count, mean, M2 over the tile's rows), the arithmetic of igemm_epilogue;
-// FULL: every row of the tile is a real row, so counts are literals and the per-element predicate disappears.
+// BatchNorm partials of the wave's columns (count, mean, M2 over the tile's rows): two-pass in registers and Welford merges like
+// igemm_epilogue.  FULL: every row of the tile is a real row: counts are literals, no per-element predicate, and the two
+// passes run on row PAIRS with packed fp32 arithmetic (half the instructions; even / odd rows are summed separately).
 template <int BM, int BN, bool FULL>
 __device__ __forceinline__ void tile_stats(const IgemmArgs& a, f32x16 (&acc)[BM / 64][BN / 64], float* xch, int mt, int m0, int n0,
                                            int wm, int wn, int l31, int lh) {
@@ -99,30 +106,52 @@ __device__ __forceinline__ void tile_stats(const IgemmArgs& a, f32x16 (&acc)[BM 
     float sc[TN], sm[TN], s2[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        float cnt = 0.f, sum = 0.f;
+        float cnt, mean, q;
+        if constexpr (FULL) {
+            // two rows per operation (v_pk_add_f32 / v_pk_fma_f32): registers r, r + 1 hold consecutive rows
+            f32x2 s2v = {0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                if (FULL || m < a.M) {
-                    cnt += 1.f;
-                    sum += acc[i][j][r];
+                for (int r = 0; r < 16; r += 2) s2v += f32x2{acc[i][j][r], acc[i][j][r + 1]};
+            cnt = (float)(TM * 16);
+            mean = (s2v[0] + s2v[1]) / cnt;
+            const f32x2 mu = {mean, mean};
+            f32x2 q2v = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 d = f32x2{acc[i][j][r], acc[i][j][r + 1]} - mu;
+                    q2v += d * d;
                 }
-            }
-        if (FULL) cnt = (float)(TM * 16);
-        const float mean = cnt > 0.f ? sum / cnt : 0.f;
-        float q = 0.f;
+            q = q2v[0] + q2v[1];
+        } else {
+            float sum = 0.f;
+            cnt = 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                if (FULL || m < a.M) {
-                    const float d = acc[i][j][r] - mean;
-                    q += d * d;
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (m < a.M) {
+                        cnt += 1.f;
+                        sum += acc[i][j][r];
+                    }
                 }
-            }
+            mean = cnt > 0.f ? sum / cnt : 0.f;
+            q = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (m < a.M) {
+                        const float d = acc[i][j][r] - mean;
+                        q += d * d;
+                    }
+                }
+        }
         float c1 = cnt, m1 = mean, q1 = q;
         float c2 = __shfl_xor(cnt, 32), m2 = __shfl_xor(mean, 32), q2 = __shfl_xor(q, 32);
         if (FULL) c2 = (float)(TM * 16);
@@ -165,6 +194,7 @@ __device__ __forceinline__ void tile_stats(const IgemmArgs& a, f32x16 (&acc)[BM 
     }
 }
 
+// (element offsets into y / the residual fit 31 bits: checked at launch)
 // Epilogue of the bf16-storage kernels: BatchNorm partials, optional folded scale / shift / bias / ReLU, then the tile leaves
 // through LDS as 16-byte stores of 8 consecutive channels.  `img` (>= BM*BN*2 bytes, 16-byte aligned) must be free: every
 // wave is past its last fragment read.  Row r of the tile is output pixel perm[m0 + r] (PERM) or m0 + r.
@@ -231,11 +261,11 @@ __device__ __forceinline__ void store_tile(const IgemmArgs& a, f32x16 (&acc)[BM 
             if (n >= a.Ng) continue;
             const int p0 = opix(2 * rp), p1 = opix(2 * rp + 1);
             if (p0 >= 0)
-                *reinterpret_cast<uint4*>(yo + (size_t)p0 * a.ldy + n) =
+                *reinterpret_cast<uint4*>(yo + (uint32_t)(p0 * a.ldy + n)) =
                     make_uint4(byte_perm(w0.y, w0.x, 0x05040100u), byte_perm(w0.w, w0.z, 0x05040100u),
                                byte_perm(w1.y, w1.x, 0x05040100u), byte_perm(w1.w, w1.z, 0x05040100u));
             if (p1 >= 0)
-                *reinterpret_cast<uint4*>(yo + (size_t)p1 * a.ldy + n) =
+                *reinterpret_cast<uint4*>(yo + (uint32_t)(p1 * a.ldy + n)) =
                     make_uint4(byte_perm(w0.y, w0.x, 0x07060302u), byte_perm(w0.w, w0.z, 0x07060302u),
                                byte_perm(w1.y, w1.x, 0x07060302u), byte_perm(w1.w, w1.z, 0x07060302u));
         }
@@ -269,14 +299,14 @@ __device__ __forceinline__ void store_tile(const IgemmArgs& a, f32x16 (&acc)[BM 
                 if (n >= a.Ng || px < 0) continue;
                 const float4 f0 = *reinterpret_cast<const float4*>(img + row * BN + cq * 8);
                 const float4 f1 = *reinterpret_cast<const float4*>(img + row * BN + cq * 8 + 4);
-                const uint4 rr = *reinterpret_cast<const uint4*>(rs + (size_t)px * a.ldr + n);
+                const uint4 rr = *reinterpret_cast<const uint4*>(rs + (uint32_t)(px * a.ldr + n));
                 float v[8] = {f0.x + bf_lo(rr.x), f0.y + bf_hi(rr.x), f0.z + bf_lo(rr.y), f0.w + bf_hi(rr.y),
                               f1.x + bf_lo(rr.z), f1.y + bf_hi(rr.z), f1.z + bf_lo(rr.w), f1.w + bf_hi(rr.w)};
                 if (relu) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                *reinterpret_cast<uint4*>(yo + (size_t)px * a.ldy + n) = make_uint4(
+                *reinterpret_cast<uint4*>(yo + (uint32_t)(px * a.ldy + n)) = make_uint4(
                     pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
             }
         }
@@ -315,6 +345,29 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds_kernel(IgemmArgs a) {
     // this lane's rows of the operand tiles: row (wave + 4 i) * RPI + lane / CH, 16-byte slot lane % CH
     const int rsub = lane / SL::CH, slot = lane % SL::CH;
     const int R = a.taps / a.S;
+    // operand descriptors: the bounds check of the buffer load zero-fills padding rows (offset OOB) and weight rows >= N
+    const Rsrc rsA = make_rsrc(a.x, a.x_bytes);
+    const Rsrc rsB = make_rsrc(a.w_hi, (uint32_t)a.Ng * (uint32_t)a.Ktot * 2u);
+    uint32_t woffB[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int row = (wave + 4 * j) * SL::RPI + rsub;
+        const int n = n0 + row;
+        woffB[j] = n < a.Ng ? (uint32_t)n * (uint32_t)a.Ktot * 2u + (uint32_t)((slot ^ SL::swz(row)) << 4) : OOB;
+    }
+
+    auto issueB = [&](int stage, int tap_, int cs_) {
+        unsigned char* const Bs = smem + stage * G::STAGE + G::A_BYTES;
+        const uint32_t kb = (uint32_t)(tap_ * a.Cp + cs_ * KT) * 2u;
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            load16_to_lds(rsB, woffB[j] == OOB ? OOB : woffB[j] + kb, Bs + (wave + 4 * j) * 1024);
+    };
+    // 1x1, stride 1, no padding (two thirds of the launches): the source pixel IS the destination pixel, and the first weight
+    // slice does not depend on any row set-up: it is on its way before the rows are looked at
+    const bool pointwise = a.taps == 1 && a.mul == 1 && a.off0 == 0 && a.off0w == 0 && a.H == a.P && a.W == a.Q;
+    if (pointwise) issueB(0, 0, 0);
+
     int roffA[NA];        // byte offset of (filter tap (0,0), this lane's chunk) of the row in the activation tensor
     unsigned tmA[NA];     // bit t: tap t of the row reads a real pixel (0 for rows >= M)
     unsigned tile_taps = 0;
@@ -324,40 +377,40 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds_kernel(IgemmArgs a) {
         const int m = m0 + row;
         int pix = m < a.M ? m : a.M - 1;
         if constexpr (PERM) pix = a.perm[pix];
-        const int img = fdiv(pix, a.fPQ);
-        const int rem = pix - img * (a.P * a.Q);
-        const int p = fdiv(rem, a.fQ);
-        const int q = rem - p * a.Q;
-        const int hb = p * a.mul + a.off0, wb = q * a.mul + a.off0w;
-        unsigned mk = 1u;
-        if (a.taps > 1) {   // separable test: R + S comparisons instead of R * S
-            unsigned hm = 0, wmk = 0;
-            for (int r = 0; r < R; ++r) {
-                const int h = hb + r * a.tapstep;
-                hm |= (h >= 0 && h < a.H) ? (1u << r) : 0u;
-            }
-            for (int s = 0; s < a.S; ++s) {
-                const int w = wb + s * a.tapstep;
-                wmk |= (w >= 0 && w < a.W) ? (1u << s) : 0u;
-            }
-            mk = 0u;
-            for (int r = 0; r < R; ++r) mk |= ((hm >> r) & 1u) ? (wmk << (r * a.S)) : 0u;
+        unsigned mk;
+        int src;   // source pixel of filter tap (0,0)
+        if (pointwise) {
+            src = pix;
+            mk = 1u;
         } else {
-            mk = (hb >= 0 && hb < a.H && wb >= 0 && wb < a.W) ? 1u : 0u;
+            const int img = fdiv(pix, a.fPQ);
+            const int rem = pix - img * (a.P * a.Q);
+            const int p = fdiv(rem, a.fQ);
+            const int q = rem - p * a.Q;
+            const int hb = p * a.mul + a.off0, wb = q * a.mul + a.off0w;
+            src = (img * a.H + hb) * a.W + wb;
+            // separable test: R + S comparisons instead of R * S
+            if (a.taps == 9 && a.S == 3) {
+                unsigned hm = 0, wmk = 0;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    hm |= ((unsigned)(hb + t * a.tapstep) < (unsigned)a.H) ? (1u << t) : 0u;
+                    wmk |= ((unsigned)(wb + t * a.tapstep) < (unsigned)a.W) ? (1u << t) : 0u;
+                }
+                mk = ((hm & 1u) ? wmk : 0u) | ((hm & 2u) ? (wmk << 3) : 0u) | ((hm & 4u) ? (wmk << 6) : 0u);
+            } else {
+                unsigned hm = 0, wmk = 0;
+                for (int r = 0; r < R; ++r) hm |= ((unsigned)(hb + r * a.tapstep) < (unsigned)a.H) ? (1u << r) : 0u;
+                for (int s = 0; s < a.S; ++s) wmk |= ((unsigned)(wb + s * a.tapstep) < (unsigned)a.W) ? (1u << s) : 0u;
+                mk = 0u;
+                for (int r = 0; r < R; ++r) mk |= ((hm >> r) & 1u) ? (wmk << (r * a.S)) : 0u;
+            }
         }
         if (m >= a.M) mk = 0u;
-        roffA[i] = ((img * a.H + hb) * a.W + wb) * a.ldx * 2 + ((slot ^ SL::swz(row)) << 4);
+        roffA[i] = src * a.ldx * 2 + ((slot ^ SL::swz(row)) << 4);
         tmA[i] = mk;
         tile_taps |= mk;
     }
-    uint32_t woffB[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int row = (wave + 4 * j) * SL::RPI + rsub;
-        const int n = n0 + row;
-        woffB[j] = n < a.Ng ? (uint32_t)n * (uint32_t)a.Ktot * 2u + (uint32_t)((slot ^ SL::swz(row)) << 4) : OOB;
-    }
-
     // the K loop visits the slices of the filter taps that are live for at least one row of the tile
     const unsigned all_taps = a.taps >= 32 ? 0xffffffffu : ((1u << a.taps) - 1u);
     unsigned live = all_taps;
@@ -374,25 +427,19 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds_kernel(IgemmArgs a) {
     unsigned rest = live;
     int tap = __builtin_ctz(rest), cs = 0;
 
-    // operand descriptors: the bounds check of the buffer load zero-fills padding rows (offset OOB) and weight rows >= N
-    const Rsrc rsA = make_rsrc(a.x, a.x_bytes);
-    const Rsrc rsB = make_rsrc(a.w_hi, (uint32_t)a.Ng * (uint32_t)a.Ktot * 2u);
-
+    bool b_issued = pointwise;   // the weight slice of the first issue is already on its way
     auto issue = [&](int stage) {
         unsigned char* const As = smem + stage * G::STAGE;
-        unsigned char* const Bs = As + G::A_BYTES;
         const int r = fdiv(tap, a.fS);
         const int sx = tap - r * a.S;
         const int delta = ((r * a.tapstep) * a.W + sx * a.tapstep) * a.ldx * 2 + cs * SL::ROWB;
-        const uint32_t kb = (uint32_t)(tap * a.Cp + cs * KT) * 2u;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const bool ok = (tmA[i] >> tap) & 1u;
             load16_to_lds(rsA, ok ? (uint32_t)(roffA[i] + delta) : OOB, As + (wave + 4 * i) * 1024);
         }
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-            load16_to_lds(rsB, woffB[j] == OOB ? OOB : woffB[j] + kb, Bs + (wave + 4 * j) * 1024);
+        if (!b_issued) issueB(stage, tap, cs);
+        b_issued = false;
         if (++cs == spt) {   // next live tap
             cs = 0;
             rest &= rest - 1u;

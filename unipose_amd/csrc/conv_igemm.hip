@@ -1623,7 +1623,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradArgs a) {
 //  spreads the same bytes over the whole chip.  profiles/r02_i_knob_ab.txt, r02_m.)
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* slab, float* dw, int splits, int K, int C,
                                                           int Cp, int taps, long long total4 /* K*taps*Cp / 4 */) {
-    // one thread = 4 consecutive input channels (Cp % 4 == 0): 16-byte slab reads, two splits in flight per step
+    // one thread = 4 consecutive input channels (Cp % 4 == 0): 16-byte slab reads
     long long q = (long long)blockIdx.x * 256 + threadIdx.x;
     if (q >= total4) return;
     const long long e = q * 4;
@@ -1632,18 +1632,24 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* slab, fl
     const int tap = (int)(t % taps);
     const int co = (int)(t / taps);
     const size_t stride = (size_t)total4 * 4;
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    // four splits in flight per step, four partial sums (fixed order: deterministic).  The pass is bound by the number of
+    // DEPENDENT load rounds per thread (14-30 splits on the layers that carry the step), not by bytes
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    auto add4 = [](float4& d, const float4& a) { d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w; };
     int sp = 0;
-    for (; sp + 1 < splits; sp += 2) {
+    for (; sp + 3 < splits; sp += 4) {
         const float4 a = *reinterpret_cast<const float4*>(slab + (size_t)sp * stride + e);
         const float4 b = *reinterpret_cast<const float4*>(slab + (size_t)(sp + 1) * stride + e);
-        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-        s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        const float4 c = *reinterpret_cast<const float4*>(slab + (size_t)(sp + 2) * stride + e);
+        const float4 d = *reinterpret_cast<const float4*>(slab + (size_t)(sp + 3) * stride + e);
+        add4(s0, a);
+        add4(s1, b);
+        add4(s2, c);
+        add4(s3, d);
     }
-    if (sp < splits) {
-        const float4 a = *reinterpret_cast<const float4*>(slab + (size_t)sp * stride + e);
-        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
-    }
+    for (; sp < splits; ++sp) add4(s0, *reinterpret_cast<const float4*>(slab + (size_t)sp * stride + e));
+    add4(s0, s2);
+    add4(s1, s3);
     const float v[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
     if (taps == 1 && ci + 3 < C && (C & 3) == 0) {
         *reinterpret_cast<float4*>(dw + (size_t)co * C + ci) = make_float4(v[0], v[1], v[2], v[3]);
@@ -2146,6 +2152,7 @@ extern "C" int up_conv_tune(const char* key, int value) {
     UP_REQUIRE(key, UP_ERR_INVALID, "conv_tune: null key");
     if (!strcmp(key, "tile_want") && value > 0) g_tile_want = value;
     else if (!strcmp(key, "tile_want_bf16") && value > 0) g_tile_want_bf16 = value;
+    else if (!strcmp(key, "bn_rows")) set_bn_rows(value);
     else if (!strcmp(key, "glds")) g_glds = value ? 1 : 0;
     else if (!strcmp(key, "glds_st") && (value == 2 || value == 3)) g_glds_st = value;
     else if (!strcmp(key, "glds_kt") && (value == 32 || value == 64)) g_glds_kt = value;
@@ -2311,7 +2318,8 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
         const int kt = (g_glds_kt == 64 && a.Cp % 64 == 0) ? 64 : 32;
         if (g_glds && fast && a.M % (a.P * a.Q) == 0 && a.Ng % 8 == 0 && a.ldy % 8 == 0 &&
             a.ldx % 8 == 0 && (!a.residual || a.ldr % 8 == 0) && !a.o_mode && a_bytes < (1ll << 31) &&
-            (long long)a.Ng * a.Ktot * 2 < (1ll << 31) && (ptrs & 15) == 0) {
+            (long long)a.Ng * a.Ktot * 2 < (1ll << 31) && (long long)a.M * a.ldy < (1ll << 31) &&
+            (!a.residual || (long long)a.M * a.ldr < (1ll << 31)) && (ptrs & 15) == 0) {
             a.no_tap_skip = g_tap_skip ? 0 : 1;
             a.perm = nullptr;
             a.x_bytes = (uint32_t)a_bytes;

@@ -220,6 +220,192 @@ __global__ void __launch_bounds__(256) bn_apply8_kernel(const bf16_t* y, int ldy
     }
 }
 
+// ---- row-strided forms of the two element-wise BatchNorm passes -----------------------------------------------------------
+// The kernels above walk a flat (row, channel group) index: every 16-byte group of y re-loads its per-channel parameters
+// (2 x 16-32 bytes forward, 5 x 16-32 bytes backward against 16-32 bytes of data) — they are bound by the number of load
+// instructions, not by HBM (3.4 TB/s measured on the backward pass at 736x736, r03_f).  When the number of 16-byte channel
+// groups per row is a power of two, a thread can keep ONE channel group for its whole life and stride over the rows: the
+// parameters are loaded once, the loop body is data loads and stores only, unrolled so four rows are in flight.
+// Same arithmetic, same bit layout of relu_bits (bit row * C + c), results bitwise equal to the flat kernels.
+template <typename T>
+struct Row16 {
+    static constexpr int E = 16 / (int)sizeof(T);   // channels per 16-byte access: 4 (fp32) or 8 (bf16)
+    float v[E];
+};
+__device__ __forceinline__ Row16<float> ld16(const float* p) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    return Row16<float>{{a.x, a.y, a.z, a.w}};
+}
+__device__ __forceinline__ Row16<bf16_t> ld16(const bf16_t* p) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    return Row16<bf16_t>{{bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y), bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w)}};
+}
+__device__ __forceinline__ void st16(float* p, const Row16<float>& a) {
+    *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+}
+__device__ __forceinline__ void st16(bf16_t* p, const Row16<bf16_t>& a) {
+    uint4 u;
+    u.x = pack_bf16x2(a.v[0], a.v[1]);
+    u.y = pack_bf16x2(a.v[2], a.v[3]);
+    u.z = pack_bf16x2(a.v[4], a.v[5]);
+    u.w = pack_bf16x2(a.v[6], a.v[7]);
+    *reinterpret_cast<uint4*>(p) = u;
+}
+template <int E>
+__device__ __forceinline__ void ldparam(const float* p, float (&o)[E]) {
+#pragma unroll
+    for (int e = 0; e < E; e += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(p + e);
+        o[e] = a.x;
+        o[e + 1] = a.y;
+        o[e + 2] = a.z;
+        o[e + 3] = a.w;
+    }
+}
+constexpr int BN_ROWS_UNROLL = 4;
+
+// lcs = log2(channel lanes per workgroup): lane tid & (LC-1) owns channel group blockIdx.y * LC + lane, the 256 / LC row
+// lanes of the workgroup and gridDim.x workgroups stride over the rows
+template <typename T>
+__global__ void __launch_bounds__(256) bn_apply_rows_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, const T* __restrict__ res, int ldr,
+                                                            int relu, T* __restrict__ z, int ldz, uint32_t* __restrict__ relu_bits,
+                                                            int rows, int C, int lcs) {
+    constexpr int E = Row16<T>::E, LPW = 32 / E;   // lanes per 32-bit word of relu_bits
+    const int lane = threadIdx.x & 63;
+    const int cl = threadIdx.x & ((1 << lcs) - 1), rl = threadIdx.x >> lcs;
+    const int rpb = 256 >> lcs;
+    const int c = ((blockIdx.y << lcs) + cl) * E;
+    float sc[E], sh[E];
+    ldparam<E>(scale + c, sc);
+    ldparam<E>(shift + c, sh);
+    const int stride = gridDim.x * rpb;
+    for (int base = blockIdx.x * rpb; base < rows; base += BN_ROWS_UNROLL * stride) {   // uniform trip count: the bit merge shuffles
+        Row16<T> v[BN_ROWS_UNROLL], r[BN_ROWS_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BN_ROWS_UNROLL; ++u) {
+            const int row = base + u * stride + rl;
+            const int rr = row < rows ? row : rows - 1;
+            v[u] = ld16(y + (size_t)rr * ldy + c);
+            if (res) r[u] = ld16(res + (size_t)rr * ldr + c);
+        }
+#pragma unroll
+        for (int u = 0; u < BN_ROWS_UNROLL; ++u) {
+            const int row = base + u * stride + rl;
+            const bool ok = row < rows;
+            uint32_t bits = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                float t = v[u].v[e] * sc[e] + sh[e];
+                if (res) t += r[u].v[e];
+                if (relu) t = fmaxf(t, 0.f);
+                v[u].v[e] = t;
+                bits |= t > 0.f ? (1u << e) : 0u;
+            }
+            if (ok) st16(z + (size_t)row * ldz + c, v[u]);
+            if (relu_bits) {   // uniform
+                uint32_t w = bits << (E * (lane & (LPW - 1)));
+#pragma unroll
+                for (int m = 1; m < LPW; m <<= 1) w |= __shfl_xor(w, m);
+                if ((lane & (LPW - 1)) == 0 && ok) relu_bits[((int64_t)row * C + c) >> 5] = w;
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bn_bwd_apply_rows_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ z, int ldz,
+                                                                const uint32_t* __restrict__ bits, const T* __restrict__ y, int ldy,
+                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, const float* __restrict__ dgamma,
+                                                                const float* __restrict__ dbeta, int relu, int use_batch, float inv_m,
+                                                                T* __restrict__ dy, int lddy, T* __restrict__ dres, int lddres,
+                                                                int rows, int C, int lcs) {
+    constexpr int E = Row16<T>::E;
+    const int cl = threadIdx.x & ((1 << lcs) - 1), rl = threadIdx.x >> lcs;
+    const int rpb = 256 >> lcs;
+    const int c = ((blockIdx.y << lcs) + cl) * E;
+    float is[E], ga[E], mu[E], dg[E], db[E];
+    ldparam<E>(invstd + c, is);
+    ldparam<E>(gamma + c, ga);
+    ldparam<E>(mean + c, mu);
+    ldparam<E>(dgamma + c, dg);
+    ldparam<E>(dbeta + c, db);
+    const int stride = gridDim.x * rpb;
+    for (int base = blockIdx.x * rpb + rl; base < rows; base += BN_ROWS_UNROLL * stride) {
+        Row16<T> g[BN_ROWS_UNROLL], yv[BN_ROWS_UNROLL], zz[BN_ROWS_UNROLL];
+        uint32_t mk[BN_ROWS_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BN_ROWS_UNROLL; ++u) {
+            const int row = base + u * stride;
+            const int rr = row < rows ? row : rows - 1;
+            g[u] = ld16(dz + (size_t)rr * lddz + c);
+            yv[u] = ld16(y + (size_t)rr * ldy + c);
+            mk[u] = 0xffffffffu;
+            if (relu) {
+                if (bits) {
+                    const int64_t b = (int64_t)rr * C + c;
+                    mk[u] = bits[b >> 5] >> (int)(b & 31);
+                } else {
+                    zz[u] = ld16(z + (size_t)rr * ldz + c);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < BN_ROWS_UNROLL; ++u) {
+            const int row = base + u * stride;
+            if (row >= rows) continue;
+            Row16<T> o;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                float ge = g[u].v[e];
+                if (relu) {
+                    const bool pos = bits ? ((mk[u] >> e) & 1u) != 0u : zz[u].v[e] > 0.f;
+                    if (!pos) ge = 0.f;
+                }
+                g[u].v[e] = ge;
+                const float k = ga[e] * is[e];
+                if (use_batch) {
+                    const float xh = (yv[u].v[e] - mu[e]) * is[e];
+                    o.v[e] = k * (ge - db[e] * inv_m - xh * dg[e] * inv_m);
+                } else {
+                    o.v[e] = k * ge;
+                }
+            }
+            if (dres) st16(dres + (size_t)row * lddres + c, g[u]);
+            st16(dy + (size_t)row * lddy + c, o);
+        }
+    }
+}
+// launch geometry of the row-strided kernels, or false when the channel-group count is not a power of two (>= 8)
+template <typename T>
+static bool rows_geometry(int64_t rows, int C, dim3& grid, int& lcs) {
+    constexpr int E = 16 / (int)sizeof(T);
+    if (C % E) return false;
+    const int cgs = C / E;
+    if (cgs < 8 || (cgs & (cgs - 1)) || rows >= (1ll << 31)) return false;
+    const int lc = cgs < 256 ? cgs : 256;
+    lcs = 0;
+    while ((1 << lcs) < lc) ++lcs;
+    const int rpb = 256 / lc, gy = cgs / lc;
+    // ~8 workgroups per CU in total, every thread walks >= BN_ROWS_UNROLL rows when there are enough of them
+    int64_t gx = (rows + (int64_t)rpb * BN_ROWS_UNROLL - 1) / ((int64_t)rpb * BN_ROWS_UNROLL);
+    const int64_t cap = 2048 / gy;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    grid = dim3((unsigned)gx, (unsigned)gy);
+    return true;
+}
+static int g_bn_rows = -1;   // UP_BN_ROWS=0 / up_conv_tune("bn_rows", 0) keeps the flat kernels (A/B)
+void set_bn_rows(int on) { g_bn_rows = on ? 1 : 0; }
+static bool bn_rows_enabled() {
+    if (g_bn_rows < 0) {
+        const char* e = getenv("UP_BN_ROWS");
+        g_bn_rows = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return g_bn_rows != 0;
+}
+
 // ---- BN backward -------------------------------------------------------------------------
 // pass 1: partial[chunk][c] = {sum g, sum g*xhat},   g = dz * (z > 0 if relu)
 // 256 threads = 16 row lanes x 16 channel quads (64 channels): every access is a 16-byte load of 4
@@ -546,6 +732,21 @@ extern "C" int up_bn_apply_t(const void* y, int ldy, const float* scale, const f
     UP_REQUIRE(rows * (C / 4) < (1ll << 31), UP_ERR_UNSUPPORTED, "bn_apply: tensor too large");
     UP_REQUIRE(dtype == UP_DT_F32 || dtype == UP_DT_BF16, UP_ERR_INVALID, "bn_apply: dtype %d", dtype);
     int64_t total = rows * (C / 4);
+    {
+        dim3 grid;
+        int lcs = 0;
+        if (bn_rows_enabled() && dtype == UP_DT_BF16 && ldy % 8 == 0 && ldz % 8 == 0 && (!res || ldr % 8 == 0) &&
+            rows_geometry<bf16_t>(rows, C, grid, lcs)) {
+            hipLaunchKernelGGL(bn_apply_rows_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)y, ldy, scale,
+                               shift, (const bf16_t*)res, ldr, relu, (bf16_t*)z, ldz, relu_bits, (int)rows, C, lcs);
+            return check_launch("bn_apply");
+        }
+        if (bn_rows_enabled() && dtype == UP_DT_F32 && rows_geometry<float>(rows, C, grid, lcs)) {
+            hipLaunchKernelGGL(bn_apply_rows_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)y, ldy, scale,
+                               shift, (const float*)res, ldr, relu, (float*)z, ldz, relu_bits, (int)rows, C, lcs);
+            return check_launch("bn_apply");
+        }
+    }
     if (dtype == UP_DT_BF16 && C % 8 == 0 && ldy % 8 == 0 && ldz % 8 == 0 && (!res || ldr % 8 == 0))
         hipLaunchKernelGGL(bn_apply8_kernel, dim3(grid_for(total / 2)), dim3(256), 0, as_stream(stream), (const bf16_t*)y, ldy,
                            scale, shift, (const bf16_t*)res, ldr, relu, (bf16_t*)z, ldz, relu_bits, total / 2, C / 8,
@@ -582,6 +783,18 @@ static void launch_bn_bwd(const T* dz, int lddz, const T* z, int ldz, const uint
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (const float*)workspace, chunks, C,
                        dgamma, dbeta, acc_dgamma, acc_dbeta);
     int64_t total = rows * (C / 4);
+    {
+        dim3 grid;
+        int lcs = 0;
+        constexpr int E = 16 / (int)sizeof(T);
+        if (bn_rows_enabled() && lddz % E == 0 && ldy % E == 0 && lddy % E == 0 && (!relu || relu_bits || ldz % E == 0) &&
+            (!dres || lddres % E == 0) && rows_geometry<T>(rows, C, grid, lcs)) {
+            hipLaunchKernelGGL(bn_bwd_apply_rows_kernel<T>, grid, dim3(256), 0, st, dz, lddz, z, ldz, relu_bits, y, ldy, gamma, mean,
+                               invstd, (const float*)dgamma, (const float*)dbeta, relu, use_batch_stats, 1.0f / (float)rows, dy,
+                               lddy, dres, lddres, (int)rows, C, lcs);
+            return;
+        }
+    }
     if constexpr (sizeof(T) == 2) {
         if (C % 8 == 0 && lddz % 8 == 0 && ldy % 8 == 0 && lddy % 8 == 0 && (!relu || relu_bits || ldz % 8 == 0) &&
             (!dres || lddres % 8 == 0)) {

@@ -219,6 +219,49 @@ __global__ void __launch_bounds__(256) bilinear_bwd_kernel(const T* dy, int lddy
     }
 }
 
+// Backward of the broadcast of a 1x1 map (the WASP global-pool branch is up-sampled from 1x1 to the feature-map size,
+// wasp.py:83): dx[n][c] = sum over all P*Q output pixels of dy.  The generic gather above would give ONE thread the whole
+// P*Q loop (868 us at 46x46); here a workgroup owns (image, 64 channels): 16 row lanes x 16 four-channel groups, four rows in
+// flight per thread, LDS tree over the row lanes (fixed order: deterministic).
+template <typename T>
+__global__ void __launch_bounds__(256) bcast_bwd_kernel(const T* dy, int lddy, T* dx, int lddx, int PQ, int C) {
+    __shared__ float red[16][64];
+    const int n = blockIdx.x;
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + cq * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) {
+        const T* base = dy + (size_t)n * PQ * lddy + c;
+        int r = rl;
+        for (; r + 48 < PQ; r += 64) {
+            const float4 a = ld4<T>(base + (size_t)r * lddy), b = ld4<T>(base + (size_t)(r + 16) * lddy);
+            const float4 e = ld4<T>(base + (size_t)(r + 32) * lddy), f = ld4<T>(base + (size_t)(r + 48) * lddy);
+            s.x += (a.x + b.x) + (e.x + f.x);
+            s.y += (a.y + b.y) + (e.y + f.y);
+            s.z += (a.z + b.z) + (e.z + f.z);
+            s.w += (a.w + b.w) + (e.w + f.w);
+        }
+        for (; r < PQ; r += 16) {
+            const float4 a = ld4<T>(base + (size_t)r * lddy);
+            s.x += a.x;
+            s.y += a.y;
+            s.z += a.z;
+            s.w += a.w;
+        }
+    }
+    red[rl][cq * 4 + 0] = s.x;
+    red[rl][cq * 4 + 1] = s.y;
+    red[rl][cq * 4 + 2] = s.z;
+    red[rl][cq * 4 + 3] = s.w;
+    __syncthreads();
+    if (threadIdx.x < 16 && c < C) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < 16; ++k)
+            for (int e = 0; e < 4; ++e) t[e] += red[k][cq * 4 + e];
+        st4(dx + (size_t)n * lddx + c, make_float4(t[0], t[1], t[2], t[3]));
+    }
+}
+
 // ---- global average pool ---------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) gap_fwd_kernel(const T* x, int ldx, T* y, int HW, int C) {
@@ -721,6 +764,16 @@ extern "C" int up_bilinear_bwd_t(const void* dy, int lddy, void* dx, int lddx, i
     if (int e = pool_args_ok(N, H, W, C, P, Q, lddx, lddy)) return e;
     UP_REQUIRE(dy && dx && UP_DT_OK(dtype), UP_ERR_INVALID, "bilinear_bwd: bad argument");
     int64_t total = (int64_t)N * H * W * (C / 4);
+    if (H == 1 && W == 1) {   // broadcast of a 1x1 map: a per-image column sum
+        dim3 grid(N, cdiv(C, 64));
+        if (dtype == UP_DT_BF16)
+            hipLaunchKernelGGL(bcast_bwd_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)dy, lddy, (bf16_t*)dx,
+                               lddx, P * Q, C);
+        else
+            hipLaunchKernelGGL(bcast_bwd_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)dy, lddy, (float*)dx, lddx,
+                               P * Q, C);
+        return check_launch("bilinear_bwd");
+    }
     if (dtype == UP_DT_BF16)
         UP_LAUNCH_1D(bilinear_bwd_kernel<bf16_t>, total, as_stream(stream), (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, H,
                      W, C / 4, P, Q, ac_scale(H, P), ac_scale(W, Q), total, make_fastdiv(C / 4), make_fastdiv(W),

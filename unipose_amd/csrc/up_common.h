@@ -19,6 +19,7 @@ namespace up {
 
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+void set_bn_rows(int on);   // norm_act.hip: row-strided BatchNorm passes on / off (up_conv_tune "bn_rows")
 
 #define UP_REQUIRE(cond, code, ...)            \
     do {                                       \
