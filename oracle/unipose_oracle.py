@@ -125,7 +125,27 @@ _LAYERS_OS16 = (
 )
 
 
-def backbone(sd: SD, x, train: bool, taps: Optional[dict] = None, prefix="backbone"):
+# output_stride 8: resnet.py:54-56 (strides [1,2,1,1], dilations [1,1,2,4]): layer3 keeps the 1/8 resolution at dilation 2,
+# the multi-grid unit runs at dilation 4 x [1,2,4]
+_LAYERS_OS8 = (
+    ("layer1", 3, 1, (1, 1, 1)),
+    ("layer2", 4, 2, (1, 1, 1, 1)),
+    ("layer3", 23, 1, (2,) * 23),
+    ("layer4", 3, 1, (4, 8, 16)),
+)
+# WASP dilations: wasp.py:39-44 ([24,18,12,6] at output stride 16, [48,36,24,12] at 8)
+_WASP_DIL = {16: (24, 18, 12, 6), 8: (48, 36, 24, 12)}
+
+
+def _layers(output_stride: int):
+    if output_stride == 16:
+        return _LAYERS_OS16
+    if output_stride == 8:
+        return _LAYERS_OS8
+    raise NotImplementedError      # resnet.py:57-58
+
+
+def backbone(sd: SD, x, train: bool, taps: Optional[dict] = None, prefix="backbone", output_stride: int = 16):
     """ResNet.forward, resnet.py:113-124."""
     x = F.conv2d(x, sd[prefix + ".conv1.weight"], stride=2, padding=3)
     x = _relu(_bn(sd, prefix + ".bn1", x, train))
@@ -133,7 +153,7 @@ def backbone(sd: SD, x, train: bool, taps: Optional[dict] = None, prefix="backbo
     if taps is not None:
         taps["stem"] = x
     low = None
-    for name, n, stride, dils in _LAYERS_OS16:
+    for name, n, stride, dils in _layers(output_stride):
         for i in range(n):
             x = bottleneck(sd, f"{prefix}.{name}.{i}", x, stride if i == 0 else 1, dils[i], train)
         if name == "layer1":
@@ -151,12 +171,13 @@ def _atrous(sd: SD, p: str, x, dil: int, k: int, train: bool):
 
 
 def wasp(sd: SD, x, train: bool, drop_masks: Optional[dict] = None,
-         video: bool = False, taps: Optional[dict] = None, p_drop: float = 0.5):
+         video: bool = False, taps: Optional[dict] = None, p_drop: float = 0.5, output_stride: int = 16):
     """wasp.forward, wasp.py:66-90 (video variant waspVideo.py:56-59: GAP branch has no BN)."""
-    x1 = _atrous(sd, "wasp.aspp1", x, 24, 1, train)
-    x2 = _atrous(sd, "wasp.aspp2", x1, 18, 3, train)
-    x3 = _atrous(sd, "wasp.aspp3", x2, 12, 3, train)
-    x4 = _atrous(sd, "wasp.aspp4", x3, 6, 3, train)
+    d1, d2, d3, d4 = _WASP_DIL[output_stride]
+    x1 = _atrous(sd, "wasp.aspp1", x, d1, 1, train)
+    x2 = _atrous(sd, "wasp.aspp2", x1, d2, 3, train)
+    x3 = _atrous(sd, "wasp.aspp3", x2, d3, 3, train)
+    x4 = _atrous(sd, "wasp.aspp4", x3, d4, 3, train)
     if taps is not None:
         taps.update(x1=x1, x2=x2, x3=x3, x4=x4)
     w2 = sd["wasp.conv2.weight"]
@@ -202,12 +223,12 @@ def decoder(sd: SD, x, low, train: bool, drop_masks: Optional[dict] = None,
 
 def unipose_forward(sd: SD, x, train: bool = False, stride: int = 8,
                     drop_masks: Optional[dict] = None, taps: Optional[dict] = None,
-                    p_drop=(0.5, 0.5, 0.1)):
-    """unipose.forward, model/unipose.py:27-38."""
+                    p_drop=(0.5, 0.5, 0.1), output_stride: int = 16):
+    """unipose.forward, model/unipose.py:27-38 (output_stride: ctor argument, model/unipose.py:9-25)."""
     if train and x.shape[0] == 1:
         raise ValueError("Expected more than 1 value per channel when training")  # wasp.py:51-54
-    f, low = backbone(sd, x, train, taps)
-    f = wasp(sd, f, train, drop_masks, False, taps, p_drop[0])
+    f, low = backbone(sd, x, train, taps, output_stride=output_stride)
+    f = wasp(sd, f, train, drop_masks, False, taps, p_drop[0], output_stride=output_stride)
     if taps is not None:
         taps["wasp"] = f
     y = decoder(sd, f, low, train, drop_masks, taps, p_drop[1:])

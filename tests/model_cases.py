@@ -255,3 +255,55 @@ def second_step_case(dev, K=16, B=2, size=32, wseed=6):
     for k, v in m.state_dict().items():
         if k.endswith("num_batches_tracked"):
             assert int(v) == (0 if k.startswith("decoder.bn2") else 2), (k, int(v))
+
+
+def tap_case(dev, golden_file, size, keys, sub, output_stride=16, tol=1e-3):
+    """Eval forward with forward hooks on the drop-in modules (backbone.layerN, wasp.asppN, wasp — real nn.Modules, NHWC
+    inside): every intermediate the reference golden holds is compared on the device under test, so an error is localised
+    to a stage instead of showing up (or cancelling) at the output.  `keys` name golden entries: stem (input of layer1),
+    layer1..4, x1..x4, wasp.  Returns {name: max_rel}."""
+    import numpy as np
+    from model.unipose import unipose
+    from unipose_amd import ops
+    g = np.load(golden_file)
+    K, wseed, xseed = (int(v) for v in g["meta"])
+    m = unipose("LSP", num_classes=K, output_stride=output_stride)
+    m.load_state_dict(O.synth_state_dict(K, wseed))
+    m = m.to(dev).eval()
+    taps = {}
+
+    def nchw(t, name):
+        c = g[name].shape[1] * sub
+        return t.detach().float().cpu()[..., :c].permute(0, 3, 1, 2).contiguous()
+
+    def post(name):
+        def f(_m, _i, o):
+            taps[name] = nchw(o[0] if isinstance(o, tuple) else o, name)
+        return f
+    hs = []
+    if "stem" in keys:
+        hs.append(m.backbone.layer1.register_forward_pre_hook(lambda _m, i: taps.__setitem__("stem", nchw(i[0], "stem"))))
+    for n in ("layer1", "layer2", "layer3", "layer4"):
+        if n in keys:
+            hs.append(getattr(m.backbone, n).register_forward_hook(post(n)))
+    for n in ("x1", "x2", "x3", "x4"):
+        if n in keys:
+            hs.append(getattr(m.wasp, "aspp" + n[1]).register_forward_hook(post(n)))
+    if "wasp" in keys:
+        hs.append(m.wasp.register_forward_hook(post("wasp")))
+    x = O.synth_input((2, 3, size, size), xseed).to(dev)
+    with torch.no_grad():
+        y = m(x)
+    for h in hs:
+        h.remove()
+    errs = {"out": O.max_rel(y.cpu(), g["out"])}
+    for k in keys:
+        errs[k] = O.max_rel(taps[k][:, ::sub], g[k])
+        s = taps[k].abs().sum(dtype=torch.float64).item()
+        assert abs(s - float(g[k + "_abs_sum"])) <= 1e-4 * abs(s), (k, s, float(g[k + "_abs_sum"]))
+    bad = {k: v for k, v in errs.items() if not v < tol}
+    assert not bad, (bad, errs)
+    if "argmax" in g.files:
+        _, _, idx = ops.heatmap_argmax(y)
+        assert np.array_equal(idx.cpu().numpy(), g["argmax"])            # bit-exact joint index
+    return errs

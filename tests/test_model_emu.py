@@ -30,3 +30,12 @@ def test_lstm_train_bptt_emu(emu_backend):
 def test_lstm_train_bptt_deferred_wgrad_emu(emu_backend):
     # three frames: every weight and every BatchNorm affine pair is summed over three uses by the library
     mc.lstm_case(emu_backend, size=32, T=3, B=2, train=True, deferred=True)
+
+
+def test_output_stride_8_vs_reference_golden_emu(emu_backend, golden_dir):
+    """output_stride = 8 through the drop-in modules (layer3 at dilation 2, multi-grid 4 / 8 / 16, WASP dilations 48 / 36 /
+    24 / 12 on a 20x20 map) against the genuine reference's output, argmax and stage taps (G12)"""
+    import os
+    errs = mc.tap_case(emu_backend, os.path.join(golden_dir, "g12_eval_os8_160.npz"), 160, ("layer2", "layer3", "layer4", "wasp"),
+                       sub=8, output_stride=8)
+    assert max(errs.values()) < 1e-4, errs

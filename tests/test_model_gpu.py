@@ -52,6 +52,22 @@ def test_g2_eval_160_vs_reference_golden(golden_dir):
     assert O.max_rel(y1.cpu()[:, ::4, ::2, ::2], g["out_stride1"]) < TOL
 
 
+def test_g2_stage_taps_vs_reference_golden(golden_dir):
+    """every stage of the 160x160 forward (stem, layer1-4, the WASP cascade x1-x4, the WASP output) against the reference's
+    own intermediates, on the MI355X: forward hooks on the drop-in modules"""
+    errs = mc.tap_case(DEV, os.path.join(golden_dir, "g2_taps_160.npz"), 160,
+                       ("stem", "layer1", "layer2", "layer3", "layer4", "x1", "x2", "x3", "x4", "wasp"), sub=4, tol=TOL)
+    assert max(errs.values()) < 1e-4, errs         # fp32 MFMA path: every stage at the fp32 noise floor
+
+
+def test_g12_output_stride_8_vs_reference_golden(golden_dir):
+    """output_stride = 8 (resnet.py:54-56: layer3 at stride 1 / dilation 2, multi-grid unit at dilation 4, 8, 16;
+    wasp.py:41-42: dilations 48, 36, 24, 12 — larger than the 20x20 map): output within 1e-3, bit-exact argmax, stage taps"""
+    errs = mc.tap_case(DEV, os.path.join(golden_dir, "g12_eval_os8_160.npz"), 160, ("layer2", "layer3", "layer4", "wasp"),
+                       sub=8, output_stride=8, tol=TOL)
+    assert max(errs.values()) < 1e-4, errs
+
+
 def test_g5_lstm_368_vs_reference_golden(golden_dir):
     from model.uniposeLSTM import unipose_lstm
     g = np.load(os.path.join(golden_dir, "g5_lstm_368.npz"))

@@ -41,8 +41,8 @@ def save(name, **arrs):
     print("wrote", name, {k: np.asarray(v).shape for k, v in arrs.items()})
 
 
-def ref_image_model(K, seed):
-    m = RefUniPose("LSP", num_classes=K)
+def ref_image_model(K, seed, output_stride=16):
+    m = RefUniPose("LSP", num_classes=K, output_stride=output_stride)
     sd = O.synth_state_dict(K, seed)
     missing = set(m.state_dict()) ^ set(sd)
     assert not missing, missing
@@ -403,6 +403,30 @@ def g11_train_b8():
          loss64=np.array(loss64.item()), **arrs, meta=np.array([K, 7, 43, 44, B]))
 
 
+def g12_eval_os8():
+    """G12: eval forward with output_stride = 8 (resnet.py:54-56: layer3 at stride 1 / dilation 2, multi-grid unit at dilation
+    4 x [1,2,4]; wasp.py:41-42: dilations [48,36,24,12]), K=14, B=2, 160x160, plus the layer3 / layer4 / wasp taps."""
+    m = ref_image_model(14, 5, output_stride=8).eval()
+    x = O.synth_input((2, 3, 160, 160), 15)
+    taps = {}
+
+    def hook(name):
+        def f(_m, _i, o):
+            taps[name] = (o[0] if isinstance(o, tuple) else o).detach().numpy()
+        return f
+    for n in ("layer2", "layer3", "layer4"):
+        getattr(m.backbone, n).register_forward_hook(hook(n))
+    m.wasp.register_forward_hook(hook("wasp"))
+    with torch.no_grad():
+        y = m(x)
+    assert taps["layer3"].shape[2:] == (20, 20) and taps["layer4"].shape[2:] == (20, 20), taps["layer3"].shape
+    flat = y.reshape(2, 15, -1)
+    small = {k: v[:, ::8] for k, v in taps.items()}
+    sums = {k + "_abs_sum": np.abs(v).sum(dtype=np.float64) for k, v in taps.items()}
+    save("g12_eval_os8_160.npz", out=y.numpy(), argmax=flat.argmax(2).numpy().astype(np.int32), **small, **sums,
+         meta=np.array([14, 5, 15]))
+
+
 def g0_keys():
     """G0: the reference's state_dict contract (names, shapes, dtypes, order) for both models."""
     import json
@@ -416,8 +440,8 @@ def g0_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     fns = dict(g0=g0_keys, g1=g1_eval_full, g2=g2_taps, g4=g4_train, g5=g5_lstm, g6=g6_argmax, g7=g7_accuracy,
-               g8=g8_targets, g9=g9_multi_person, g10=g10_eval_736, g11=g11_train_b8)
+               g8=g8_targets, g9=g9_multi_person, g10=g10_eval_736, g11=g11_train_b8, g12=g12_eval_os8)
     for w in which:
         fns[w]()
