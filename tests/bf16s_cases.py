@@ -262,3 +262,57 @@ def model_train_case(dev, K=16, B=4, size=64, cos_min=0.5, cos_head=0.9):
         if "running_" in k and not k.startswith("decoder.bn2"):
             assert O.max_rel(msd[k].cpu(), v) < 2e-2, k
     return cos[worst]
+
+
+def model_train_yardstick_case(dev, golden_file):
+    """The bf16-storage train step against G13: the genuine reference run (a) under bf16 autocast and (b) in fp32 arithmetic
+    with every stored tensor rounded to bf16 once — what a CORRECT bf16 implementation gets on this input (K=16, B=8,
+    128x128, residual branches damped so that the comparison is not drowned in ReLU flips).  Per parameter (>= 4096
+    elements) the HIP path's gradient must be at most twice as far from the fp32 gradient as the worse of the two
+    yardsticks, in direction (1 - cosine) and in relative L2; the fp32 gradient is the oracle's (pinned to the reference by
+    G4 / G11)."""
+    import numpy as np
+    import model_cases as mc
+    from oracle import unipose_oracle as O
+    g = np.load(golden_file)
+    K, wseed, xseed, tseed, B = (int(v) for v in g["meta"])
+    m, sd = mc.build_image_model(K, wseed, dev)
+    sd = {k: (v * 0.25 if k.endswith("bn3.weight") else v) for k, v in sd.items()}
+    m.load_state_dict(sd)
+    m.train()
+    for d in (m.wasp.dropout, m.decoder.last_conv[3], m.decoder.last_conv[7]):
+        d.p = 0.0
+    x = O.synth_input((B, 3, 128, 128), xseed)
+    t = O.synth_input((B, K + 1, 16, 16), tseed, "rand")
+    ops.set_conv_math("bf16s")
+    try:
+        y = m(x.to(dev))
+        loss = ops.mse_loss(y, t.to(dev))
+        loss.backward()
+        ops.wgrad_fence()
+    finally:
+        ops.set_conv_math("f32")
+    sdr = O.clone_sd(sd, requires_grad=True)
+    lr = F.mse_loss(O.unipose_forward(sdr, x, train=True, p_drop=(0, 0, 0)), t)
+    lr.backward()
+    assert abs(float(lr.detach()) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))      # same problem as the fixture
+    assert abs(float(loss.detach()) - float(lr.detach())) < 2.0 * max(abs(float(g["autocast_loss"]) - float(g["loss"])),
+                                                                      abs(float(g["rounded_loss"]) - float(g["loss"]))) + 1e-3
+    params = dict(m.named_parameters())
+    worst = {}
+    for i, name in enumerate(g["names"]):
+        name = str(name)
+        a, b = params[name].grad.cpu().double().flatten(), sdr[name].grad.double().flatten()
+        cos = float(a @ b / (a.norm() * b.norm() + 1e-300))
+        rel = float((a - b).norm() / (b.norm() + 1e-300))
+        ycos = min(float(g["autocast_cos"][i]), float(g["rounded_cos"][i]))
+        yrel = max(float(g["autocast_rel"][i]), float(g["rounded_rel"][i]))
+        if 1.0 - cos > 2.0 * (1.0 - ycos) + 0.01 or rel > 2.0 * yrel + 0.02:
+            worst[name] = (cos, ycos, rel, yrel)
+    ratios = [(1.0 - float(params[str(n)].grad.cpu().double().flatten() @ sdr[str(n)].grad.double().flatten() /
+                     (params[str(n)].grad.cpu().double().norm() * sdr[str(n)].grad.double().norm() + 1e-300))) /
+              (1.0 - min(float(g["autocast_cos"][i]), float(g["rounded_cos"][i]))) for i, n in enumerate(g["names"])]
+    print("bf16-storage gradients: (1 - cos) relative to the bf16 yardstick of the reference, median %.2f max %.2f" %
+          (float(np.median(ratios)), max(ratios)))
+    assert not worst, worst
+    return max(ratios)

@@ -134,3 +134,10 @@ def test_736_b16_train_step_bf16_storage():
     assert O.max_rel(parts.cpu(), y.cpu()) < 1e-5
     _, _, idx = ops.heatmap_argmax(y)
     assert torch.equal(idx.cpu().long(), y.cpu().reshape(B, K + 1, -1).argmax(2))
+
+
+def test_train_step_b8_within_twice_the_reference_bf16_yardstick(golden_dir):
+    """G13: the genuine reference under bf16 autocast / with bf16-rounded stored tensors defines how far a correct bf16
+    implementation lands from the fp32 gradients on this input; the HIP bf16-storage step must stay within twice that,
+    parameter by parameter"""
+    bc.model_train_yardstick_case(DEV, os.path.join(golden_dir, "g13_bf16_yardstick_b8_128.npz"))

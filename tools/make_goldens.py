@@ -427,6 +427,84 @@ def g12_eval_os8():
          meta=np.array([14, 5, 15]))
 
 
+def g13_bf16_yardstick():
+    """G13: what does a CORRECT bf16 implementation get on the G11 train step (K=16, B=8, 128x128, dropout off)?  The genuine
+    reference is run three times: fp32; under torch.autocast(bfloat16); and in fp32 arithmetic with every tensor a bf16-STORAGE
+    implementation keeps in HBM rounded to bf16 once (convolution weights, the output of every Conv2d / BatchNorm2d / ReLU /
+    pooling / up-sampling module, and the gradient flowing into each of them).  Stored per parameter with >= 4096 elements:
+    cosine and relative L2 distance of both bf16 gradients to the reference's own fp32 gradient, plus loss and output error.
+    The residual branches are damped (every bn3.weight x 0.25, DAMP): with the plain synthetic weights the ReLU decisions of
+    101 layers flip under ANY 2^-9 rounding and the yardstick itself lands at cosine 0.66-0.75 (measured), too loose to show
+    a wrong gradient path; damped, a correct bf16 implementation sits at 0.91-0.98.
+    tests/test_bf16s_gpu.py holds the HIP bf16-storage path to twice the larger of the two distances."""
+    K, B = 16, 8
+    DAMP = float(os.environ.get("G13_DAMP", "0.25"))
+    x = O.synth_input((B, 3, 128, 128), 43)
+    t = O.synth_input((B, K + 1, 16, 16), 44, "rand")
+
+    def rb(v):
+        return v.to(torch.bfloat16).to(v.dtype)
+
+    class _RoundGrad(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, v):
+            return rb(v)
+
+        @staticmethod
+        def backward(ctx, g):
+            return rb(g)
+
+    def build(mode):
+        m = ref_image_model(K, 7).train()
+        with torch.no_grad():     # damped residual branches (see the docstring)
+            for k, v in m.state_dict().items():
+                if k.endswith("bn3.weight"):
+                    v.mul_(DAMP)
+        m.wasp.dropout.p = 0.0
+        m.decoder.last_conv[3].p = 0.0
+        m.decoder.last_conv[7].p = 0.0
+        if mode == "rounded":
+            kinds = (torch.nn.Conv2d, torch.nn.BatchNorm2d, torch.nn.ReLU, torch.nn.MaxPool2d, torch.nn.AdaptiveAvgPool2d)
+            stem = {id(m.backbone.conv1), id(m.backbone.bn1), id(m.backbone.relu)}    # the stem stays fp32 up to the max-pool
+            for mod in m.modules():
+                if isinstance(mod, kinds) and id(mod) not in stem:
+                    mod.register_forward_hook(lambda _m, _i, o: _RoundGrad.apply(o))
+                if isinstance(mod, torch.nn.Conv2d) and id(mod) not in stem:
+                    mod.register_forward_pre_hook(lambda mm, _i: None)
+                    w = mod.weight
+                    mod.forward = (lambda inp, mod=mod: torch.nn.functional.conv2d(
+                        inp, rb(mod.weight.detach()) + (mod.weight - mod.weight.detach()), mod.bias, mod.stride, mod.padding, mod.dilation))
+        return m
+
+    grads, outs, losses = {}, {}, {}
+    for mode in ("fp32", "autocast", "rounded"):
+        m = build(mode)
+        if mode == "autocast":
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                y = m(x)
+            y = y.float()
+        else:
+            y = m(x)
+        loss = torch.nn.MSELoss()(y, t)
+        loss.backward()
+        grads[mode] = {k: p.grad.detach().double() for k, p in m.named_parameters() if p.grad is not None}
+        outs[mode], losses[mode] = y.detach(), float(loss)
+    names = [k for k, g in grads["fp32"].items() if g.numel() >= 4096]
+    arrs = {"names": np.array(names)}
+    for mode in ("autocast", "rounded"):
+        cos, rel = [], []
+        for k in names:
+            a, b = grads[mode][k].flatten(), grads["fp32"][k].flatten()
+            cos.append(float(a @ b / (a.norm() * b.norm() + 1e-300)))
+            rel.append(float((a - b).norm() / (b.norm() + 1e-300)))
+        arrs[mode + "_cos"], arrs[mode + "_rel"] = np.array(cos), np.array(rel)
+        arrs[mode + "_out"] = np.array(O.max_rel(outs[mode], outs["fp32"]))
+        arrs[mode + "_loss"] = np.array(losses[mode])
+        print("g13", mode, "loss", losses[mode], "(fp32", losses["fp32"], ") out", float(arrs[mode + "_out"]),
+              "cos min / median", min(cos), float(np.median(cos)), "rel max / median", max(rel), float(np.median(rel)))
+    save("g13_bf16_yardstick_b8_128.npz", loss=np.array(losses["fp32"]), **arrs, meta=np.array([K, 7, 43, 44, B]))
+
+
 def g0_keys():
     """G0: the reference's state_dict contract (names, shapes, dtypes, order) for both models."""
     import json
@@ -440,8 +518,8 @@ def g0_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     fns = dict(g0=g0_keys, g1=g1_eval_full, g2=g2_taps, g4=g4_train, g5=g5_lstm, g6=g6_argmax, g7=g7_accuracy,
-               g8=g8_targets, g9=g9_multi_person, g10=g10_eval_736, g11=g11_train_b8, g12=g12_eval_os8)
+               g8=g8_targets, g9=g9_multi_person, g10=g10_eval_736, g11=g11_train_b8, g12=g12_eval_os8, g13=g13_bf16_yardstick)
     for w in which:
         fns[w]()
