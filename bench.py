@@ -35,6 +35,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+BF16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA (32x32x16)
 FLOP_PER_IMAGE_FWD_BWD = 187.7e9    # 3 x 31.279 GMAC x 2 at 368x368, K=16
 
 
@@ -46,9 +47,32 @@ def log(msg):
 
 
 def cpu_baseline(num_classes, size, batch, steps, threads):
-    """Reference graph (oracle restatement) fwd+MSE+bwd on the host cores; images/sec."""
+    """Reference graph (oracle restatement) on the host cores: the train step (fwd+MSE+bwd) in images/sec as `value`, and
+    BASELINE.json configs[0] — K=14, batch 1, eval forward only, the reference's own CPU-runnable case (SURVEY 8d config 1:
+    7.0 img/s on 8 threads in the survey container) — as `eval_forward`.  The thread count is chosen by a quick sweep of the
+    eval forward (oneDNN stops scaling long before 64 threads on this graph; an oversubscribed run is not a baseline)."""
     from oracle import unipose_oracle as O
-    torch.set_num_threads(threads)
+    cores = os.cpu_count() or 1
+    sd14 = O.synth_state_dict(14, 0)
+    x1 = O.synth_input((1, 3, size, size), 0)
+
+    def eval_ms(n_threads, reps):
+        torch.set_num_threads(n_threads)
+        with torch.no_grad():
+            O.unipose_forward(sd14, x1)
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                O.unipose_forward(sd14, x1)
+                ts.append((time.perf_counter() - t0) * 1e3)
+        return sorted(ts)[len(ts) // 2]
+
+    cand = sorted({t for t in (4, 8, 16, 32, 64, threads) if 1 <= t <= max(cores, 1)})
+    sweep = {t: round(eval_ms(t, 3), 2) for t in cand}
+    best = min(sweep, key=sweep.get)
+    ev = eval_ms(best, 10)
+    log(f"cpu baseline: eval-forward thread sweep {sweep} -> {best} threads, median of 10: {ev:.1f} ms")
+    torch.set_num_threads(best)
     sd = O.clone_sd(O.synth_state_dict(num_classes, 0), requires_grad=True)
     x = O.synth_input((batch, 3, size, size), 1)
     t = O.synth_input((batch, num_classes + 1, size // 8, size // 8), 2, "rand")
@@ -66,9 +90,12 @@ def cpu_baseline(num_classes, size, batch, steps, threads):
         one()
     dt = time.perf_counter() - t0
     return {"value": round(batch * steps / dt, 3), "unit": "images/sec", "cores": torch.get_num_threads(),
-            "kind": "port",
+            "kind": "port", "host_cores": cores, "thread_sweep_eval_ms": sweep,
             "sample": f"{steps} train steps (fwd+MSE+bwd, no optimizer) of batch {batch} at {size}x{size}, "
-                      f"torch {torch.__version__} CPU, after 1 warm-up step"}
+                      f"torch {torch.__version__} CPU, after 1 warm-up step, {best} threads (best of the sweep)",
+            "eval_forward": {"value": round(1e3 / ev, 3), "unit": "images/sec", "ms": round(ev, 2), "cores": best,
+                             "sample": f"BASELINE.json configs[0]: K=14, batch 1, eval forward at {size}x{size}, median of 10 "
+                                       f"after 1 warm-up"}}
 
 
 def stock_gpu_baseline(dev, num_classes, size, batch, steps=5, warmup=3, benchmark=False, lstm_frames=0):
@@ -136,19 +163,23 @@ def stock_gpu_baseline(dev, num_classes, size, batch, steps=5, warmup=3, benchma
         torch.backends.cudnn.benchmark = old
 
 
-def wasp_dilated_leg(dev, batch=32, hw=23, iters=20):
-    """The quantity BASELINE.json's north_star names for the WASP branch: the three dilated 3x3 256->256 convolutions
-    (wasp.py:46-49, dilation 6 / 12 / 18 at 23x23) timed alone with HIP events on the launch stream.  Reported per
-    dilation: nominal and effective (taps that touch the image) TFLOP/s against the fp32 MFMA peak, and the
-    algorithmic bytes (input once + output once + weights once, SURVEY 8d: 37.0 MB at B=32) per second against the
-    8 TB/s HBM peak.  These kernels are compute-bound in fp32 (AI ~540 FLOP/B): the HBM fraction is stated because the
-    north star asks for it, the MFMA fraction is the meaningful one."""
+def wasp_dilated_leg(dev, batch=32, hw=23, iters=20, bf16=False, dilations=(6, 12, 18)):
+    """The quantity BASELINE.json's north_star names for the WASP branch: the dilated 3x3 256->256 convolutions
+    (wasp.py:46-49, dilation 6 / 12 / 18 at 23x23; 24 is the video variant's / output-stride-8 value) timed alone with HIP
+    events on the launch stream.  Reported per dilation: nominal and effective (taps that touch the image) TFLOP/s against
+    the MFMA peak of the arithmetic, and the algorithmic bytes (input once + output once + weights once, SURVEY 8d: 37.0 MB
+    at B=32 fp32, 35.8 MB at B=16 736x736 bf16) per second against the 8 TB/s HBM peak.  In fp32 these kernels are
+    compute-bound (AI ~540 FLOP/B) and the MFMA fraction is the meaningful one; bf16=True is the same leg in bf16 storage
+    at the geometry of configs[4] (46x46, B=16: the "dilated-conv HBM stress" case)."""
     from unipose_amd import _C, ops
     g = torch.Generator(device="cpu").manual_seed(1)
     x = torch.randn(batch, hw, hw, 256, generator=g).to(dev)
     w = (torch.randn(256, 256, 3, 3, generator=g) * 0.02).to(dev)
+    esize, peak = (2.0, BF16_MFMA_PEAK_TFLOPS) if bf16 else (4.0, F32_MFMA_PEAK_TFLOPS)
+    if bf16:
+        x = x.to(torch.bfloat16)
     rows = []
-    for dil in (6, 12, 18):
+    for dil in dilations:
         cfg = ops.ConvCfg(1, dil, dil)
         y, _, _ = ops.conv_fwd_raw(x, w, cfg)
         for _ in range(3):
@@ -168,17 +199,16 @@ def wasp_dilated_leg(dev, batch=32, hw=23, iters=20):
         ms = sum(arr[i * 3 + 1] for i in range(nv)) / max(launches, 1.0)
         live = sum(1 for p in range(hw) for r in (-1, 0, 1) if 0 <= p + r * dil < hw) ** 2 / float(hw * hw * 9)
         flop = 2.0 * batch * hw * hw * 256 * 256 * 9
-        nbytes = 4.0 * (x.numel() + batch * hw * hw * 256 + w.numel())
+        nbytes = esize * (x.numel() + batch * hw * hw * 256 + w.numel())
         rows.append({"dilation": dil, "ms": round(ms, 4), "live_tap_fraction": round(live, 3),
                      "nominal_tflops": round(flop / ms / 1e9, 1),
                      "effective_tflops": round(flop * live / ms / 1e9, 1),
-                     "effective_mfma_frac": round(flop * live / ms / 1e9 / F32_MFMA_PEAK_TFLOPS, 3),
+                     "effective_mfma_frac": round(flop * live / ms / 1e9 / peak, 3),
                      "algorithmic_gbps": round(nbytes / ms / 1e6, 1),
                      "hbm_frac": round(nbytes / ms / 1e6 / 8000.0, 4)})
     return rows
 
 
-BF16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA (32x32x16)
 HBM_PEAK_TBPS = 8.0
 
 
@@ -246,6 +276,14 @@ def profile_rows(lib, steps_profiled=1):
     return rows
 
 
+def top_by_time(rows):
+    """The variant with the largest summed launch duration, next to the FLOP ranking `profile_rows` returns: in the two-stream
+    timed region the side-stream weight gradient can be the larger one by time although it carries fewer FLOP."""
+    r = max(rows, key=lambda q: q["total_ms"])
+    return {"kernel": r["kernel"], "achieved": round(r["tflops"], 2), "frac": round(r["tflops"] / r["peak_tflops"], 4),
+            "total_ms": round(r["total_ms"], 3), "launches": r["launches"]}
+
+
 def other_config_leg(dev, name):
     """A BASELINE.json configuration other than the headline one, timed by the same driver run (rank 0, N=1 only, a few
     seconds each): its own throughput and the roofline of its dominant MFMA kernel from per-launch HIP events."""
@@ -294,9 +332,15 @@ def other_config_leg(dev, name):
         out["roofline"] = {"bound": "mfma", "kernel": top["kernel"], "achieved": round(top["tflops"], 2),
                            "peak": top["peak_tflops"], "unit": "TFLOP/s", "frac": round(top["tflops"] / top["peak_tflops"], 4),
                            "traffic": None, "avg_launch_ms": round(top["avg_ms"], 4), "launches": top["launches"],
-                           "mfma_ms_per_step": round(tot_ms, 3),
+                           "mfma_ms_per_step": round(tot_ms, 3), "top_by_time": top_by_time(rows),
                            "by_kernel": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()}
                                          for r in rows[:6]]}
+        if name != "lstm":
+            try:      # north_star's number for the dilated branch at the "HBM stress" configuration
+                out["roofline"]["wasp_dilated_bf16"] = wasp_dilated_leg(dev, batch=B, hw=S // 16, bf16=True,
+                                                                        dilations=(6, 12, 18, 24))
+            except Exception as e:      # a reporting extra must never cost the bench line
+                log(f"bf16 wasp leg skipped: {type(e).__name__}: {e}")
     del model, opt, step
     return out
 
@@ -325,6 +369,9 @@ def main():
     ap.add_argument("--frames", type=int, default=5)
     ap.add_argument("--force-dp", action="store_true",
                     help="run the gradient exchange (RCCL all-reduce, buckets, hooks) even with one rank")
+    ap.add_argument("--overlap", action="store_true",
+                    help="bucketed gradient exchange launched during backward (one hook per 32 MB bucket) instead of one flat "
+                         "all-reduce after it")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the extra split-bf16 timing loop")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the BASELINE configs[3] (LSTM) and configs[4] (736x736 bf16) legs appended at N=1")
@@ -374,6 +421,14 @@ def main():
     from model.unipose import unipose
     from unipose_amd import _C, ops
     from unipose_amd.dist import GradAllReducer, shard_seed
+    comm_ranks = None
+    if use_dist:       # the ranks that REALLY take part in a collective: an all-reduce of ones (not get_world_size())
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(ones)
+        comm_ranks = int(round(float(ones.item())))
+        log(f"process group up: backend {dist.get_backend()}, all-reduce of ones = {comm_ranks} (WORLD_SIZE {world})")
+        if comm_ranks != world:
+            raise SystemExit(f"all-reduce over {comm_ranks} ranks but WORLD_SIZE={world}")
     if args.wasp_only:
         print(json.dumps({"wasp_dilated": wasp_dilated_leg(dev)}), flush=True)
         return
@@ -396,7 +451,31 @@ def main():
     model, opt, step1 = make_workload(dev, lstm, K, B, S, T, seed=shard_seed(0, rank), emu=emu)
     ops.manual_seed(shard_seed(0, rank))
     ops.set_conv_math(args.math)
-    reducer = GradAllReducer(model, bucket_bytes=256 << 20, force=args.force_dp) if use_dist else None
+    # default: ONE flat all-reduce after backward (190 MB: ~1-2 ms on xGMI against a 66 ms fp32 step); --overlap: 32 MB
+    # buckets launched during backward by one hook per bucket (unipose_amd/dist.py)
+    reducer = None
+    if use_dist:
+        reducer = GradAllReducer(model, bucket_bytes=(32 << 20) if args.overlap else (256 << 20), force=args.force_dp,
+                                 overlap=args.overlap)
+    xch = {"ms": 0.0, "n": 0, "on": False}
+    if reducer is not None:       # host-side duration of the exchange call (copy into the flat buffer, all-reduce, wait) on
+        inner_finish = reducer.finish          # every step of the timed region; with --overlap only what is NOT hidden
+
+        def timed_finish():
+            if not xch["on"]:
+                return inner_finish()
+            if dev.type == "cuda":
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                inner_finish()
+                e1.record()
+                xch.setdefault("events", []).append((e0, e1))
+            else:
+                t_ = time.perf_counter()
+                inner_finish()
+                xch["ms"] += (time.perf_counter() - t_) * 1e3
+            xch["n"] += 1
+        reducer.finish = timed_finish
 
     def step():
         return step1(reducer)
@@ -416,6 +495,7 @@ def main():
     profile = (not args.no_profile) and rank == 0
     if profile:
         _C.lib().up_profile_begin()
+    xch["on"] = True
     t0 = time.perf_counter()
     for i in range(args.steps):
         if profile:        # every 4th step of the timed region is bracketed launch by launch (the events cost ~3 % of a step)
@@ -423,9 +503,24 @@ def main():
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    xch["on"] = False
     log(f"timed region: {args.steps} steps in {dt:.3f}s")
     loss_val = float(loss.detach())
+    dp = None
     if use_dist:
+        # first-run proof for N > 1: every rank's own clock, the exchange's share, and whether the replicas still agree
+        for e0, e1 in xch.get("events", []):
+            xch["ms"] += e0.elapsed_time(e1)
+        mine = torch.tensor([dt, xch["ms"] / max(xch["n"], 1),
+                             float(sum(p.detach().double().sum() for p in model.parameters()))],
+                            dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        dp = {"comm_ranks": comm_ranks, "backend": dist.get_backend(), "exchange": "overlap" if args.overlap else "flat",
+              "payload_mb": round(reducer.payload_bytes() / 1e6, 1),
+              "ms_per_step_by_rank": [round(1e3 * float(r[0]) / args.steps, 3) for r in allr],
+              "exchange_ms_by_rank": [round(float(r[1]), 3) for r in allr],
+              "weights_identical_across_ranks": all(float(r[2]) == float(allr[0][2]) for r in allr)}
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -442,6 +537,7 @@ def main():
                         "frac": round(top["tflops"] / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                         "avg_launch_ms": round(top["avg_ms"], 4), "launches": top["launches"],
                         "dominant_by": "algorithmic FLOP in the timed region (see profile_rows)",
+                        "top_by_time": top_by_time(rows),
                         "all_mfma_kernels": {"achieved": round(tot_fl / tot_ms, 2),
                                              "frac": round(tot_fl / tot_ms / F32_MFMA_PEAK_TFLOPS, 4),
                                              "ms_per_step": round(tot_ms / ((args.steps + 3) // 4), 3)},
@@ -457,6 +553,8 @@ def main():
                     roofline["traffic"] = round(rec["traffic_mb"] * 1e6)
                     roofline["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes, " \
                                                f"profiles/{pmc['tag']}_pmc_summary.txt)"
+                    roofline["traffic_source"] = (f"builder PMC pass, tag {pmc['tag']} (profiles/pmc_traffic.json): counters need "
+                                                  "their own rocprofv3 runs, this value is NOT measured inside this bench run")
             except (OSError, ValueError, KeyError):
                 pass
 
@@ -550,6 +648,9 @@ def main():
         if emu:
             out["dry_run"] = "CPU emulator + gloo: control-flow test only, the numbers mean nothing"
             out["metric"] = "DRY RUN (not a measurement): " + out["metric"]
+        if dp:
+            out["rccl_ranks"] = dp["comm_ranks"]
+            out["data_parallel"] = dp
         if roofline:
             out["roofline"] = roofline
         if alt:

@@ -25,7 +25,7 @@ def _run(nproc, extra=()):
     # the emulator needs ~10-20 s per training step of the full ResNet-101: no warm-up, one timed step (plus the two of the
     # exclusive pass), no alt-math loop (that loop has no rank-dependent branch)
     args = ["--gpus", str(nproc), "--steps", "1", "--warmup", "0", "--batch", "2", "--size", "32", "--dry-run-emu",
-            "--no-alt-math", *extra]
+            "--no-alt-math", *extra]     # (a later --steps in `extra` wins)
     if nproc == 1:
         cmd = [sys.executable, "bench.py", *args]
     else:
@@ -39,8 +39,13 @@ def _run(nproc, extra=()):
 
 
 def test_bench_flow_two_ranks():
-    out = _run(2)
-    assert out["n_gpus"] == 2 and out["steps"] == 1 and out["warmup"] == 0
+    out = _run(2, ["--steps", "2"])     # step 1: unbucketed exchange, step 2: flat-buffer exchange
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 0
+    dp = out["data_parallel"]
+    assert out["rccl_ranks"] == 2 and dp["comm_ranks"] == 2          # an all-reduce of ones really spans two ranks
+    assert len(dp["ms_per_step_by_rank"]) == 2 and len(dp["exchange_ms_by_rank"]) == 2
+    assert dp["weights_identical_across_ranks"] is True              # replicas agree after averaged-gradient Adam steps
+    assert dp["payload_mb"] > 100                                     # the 190 MB of live gradients went through the buckets
     assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     assert "dry_run" in out and out["metric"].startswith("DRY RUN")
     assert "cpu_baseline" not in out                   # rank 0 at N = 1 only

@@ -8,9 +8,10 @@ SURVEY D9) are detected on the first step and left out of the exchange.
 Two forms (``overlap``):
   * default — after backward: ONE multi-tensor copy of every gradient into flat buffers and one all-reduce per
     buffer (32 MB granularity); measured faster for this model than the hook form (see ``GradAllReducer``).
-  * ``overlap=True`` — buckets in reverse-registration (~ reverse autograd) order, each launched from
-    post-accumulate-grad hooks on the weight-gradient side stream of ``unipose_amd.ops`` so the main stream — the
-    critical path of backward — never waits for the exchange until ``finish()``.
+  * ``overlap=True`` — buckets in the order autograd hands out the gradients (recorded once, on the second step), each
+    launched by ONE post-accumulate-grad hook on the parameter that completes it, on the weight-gradient side stream of
+    ``unipose_amd.ops``: the main stream — the critical path of backward — never waits for the exchange until ``finish()``.
+    Needs ``zero_grad(set_to_none=True)`` (a missing gradient is how a changed graph is noticed).
 After the all-reduce ``param.grad`` simply becomes a view of the flat buffer (no copy back, no scaling pass:
 the collective averages).
 """
@@ -27,7 +28,7 @@ _DEBUG = os.environ.get("UP_DP_DEBUG", "")      # development switch: "hook-only
 
 
 class _Bucket:
-    __slots__ = ("params", "buf", "views", "pending", "work")
+    __slots__ = ("params", "buf", "views", "work")
 
     def __init__(self, params):
         self.params = params
@@ -37,7 +38,6 @@ class _Bucket:
         for p in params:
             self.views.append(self.buf[off:off + p.numel()].view_as(p))
             off += p.numel()
-        self.pending = len(params)
         self.work = None
 
 
@@ -51,7 +51,7 @@ class GradAllReducer:
         after backward.  The 190 MB exchange takes ~1-2 ms on xGMI against an 80+ ms fp32 step, while merely
         REGISTERING 345 post-accumulate-grad hooks was measured to cost 8.6 ms per step on the MI355X box
         (profiles/README.md), so the un-overlapped form is the faster one for this model.
-        overlap=True: bucketed exchange launched from post-accumulate-grad hooks during backward."""
+        overlap=True: bucketed exchange launched during backward from one hook per BUCKET (see _build)."""
         self.overlap = overlap
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -59,7 +59,6 @@ class GradAllReducer:
         self.bucket_bytes = bucket_bytes
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.buckets: Optional[List[_Bucket]] = None
-        self._where = {}
         self._handles = []
         backend = dist.get_backend(group) if dist.is_initialized() else ""
         self._avg = backend == "nccl"              # gloo has no AVG: sum, then scale
@@ -84,10 +83,9 @@ class GradAllReducer:
         return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     # -- first step: plain post-backward exchange, then build the buckets from what received a grad --
-    def _build(self):
-        live = [p for p in reversed(self.params) if p.grad is not None]
+    def _make_buckets(self, ordered):
         self.buckets, cur, size = [], [], 0
-        for p in live:
+        for p in ordered:
             cur.append(p)
             size += p.numel() * p.element_size()
             if size >= self.bucket_bytes:
@@ -95,23 +93,23 @@ class GradAllReducer:
                 cur, size = [], 0
         if cur:
             self.buckets.append(_Bucket(cur))
-        for bi, b in enumerate(self.buckets):
-            for p in b.params:
-                self._where[p] = bi
-                if self.overlap:
-                    self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
 
-    def _hook(self, p):
-        b = self.buckets[self._where[p]]
-        b.pending -= 1
-        if b.pending:
-            return
-        if _DEBUG == "hook-only":
-            b.pending = len(b.params)
-            return
-        # bucket complete: ONE multi-tensor copy + the collective, both on the side stream
+    def _build(self):
+        live = [p for p in reversed(self.params) if p.grad is not None]
+        self._make_buckets(live)
+        if self.overlap:
+            # Registering a post-accumulate hook on each of the 342 live parameters costs 8.6 ms of a 67 ms step on the MI355X box
+            # (profiles/README.md).  The order in which autograd hands out the gradients is a property of the (static) graph: the
+            # NEXT step records it through temporary per-parameter hooks, then the buckets are rebuilt in that order and only the
+            # parameter that completes a bucket keeps a hook (a handful per step).
+            self._order = []
+            self._handles = [p.register_post_accumulate_grad_hook(self._order.append) for p in live]
+            self._calibrating = True
+
+    def _launch(self, b, side_stream: bool):
+        """copy the bucket's gradients into its flat buffer and start the collective"""
         grads = [q.grad for q in b.params]
-        main, side = self._streams(b.buf.device)
+        main, side = self._streams(b.buf.device) if side_stream else (None, None)
         if side is not None:
             side.wait_stream(main)                 # BN / bias gradients come from the main stream
             with torch.cuda.stream(side):
@@ -121,8 +119,33 @@ class GradAllReducer:
             torch._foreach_copy_(b.views, grads)
             b.work = self._reduce(b.buf)
 
+    def _tail_hook(self, bi):
+        def hook(_p):
+            b = self.buckets[bi]
+            if _DEBUG == "hook-only" or b.work is not None:
+                return
+            # the tail parameter is the LAST of its bucket in the recorded order; if the graph changed and a gradient is still
+            # missing (zero_grad(set_to_none=True) leaves None), finish() exchanges this bucket after backward instead
+            if all(q.grad is not None for q in b.params):
+                self._launch(b, side_stream=True)
+        return hook
+
+    def _finish_calibration(self):
+        for h in self._handles:
+            h.remove()
+        seen, order = set(), []
+        for p in self._order:                      # first hand-out of every parameter, in autograd's order
+            if id(p) not in seen:
+                seen.add(id(p))
+                order.append(p)
+        order += [p for b in self.buckets for p in b.params if id(p) not in seen]
+        self._make_buckets(order)
+        self._handles = [b.params[-1].register_post_accumulate_grad_hook(self._tail_hook(bi))
+                         for bi, b in enumerate(self.buckets)]
+        self._calibrating = False
+
     def finish(self):
-        """Call after loss.backward(): waits for the in-flight buckets; param.grad becomes the averaged bucket view."""
+        """Call after loss.backward(): exchanges what is not in flight yet, waits; param.grad becomes the averaged bucket view."""
         if not self.active:
             return
         if self.buckets is None:
@@ -141,26 +164,24 @@ class GradAllReducer:
             return
         if _DEBUG == "hook-only":
             return
-        if not self.overlap:
-            if self.buckets and self.buckets[0].buf.is_cuda:
+        pending = [b for b in self.buckets if b.work is None]
+        if pending:
+            if pending[0].buf.is_cuda:
                 from . import ops
-                ops.wgrad_fence(self.buckets[0].buf.device)
-            for b in self.buckets:
-                grads = [p.grad for p in b.params]
-                if any(g is None for g in grads):
+                ops.wgrad_fence(pending[0].buf.device)
+            for b in pending:
+                if any(p.grad is None for p in b.params):
                     raise RuntimeError("a bucketed parameter received no gradient this step")
-                torch._foreach_copy_(b.views, grads)
-                b.work = self._reduce(b.buf)
-                b.pending = 0
+                self._launch(b, side_stream=False)
         for b in self.buckets:
-            if b.pending != 0:
-                raise RuntimeError("a bucketed parameter received no gradient this step")
             b.work.wait()                          # current (main) stream waits for the collective
             if not self._avg:
                 b.buf.div_(self.world)
             for p, v in zip(b.params, b.views):
                 p.grad = v
-            b.pending, b.work = len(b.params), None
+            b.work = None
+        if getattr(self, "_calibrating", False):
+            self._finish_calibration()
 
     def payload_bytes(self) -> int:
         return sum(b.buf.numel() * b.buf.element_size() for b in self.buckets) if self.buckets else 0
