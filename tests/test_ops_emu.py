@@ -219,6 +219,7 @@ def test_wgrad_bf16_kernel(emu_backend, cfg):
     from unipose_amd import _C, ops
     n, c, h, w, k, r, s, p, d, bias = cfg
     ops.set_conv_math("bf16")
+    ops.WGRAD_BF16_ANY_WIDTH = True      # (the model keeps layers that are not 32-channel aligned on the fp32 MFMA)
     try:
         for rect in (1, 0):
             _C.check(_C.lib().up_conv_tune(b"wgrad_rect", rect), "tune")
@@ -227,16 +228,19 @@ def test_wgrad_bf16_kernel(emu_backend, cfg):
     finally:
         _C.lib().up_conv_tune(b"wgrad_rect", 1)
         ops.set_conv_math("f32")
+        ops.WGRAD_BF16_ANY_WIDTH = False
 
 
 def test_wgrad_bf16_no_out_of_bounds(guard_pages):
     from unipose_amd import ops
     ops.set_conv_math("bf16")
+    ops.WGRAD_BF16_ANY_WIDTH = True
     try:
         for n, c, h, w, k, r, s, p, d, bias in WGRAD_BF16_CASES[:6]:
             oc.conv_case(torch.device("cpu"), n, c, h, w, k, r, s, p, d, bias=bias, tol=3e-2)
     finally:
         ops.set_conv_math("f32")
+        ops.WGRAD_BF16_ANY_WIDTH = False
 
 
 def test_conv_bn_no_out_of_bounds(guard_pages):

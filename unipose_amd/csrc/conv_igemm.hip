@@ -2016,6 +2016,15 @@ static const int* tap_sort_perm(const IgemmArgs& a) {
     std::lock_guard<std::mutex> lock(mu);
     auto it = table.find(key);
     if (it != table.end()) return it->second;
+    if (table.size() >= 1024) {   // variable-size inference: bound the per-geometry tables (in-flight launches finish first)
+#ifndef UP_EMU
+        (void)hipDeviceSynchronize();
+        for (auto& kv : table) (void)hipFree(kv.second);
+#else
+        for (auto& kv : table) free(kv.second);
+#endif
+        table.clear();
+    }
     const std::vector<int> perm = tap_sort_order(a, tap_masks(a));
     int* dev = nullptr;
     if ((int)perm.size() == a.M) {
@@ -2103,12 +2112,13 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     a.parts = 1;
     a.no_tap_skip = g_tap_skip ? 0 : 1;
     int grid = a.nwg;
-    SplitScratch* sc0 = aligned && tail_split_enabled() ? split_scratch(st) : nullptr;
+    // the scratch (16 MB + flags per stream) is only allocated for a launch that really splits: decide with the capacity
+    // it WOULD have (split_scratch: one 128x128 partial per CU, four flags per CU)
     bool all_tiles = false;
-    const size_t slots = sc0 ? std::min(sc0->pfloats / (size_t)(BM * BN), sc0->nflags) : 0;
-    const int p = aligned ? split_parts(a.nwg, a.Ktot, slots, &all_tiles) : 1;
+    const size_t slots = std::min((size_t)cu_count() * (128 * 128) / (size_t)(BM * BN), 4 * (size_t)cu_count());
+    const int p = aligned && tail_split_enabled() ? split_parts(a.nwg, a.Ktot, slots, &all_tiles) : 1;
     if (p >= 2) {
-        if (SplitScratch* sc = sc0) {
+        if (SplitScratch* sc = split_scratch(st)) {
             a.full_blocks = all_tiles ? 0 : a.nwg / cu_count() * cu_count();
             a.parts = p;
             a.partials = sc->partials;
@@ -2621,6 +2631,15 @@ static const int* wgrad_rect_device(const up_conv_desc* d, const WgradPlan& p) {
     std::lock_guard<std::mutex> lock(mu);
     auto it = table.find(key);
     if (it != table.end()) return it->second;
+    if (table.size() >= 1024) {   // bound the per-geometry tables (see tap_sort_perm)
+#ifndef UP_EMU
+        (void)hipDeviceSynchronize();
+        for (auto& kv : table) (void)hipFree(kv.second);
+#else
+        for (auto& kv : table) free(kv.second);
+#endif
+        table.clear();
+    }
     std::vector<int> tab;
     int* dev = nullptr;
     if (wgrad_rect_table(d, p, tab) < 0.999) {   // every tile sees the whole image (1x1, unpadded): keep the plain form

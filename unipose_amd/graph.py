@@ -18,6 +18,18 @@ Reference call sites: the validation / test loops `unipose.py:150-160`, `unipose
 import torch
 
 
+_CAPTURE_STREAMS = {}
+
+
+def _capture_stream(dev):
+    """ONE capture stream per device, shared by every GraphedForward: the library keeps per-stream scratch (K-split
+    partials), a private stream per instance would leak one scratch per graph."""
+    st = _CAPTURE_STREAMS.get(dev.index)
+    if st is None:
+        st = _CAPTURE_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+    return st
+
+
 class GraphedForward:
     def __init__(self, model, *example_args, warmup=3):
         if model.training:
@@ -30,7 +42,7 @@ class GraphedForward:
         self.warmup = warmup
         # library-owned scratch (K-split partials, tap-sort tables) is keyed by stream and allocated on first use: warm up
         # on the stream the capture will run on, so nothing allocates while capturing
-        self.stream = torch.cuda.Stream(device=self.device)
+        self.stream = _capture_stream(self.device)
         self.static_args = [a.clone() if torch.is_tensor(a) else a for a in example_args]
         self.graph = None
         self.static_out = None

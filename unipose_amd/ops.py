@@ -217,6 +217,7 @@ if os.environ.get("UNIPOSE_CONV_MATH"):           # e.g. UNIPOSE_CONV_MATH=bf16x
     set_conv_math(os.environ["UNIPOSE_CONV_MATH"])
 
 _PACK16_CACHE = {}
+WGRAD_BF16_ANY_WIDTH = False     # tests only: drive the bf16 weight-gradient kernel at channel counts the model keeps in fp32
 
 
 def _packed_bf16(weight: torch.Tensor, d: _C.ConvDesc):
@@ -343,7 +344,10 @@ def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws
     elif x.dtype != torch.float32 or dy.dtype != torch.float32:
         raise TypeError(f"weight gradient of mixed element types {x.dtype} / {dy.dtype}")
     else:
-        fn = _C.lib().up_conv2d_bwd_weight_bf16 if CONV_MATH in (MATH_BF16, MATH_BF16S) else _C.lib().up_conv2d_bwd_weight
+        # bf16 operands only where forward and data gradient use them too (32-aligned channel counts): the 3-channel stem and
+        # the 15-channel ConvLSTM convolutions stay on the exact fp32 MFMA in every pass
+        bf = CONV_MATH in (MATH_BF16, MATH_BF16S) and (WGRAD_BF16_ANY_WIDTH or (dd.Cp % 32 == 0 and dd.Kp % 32 == 0))
+        fn = _C.lib().up_conv2d_bwd_weight_bf16 if bf else _C.lib().up_conv2d_bwd_weight
     _C.check(fn(C.byref(dd), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel(),
                 _stream(x)), "conv2d_bwd_weight")
     return dw, db
@@ -409,8 +413,14 @@ def _side_stream(dev):
 
 def wgrad_fence(dev=None):
     """Make the current stream wait for every weight gradient issued so far."""
+    want = None
+    if dev is not None:                      # torch.device("cuda") has no index: it means the current device
+        dev = torch.device(dev)
+        if dev.type != "cuda":
+            return
+        want = dev.index if dev.index is not None else torch.cuda.current_device()
     for idx, st in _SIDE.items():
-        if dev is None or dev.index == idx:
+        if want is None or want == idx:
             torch.cuda.current_stream(st.device).wait_stream(st)
 
 
@@ -513,7 +523,7 @@ class ConvBias(Function):
         if ctx.needs_input_grad[1]:
             dw, db = conv_bwd_weight(x, dy, weight, ctx.d, ctx.has_bias and ctx.needs_input_grad[2])
         elif ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.reshape(-1, dy.shape[3]).sum(0)[:weight.shape[0]]
+            db = dy.reshape(-1, dy.shape[3]).float().sum(0)[:weight.shape[0]]      # fp32 sum for an fp32 bias, also in bf16 storage
         return dx, dw, db, None, None
 
 
