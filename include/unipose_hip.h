@@ -37,7 +37,7 @@ typedef enum {
 } up_status;
 
 const char* up_last_error(void);
-int up_abi_version(void);   /* 4 */
+int up_abi_version(void);   /* 5 */
 
 /* Geometry of one 2-D convolution (nn.Conv2d as used at resnet.py:10-16,61,80-84,104-109;
  * wasp.py:9,52,59-60; decoder.py:17,22,26,30; model/uniposeLSTM.py:12-14,30-38,85-89). */
@@ -159,6 +159,14 @@ int up_conv2d_bwd_weight_bf16(const up_conv_desc* d, const float* x, const float
 enum { UP_DT_F32 = 0, UP_DT_BF16 = 1 };
 int up_conv2d_bwd_weight_bf16s(const up_conv_desc* d, const void* x_bf16, const void* dy_bf16, float* dw_oihw,
                                float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+
+/* The three weight-gradient entry points above behind one signature, plus accumulation: `math` = UP_MATH_F32 (fp32 tensors,
+ * fp32 MFMA), UP_MATH_BF16 (fp32 tensors, bf16 operands) or UP_MATH_BF16S (bf16 tensors); accumulate != 0 ADDS the result to
+ * dw_oihw / dbias instead of overwriting them (dw += sum of the split-K slabs, in one rounding step like a separate add).
+ * A weight that is used several times per backward pass — every weight of the video model, once per frame
+ * (uniposeLSTM.py:116-133) — is then summed by the reduce pass itself: no extra buffer, no add kernel per use. */
+int up_conv2d_bwd_weight_acc(const up_conv_desc* d, const void* x, const void* dy, float* dw_oihw, float* dbias,
+                             void* workspace, size_t workspace_bytes, int math, int accumulate, void* stream);
 
 /* ---- BatchNorm (nn.BatchNorm2d, K7; every bnX site, e.g. resnet.py:11,14,16; wasp.py:11,53,61) ---- */
 /* eval: scale = g/sqrt(rv+eps), shift = b - rm*scale */

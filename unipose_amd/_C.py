@@ -51,6 +51,7 @@ SIGNATURES = {
     "up_conv2d_bwd_weight": (_i, [_D, _p, _p, _p, _p, _p, _sz, _p]),
     "up_conv2d_bwd_weight_bf16": (_i, [_D, _p, _p, _p, _p, _p, _sz, _p]),
     "up_conv2d_bwd_weight_bf16s": (_i, [_D, _p, _p, _p, _p, _p, _sz, _p]),
+    "up_conv2d_bwd_weight_acc": (_i, [_D, _p, _p, _p, _p, _p, _sz, _i, _i, _p]),
     "up_bn_eval_coeffs": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
     "up_bn_finalize": (_i, [_p, _i, _i, _f, _f, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "up_bn_apply": (_i, [_p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i64, _i, _p]),

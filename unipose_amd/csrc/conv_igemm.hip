@@ -1622,7 +1622,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradArgs a) {
 //  run 32-256 splits per tile, and ONE workgroup per tile then reads all of them, ~1.5 us per 64 KB slab tile, while this pass
 //  spreads the same bytes over the whole chip.  profiles/r02_i_knob_ab.txt, r02_m.)
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* slab, float* dw, int splits, int K, int C,
-                                                          int Cp, int taps, long long total4 /* K*taps*Cp / 4 */) {
+                                                          int Cp, int taps, long long total4 /* K*taps*Cp / 4 */,
+                                                          int accumulate /* dw += the sum instead of dw = the sum */) {
     // one thread = 4 consecutive input channels (Cp % 4 == 0): 16-byte slab reads
     long long q = (long long)blockIdx.x * 256 + threadIdx.x;
     if (q >= total4) return;
@@ -1652,11 +1653,20 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* slab, fl
     add4(s1, s3);
     const float v[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
     if (taps == 1 && ci + 3 < C && (C & 3) == 0) {
-        *reinterpret_cast<float4*>(dw + (size_t)co * C + ci) = make_float4(v[0], v[1], v[2], v[3]);
+        float4* o = reinterpret_cast<float4*>(dw + (size_t)co * C + ci);
+        float4 r = make_float4(v[0], v[1], v[2], v[3]);
+        if (accumulate) {
+            const float4 old = *o;
+            r = make_float4(old.x + r.x, old.y + r.y, old.z + r.z, old.w + r.w);
+        }
+        *o = r;
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (ci + j < C) dw[((size_t)co * C + ci + j) * taps + tap] = v[j];
+            if (ci + j < C) {
+                float* o = dw + ((size_t)co * C + ci + j) * taps + tap;
+                *o = accumulate ? *o + v[j] : v[j];
+            }
     }
 }
 
@@ -2676,7 +2686,21 @@ extern "C" size_t up_conv2d_bwd_weight_workspace(const up_conv_desc* d) {
 
 namespace up {
 static int conv2d_bwd_weight_impl(const up_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
-                                  void* workspace, size_t workspace_bytes, int bf16, void* stream);
+                                  void* workspace, size_t workspace_bytes, int bf16, void* stream, int accumulate = 0);
+}
+extern "C" int up_conv2d_bwd_weight_acc(const up_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
+                                        void* workspace, size_t workspace_bytes, int math, int accumulate, void* stream) {
+    UP_REQUIRE(math == UP_MATH_F32 || math == UP_MATH_BF16 || math == UP_MATH_BF16S, UP_ERR_INVALID,
+               "conv2d_bwd_weight_acc: math mode %d", math);
+    if (math == UP_MATH_BF16S) {
+        UP_REQUIRE(d && d->Cp % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0, UP_ERR_INVALID,
+                   "conv2d_bwd_weight_acc: bf16 storage needs Cp, ldx and ldy to be multiples of 8 (16-byte channel groups)");
+        UP_REQUIRE((int64_t)d->N * d->H * d->W * d->ldx < (1ll << 31) && (int64_t)d->N * d->P * d->Q * d->ldy < (1ll << 31),
+                   UP_ERR_UNSUPPORTED, "conv2d_bwd_weight_acc: more than 2^31 elements");
+    }
+    return conv2d_bwd_weight_impl(d, static_cast<const float*>(x), static_cast<const float*>(dy), dw, dbias, workspace,
+                                  workspace_bytes, math == UP_MATH_F32 ? 0 : math == UP_MATH_BF16 ? 1 : 2, stream,
+                                  accumulate ? 1 : 0);
 }
 extern "C" int up_conv2d_bwd_weight(const up_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
                                     void* workspace, size_t workspace_bytes, void* stream) {
@@ -2696,7 +2720,7 @@ extern "C" int up_conv2d_bwd_weight_bf16s(const up_conv_desc* d, const void* x, 
                                   workspace_bytes, 2, stream);
 }
 static int up::conv2d_bwd_weight_impl(const up_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
-                                      void* workspace, size_t workspace_bytes, int bf16, void* stream) {
+                                      void* workspace, size_t workspace_bytes, int bf16, void* stream, int accumulate) {
     if (int e = check_desc(d)) return e;
     UP_REQUIRE(x && dy && dw && workspace, UP_ERR_INVALID, "conv2d_bwd_weight: null pointer");
     UP_REQUIRE(d->ldy % 4 == 0, UP_ERR_INVALID, "conv2d_bwd_weight: ldy=%d must be a multiple of 4", d->ldy);
@@ -2842,9 +2866,9 @@ static int up::conv2d_bwd_weight_impl(const up_conv_desc* d, const float* x, con
     }
     long long total4 = (long long)d->K * a.Ncols / 4;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, st, (const float*)workspace, dw,
-                       p.splits, d->K, d->C, d->Cp, d->R * d->S, total4);
+                       p.splits, d->K, d->C, d->Cp, d->R * d->S, total4, accumulate);
     if (dbias) {
-        if (hipMemsetAsync(dbias, 0, sizeof(float) * d->K, st) != hipSuccess) return check_launch("dbias memset");
+        if (!accumulate && hipMemsetAsync(dbias, 0, sizeof(float) * d->K, st) != hipSuccess) return check_launch("dbias memset");
         int rpb = 1024;
         dim3 g(cdiv(a.M, rpb), cdiv(d->K, 64));
         if (bf16 == 2)

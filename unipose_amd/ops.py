@@ -331,25 +331,29 @@ class GradLink:
         self.armed = False
 
 
-def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws_tag: str = "main"):
+def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws_tag: str = "main", out=None):
+    """dw (and db) of one convolution.  `out`: an existing fp32 gradient buffer the result is ADDED to by the split-K reduce
+    pass itself (up_conv2d_bwd_weight_acc, accumulate = 1): the sum over the uses of a shared weight without an add kernel."""
     dd = _C.ConvDesc.from_buffer_copy(d)
     dd.ldx = _nhwc_ok(x)
     dd.ldy = _nhwc_ok(dy)
     need = _C.lib().up_conv2d_bwd_weight_workspace(C.byref(dd))
     ws = workspace(x.device, need, ws_tag)
-    dw = torch.empty(weight_shape, dtype=torch.float32, device=x.device)
+    dw = out if out is not None else torch.empty(weight_shape, dtype=torch.float32, device=x.device)
     db = torch.empty(weight_shape[0], dtype=torch.float32, device=x.device) if want_bias else None
     if x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16:
-        fn = _C.lib().up_conv2d_bwd_weight_bf16s
+        math = MATH_BF16S
     elif x.dtype != torch.float32 or dy.dtype != torch.float32:
         raise TypeError(f"weight gradient of mixed element types {x.dtype} / {dy.dtype}")
     else:
         # bf16 operands only where forward and data gradient use them too (32-aligned channel counts): the 3-channel stem and
         # the 15-channel ConvLSTM convolutions stay on the exact fp32 MFMA in every pass
         bf = CONV_MATH in (MATH_BF16, MATH_BF16S) and (WGRAD_BF16_ANY_WIDTH or (dd.Cp % 32 == 0 and dd.Kp % 32 == 0))
-        fn = _C.lib().up_conv2d_bwd_weight_bf16 if bf else _C.lib().up_conv2d_bwd_weight
-    _C.check(fn(C.byref(dd), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(), ws.numel(),
-                _stream(x)), "conv2d_bwd_weight")
+        math = MATH_BF16 if bf else MATH_F32
+    if out is not None and want_bias:
+        raise ValueError("accumulating weight gradient: the bias gradient is not accumulated here")
+    _C.check(_C.lib().up_conv2d_bwd_weight_acc(C.byref(dd), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(),
+                                               ws.numel(), math, int(out is not None), _stream(x)), "conv2d_bwd_weight")
     return dw, db
 
 
@@ -460,13 +464,16 @@ def conv_bwd_weight(x, dy, weight, d, want_bias):
             return conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias)
     side.wait_stream(main)
     with torch.cuda.stream(side):
+        defer = _DEFER["on"] and not want_bias and not getattr(weight, "_post_accumulate_grad_hooks", None)
+        entry = _DEFER["acc"].get(id(weight)) if defer else None
+        if entry is not None:             # a later use of the weight: the reduce pass adds to the first use's buffer
+            conv_bwd_weight_raw(x, dy, weight.shape, d, False, ws_tag="side", out=entry[1])
+            for t in (x, dy):
+                t.record_stream(side)
+            return None, None
         dw, db = conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias, ws_tag="side")
-        if _DEFER["on"] and db is None and not getattr(weight, "_post_accumulate_grad_hooks", None):
-            entry = _DEFER["acc"].get(id(weight))
-            if entry is None:
-                _DEFER["acc"][id(weight)] = (weight, dw)
-            else:
-                entry[1].add_(dw)             # on the side stream, ordered behind both weight-gradient kernels
+        if defer:
+            _DEFER["acc"][id(weight)] = (weight, dw)
             for t in (x, dy):
                 t.record_stream(side)
             dw.record_stream(main)
