@@ -205,6 +205,25 @@ int up_bn_bwd_acc_t(const void* dz, int lddz, const void* z, int ldz, const uint
                 void* dy, int lddy, void* dres, int lddres, float* dgamma, float* dbeta, float* acc_dgamma, float* acc_dbeta,
                 float* workspace, size_t workspace_bytes, int64_t rows, int C, int dtype, void* stream);
 
+/* ---- grouped BatchNorm: one tensor holds `groups` row groups of equal size (the T frames of a clip batch, frame-major), each
+ * normalised with ITS OWN batch statistics — what `groups` separate module calls do in the reference's video loop
+ * (uniposeLSTM.py:116-133 runs the trunk once per frame), while every convolution sees one T-times larger batch.
+ *   up_bn_batch_stats_t      partial (count, mean, M2) per (group, 256-row chunk, channel): stats[groups][tiles][C][3]
+ *   up_bn_finalize_groups    coef[groups][4][C] = mean, invstd, scale, shift; running statistics updated group by group
+ *   up_bn_apply_groups_t     z = relu(y * scale_g + shift_g (+ res)) per group, relu_bits as in up_bn_apply
+ *   up_bn_bwd_groups_t       data gradient per group from that group's sums; dgamma / dbeta = sums over all groups */
+int up_bn_batch_stats_tiles(int64_t rows_per_group);
+int up_bn_batch_stats_t(const void* y, int ldy, int64_t rows_per_group, int C, int groups, int dtype, float* stats, void* stream);
+int up_bn_finalize_groups(const float* stats, int tiles, int C, int groups, float eps, float momentum, float* running_mean,
+                          float* running_var, const float* gamma, const float* beta, float* coef, void* stream);
+int up_bn_apply_groups_t(const void* y, int ldy, const float* coef, const void* res, int ldr, int relu, void* z, int ldz,
+                         uint32_t* relu_bits, int64_t rows_per_group, int C, int groups, int dtype, void* stream);
+size_t up_bn_bwd_groups_workspace(int64_t rows_per_group, int C);
+int up_bn_bwd_groups_t(const void* dz, int lddz, const uint32_t* relu_bits, const void* y, int ldy, const float* gamma,
+                       const float* coef, int relu, void* dy, int lddy, void* dres, int lddres, float* dgamma, float* dbeta,
+                       float* workspace, size_t workspace_bytes, int64_t rows_per_group, int C, int groups, int dtype,
+                       void* stream);
+
 /* ---- pointwise / data movement ---- */
 int up_relu_bwd(const float* dz, const float* z, float* dx, int64_t n, void* stream);              /* K8 */
 int up_copy2d(const float* src, int lds, float* dst, int ldd, int64_t rows, int C, void* stream);   /* K13 */

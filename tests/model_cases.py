@@ -137,7 +137,7 @@ def train_case(dev, K=16, B=2, size=32, wseed=3, dropout_masks=False):
             assert int(msd[k]) == int(v) == 1, k
 
 
-def lstm_case(dev, K=13, B=1, size=32, T=3, wseed=4, tol=1e-3, train=False, deferred=False):
+def lstm_case(dev, K=13, B=1, size=32, T=3, wseed=4, tol=1e-3, train=False, deferred=False, batch_frames=False):
     """T-frame unroll with the reference driver's call pattern (uniposeLSTM.py:116-133).  eval: strict
     tolerance per frame.  train: summed MSE, ONE backward through all frames (BPTT), fp64 yardstick."""
     from model.uniposeLSTM import unipose_lstm
@@ -147,6 +147,7 @@ def lstm_case(dev, K=13, B=1, size=32, T=3, wseed=4, tol=1e-3, train=False, defe
     m.load_state_dict(sd)
     m = m.to(dev)
     m.train(train)
+    m.batch_frames = batch_frames        # trunk once on all T frames (per-frame BatchNorm statistics): same results
     if train:
         m.wasp.dropout.p = 0.0
         m.decoder.last_conv[3].p = 0.0
@@ -188,6 +189,13 @@ def lstm_case(dev, K=13, B=1, size=32, T=3, wseed=4, tol=1e-3, train=False, defe
             ops.set_relu_trace(None)
         if train:                                            # same ReLU sign patterns on both sides
             trace = [z.cpu() for z in trace]
+            if batch_frames and T > 1:
+                # the batched trunk recorded ONE entry per ReLU for all T frames (frame-major rows), then the head's five
+                # per frame; the oracle consumes them frame by frame: trunk entries of frame j, then its head entries
+                nh = 5
+                trunk, head = trace[:len(trace) - T * nh], trace[len(trace) - T * nh:]
+                assert all(z.shape[0] == T * B for z in trunk) and all(z.shape[0] == B for z in head)
+                trace = [e for j in range(T) for e in [z[j * B:(j + 1) * B] for z in trunk] + head[j * nh:(j + 1) * nh]]
             with O.relu_masks_from(trace):
                 o32, l32 = run_oracle(sd32, torch.float32)
             sd64 = _sd64(sd, True)

@@ -390,3 +390,75 @@ def bn_rows_ab_case(dev, n, c, h, w, k, relu=True, residual=True, dtype=torch.fl
         else:
             err = float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
             assert err < tol, (what, err)
+
+
+def bn_groups_case(dev, groups, n, c, h, w, k, r=1, relu=True, residual=False, dtype=torch.float32, seed=0, tol=5e-5):
+    """conv -> BatchNorm inside ops.bn_groups(G) on a batch of G*n images (group-major) against G separate train-mode calls
+    of torch's conv + BatchNorm on the G sub-batches with the SAME modules: outputs, data / residual gradients per group,
+    parameter gradients summed over the groups, running statistics after G sequential momentum updates, the batch counter."""
+    import copy
+    pad = r // 2
+    x = torch.randn(groups * n, c, h, w, generator=g(seed)) + 0.3
+    conv = torch.nn.Conv2d(c, k, r, padding=pad, bias=False)
+    bn = torch.nn.BatchNorm2d(k)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g(seed + 1)) * (2.0 / (c * r * r)) ** 0.5)
+        bn.weight.copy_(0.5 + torch.rand(k, generator=g(seed + 2)))
+        bn.bias.copy_(0.2 * torch.randn(k, generator=g(seed + 3)))
+        bn.running_mean.copy_(0.1 * torch.randn(k, generator=g(seed + 4)))
+        bn.running_var.copy_(0.5 + torch.rand(k, generator=g(seed + 5)))
+    bf = dtype == torch.bfloat16
+    if bf:
+        x = x.to(dtype).float()
+        with torch.no_grad():
+            conv.weight.copy_(conv.weight.to(dtype).float())
+    conv_d, bn_d = copy.deepcopy(conv).to(dev).train(), copy.deepcopy(bn).to(dev).train()
+    conv.train(), bn.train()
+    res = torch.randn(groups * n, k, h, w, generator=g(seed + 6)) if residual else None
+    if bf and residual:
+        res = res.to(dtype).float()
+    dy = torch.randn(groups * n, k, h, w, generator=g(seed + 7))
+    if bf:
+        dy = dy.to(dtype).float()
+    xr = x.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if residual else None
+    outs = []
+    for gi in range(groups):                     # the reference's way: one module call per group (frame)
+        sl = slice(gi * n, (gi + 1) * n)
+        o = bn(conv(xr[sl]))
+        if residual:
+            o = o + rr[sl]
+        outs.append(o)
+    yr = torch.cat(outs, 0)
+
+    def to_dev(t, ch):
+        cp = ops.rup32(ch) if bf else ops.rup4(ch)
+        o = torch.zeros(t.shape[0], t.shape[2], t.shape[3], cp)
+        o[..., :ch] = t.permute(0, 2, 3, 1)
+        return o.to(dtype).to(dev)
+    xd = to_dev(x, c).requires_grad_(True)
+    rd = to_dev(res, k).requires_grad_(True) if residual else None
+    with ops.bn_groups(groups):
+        y = ops.conv_bn_act(xd, conv_d, bn_d, relu=relu, residual=rd)
+    yo = nchw(y, k)
+    yr_fwd = F.relu(yr) if relu else yr
+    if relu:
+        yr = yr * (yo > 0).float()
+    yr.backward(dy)
+    y.backward(to_dev(dy, k))
+    errs = {
+        "y": rel(yo, yr_fwd.detach()),
+        "dx": rel(nchw(xd.grad, c), xr.grad),
+        "dw": rel(conv_d.weight.grad.cpu(), conv.weight.grad),
+        "dgamma": rel(bn_d.weight.grad.cpu(), bn.weight.grad),
+        "dbeta": rel(bn_d.bias.grad.cpu(), bn.bias.grad),
+        "rm": rel(bn_d.running_mean.cpu(), bn.running_mean),
+        "rv": rel(bn_d.running_var.cpu(), bn.running_var),
+    }
+    if residual:
+        errs["dres"] = rel(nchw(rd.grad, k), rr.grad)
+    assert int(bn_d.num_batches_tracked) == int(bn.num_batches_tracked) == groups
+    # bf16 storage: the group statistics are taken from the STORED (rounded) convolution output
+    bad = {k_: v for k_, v in errs.items() if not v < (tol if not bf else 2e-3 if k_ in ("rm", "rv") else 3e-2)}
+    assert not bad, (bad, errs)
+    return errs

@@ -32,6 +32,16 @@ def test_lstm_train_bptt_deferred_wgrad_emu(emu_backend):
     mc.lstm_case(emu_backend, size=32, T=3, B=2, train=True, deferred=True)
 
 
+def test_lstm_eval_batched_frames_emu(emu_backend):
+    # trunk once on all T frames: eval mode (running statistics), per-frame outputs unchanged
+    mc.lstm_case(emu_backend, size=32, T=3, B=1, batch_frames=True)
+
+
+def test_lstm_train_bptt_batched_frames_emu(emu_backend):
+    # trunk once on all T frames, BatchNorm statistics per frame (ops.bn_groups), one backward through everything
+    mc.lstm_case(emu_backend, size=32, T=3, B=2, train=True, deferred=True, batch_frames=True)
+
+
 def test_output_stride_8_vs_reference_golden_emu(emu_backend, golden_dir):
     """output_stride = 8 through the drop-in modules (layer3 at dilation 2, multi-grid 4 / 8 / 16, WASP dilations 48 / 36 /
     24 / 12 on a 20x20 map) against the genuine reference's output, argmax and stage taps (G12)"""

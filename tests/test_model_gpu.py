@@ -68,13 +68,15 @@ def test_g12_output_stride_8_vs_reference_golden(golden_dir):
     assert max(errs.values()) < 1e-4, errs
 
 
-def test_g5_lstm_368_vs_reference_golden(golden_dir):
+@pytest.mark.parametrize("batch_frames", [False, True], ids=["per_frame", "batched_frames"])
+def test_g5_lstm_368_vs_reference_golden(golden_dir, batch_frames):
     from model.uniposeLSTM import unipose_lstm
     g = np.load(os.path.join(golden_dir, "g5_lstm_368.npz"))
     K, wseed, xseed, cseed = (int(v) for v in g["meta"])
     m = unipose_lstm(num_classes=K)
     m.load_state_dict(O.synth_state_dict(K, wseed, lstm=True))
     m = m.to(DEV).eval()
+    m.batch_frames = batch_frames                                       # trunk once on all five frames
     x = O.synth_input((1, 5, 3, 368, 368), xseed).to(DEV)
     cm = O.synth_input((1, 5, 1, 368, 368), cseed, "rand").to(DEV)
     heat = torch.zeros(K + 1, 46, 46, device=DEV)
@@ -144,6 +146,11 @@ def test_eval_vs_oracle_odd_sizes():
 
 def test_lstm_train_bptt_vs_oracle():
     mc.lstm_case(DEV, size=96, T=3, B=2, train=True)
+
+
+def test_lstm_train_bptt_batched_frames_vs_oracle():
+    """trunk once on all T frames with per-frame BatchNorm statistics (ops.bn_groups): same yardsticks as the per-frame form"""
+    mc.lstm_case(DEV, size=96, T=3, B=2, train=True, deferred=True, batch_frames=True)
 
 
 def test_lstm_batch_generalisation():

@@ -289,3 +289,17 @@ def test_bn_row_strided_passes_match_flat_passes(emu_backend, cfg):
     n, c, h, w, k, relu, residual, dt = cfg
     oc.bn_rows_ab_case(emu_backend, n, c, h, w, k, relu=relu, residual=residual,
                        dtype=torch.float32 if dt == "f32" else torch.bfloat16)
+
+
+@pytest.mark.parametrize("cfg", [
+    (3, 2, 32, 5, 7, 32, 1, True, False, "f32"),      # three groups of two images
+    (5, 2, 32, 6, 6, 48, 3, True, True, "f32"),       # 3x3, residual, channel groups not a power of two (flat kernels)
+    (2, 3, 32, 9, 9, 64, 1, False, True, "f32"),      # no ReLU: no bit array
+    (3, 2, 32, 5, 8, 64, 1, True, True, "bf16"),
+])
+def test_grouped_batchnorm_matches_separate_calls(emu_backend, cfg):
+    """ops.bn_groups(G): one convolution over G*n images, BatchNorm statistics / running updates / gradients of G calls"""
+    import torch
+    groups, n, c, h, w, k, r, relu, residual, dt = cfg
+    oc.bn_groups_case(emu_backend, groups, n, c, h, w, k, r=r, relu=relu, residual=residual,
+                      dtype=torch.float32 if dt == "f32" else torch.bfloat16)

@@ -177,3 +177,16 @@ def test_targets(golden_dir):
 def test_bn_row_strided_passes_match_flat_passes(cfg):
     n, c, h, w, k, relu, residual, dt = cfg
     oc.bn_rows_ab_case(DEV, n, c, h, w, k, relu=relu, residual=residual, dtype=torch.float32 if dt == "f32" else torch.bfloat16)
+
+
+@pytest.mark.parametrize("cfg", [
+    (5, 8, 64, 23, 23, 256, 1, True, False, "f32"),      # configs[3] geometry: five frames of eight images
+    (5, 8, 64, 23, 23, 1024, 1, True, True, "f32"),
+    (5, 2, 64, 46, 46, 64, 3, True, False, "f32"),
+    (3, 2, 64, 23, 23, 48, 1, True, True, "f32"),        # channel groups not a power of two
+    (5, 4, 64, 23, 23, 256, 1, True, True, "bf16"),
+])
+def test_grouped_batchnorm_matches_separate_calls(cfg):
+    groups, n, c, h, w, k, r, relu, residual, dt = cfg
+    oc.bn_groups_case(DEV, groups, n, c, h, w, k, r=r, relu=relu, residual=residual,
+                      dtype=torch.float32 if dt == "f32" else torch.bfloat16)

@@ -406,6 +406,62 @@ static bool bn_rows_enabled() {
     return g_bn_rows != 0;
 }
 
+// ---- batch statistics of row GROUPS (video model: the trunk runs ONCE on all T frames of a clip batch, but the reference
+// normalises every frame's batch on its own, uniposeLSTM.py:116-133 calls the trunk per frame) ------------------------------
+// The convolution epilogue's per-tile partials cannot serve here: a row tile may straddle two frames.  One extra read of y
+// instead: partial (count, mean, M2) per (group, 256-row chunk, channel), the format bn_finalize_kernel merges.  A thread
+// accumulates shifted sums (shift = its first sample, so there is no cancellation) over its 16 rows, the 16 row lanes are
+// merged in a fixed order.
+constexpr int BNS_ROWS = 256;
+template <typename T>
+__global__ void __launch_bounds__(256) bn_batch_stats_kernel(const T* y, int ldy, int rows_per_group, int C, float* stats, int tiles) {
+    __shared__ float red[16][64][3];
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + cq * 4;
+    const int g = blockIdx.z;
+    const int r0 = blockIdx.x * BNS_ROWS, r1 = min(rows_per_group, r0 + BNS_ROWS);
+    float n = 0.f, sh[4] = {0.f, 0.f, 0.f, 0.f}, s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        const T* base = y + (size_t)g * rows_per_group * ldy + c;
+        for (int r = r0 + rl; r < r1; r += 16) {
+            const float4 v = ld4<T>(base + (size_t)r * ldy);
+            const float x[4] = {v.x, v.y, v.z, v.w};
+            if (n == 0.f) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sh[e] = x[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = x[e] - sh[e];
+                s[e] += d;
+                q[e] += d * d;
+            }
+            n += 1.f;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float mean = n > 0.f ? sh[e] + s[e] / n : 0.f;
+        const float m2 = n > 0.f ? fmaxf(q[e] - s[e] * s[e] / n, 0.f) : 0.f;
+        red[rl][cq * 4 + e][0] = n;
+        red[rl][cq * 4 + e][1] = mean;
+        red[rl][cq * 4 + e][2] = m2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int ch = threadIdx.x;
+        float cn = 0.f, cm = 0.f, cs = 0.f;
+        for (int k = 0; k < 16; ++k) wf_merge3(cn, cm, cs, red[k][ch][0], red[k][ch][1], red[k][ch][2]);
+        const int cc = blockIdx.y * 64 + ch;
+        if (cc < C) {
+            float* o = stats + (((size_t)g * tiles + blockIdx.x) * C + cc) * 3;
+            o[0] = cn;
+            o[1] = cm;
+            o[2] = cs;
+        }
+    }
+}
+
 // ---- BN backward -------------------------------------------------------------------------
 // pass 1: partial[chunk][c] = {sum g, sum g*xhat},   g = dz * (z > 0 if relu)
 // 256 threads = 16 row lanes x 16 channel quads (64 channels): every access is a 16-byte load of 4
@@ -850,6 +906,83 @@ extern "C" int up_bn_bwd(const float* dz, int lddz, const float* z, int ldz, con
                          float* workspace, size_t workspace_bytes, int64_t rows, int C, void* stream) {
     return up_bn_bwd_t(dz, lddz, z, ldz, relu_bits, y, ldy, gamma, mean, invstd, relu, use_batch_stats, dy, lddy, dres,
                        lddres, dgamma, dbeta, workspace, workspace_bytes, rows, C, UP_DT_F32, stream);
+}
+
+// ---- grouped BatchNorm: G row groups of equal size in one tensor, each normalised with its own batch statistics ------------
+extern "C" int up_bn_batch_stats_tiles(int64_t rows_per_group) { return cdiv(rows_per_group, BNS_ROWS); }
+extern "C" int up_bn_batch_stats_t(const void* y, int ldy, int64_t rows_per_group, int C, int groups, int dtype, float* stats,
+                                   void* stream) {
+    UP_REQUIRE(y && stats && rows_per_group > 0 && rows_per_group < (1ll << 31) && C > 0 && groups > 0 && groups <= 65535,
+               UP_ERR_INVALID, "bn_batch_stats: bad argument");
+    UP_REQUIRE(C % 4 == 0 && ldy % 4 == 0, UP_ERR_INVALID, "bn_batch_stats: C and ldy must be multiples of 4");
+    UP_REQUIRE(dtype == UP_DT_F32 || dtype == UP_DT_BF16, UP_ERR_INVALID, "bn_batch_stats: dtype %d", dtype);
+    const int tiles = cdiv(rows_per_group, BNS_ROWS);
+    dim3 grid(tiles, cdiv(C, 64), groups);
+    if (dtype == UP_DT_BF16)
+        hipLaunchKernelGGL(bn_batch_stats_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)y, ldy,
+                           (int)rows_per_group, C, stats, tiles);
+    else
+        hipLaunchKernelGGL(bn_batch_stats_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)y, ldy,
+                           (int)rows_per_group, C, stats, tiles);
+    return check_launch("bn_batch_stats");
+}
+// coef: [groups][4][C] = mean, invstd, scale, shift per group.  The groups are finalised IN ORDER on the stream, so the running
+// statistics receive the same sequence of momentum updates as `groups` separate forward calls.
+extern "C" int up_bn_finalize_groups(const float* stats, int tiles, int C, int groups, float eps, float momentum, float* rm,
+                                     float* rv, const float* gamma, const float* beta, float* coef, void* stream) {
+    UP_REQUIRE(stats && gamma && beta && coef && tiles > 0 && C > 0 && groups > 0, UP_ERR_INVALID, "bn_finalize_groups: bad argument");
+    UP_REQUIRE((rm == nullptr) == (rv == nullptr), UP_ERR_INVALID, "bn_finalize_groups: running stats must come in pairs");
+    for (int g = 0; g < groups; ++g) {
+        float* cg = coef + (size_t)g * 4 * C;
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, as_stream(stream), stats + (size_t)g * tiles * C * 3, tiles, C,
+                           eps, momentum, rm, rv, gamma, beta, cg, cg + C, cg + 2 * C, cg + 3 * C);
+    }
+    return check_launch("bn_finalize_groups");
+}
+extern "C" int up_bn_apply_groups_t(const void* y, int ldy, const float* coef, const void* res, int ldr, int relu, void* z, int ldz,
+                                    uint32_t* relu_bits, int64_t rows_per_group, int C, int groups, int dtype, void* stream) {
+    UP_REQUIRE(coef && groups > 0, UP_ERR_INVALID, "bn_apply_groups: bad argument");
+    UP_REQUIRE(!relu_bits || (rows_per_group * C) % 32 == 0, UP_ERR_UNSUPPORTED,
+               "bn_apply_groups: rows_per_group * C must be a multiple of 32 (a group's ReLU bits start on a word)");
+    const size_t es = dtype == UP_DT_BF16 ? 2 : 4;
+    for (int g = 0; g < groups; ++g) {
+        const float* cg = coef + (size_t)g * 4 * C;
+        const size_t r0 = (size_t)g * rows_per_group;
+        if (int e = up_bn_apply_t((const char*)y + r0 * ldy * es, ldy, cg + 2 * C, cg + 3 * C, res ? (const char*)res + r0 * ldr * es : nullptr,
+                                  ldr, relu, (char*)z + r0 * ldz * es, ldz, relu_bits ? relu_bits + r0 * C / 32 : nullptr, rows_per_group,
+                                  C, dtype, stream))
+            return e;
+    }
+    return UP_OK;
+}
+extern "C" size_t up_bn_bwd_groups_workspace(int64_t rows_per_group, int C) {
+    return up_bn_bwd_workspace(rows_per_group, C) + (size_t)2 * C * sizeof(float);
+}
+// dgamma / dbeta: sums over ALL groups (the parameter gradients); every group's data gradient uses its own batch sums
+extern "C" int up_bn_bwd_groups_t(const void* dz, int lddz, const uint32_t* relu_bits, const void* y, int ldy, const float* gamma,
+                                  const float* coef, int relu, void* dy, int lddy, void* dres, int lddres, float* dgamma,
+                                  float* dbeta, float* workspace, size_t workspace_bytes, int64_t rows_per_group, int C, int groups,
+                                  int dtype, void* stream) {
+    UP_REQUIRE(coef && dgamma && dbeta && workspace && groups > 0, UP_ERR_INVALID, "bn_bwd_groups: bad argument");
+    UP_REQUIRE(workspace_bytes >= up_bn_bwd_groups_workspace(rows_per_group, C), UP_ERR_WORKSPACE, "bn_bwd_groups: workspace too small");
+    UP_REQUIRE(!relu_bits || (rows_per_group * C) % 32 == 0, UP_ERR_UNSUPPORTED,
+               "bn_bwd_groups: rows_per_group * C must be a multiple of 32 (a group's ReLU bits start on a word)");
+    const size_t es = dtype == UP_DT_BF16 ? 2 : 4;
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(dgamma, 0, sizeof(float) * C, st) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * C, st) != hipSuccess)
+        return check_launch("bn_bwd_groups memset");
+    float* gsum = workspace;                 // per-group dgamma | dbeta
+    float* ws = workspace + 2 * (size_t)C;
+    for (int g = 0; g < groups; ++g) {
+        const float* cg = coef + (size_t)g * 4 * C;
+        const size_t r0 = (size_t)g * rows_per_group;
+        if (int e = up_bn_bwd_acc_t((const char*)dz + r0 * lddz * es, lddz, nullptr, 0, relu_bits ? relu_bits + r0 * C / 32 : nullptr,
+                                    (const char*)y + r0 * ldy * es, ldy, gamma, cg, cg + C, relu, 1, (char*)dy + r0 * lddy * es, lddy,
+                                    dres ? (char*)dres + r0 * lddres * es : nullptr, lddres, gsum, gsum + C, dgamma, dbeta, ws,
+                                    workspace_bytes - 2 * (size_t)C * sizeof(float), rows_per_group, C, dtype, stream))
+            return e;
+    }
+    return UP_OK;
 }
 
 extern "C" int up_relu_bwd(const float* dz, const float* z, float* dx, int64_t n, void* stream) {

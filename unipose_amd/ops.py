@@ -534,6 +534,27 @@ class ConvBias(Function):
         return dx, dw, db, None, None
 
 
+_BN_GROUPS = {"n": 1}
+
+
+class bn_groups:
+    """Inside the context every train-mode conv + BatchNorm normalises `n` equal row groups of its input batch separately
+    (frame-major clips: group g = frame g).  The video model uses it to run its trunk ONCE on all T frames of a clip batch —
+    every convolution sees a T-times larger batch — while each frame keeps the batch statistics, running-statistics updates
+    and gradients of its own module call in the reference loop (uniposeLSTM.py:116-133)."""
+
+    def __init__(self, n: int):
+        self.n, self.prev = int(n), 1
+
+    def __enter__(self):
+        self.prev, _BN_GROUPS["n"] = _BN_GROUPS["n"], self.n
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        _BN_GROUPS["n"] = self.prev
+        return False
+
+
 class ConvBnAct(Function):
     """conv -> BatchNorm2d -> (+residual) -> (ReLU): Bottleneck.forward resnet.py:22-42, the stem
     :113-116, _AtrousModule wasp.py:16-20, wasp.py:86-88, decoder.py:39-41,52.
@@ -547,7 +568,25 @@ class ConvBnAct(Function):
         L = _C.lib()
         dev = x.device
         k = weight.shape[0]
-        if train:
+        groups = _BN_GROUPS["n"] if train else 1
+        if groups > 1:
+            # `groups` row groups (frames), each with its own batch statistics: one extra pass over y collects them (a row
+            # tile of the convolution may straddle two frames, so its epilogue partials cannot be used)
+            if x.shape[0] % groups:
+                raise ValueError(f"batch {x.shape[0]} is not a multiple of {groups} BatchNorm groups")
+            y, d, _ = conv_fwd_raw(x, weight, cfg)
+            rows = d.N * d.P * d.Q
+            rpg = rows // groups
+            if rpg <= 1:
+                raise ValueError(f"Expected more than 1 value per channel when training, got input size "
+                                 f"{(d.N // groups, k, d.P, d.Q)}")
+            tiles = L.up_bn_batch_stats_tiles(rpg)
+            st = torch.empty((groups, tiles, k, 3), dtype=torch.float32, device=dev)
+            coef = torch.empty((groups, 4, k), dtype=torch.float32, device=dev)   # per group: mean, invstd, scale, shift
+            _C.check(L.up_bn_batch_stats_t(y.data_ptr(), d.ldy, rpg, k, groups, _dt(y), st.data_ptr(), _stream(x)), "bn_batch_stats")
+            _C.check(L.up_bn_finalize_groups(st.data_ptr(), tiles, k, groups, eps, momentum, _ptr(rm), _ptr(rv), gamma.data_ptr(),
+                                             beta.data_ptr(), coef.data_ptr(), _stream(x)), "bn_finalize_groups")
+        elif train:
             y, d, st = conv_fwd_raw(x, weight, cfg, stats=True)
             rows = d.N * d.P * d.Q
             if rows <= 1:
@@ -571,12 +610,17 @@ class ConvBnAct(Function):
             if relu and any(ctx.needs_input_grad[:5]) else None
         if residual is not None and residual.dtype != y.dtype:
             raise TypeError(f"residual {residual.dtype} vs convolution output {y.dtype}")
-        _C.check(L.up_bn_apply_t(y.data_ptr(), d.ldy, coef[2].data_ptr(), coef[3].data_ptr(), _ptr(residual),
-                                 _nhwc_ok(residual) if residual is not None else 0, int(relu), z.data_ptr(), d.ldy,
-                                 _ptr(bits), rows, k, _dt(y), _stream(x)), "bn_apply")
+        if groups > 1:
+            _C.check(L.up_bn_apply_groups_t(y.data_ptr(), d.ldy, coef.data_ptr(), _ptr(residual),
+                                            _nhwc_ok(residual) if residual is not None else 0, int(relu), z.data_ptr(), d.ldy,
+                                            _ptr(bits), rows // groups, k, groups, _dt(y), _stream(x)), "bn_apply_groups")
+        else:
+            _C.check(L.up_bn_apply_t(y.data_ptr(), d.ldy, coef[2].data_ptr(), coef[3].data_ptr(), _ptr(residual),
+                                     _nhwc_ok(residual) if residual is not None else 0, int(relu), z.data_ptr(), d.ldy,
+                                     _ptr(bits), rows, k, _dt(y), _stream(x)), "bn_apply")
         if relu and _RELU_TRACE is not None:
             _RELU_TRACE.append(z.detach())
-        ctx.d, ctx.relu, ctx.train, ctx.has_res = d, relu, train, residual is not None
+        ctx.d, ctx.relu, ctx.train, ctx.has_res, ctx.groups = d, relu, train, residual is not None, groups
         ctx.beta = beta                       # (the parameter object: deferred_wgrad installs its gradient)
         ctx.link_in, ctx.link_out = link_in, link_out
         if link_in is not None:
@@ -596,10 +640,18 @@ class ConvBnAct(Function):
         dy = fresh(y)
         dres = fresh(y) if ctx.has_res else None
         dgb = torch.empty((2, k), dtype=torch.float32, device=x.device)
-        need = L.up_bn_bwd_workspace(rows, k)
-        ws = workspace(x.device, need)
         if dz.dtype != y.dtype:
             raise TypeError(f"gradient {dz.dtype} vs saved convolution output {y.dtype}")
+        if ctx.groups > 1:                    # per-group data gradient, parameter gradients summed over the groups
+            rpg = rows // ctx.groups
+            ws = workspace(x.device, L.up_bn_bwd_groups_workspace(rpg, k))
+            _C.check(L.up_bn_bwd_groups_t(dz.data_ptr(), d.ldy, _ptr(bits), y.data_ptr(), d.ldy, gamma.data_ptr(), coef.data_ptr(),
+                                          int(ctx.relu), dy.data_ptr(), d.ldy, _ptr(dres), d.ldy, dgb[0].data_ptr(),
+                                          dgb[1].data_ptr(), ws.data_ptr(), ws.numel(), rpg, k, ctx.groups, _dt(y), _stream(x)),
+                     "bn_bwd_groups")
+            return ConvBnAct._finish_backward(ctx, x, weight, d, dy, dres, dgb, True)
+        need = L.up_bn_bwd_workspace(rows, k)
+        ws = workspace(x.device, need)
         beta = ctx.beta
         hand_over = True                      # autograd gets dgamma / dbeta
         acc = None
@@ -617,6 +669,10 @@ class ConvBnAct(Function):
                                    acc[0].data_ptr() if acc is not None else None,
                                    acc[1].data_ptr() if acc is not None else None, ws.data_ptr(),
                                    ws.numel(), rows, k, _dt(y), _stream(x)), "bn_bwd")
+        return ConvBnAct._finish_backward(ctx, x, weight, d, dy, dres, dgb, hand_over)
+
+    @staticmethod
+    def _finish_backward(ctx, x, weight, d, dy, dres, dgb, hand_over):
         add = None
         if ctx.link_in is not None:
             add, ctx.link_in.grad, ctx.link_in.armed = ctx.link_in.grad, None, False
@@ -663,7 +719,7 @@ class bn_counters:
         plan = self.module.__dict__.get("_up_bn_plan")
         if plan is not None and plan[0] == self.sig:
             if plan[1]:
-                torch._foreach_add_(plan[1], 1)
+                torch._foreach_add_(plan[1], _BN_GROUPS["n"] if any(self.sig) else 1)
             _BN_COUNT["mode"] = "skip"
         else:
             _BN_COUNT["mode"], _BN_COUNT["seen"] = "record", []
@@ -694,8 +750,10 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, link_in=None, link_out=No
     if not train and not need_grad:
         return conv_bn_act_eval_fused(x, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, cfg, relu,
                                       residual, bn.eps)
+    if train and _BN_GROUPS["n"] > 1 and bn.momentum is None:
+        raise NotImplementedError("grouped BatchNorm (ops.bn_groups) with momentum=None (cumulative average)")
     if train and bn.track_running_stats and _BN_COUNT["mode"] != "skip":
-        bn.num_batches_tracked.add_(1)
+        bn.num_batches_tracked.add_(_BN_GROUPS["n"])            # one "batch" per group, like separate module calls
         if _BN_COUNT["mode"] == "record":
             _BN_COUNT["seen"].append(bn.num_batches_tracked)
     if bn.momentum is not None:

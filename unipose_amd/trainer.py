@@ -332,6 +332,7 @@ class VideoTrainer(_TrainerBase):
         self.batcher = DeviceBatcher(dev, self.stride, self.sigma)
         model = unipose_lstm(num_classes=self.numClasses, backbone="resnet", output_stride=16, sync_bn=True,
                              freeze_bn=False, stride=self.stride)
+        model.batch_frames = True      # this loop always walks all frames of a clip: trunk once per clip batch, not per frame
         self._setup(model, args, dev)
 
     def _load_pretrained(self, path):

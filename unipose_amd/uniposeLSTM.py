@@ -46,8 +46,37 @@ class unipose(nn.Module):
         self.conv4 = nn.Conv2d(128, 128, kernel_size=1, padding=0)
         self.conv5 = nn.Conv2d(128, num_classes + 1, kernel_size=1, padding=0)
         self.pool_center = nn.AvgPool2d(kernel_size=9, stride=8, padding=1)
+        # batch_frames: run the trunk ONCE, at iter == 0, on all T frames of the clip batch (the call receives the whole clip
+        # tensor anyway) and serve the later calls from that result.  Every frame keeps its own BatchNorm batch statistics
+        # (ops.bn_groups) and the running statistics receive the same T updates in the same order, so outputs, gradients and
+        # buffers are those of T separate trunk calls — but every convolution runs on B*T images instead of B (B = 8:
+        # 268-tile launches become 1300-tile launches).  Off by default: a caller that only ever asks for iter == 0 would pay
+        # for T frames and see T running-statistics updates.  unipose_amd.trainer.VideoTrainer and bench.py switch it on.
+        self.batch_frames = False
+        self._frames = None
         if freeze_bn:
             self.freeze_bn()
+
+    def _trunk(self, x_nchw):
+        x = ops.ToNHWC.apply(x_nchw)
+        x, low = self.backbone(x)
+        x = self.wasp(x)
+        return self.decoder(x, low)                                # (N,h,w,16), 14 real channels
+
+    def _trunk_frame(self, input, iter):
+        b, T = input.shape[0], input.shape[1]
+        if not self.batch_frames or T == 1:
+            with ops.bn_counters(self):
+                return self._trunk(input[:, iter])
+        key = (id(input), input._version, input.data_ptr(), tuple(input.shape), self.training, torch.is_grad_enabled())
+        if iter == 0 or self._frames is None or self._frames[0] != key:
+            xa = input.transpose(0, 1).reshape(T * b, *input.shape[2:])      # frame-major: BatchNorm group g = frame g
+            with ops.bn_groups(T if self.training else 1), ops.bn_counters(self):
+                self._frames = (key, self._trunk(xa))
+        x = self._frames[1][iter * b:(iter + 1) * b]
+        if iter == T - 1:
+            self._frames = None                                     # the clip is served: nothing outlives the unroll
+        return x
 
     def _state(self, t, like, b):
         """(C,h,w) zeros from the first call, or the (B,C,h,w) tensor returned by the previous one."""
@@ -60,11 +89,7 @@ class unipose(nn.Module):
         if ops.storage_dtype() != torch.float32:
             raise NotImplementedError("bf16 storage (BASELINE configs[4]) is an image-model configuration: the ConvLSTM "
                                       "head (15-channel state, configs[3]) runs in fp32")
-        with ops.bn_counters(self):
-            x = ops.ToNHWC.apply(input[:, iter])
-            x, low = self.backbone(x)
-            x = self.wasp(x)
-            x = self.decoder(x, low)                               # (B,h,w,16), 14 real channels
+        x = self._trunk_frame(input, iter)                         # (B,h,w,16), 14 real channels
         z = _AddCenter.apply(x, centermap[:, iter], self.num_classes + 1)
         if iter == 0:
             cell, hide = self.lstm_0(z)
