@@ -180,8 +180,9 @@ def lstm_case(dev, K=13, B=1, size=32, T=3, wseed=4, tol=1e-3, train=False, defe
         trace = []
         ops.set_relu_trace(trace if train else None)
         try:
+            xd, cd = x.to(dev), cm.to(dev)                   # ONE clip tensor for all calls, like the driver's input_var
             for j in range(T):                               # uniposeLSTM.py:124-128 call pattern
-                heat, cell, hide = m(x.to(dev), cm.to(dev), j, heat, hide, cell)
+                heat, cell, hide = m(xd, cd, j, heat, hide, cell)
                 ours.append((heat, cell, hide))
                 if train:
                     loss = loss + ops.mse_loss(heat, tg[:, j].to(dev))

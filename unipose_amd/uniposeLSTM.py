@@ -68,12 +68,19 @@ class unipose(nn.Module):
         if not self.batch_frames or T == 1:
             with ops.bn_counters(self):
                 return self._trunk(input[:, iter])
-        key = (id(input), input._version, input.data_ptr(), tuple(input.shape), self.training, torch.is_grad_enabled())
-        if iter == 0 or self._frames is None or self._frames[0] != key:
+        # the cache holds a reference to the clip tensor itself: "same object, same version" cannot be faked by a recycled
+        # id / address.  A caller that passes a different tensor for a later frame simply gets the per-frame trunk.
+        hit = self._frames is not None and self._frames[0] is input and self._frames[1] == (input._version, self.training,
+                                                                                             torch.is_grad_enabled())
+        if iter == 0:
             xa = input.transpose(0, 1).reshape(T * b, *input.shape[2:])      # frame-major: BatchNorm group g = frame g
             with ops.bn_groups(T if self.training else 1), ops.bn_counters(self):
-                self._frames = (key, self._trunk(xa))
-        x = self._frames[1][iter * b:(iter + 1) * b]
+                self._frames = (input, (input._version, self.training, torch.is_grad_enabled()), self._trunk(xa))
+        elif not hit:
+            self._frames = None
+            with ops.bn_counters(self):
+                return self._trunk(input[:, iter])
+        x = self._frames[2][iter * b:(iter + 1) * b]
         if iter == T - 1:
             self._frames = None                                     # the clip is served: nothing outlives the unroll
         return x
