@@ -214,11 +214,12 @@ int up_bn_bwd_acc_t(const void* dz, int lddz, const void* z, int ldz, const uint
  *   up_bn_bwd_groups_t       data gradient per group from that group's sums; dgamma / dbeta = sums over all groups */
 int up_bn_batch_stats_tiles(int64_t rows_per_group);
 int up_bn_batch_stats_t(const void* y, int ldy, int64_t rows_per_group, int C, int groups, int dtype, float* stats, void* stream);
-int up_bn_finalize_groups(const float* stats, int tiles, int C, int groups, float eps, float momentum, float* running_mean,
-                          float* running_var, const float* gamma, const float* beta, float* coef, void* stream);
+int up_bn_finalize_groups(const float* stats, int tiles, int C, int groups, int64_t rows_per_group, float eps, float momentum,
+                          float* running_mean, float* running_var, const float* gamma, const float* beta, float* coef,
+                          void* stream);
 int up_bn_apply_groups_t(const void* y, int ldy, const float* coef, const void* res, int ldr, int relu, void* z, int ldz,
                          uint32_t* relu_bits, int64_t rows_per_group, int C, int groups, int dtype, void* stream);
-size_t up_bn_bwd_groups_workspace(int64_t rows_per_group, int C);
+size_t up_bn_bwd_groups_workspace(int64_t rows_per_group, int C, int groups);
 int up_bn_bwd_groups_t(const void* dz, int lddz, const uint32_t* relu_bits, const void* y, int ldy, const float* gamma,
                        const float* coef, int relu, void* dy, int lddy, void* dres, int lddres, float* dgamma, float* dbeta,
                        float* workspace, size_t workspace_bytes, int64_t rows_per_group, int C, int groups, int dtype,

@@ -59,6 +59,13 @@ __global__ void __launch_bounds__(256) bn_eval_coeffs_kernel(const float* g, con
     shift[c] = b[c] - rm[c] * sc;
 }
 
+// Row groups (grouped BatchNorm, see up_bn_*_groups): blockIdx.z / blockIdx.y = group; `rows` of a kernel is then the row count
+// of ONE group, the group's rows start at g * rows, its per-channel parameters at g * pstride floats (coef[g][4][C]), its
+// backward sums at g * gstride floats.  All zero for an ordinary launch.
+struct GroupArgs {
+    int pstride, gstride;
+};
+
 // One workgroup per channel: thread t merges the partials of row tiles t, t+256, ... (one or two independent loads for
 // the layer shapes of this network: 265 tiles at 23x23 / B = 32), then an 8-level merge tree over LDS.  These few-hundred-
 // byte kernels sit on the critical path of the forward pass between every convolution and its apply pass, and their
@@ -67,9 +74,17 @@ __global__ void __launch_bounds__(256) bn_eval_coeffs_kernel(const float* g, con
 __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* stats, int tiles, int C, float eps, float mom,
                                                           float* rm, float* rv, const float* gamma,
                                                           const float* beta, float* mean_o, float* invstd_o,
-                                                          float* scale, float* shift) {
+                                                          float* scale, float* shift, GroupArgs grp) {
     __shared__ float red[256][3];
     const int c = blockIdx.x, t0 = threadIdx.x;
+    {
+        const int g = blockIdx.y;
+        stats += (size_t)g * tiles * C * 3;
+        mean_o += (size_t)g * grp.pstride;
+        invstd_o += (size_t)g * grp.pstride;
+        scale += (size_t)g * grp.pstride;
+        shift += (size_t)g * grp.pstride;
+    }
     float n = 0.f, m = 0.f, q = 0.f;
     for (int t = t0; t < tiles; t += 512) {      // two loads in flight per round
         const float* s = stats + ((size_t)t * C + c) * 3;
@@ -270,9 +285,15 @@ template <typename T>
 __global__ void __launch_bounds__(256) bn_apply_rows_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, const T* __restrict__ res, int ldr,
                                                             int relu, T* __restrict__ z, int ldz, uint32_t* __restrict__ relu_bits,
-                                                            int rows, int C, int lcs) {
+                                                            int rows, int C, int lcs, GroupArgs grp) {
     constexpr int E = Row16<T>::E, LPW = 32 / E;   // lanes per 32-bit word of relu_bits
     const int lane = threadIdx.x & 63;
+    const int64_t grow0 = (int64_t)blockIdx.z * rows;      // first row of this group
+    y += grow0 * ldy;
+    z += grow0 * ldz;
+    if (res) res += grow0 * ldr;
+    scale += (size_t)blockIdx.z * grp.pstride;
+    shift += (size_t)blockIdx.z * grp.pstride;
     const int cl = threadIdx.x & ((1 << lcs) - 1), rl = threadIdx.x >> lcs;
     const int rpb = 256 >> lcs;
     const int c = ((blockIdx.y << lcs) + cl) * E;
@@ -307,7 +328,7 @@ __global__ void __launch_bounds__(256) bn_apply_rows_kernel(const T* __restrict_
                 uint32_t w = bits << (E * (lane & (LPW - 1)));
 #pragma unroll
                 for (int m = 1; m < LPW; m <<= 1) w |= __shfl_xor(w, m);
-                if ((lane & (LPW - 1)) == 0 && ok) relu_bits[((int64_t)row * C + c) >> 5] = w;
+                if ((lane & (LPW - 1)) == 0 && ok) relu_bits[((grow0 + row) * C + c) >> 5] = w;
             }
         }
     }
@@ -320,8 +341,18 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_rows_kernel(const T* __restr
                                                                 const float* __restrict__ invstd, const float* __restrict__ dgamma,
                                                                 const float* __restrict__ dbeta, int relu, int use_batch, float inv_m,
                                                                 T* __restrict__ dy, int lddy, T* __restrict__ dres, int lddres,
-                                                                int rows, int C, int lcs) {
+                                                                int rows, int C, int lcs, GroupArgs grp) {
     constexpr int E = Row16<T>::E;
+    const int64_t grow0 = (int64_t)blockIdx.z * rows;      // first row of this group
+    dz += grow0 * lddz;
+    y += grow0 * ldy;
+    dy += grow0 * lddy;
+    if (z) z += grow0 * ldz;
+    if (dres) dres += grow0 * lddres;
+    mean += (size_t)blockIdx.z * grp.pstride;
+    invstd += (size_t)blockIdx.z * grp.pstride;
+    dgamma += (size_t)blockIdx.z * grp.gstride;
+    dbeta += (size_t)blockIdx.z * grp.gstride;
     const int cl = threadIdx.x & ((1 << lcs) - 1), rl = threadIdx.x >> lcs;
     const int rpb = 256 >> lcs;
     const int c = ((blockIdx.y << lcs) + cl) * E;
@@ -344,7 +375,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_rows_kernel(const T* __restr
             mk[u] = 0xffffffffu;
             if (relu) {
                 if (bits) {
-                    const int64_t b = (int64_t)rr * C + c;
+                    const int64_t b = (grow0 + rr) * C + c;
                     mk[u] = bits[b >> 5] >> (int)(b & 31);
                 } else {
                     zz[u] = ld16(z + (size_t)rr * ldz + c);
@@ -481,8 +512,16 @@ template <typename T>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* dz, int lddz, const T* z, int ldz,
                                                             const uint32_t* bits, const T* y, int ldy,
                                                             const float* mean, const float* invstd, int relu,
-                                                            float* partial, int64_t rows, int C, int rows_per_chunk) {
+                                                            float* partial, int64_t rows, int C, int rows_per_chunk, GroupArgs grp) {
     __shared__ float red[16][64][2];
+    const int64_t grow0 = (int64_t)blockIdx.z * rows;      // first row of this group (rows = rows of one group)
+    dz += grow0 * lddz;
+    y += grow0 * ldy;
+    if (z) z += grow0 * ldz;
+    mean += (size_t)blockIdx.z * grp.pstride;
+    invstd += (size_t)blockIdx.z * grp.pstride;
+    partial += (size_t)blockIdx.z * gridDim.x * C * 2;
+    const int64_t bq0 = grow0 * (C >> 2);                  // quad index of the group's first element in the bit array
     const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.y * 64 + cq * 4;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk;
@@ -516,14 +555,14 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* dz, int ldd
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                zv[u] = relu ? relu_mask4(bits, (r + 16 * u) * (C >> 2) + (c >> 2), z, (r + 16 * u) * ldz + c) : g[u];
+                zv[u] = relu ? relu_mask4(bits, bq0 + (r + 16 * u) * (C >> 2) + (c >> 2), z, (r + 16 * u) * ldz + c) : g[u];
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc(g[u], zv[u], yv[u]);
         }
         for (; r < r1; r += 16) {
             float4 ga = ld4<T>(dz + r * lddz + c);
             float4 ya = ld4<T>(y + r * ldy + c);
-            float4 za = relu ? relu_mask4(bits, r * (C >> 2) + (c >> 2), z, r * ldz + c) : ga;
+            float4 za = relu ? relu_mask4(bits, bq0 + r * (C >> 2) + (c >> 2), z, r * ldz + c) : ga;
             acc(ga, za, ya);
         }
         const float4 is = *reinterpret_cast<const float4*>(invstd + c);
@@ -552,9 +591,12 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* dz, int ldd
 // acc_dgamma / acc_dbeta (optional): running sums over several calls (a BatchNorm used once per frame of the video unroll):
 // the per-call sums still go to dgamma / dbeta, pass 3 needs them.
 __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* partial, int chunks, int C, float* dgamma,
-                                                              float* dbeta, float* acc_dgamma, float* acc_dbeta) {
+                                                              float* dbeta, float* acc_dgamma, float* acc_dbeta, GroupArgs grp) {
     __shared__ float red[256][2];
     const int c = blockIdx.x, t0 = threadIdx.x;
+    partial += (size_t)blockIdx.y * chunks * C * 2;
+    dgamma += (size_t)blockIdx.y * grp.gstride;
+    dbeta += (size_t)blockIdx.y * grp.gstride;
     float a = 0.f, b = 0.f;
     for (int t = t0; t < chunks; t += 1024) {
         float va[4], vb[4];
@@ -775,7 +817,7 @@ extern "C" int up_bn_finalize(const float* stats, int tiles, int C, float eps, f
                "bn_finalize: bad argument");
     UP_REQUIRE((rm == nullptr) == (rv == nullptr), UP_ERR_INVALID, "bn_finalize: running stats must come in pairs");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, as_stream(stream), stats, tiles, C, eps,
-                       momentum, rm, rv, gamma, beta, mean, invstd, scale, shift);
+                       momentum, rm, rv, gamma, beta, mean, invstd, scale, shift, GroupArgs{0, 0});
     return check_launch("bn_finalize");
 }
 
@@ -794,12 +836,12 @@ extern "C" int up_bn_apply_t(const void* y, int ldy, const float* scale, const f
         if (bn_rows_enabled() && dtype == UP_DT_BF16 && ldy % 8 == 0 && ldz % 8 == 0 && (!res || ldr % 8 == 0) &&
             rows_geometry<bf16_t>(rows, C, grid, lcs)) {
             hipLaunchKernelGGL(bn_apply_rows_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)y, ldy, scale,
-                               shift, (const bf16_t*)res, ldr, relu, (bf16_t*)z, ldz, relu_bits, (int)rows, C, lcs);
+                               shift, (const bf16_t*)res, ldr, relu, (bf16_t*)z, ldz, relu_bits, (int)rows, C, lcs, GroupArgs{0, 0});
             return check_launch("bn_apply");
         }
         if (bn_rows_enabled() && dtype == UP_DT_F32 && rows_geometry<float>(rows, C, grid, lcs)) {
             hipLaunchKernelGGL(bn_apply_rows_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)y, ldy, scale,
-                               shift, (const float*)res, ldr, relu, (float*)z, ldz, relu_bits, (int)rows, C, lcs);
+                               shift, (const float*)res, ldr, relu, (float*)z, ldz, relu_bits, (int)rows, C, lcs, GroupArgs{0, 0});
             return check_launch("bn_apply");
         }
     }
@@ -835,9 +877,9 @@ static void launch_bn_bwd(const T* dz, int lddz, const T* z, int ldz, const uint
                           float* workspace, int64_t rows, int C, hipStream_t st) {
     int chunks = cdiv(rows, BNB_ROWS);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(chunks, cdiv(C, 64)), dim3(256), 0, st, dz, lddz, z, ldz, relu_bits,
-                       y, ldy, mean, invstd, relu, workspace, rows, C, BNB_ROWS);
+                       y, ldy, mean, invstd, relu, workspace, rows, C, BNB_ROWS, GroupArgs{0, 0});
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (const float*)workspace, chunks, C,
-                       dgamma, dbeta, acc_dgamma, acc_dbeta);
+                       dgamma, dbeta, acc_dgamma, acc_dbeta, GroupArgs{0, 0});
     int64_t total = rows * (C / 4);
     {
         dim3 grid;
@@ -847,7 +889,7 @@ static void launch_bn_bwd(const T* dz, int lddz, const T* z, int ldz, const uint
             (!dres || lddres % E == 0) && rows_geometry<T>(rows, C, grid, lcs)) {
             hipLaunchKernelGGL(bn_bwd_apply_rows_kernel<T>, grid, dim3(256), 0, st, dz, lddz, z, ldz, relu_bits, y, ldy, gamma, mean,
                                invstd, (const float*)dgamma, (const float*)dbeta, relu, use_batch_stats, 1.0f / (float)rows, dy,
-                               lddy, dres, lddres, (int)rows, C, lcs);
+                               lddy, dres, lddres, (int)rows, C, lcs, GroupArgs{0, 0});
             return;
         }
     }
@@ -908,6 +950,35 @@ extern "C" int up_bn_bwd(const float* dz, int lddz, const float* z, int ldz, con
                        lddres, dgamma, dbeta, workspace, workspace_bytes, rows, C, UP_DT_F32, stream);
 }
 
+// running statistics after `groups` batches, in order (one thread per channel): the momentum updates of `groups` module calls
+__global__ void __launch_bounds__(256) bn_running_groups_kernel(const float* coef, int groups, int C, float n, float eps, float mom,
+                                                                float* rm, float* rv) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float m = rm[c], v = rv[c];
+    for (int g = 0; g < groups; ++g) {
+        const float mean = coef[(size_t)g * 4 * C + c], is = coef[(size_t)g * 4 * C + C + c];
+        const float var = 1.0f / (is * is) - eps;
+        const float unb = n > 1.f ? var * (n / (n - 1.f)) : var;
+        m = (1.f - mom) * m + mom * mean;
+        v = (1.f - mom) * v + mom * unb;
+    }
+    rm[c] = m;
+    rv[c] = v;
+}
+// parameter gradients = sums of the per-group sums, in group order (gsum[g] = dgamma | dbeta of group g)
+__global__ void __launch_bounds__(256) bn_sum_groups_kernel(const float* gsum, int groups, int C, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int g = 0; g < groups; ++g) {
+        a += gsum[(size_t)g * 2 * C + c];
+        b += gsum[(size_t)g * 2 * C + C + c];
+    }
+    dgamma[c] = a;
+    dbeta[c] = b;
+}
+
 // ---- grouped BatchNorm: G row groups of equal size in one tensor, each normalised with its own batch statistics ------------
 extern "C" int up_bn_batch_stats_tiles(int64_t rows_per_group) { return cdiv(rows_per_group, BNS_ROWS); }
 extern "C" int up_bn_batch_stats_t(const void* y, int ldy, int64_t rows_per_group, int C, int groups, int dtype, float* stats,
@@ -928,24 +999,45 @@ extern "C" int up_bn_batch_stats_t(const void* y, int ldy, int64_t rows_per_grou
 }
 // coef: [groups][4][C] = mean, invstd, scale, shift per group.  The groups are finalised IN ORDER on the stream, so the running
 // statistics receive the same sequence of momentum updates as `groups` separate forward calls.
-extern "C" int up_bn_finalize_groups(const float* stats, int tiles, int C, int groups, float eps, float momentum, float* rm,
-                                     float* rv, const float* gamma, const float* beta, float* coef, void* stream) {
-    UP_REQUIRE(stats && gamma && beta && coef && tiles > 0 && C > 0 && groups > 0, UP_ERR_INVALID, "bn_finalize_groups: bad argument");
+extern "C" int up_bn_finalize_groups(const float* stats, int tiles, int C, int groups, int64_t rows_per_group, float eps,
+                                     float momentum, float* rm, float* rv, const float* gamma, const float* beta, float* coef,
+                                     void* stream) {
+    UP_REQUIRE(stats && gamma && beta && coef && tiles > 0 && C > 0 && groups > 0 && groups <= 65535 && rows_per_group > 0,
+               UP_ERR_INVALID, "bn_finalize_groups: bad argument");
     UP_REQUIRE((rm == nullptr) == (rv == nullptr), UP_ERR_INVALID, "bn_finalize_groups: running stats must come in pairs");
-    for (int g = 0; g < groups; ++g) {
-        float* cg = coef + (size_t)g * 4 * C;
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, as_stream(stream), stats + (size_t)g * tiles * C * 3, tiles, C,
-                           eps, momentum, rm, rv, gamma, beta, cg, cg + C, cg + 2 * C, cg + 3 * C);
-    }
+    // every group's partials are merged by its own workgroups (grid C x groups); the running statistics then take the groups'
+    // momentum updates in order (the unbiased variance is recovered from invstd: var = 1 / invstd^2 - eps)
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C, groups), dim3(256), 0, as_stream(stream), stats, tiles, C, eps, momentum,
+                       (float*)nullptr, (float*)nullptr, gamma, beta, coef, coef + C, coef + 2 * C, coef + 3 * C, GroupArgs{4 * C, 0});
+    if (rm)
+        hipLaunchKernelGGL(bn_running_groups_kernel, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(stream), (const float*)coef, groups,
+                           C, (float)rows_per_group, eps, momentum, rm, rv);
     return check_launch("bn_finalize_groups");
 }
 extern "C" int up_bn_apply_groups_t(const void* y, int ldy, const float* coef, const void* res, int ldr, int relu, void* z, int ldz,
                                     uint32_t* relu_bits, int64_t rows_per_group, int C, int groups, int dtype, void* stream) {
-    UP_REQUIRE(coef && groups > 0, UP_ERR_INVALID, "bn_apply_groups: bad argument");
+    UP_REQUIRE(y && z && coef && groups > 0 && groups <= 65535 && rows_per_group > 0, UP_ERR_INVALID, "bn_apply_groups: bad argument");
+    UP_REQUIRE(dtype == UP_DT_F32 || dtype == UP_DT_BF16, UP_ERR_INVALID, "bn_apply_groups: dtype %d", dtype);
     UP_REQUIRE(!relu_bits || (rows_per_group * C) % 32 == 0, UP_ERR_UNSUPPORTED,
                "bn_apply_groups: rows_per_group * C must be a multiple of 32 (a group's ReLU bits start on a word)");
     const size_t es = dtype == UP_DT_BF16 ? 2 : 4;
-    for (int g = 0; g < groups; ++g) {
+    dim3 grid;
+    int lcs = 0;
+    const GroupArgs ga{4 * C, 0};
+    if (dtype == UP_DT_F32 && ldy % 4 == 0 && ldz % 4 == 0 && (!res || ldr % 4 == 0) && rows_geometry<float>(rows_per_group, C, grid, lcs)) {
+        grid.z = groups;   // ONE launch: blockIdx.z = group
+        hipLaunchKernelGGL(bn_apply_rows_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)y, ldy, coef + 2 * C,
+                           coef + 3 * C, (const float*)res, ldr, relu, (float*)z, ldz, relu_bits, (int)rows_per_group, C, lcs, ga);
+        return check_launch("bn_apply_groups");
+    }
+    if (dtype == UP_DT_BF16 && ldy % 8 == 0 && ldz % 8 == 0 && (!res || ldr % 8 == 0) &&
+        rows_geometry<bf16_t>(rows_per_group, C, grid, lcs)) {
+        grid.z = groups;
+        hipLaunchKernelGGL(bn_apply_rows_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)y, ldy, coef + 2 * C,
+                           coef + 3 * C, (const bf16_t*)res, ldr, relu, (bf16_t*)z, ldz, relu_bits, (int)rows_per_group, C, lcs, ga);
+        return check_launch("bn_apply_groups");
+    }
+    for (int g = 0; g < groups; ++g) {       // channel counts without a row-strided geometry: one flat launch per group
         const float* cg = coef + (size_t)g * 4 * C;
         const size_t r0 = (size_t)g * rows_per_group;
         if (int e = up_bn_apply_t((const char*)y + r0 * ldy * es, ldy, cg + 2 * C, cg + 3 * C, res ? (const char*)res + r0 * ldr * es : nullptr,
@@ -955,20 +1047,58 @@ extern "C" int up_bn_apply_groups_t(const void* y, int ldy, const float* coef, c
     }
     return UP_OK;
 }
-extern "C" size_t up_bn_bwd_groups_workspace(int64_t rows_per_group, int C) {
-    return up_bn_bwd_workspace(rows_per_group, C) + (size_t)2 * C * sizeof(float);
+extern "C" size_t up_bn_bwd_groups_workspace(int64_t rows_per_group, int C, int groups) {
+    return (size_t)groups * (up_bn_bwd_workspace(rows_per_group, C) + (size_t)2 * C * sizeof(float));
 }
+namespace up {
+template <typename T>
+static bool launch_bn_bwd_groups(const T* dz, int lddz, const uint32_t* relu_bits, const T* y, int ldy, const float* gamma,
+                                 const float* coef, int relu, T* dy, int lddy, T* dres, int lddres, float* dgamma, float* dbeta,
+                                 float* workspace, int64_t rows, int C, int groups, hipStream_t st) {
+    constexpr int E = 16 / (int)sizeof(T);
+    dim3 grid;
+    int lcs = 0;
+    if (!(lddz % E == 0 && ldy % E == 0 && lddy % E == 0 && (!dres || lddres % E == 0) && rows_geometry<T>(rows, C, grid, lcs)))
+        return false;
+    const int chunks = cdiv(rows, BNB_ROWS);
+    float* gsum = workspace;                                   // [groups][dgamma | dbeta]
+    float* partial = workspace + (size_t)groups * 2 * C;       // [groups][chunks][C][2]
+    const GroupArgs ga{4 * C, 2 * C};
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(chunks, cdiv(C, 64), groups), dim3(256), 0, st, dz, lddz, (const T*)nullptr, 0,
+                       relu_bits, y, ldy, coef, coef + C, relu, partial, rows, C, BNB_ROWS, ga);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C, groups), dim3(256), 0, st, (const float*)partial, chunks, C, gsum, gsum + C,
+                       (float*)nullptr, (float*)nullptr, ga);
+    hipLaunchKernelGGL(bn_sum_groups_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)gsum, groups, C, dgamma, dbeta);
+    grid.z = groups;
+    hipLaunchKernelGGL(bn_bwd_apply_rows_kernel<T>, grid, dim3(256), 0, st, dz, lddz, (const T*)nullptr, 0, relu_bits, y, ldy, gamma,
+                       coef, coef + C, (const float*)gsum, (const float*)(gsum + C), relu, 1, 1.0f / (float)rows, dy, lddy, dres, lddres,
+                       (int)rows, C, lcs, ga);
+    return true;
+}
+}  // namespace up
 // dgamma / dbeta: sums over ALL groups (the parameter gradients); every group's data gradient uses its own batch sums
 extern "C" int up_bn_bwd_groups_t(const void* dz, int lddz, const uint32_t* relu_bits, const void* y, int ldy, const float* gamma,
                                   const float* coef, int relu, void* dy, int lddy, void* dres, int lddres, float* dgamma,
                                   float* dbeta, float* workspace, size_t workspace_bytes, int64_t rows_per_group, int C, int groups,
                                   int dtype, void* stream) {
-    UP_REQUIRE(coef && dgamma && dbeta && workspace && groups > 0, UP_ERR_INVALID, "bn_bwd_groups: bad argument");
-    UP_REQUIRE(workspace_bytes >= up_bn_bwd_groups_workspace(rows_per_group, C), UP_ERR_WORKSPACE, "bn_bwd_groups: workspace too small");
+    UP_REQUIRE(dz && y && dy && gamma && coef && dgamma && dbeta && workspace && groups > 0 && groups <= 65535 && rows_per_group > 0,
+               UP_ERR_INVALID, "bn_bwd_groups: bad argument");
+    UP_REQUIRE(dtype == UP_DT_F32 || dtype == UP_DT_BF16, UP_ERR_INVALID, "bn_bwd_groups: dtype %d", dtype);
+    UP_REQUIRE(!relu || relu_bits, UP_ERR_INVALID, "bn_bwd_groups: relu needs the sign bits of the forward output");
+    UP_REQUIRE(C % 4 == 0 && rows_per_group * (C / 4) < (1ll << 31), UP_ERR_UNSUPPORTED, "bn_bwd_groups: C %% 4 or tensor too large");
+    UP_REQUIRE(workspace_bytes >= up_bn_bwd_groups_workspace(rows_per_group, C, groups), UP_ERR_WORKSPACE,
+               "bn_bwd_groups: workspace too small");
     UP_REQUIRE(!relu_bits || (rows_per_group * C) % 32 == 0, UP_ERR_UNSUPPORTED,
                "bn_bwd_groups: rows_per_group * C must be a multiple of 32 (a group's ReLU bits start on a word)");
     const size_t es = dtype == UP_DT_BF16 ? 2 : 4;
     hipStream_t st = as_stream(stream);
+    const bool done = dtype == UP_DT_BF16
+        ? launch_bn_bwd_groups<bf16_t>((const bf16_t*)dz, lddz, relu_bits, (const bf16_t*)y, ldy, gamma, coef, relu, (bf16_t*)dy, lddy,
+                                       (bf16_t*)dres, lddres, dgamma, dbeta, workspace, rows_per_group, C, groups, st)
+        : launch_bn_bwd_groups<float>((const float*)dz, lddz, relu_bits, (const float*)y, ldy, gamma, coef, relu, (float*)dy, lddy,
+                                      (float*)dres, lddres, dgamma, dbeta, workspace, rows_per_group, C, groups, st);
+    if (done) return check_launch("bn_bwd_groups");
+    // channel counts without a row-strided geometry: the three passes group by group
     if (hipMemsetAsync(dgamma, 0, sizeof(float) * C, st) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * C, st) != hipSuccess)
         return check_launch("bn_bwd_groups memset");
     float* gsum = workspace;                 // per-group dgamma | dbeta

@@ -584,8 +584,8 @@ class ConvBnAct(Function):
             st = torch.empty((groups, tiles, k, 3), dtype=torch.float32, device=dev)
             coef = torch.empty((groups, 4, k), dtype=torch.float32, device=dev)   # per group: mean, invstd, scale, shift
             _C.check(L.up_bn_batch_stats_t(y.data_ptr(), d.ldy, rpg, k, groups, _dt(y), st.data_ptr(), _stream(x)), "bn_batch_stats")
-            _C.check(L.up_bn_finalize_groups(st.data_ptr(), tiles, k, groups, eps, momentum, _ptr(rm), _ptr(rv), gamma.data_ptr(),
-                                             beta.data_ptr(), coef.data_ptr(), _stream(x)), "bn_finalize_groups")
+            _C.check(L.up_bn_finalize_groups(st.data_ptr(), tiles, k, groups, rpg, eps, momentum, _ptr(rm), _ptr(rv),
+                                             gamma.data_ptr(), beta.data_ptr(), coef.data_ptr(), _stream(x)), "bn_finalize_groups")
         elif train:
             y, d, st = conv_fwd_raw(x, weight, cfg, stats=True)
             rows = d.N * d.P * d.Q
@@ -644,7 +644,7 @@ class ConvBnAct(Function):
             raise TypeError(f"gradient {dz.dtype} vs saved convolution output {y.dtype}")
         if ctx.groups > 1:                    # per-group data gradient, parameter gradients summed over the groups
             rpg = rows // ctx.groups
-            ws = workspace(x.device, L.up_bn_bwd_groups_workspace(rpg, k))
+            ws = workspace(x.device, L.up_bn_bwd_groups_workspace(rpg, k, ctx.groups))
             _C.check(L.up_bn_bwd_groups_t(dz.data_ptr(), d.ldy, _ptr(bits), y.data_ptr(), d.ldy, gamma.data_ptr(), coef.data_ptr(),
                                           int(ctx.relu), dy.data_ptr(), d.ldy, _ptr(dres), d.ldy, dgb[0].data_ptr(),
                                           dgb[1].data_ptr(), ws.data_ptr(), ws.numel(), rpg, k, ctx.groups, _dt(y), _stream(x)),
