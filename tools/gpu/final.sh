@@ -1,8 +1,12 @@
 # Round-end measurement set: smoke, default bench line (cpu_baseline, stock_gpu_baseline, alt_math, other_configs), rocprofv3 kernel
 # stats of the bench command in both stream modes, PMC passes; with TESTS=1 also the full -m gpu suite (default + bf16x3 arithmetic).
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r02_z}
+TAG=${1:-r03_z}
 mkdir -p gpurun_out/$TAG
+# the measured binary is the tree's: the stamp next to the shipped library names the sha256 of the sources it was built from
+python -c "
+from unipose_amd.build import library_is_current, source_hash
+print('libunipose_hip.so built from this tree:', library_is_current(), 'sources sha256', source_hash())" | tee gpurun_out/$TAG/build_identity.txt
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/$TAG/smoke.log 2>&1; echo "smoke exit $?"; tail -1 gpurun_out/$TAG/smoke.log
 timeout 900 python bench.py > gpurun_out/$TAG/bench.log 2> gpurun_out/$TAG/bench.err; echo "bench exit $?"
 tail -1 gpurun_out/$TAG/bench.log > gpurun_out/$TAG/bench.json
@@ -20,10 +24,14 @@ ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-stock-baseline --no-profile --
 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof.log 2>&1
 UNIPOSE_SYNC_WGRAD=1 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_sync -o bench -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_sync.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_736 -o bench -- python $GRAFT_REPO_ROOT/bench.py --size 736 --batch 16 --math bf16s $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_736.log 2>&1
+UNIPOSE_SYNC_WGRAD=1 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_736x -o bench -- python $GRAFT_REPO_ROOT/bench.py --size 736 --batch 16 --math bf16s $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_736x.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_lstm -o bench -- python $GRAFT_REPO_ROOT/bench.py --model lstm $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_lstm.log 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof -name "*.db" | head -1) 4 > gpurun_out/$TAG/kernel_stats.txt 2>&1
 python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof_sync -name "*.db" | head -1) 4 > gpurun_out/$TAG/kernel_stats_exclusive.txt 2>&1
 python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof_736 -name "*.db" | head -1) 4 > gpurun_out/$TAG/kernel_stats_736_bf16s.txt 2>&1
+python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof_736x -name "*.db" | head -1) 4 > gpurun_out/$TAG/kernel_stats_736_bf16s_exclusive.txt 2>&1
+python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof_lstm -name "*.db" | head -1) 4 > gpurun_out/$TAG/kernel_stats_lstm.txt 2>&1
 find gpurun_out/$TAG -name "*.db" -delete
 head -8 gpurun_out/$TAG/kernel_stats.txt
 head -8 gpurun_out/$TAG/kernel_stats_exclusive.txt
@@ -32,6 +40,9 @@ UNIPOSE_SYNC_WGRAD=1 UP_PROFILE_CSV=$GRAFT_REPO_ROOT/gpurun_out/$TAG/launches.cs
 python tools/gpu/csv_loss.py gpurun_out/$TAG/launches.csv.1 157.3 20 > gpurun_out/$TAG/lost_time_by_shape.txt 2>&1 || python tools/gpu/csv_loss.py gpurun_out/$TAG/launches.csv 157.3 20 > gpurun_out/$TAG/lost_time_by_shape.txt 2>&1
 head -4 gpurun_out/$TAG/lost_time_by_shape.txt
 bash tools/gpu/pmc.sh $TAG
+UNIPOSE_SYNC_WGRAD=1 UP_PROFILE_CSV=$GRAFT_REPO_ROOT/gpurun_out/$TAG/launches_736.csv timeout 300 python bench.py --size 736 --batch 16 --math bf16s --steps 4 --warmup 2 --no-cpu-baseline --no-stock-baseline --no-alt-math --no-other-configs > gpurun_out/$TAG/bench_csv_736.log 2>&1
+python tools/gpu/csv_loss.py $(ls gpurun_out/$TAG/launches_736.csv* | tail -1) 2500 24 > gpurun_out/$TAG/lost_time_by_shape_736.txt 2>&1; head -3 gpurun_out/$TAG/lost_time_by_shape_736.txt
+bash tools/gpu/pmc_sq.sh ${TAG}_736 --size 736 --batch 16 --math bf16s
 if [ -n "$TESTS" ]; then
 timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > gpurun_out/$TAG/pytest_gpu.log 2>&1; echo "pytest exit $?"
 tail -2 gpurun_out/$TAG/pytest_gpu.log

@@ -8,7 +8,34 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["conv_igemm.hip", "norm_act.hip", "spatial.hip"]
+HEADERS = ["up_common.h", "bf16s_glds.h"]
 OUT = os.path.join(HERE, "libunipose_hip.so")
+STAMP = OUT + ".stamp"          # sha256 of the sources the library next to it was built from
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+
+
+def _deps():
+    return [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.join(HERE, "..", "include", "unipose_hip.h")]
+
+
+def source_hash() -> str:
+    """sha256 over the kernel sources, headers and build flags: what a library must have been built from to be the tree's."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in _deps():
+        with open(d, "rb") as f:
+            h.update(os.path.basename(d).encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def library_is_current() -> bool:
+    """True when libunipose_hip.so exists and its stamp names exactly the sources of this tree (not a time-stamp comparison:
+    a shipped binary must be provably the tree's)."""
+    try:
+        with open(STAMP) as f:
+            return os.path.exists(OUT) and f.read().strip() == source_hash()
+    except OSError:
+        return False
 
 
 def _hipcc() -> str:
@@ -19,14 +46,17 @@ def _hipcc() -> str:
 
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "up_common.h"), os.path.join(HERE, "..", "include", "unipose_hip.h")]
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+    if not force and library_is_current():
         return OUT
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *srcs, "-o", OUT]
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [_hipcc(), *FLAGS, *srcs, "-o", OUT]
     if verbose:
         print(" ".join(cmd))
+    if os.path.exists(STAMP):
+        os.remove(STAMP)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
     return OUT
 
 
