@@ -59,7 +59,7 @@ def _merge(st):
 
 
 def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, affine=False, residual=False, relu=False,
-            add=False, seed=0, kt=64, st=2):
+            add=False, seed=0, kt=64, st=2, wkp=64, wst=2):
     """forward (+ optional BatchNorm partials / folded epilogue / residual) and data gradient (+ optional addend) of one
     convolution in bf16 storage: glds = 1 against glds = 0 under the same tile rule."""
     cp, kp = ops.rup32(c), ops.rup32(k)
@@ -73,7 +73,7 @@ def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, 
         kw["bias"] = torch.randn(k, generator=_g(seed + 4)).to(dev)
     out = {}
     try:
-        _tune(tile_want_bf16=tile_want, glds_kt=kt, glds_st=st)
+        _tune(tile_want_bf16=tile_want, glds_kt=kt, glds_st=st, wgrad_kp=wkp, wgrad_st=wst)
         for mode in (1, 0):
             _tune(glds=mode)
             d0 = ops.make_desc(x, wt, cfg)
@@ -87,7 +87,7 @@ def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, 
             dw, _ = ops.conv_bwd_weight_raw(x, dy, wt.shape, d, False)
             out[mode] = (y, st, dx, dw)
     finally:
-        _tune(glds=1, tile_want_bf16=500, glds_kt=32, glds_st=2)
+        _tune(glds=1, tile_want_bf16=500, glds_kt=32, glds_st=2, wgrad_kp=64, wgrad_st=2)
     (y1, s1, dx1, dw1), (y0, s0, dx0, dw0) = out[1], out[0]
     _same(dw1, dw0, "dw")
     _same(y1, y0, "y")

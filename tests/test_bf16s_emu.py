@@ -66,9 +66,9 @@ import glds_cases as gc
 
 
 @pytest.mark.parametrize("case", gc.SMALL, ids=lambda c: "c%d_%dx%d_k%d_r%d_d%d_t%d" % (c["c"], c["h"], c["w"], c["k"], c["r"], c["dil"], c["tile_want"]))
-@pytest.mark.parametrize("form", [(64, 2), (32, 2), (32, 3)], ids=lambda f: "kt%d_st%d" % f)
+@pytest.mark.parametrize("form", [(64, 2, 64, 2), (32, 2, 32, 2), (32, 3, 32, 3)], ids=lambda f: "kt%d_st%d_wkp%d_wst%d" % f)
 def test_glds_kernel_matches_register_staged_kernel(emu_backend, case, form):
     """second-generation bf16-storage kernels (direct-to-LDS loads, tap skipping, tap-sorted rows, 16-byte stores; 64- and
     32-channel slices, two and three LDS stages) == the register-staged kernels, element for element: outputs, BatchNorm
     partials, data gradients, weight gradients"""
-    gc.conv_ab(emu_backend, kt=form[0], st=form[1], **case)
+    gc.conv_ab(emu_backend, kt=form[0], st=form[1], wkp=form[2], wst=form[3], **case)

@@ -51,14 +51,14 @@ def test_small_ops_bf16_storage():
     bc.small_ops_case(DEV)
 
 
-@pytest.mark.parametrize("form", [(32, 2), (64, 2), (32, 3)], ids=lambda f: "kt%d_st%d" % f)
+@pytest.mark.parametrize("form", [(32, 2, 64, 2), (64, 2, 32, 2), (32, 3, 32, 3)], ids=lambda f: "kt%d_st%d_wkp%d_wst%d" % f)
 @pytest.mark.parametrize("case", gc.SMALL + gc.FULL,
                          ids=lambda c: "n%d_c%d_%dx%d_k%d_r%d_d%d_t%d" % (c["n"], c["c"], c["h"], c["w"], c["k"], c["r"], c["dil"], c["tile_want"]))
 def test_glds_kernel_matches_register_staged_kernel(case, form):
     """second-generation bf16-storage kernels (direct-to-LDS loads, tap skipping, tap-sorted rows, 16-byte stores, transposing
     LDS reads in the weight gradient) == the register-staged kernels, element for element, at small sizes and at the
     geometries of BASELINE configs[4]"""
-    gc.conv_ab(DEV, kt=form[0], st=form[1], **case)
+    gc.conv_ab(DEV, kt=form[0], st=form[1], wkp=form[2], wst=form[3], **case)
 
 
 def _golden_eval(golden_dir, name, size, B):

@@ -110,7 +110,33 @@ static void shape(const char* name, up_conv_desc d, bool stats, std::vector<Vari
 
 #define G(BM, BN, KT, ST, OCC, EPI, DBG) glds::igemm_glds_kernel<BM, BN, false, KT, ST, OCC, EPI, DBG>
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "forms")) {   // which slice form per layer shape?  (64 | 32 channels, 2 | 3 stages)
+        std::vector<Variant> v = {
+            {"register-staged <128,128> (round 2)", igemm_bf16_kernel<128, 128, 2, false, 32, true>, 128, 128, false},
+            {"glds 128x128 kt32 st2", G(128, 128, 32, 2, 3, 0, 0), 128, 128, false},
+            {"glds 128x128 kt32 st3", G(128, 128, 32, 3, 3, 0, 0), 128, 128, false},
+            {"glds 128x128 kt64 st2", G(128, 128, 64, 2, 2, 0, 0), 128, 128, false},
+        };
+        std::vector<Variant> v64 = {
+            {"register-staged <128,64> (round 2)", igemm_bf16_kernel<128, 64, 2, false, 32, true>, 128, 64, false},
+            {"glds 128x64 kt32 st2", G(128, 64, 32, 2, 3, 0, 0), 128, 64, false},
+            {"glds 128x64 kt32 st3", G(128, 64, 32, 3, 3, 0, 0), 128, 64, false},
+            {"glds 128x64 kt64 st2", G(128, 64, 64, 2, 2, 0, 0), 128, 64, false},
+        };
+        shape("layer4 conv2 3x3 512->512 d4 @46", mk(16, 46, 512, 512, 3, 4, 4), true, v);
+        shape("layer4 conv1 1x1 2048->512 @46", mk(16, 46, 2048, 512, 1, 0, 1), true, v);
+        shape("layer4 conv3 1x1 512->2048 @46", mk(16, 46, 512, 2048, 1, 0, 1), true, v);
+        shape("layer4.0 downsample 1x1 1024->2048 @46", mk(16, 46, 1024, 2048, 1, 0, 1), true, v);
+        shape("decoder 3x3 320->256 @92", mk(16, 92, 320, 256, 3, 1, 1), true, v);
+        shape("decoder 3x3 256->256 @92", mk(16, 92, 256, 256, 3, 1, 1), true, v);
+        shape("layer2 conv2 3x3 128->128 @92", mk(16, 92, 128, 128, 3, 1, 1), true, v);
+        shape("layer2 conv1 1x1 512->128 @92", mk(16, 92, 512, 128, 1, 0, 1), true, v);
+        shape("wasp 3x3 256->256 d6 @46", mk(16, 46, 256, 256, 3, 6, 6), true, v);
+        shape("layer1 conv2 3x3 64->64 @184", mk(16, 184, 64, 64, 3, 1, 1), true, v64);
+        shape("layer1 conv1 1x1 256->64 @184", mk(16, 184, 256, 64, 1, 0, 1), true, v64);
+        return 0;
+    }
     std::vector<Variant> v128 = {
         {"register-staged <128,128> (round 2)", igemm_bf16_kernel<128, 128, 2, false, 32, true>, 128, 128, false},
         {"glds 128x128 kt32 st2", G(128, 128, 32, 2, 3, 0, 0), 128, 128, false},

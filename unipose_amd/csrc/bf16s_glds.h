@@ -532,7 +532,6 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds_kernel(IgemmArgs a) {
 // A 64-entry table per slice (pixel -> byte offsets of its dY row and of filter tap (0,0) of its X row, + the tap-(0,0)
 // coordinates for the bounds test) is computed by wave 0 one slice ahead, so the other waves only add per-lane constants.
 // ======================================================================================================================
-constexpr int KP = 64;   // pixels per K slice
 
 struct PixRec {
     uint32_t dyoff;   // byte offset of the pixel's dY row (OOB for pixels >= mend)
@@ -562,17 +561,20 @@ __device__ __forceinline__ bf16x8 lds_read_tr16x2(const unsigned char* lds, int 
 }
 #endif
 
-template <int BM, int BN>
+// KP: pixels per K slice (64 | 32), ST: LDS stages (2 | 3, see igemm_glds_kernel), OCC: workgroups per CU the registers allow
+template <int BM, int BN, int KP, int ST>
 struct WGeom {
     static constexpr int ROWA = BM * 2, ROWB_ = BN * 2;                 // bytes per pixel row of the two slices
     static constexpr int A_BYTES = KP * ROWA, B_BYTES = KP * ROWB_, STAGE = A_BYTES + B_BYTES;
-    static constexpr int TAB_OFF = 2 * STAGE;                            // PixRec[2][KP]
-    static constexpr int TOTAL = TAB_OFF + 2 * KP * (int)sizeof(PixRec);
+    static constexpr int TAB_OFF = ST * STAGE;                           // PixRec[ST][KP]
+    static constexpr int TOTAL = TAB_OFF + ST * KP * (int)sizeof(PixRec);
 };
 
-template <int BM, int BN>
-__global__ void __launch_bounds__(256, 2) wgrad_glds_kernel(WgradArgs a) {
-    using G = WGeom<BM, BN>;
+template <int BM, int BN, int KP = 64, int ST = 2, int OCC = 2>
+__global__ void __launch_bounds__(256, OCC) wgrad_glds_kernel(WgradArgs a) {
+    using G = WGeom<BM, BN, KP, ST>;
+    static_assert(KP == 64 || KP == 32, "64 or 32 pixels per slice");
+    static_assert(KP / (4 * (1024 / (BM * 2))) >= 1 && KP / (4 * (1024 / (BN * 2))) >= 1, "a wave issues at least one LDS-DMA instruction per operand");
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int RPA = 1024 / G::ROWA, RPB = 1024 / G::ROWB_;    // pixel rows per LDS-DMA instruction (4 or 8)
     constexpr int NIA = KP / (4 * RPA), NIB = KP / (4 * RPB);     // instructions per wave, slice and operand (4 or 2)
@@ -630,7 +632,8 @@ __global__ void __launch_bounds__(256, 2) wgrad_glds_kernel(WgradArgs a) {
     const int dhB = rB * a.dil, dwB = (tapB - rB * a.S) * a.dil;
     const int deltaB = (dhB * a.W + dwB) * a.ldx * 2 + ciB * 2;
 
-    auto fill_table = [&](int sl) {   // wave 0: one lane per pixel of slice sl
+    auto fill_table = [&](int sl, int slot) {   // wave 0: one lane per pixel of slice sl
+        if (KP < 64 && lane >= KP) return;
         const int m = mbeg + sl * KP + lane;
         const bool ok = m < mend;
         const int mm = ok ? m : mbeg;
@@ -644,12 +647,12 @@ __global__ void __launch_bounds__(256, 2) wgrad_glds_kernel(WgradArgs a) {
         rec.h0 = ok ? p * a.stride - a.pad : -(1 << 20);
         rec.w0 = q * a.stride - a.pad;
         rec.xoff = ok ? ((img * a.H + rec.h0) * a.W + rec.w0) * a.ldx * 2 : 0;
-        tab[(sl & 1) * KP + lane] = rec;
+        tab[slot * KP + lane] = rec;
     };
-    auto issue = [&](int sl) {
-        unsigned char* const As = smem + (sl & 1) * G::STAGE;
+    auto issue = [&](int slot) {   // the slice whose table sits in `slot`, into LDS stage `slot`
+        unsigned char* const As = smem + slot * G::STAGE;
         unsigned char* const Bs = As + G::A_BYTES;
-        const PixRec* const t = tab + (sl & 1) * KP;
+        const PixRec* const t = tab + slot * KP;
 #pragma unroll
         for (int i = 0; i < NIA; ++i) {
             const int grp = wave + 4 * i;
@@ -679,50 +682,76 @@ __global__ void __launch_bounds__(256, 2) wgrad_glds_kernel(WgradArgs a) {
     const int fpix = 8 * (grp16 >> 1) + (jq >> 2);           // + 4 * h + 16 * s
     const int fch = 16 * (grp16 & 1) + 4 * (jq & 3);         // channel inside the 32-wide MFMA tile
 
+    auto mfmas = [&](const unsigned char* As) {
+        const unsigned char* Bs = As + G::A_BYTES;
+#pragma unroll
+        for (int s = 0; s < KP / 16; ++s) {
+            bf16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int ch = wm * (BM / 2) + i * 32 + fch;            // channel inside the tile (multiple of 4)
+                int ad[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int p = 16 * s + 4 * h + fpix;
+                    const int sw = CHA == 16 ? 4 * (p & 3) : 4 * ((p >> 1) & 1);
+                    ad[h] = p * G::ROWA + (((ch >> 3) ^ sw) << 4) + (ch & 7) * 2;
+                }
+                af[i] = lds_read_tr16x2(As, ad[0], ad[1]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int ch = wn * (BN / 2) + j * 32 + fch;
+                int ad[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int p = 16 * s + 4 * h + fpix;
+                    const int sw = CHB == 16 ? 4 * (p & 3) : 4 * ((p >> 1) & 1);
+                    ad[h] = p * G::ROWB_ + (((ch >> 3) ^ sw) << 4) + (ch & 7) * 2;
+                }
+                bf[j] = lds_read_tr16x2(Bs, ad[0], ad[1]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
     if (nsl > 0) {
-        if (wave == 0) fill_table(0);
-        __syncthreads();
-        issue(0);
-        if (wave == 0 && nsl > 1) fill_table(1);
-        for (int it = 0; it < nsl; ++it) {
-            wait_dma();
-            __syncthreads();   // slice `it` has landed, table it+1 is written, everyone is done with the other stage
-            if (it + 1 < nsl) issue(it + 1);
-            if (wave == 0 && it + 2 < nsl) fill_table(it + 2);
-            const unsigned char* As = smem + (it & 1) * G::STAGE;
-            const unsigned char* Bs = As + G::A_BYTES;
-#pragma unroll
-            for (int s = 0; s < KP / 16; ++s) {
-                bf16x8 af[TM], bf[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int ch = wm * (BM / 2) + i * 32 + fch;            // channel inside the tile (multiple of 4)
-                    int ad[2];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int p = 16 * s + 4 * h + fpix;
-                        const int sw = CHA == 16 ? 4 * (p & 3) : 4 * ((p >> 1) & 1);
-                        ad[h] = p * G::ROWA + (((ch >> 3) ^ sw) << 4) + (ch & 7) * 2;
-                    }
-                    af[i] = lds_read_tr16x2(As, ad[0], ad[1]);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int ch = wn * (BN / 2) + j * 32 + fch;
-                    int ad[2];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int p = 16 * s + 4 * h + fpix;
-                        const int sw = CHB == 16 ? 4 * (p & 3) : 4 * ((p >> 1) & 1);
-                        ad[h] = p * G::ROWB_ + (((ch >> 3) ^ sw) << 4) + (ch & 7) * 2;
-                    }
-                    bf[j] = lds_read_tr16x2(Bs, ad[0], ad[1]);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        if constexpr (ST == 2) {
+            if (wave == 0) fill_table(0, 0);
+            __syncthreads();
+            issue(0);
+            if (wave == 0 && nsl > 1) fill_table(1, 1);
+            for (int it = 0; it < nsl; ++it) {
+                wait_dma();
+                __syncthreads();   // slice `it` has landed, table it+1 is written, everyone is done with the other stage
+                if (it + 1 < nsl) issue((it + 1) & 1);
+                if (wave == 0 && it + 2 < nsl) fill_table(it + 2, it & 1);
+                mfmas(smem + (it & 1) * G::STAGE);
+            }
+        } else {
+            static_assert(ST == 3, "two or three LDS stages");
+            // two slices in flight: slice it+2 is issued (and table it+3 written) right behind barrier `it`
+            if (wave == 0) {
+                fill_table(0, 0);
+                if (nsl > 1) fill_table(1, 1);
+            }
+            __syncthreads();
+            issue(0);
+            if (nsl > 1) issue(1);
+            if (wave == 0 && nsl > 2) fill_table(2, 2);
+            int cur = 0, nxt = 2;
+            for (int it = 0; it < nsl; ++it) {
+                if (it + 1 < nsl) wait_dma_but<NIA + NIB>();
+                else wait_dma();
+                raw_barrier();     // slice `it` landed; table it+2 is written; every wave is done with stage nxt (slice it-1)
+                if (it + 2 < nsl) issue(nxt);
+                if (wave == 0 && it + 3 < nsl) fill_table(it + 3, cur);   // slot of slice `it`: its table was consumed by issue(it)
+                mfmas(smem + cur * G::STAGE);
+                cur = cur == 2 ? 0 : cur + 1;
+                nxt = nxt == 2 ? 0 : nxt + 1;
             }
         }
     }

@@ -39,7 +39,7 @@ namespace up {
 // up_profile_begin() arms it; every igemm/wgrad launch is then bracketed by two hipEvents on the
 // launch stream; up_profile_end() synchronises and returns, per kernel variant, {launches, total ms,
 // total algorithmic flops}.  Off by default: no events, no overhead.
-constexpr int PROF_VARIANTS = 20;
+constexpr int PROF_VARIANTS = 28;
 static const char* const kVariantNames[PROF_VARIANTS] = {
     "igemm_kernel<128,128,aligned>", "igemm_kernel<128,128,generic>", "igemm_kernel<64,128,aligned>",
     "igemm_kernel<64,128,generic>",  "igemm_kernel<128,64,aligned>",  "igemm_kernel<128,64,generic>",
@@ -47,7 +47,11 @@ static const char* const kVariantNames[PROF_VARIANTS] = {
     "wgrad_kernel<128,64>",          "wgrad_kernel<64,128>",          "wgrad_kernel<64,64>",
     "igemm_bf16_kernel<128,128>",    "igemm_bf16_kernel<64,128>",     "igemm_bf16_kernel<128,64>",
     "igemm_bf16_kernel<64,64>",      "wgrad_bf16_kernel<128,128>",    "wgrad_bf16_kernel<128,64>",
-    "wgrad_bf16_kernel<64,128>",     "wgrad_bf16_kernel<64,64>"};
+    "wgrad_bf16_kernel<64,128>",     "wgrad_bf16_kernel<64,64>",
+    // bf16 storage, direct-to-LDS generation (bf16s_glds.h)
+    "igemm_glds_kernel<128,128> (bf16)", "igemm_glds_kernel<64,128> (bf16)", "igemm_glds_kernel<128,64> (bf16)",
+    "igemm_glds_kernel<64,64> (bf16)",   "wgrad_glds_kernel<128,128> (bf16)", "wgrad_glds_kernel<128,64> (bf16)",
+    "wgrad_glds_kernel<64,128> (bf16)",  "wgrad_glds_kernel<64,64> (bf16)"};
 #ifndef UP_EMU
 struct ProfRec {
     hipEvent_t a, b;
@@ -1825,6 +1829,8 @@ static int env_int(const char* name, int dflt, int min_ok) {
 static int g_tile_want = env_int("UP_TILE_WANT", 1500, 1);   // A/B in the network: 700 / 1000 / 1500 / 2200 / 4300 -> 70.1 / 69.9 / 69.6 / 69.9 / 69.8 ms
 static int g_tile_want_bf16 = env_int("UP_TILE_WANT_BF16", 500, 1);
 static int g_glds_kt = env_int("UP_GLDS_KT", 32, 32);   // channels per K slice of the direct-to-LDS kernels (64 | 32); 736^2 step (r03_b): register-staged 46.6 ms, 64: 43.6, 32: 41.7, 32 with three stages 42.1
+static int g_wgrad_kp = env_int("UP_WGRAD_KP", 64, 32);  // pixels per slice of the direct-to-LDS weight gradient (64 | 32)
+static int g_wgrad_st = env_int("UP_WGRAD_ST", 2, 2);   // its LDS stages at 32 pixels per slice (2 | 3)
 static int g_glds_st = env_int("UP_GLDS_ST", 2, 2);    // LDS stages of the 32-channel form (2 | 3)
 static int g_glds = env_int("UP_GLDS", 1, 0);   // bf16 storage: direct-to-LDS kernels of bf16s_glds.h (0 = the register-staged round-2 kernels)
 static int g_db_min_k = env_int("UP_DB_MIN_K", 1024, 1);
@@ -2122,13 +2128,12 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     a.parts = 1;
     a.no_tap_skip = g_tap_skip ? 0 : 1;
     int grid = a.nwg;
-    // the scratch (16 MB + flags per stream) is only allocated for a launch that really splits: decide with the capacity
-    // it WOULD have (split_scratch: one 128x128 partial per CU, four flags per CU)
+    SplitScratch* sc0 = aligned && tail_split_enabled() ? split_scratch(st) : nullptr;
     bool all_tiles = false;
-    const size_t slots = std::min((size_t)cu_count() * (128 * 128) / (size_t)(BM * BN), 4 * (size_t)cu_count());
-    const int p = aligned && tail_split_enabled() ? split_parts(a.nwg, a.Ktot, slots, &all_tiles) : 1;
+    const size_t slots = sc0 ? std::min(sc0->pfloats / (size_t)(BM * BN), sc0->nflags) : 0;
+    const int p = aligned ? split_parts(a.nwg, a.Ktot, slots, &all_tiles) : 1;
     if (p >= 2) {
-        if (SplitScratch* sc = split_scratch(st)) {
+        if (SplitScratch* sc = sc0) {
             a.full_blocks = all_tiles ? 0 : a.nwg / cu_count() * cu_count();
             a.parts = p;
             a.partials = sc->partials;
@@ -2175,6 +2180,8 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "bn_rows")) set_bn_rows(value);
     else if (!strcmp(key, "glds")) g_glds = value ? 1 : 0;
     else if (!strcmp(key, "glds_st") && (value == 2 || value == 3)) g_glds_st = value;
+    else if (!strcmp(key, "wgrad_kp") && (value == 32 || value == 64)) g_wgrad_kp = value;
+    else if (!strcmp(key, "wgrad_st") && (value == 2 || value == 3)) g_wgrad_st = value;
     else if (!strcmp(key, "glds_kt") && (value == 32 || value == 64)) g_glds_kt = value;
     else if (!strcmp(key, "db_min_k") && value > 0) g_db_min_k = value;
     else if (!strcmp(key, "short_k") && value > 0) g_short_k = value;
@@ -2316,6 +2323,16 @@ static int fill_dgrad_args(IgemmArgs& a, const up_conv_desc* d, const float* dy,
 }
 
 // ---- bf16-operand launches ----
+// second-generation bf16-storage kernel (bf16s_glds.h): needs 8-channel (16-byte) output rows, 31-bit byte offsets, 16-byte
+// aligned pointers and no strided gather
+static bool glds_eligible(const IgemmArgs& a, bool fast) {
+    const long long a_bytes = (long long)(a.M / (a.P * a.Q)) * a.H * a.W * a.ldx * 2;
+    const uintptr_t ptrs = reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.y) |
+                           reinterpret_cast<uintptr_t>(a.w_hi) | reinterpret_cast<uintptr_t>(a.residual);
+    return g_glds && fast && a.M % (a.P * a.Q) == 0 && a.Ng % 8 == 0 && a.ldy % 8 == 0 && a.ldx % 8 == 0 &&
+           (!a.residual || a.ldr % 8 == 0) && !a.o_mode && a_bytes < (1ll << 31) && (long long)a.Ng * a.Ktot * 2 < (1ll << 31) &&
+           (long long)a.M * a.ldy < (1ll << 31) && (!a.residual || (long long)a.M * a.ldr < (1ll << 31)) && (ptrs & 15) == 0;
+}
 template <int BM, int BN>
 static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
     int ntm = cdiv(a.M, BM);
@@ -2323,9 +2340,10 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
     a.nwg = ntm * a.ntn;
     a.fNtn = make_fastdiv(a.ntn);
     const int v = 12 + ((BM == 128 && BN == 128) ? 0 : (BM == 64 && BN == 128) ? 1 : (BM == 128 && BN == 64) ? 2 : 3);
-    ProfScope prof(v, 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st, a.M, a.Ng, a.Ktot, a.nwg);
     const bool fast = a.taps <= 32 && a.divshift == 0 &&
                       (long long)a.H * a.W * a.ldx * ((long long)a.M / (a.P * a.Q) + 1) < (1ll << 31);
+    const bool glds_form = math == UP_MATH_BF16S && glds_eligible(a, fast);
+    ProfScope prof(glds_form ? v + 8 : v, 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st, a.M, a.Ng, a.Ktot, a.nwg);
     const bool split = math == UP_MATH_BF16X3;
     // K slice: 64 on the 64x64 tile (6 -> 12 MFMAs per wave and barrier) measured no faster than 32 (141.7 vs 145.1 TF)
     constexpr int KT = 32;
@@ -2333,13 +2351,8 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
         // second-generation kernel (bf16s_glds.h): operands HBM -> LDS directly, 64-channel slices, 16-byte epilogue stores.
         // Needs 64-channel alignment, 8-channel (16-byte) output rows, 31-bit byte offsets and no strided gather.
         const long long a_bytes = (long long)(a.M / (a.P * a.Q)) * a.H * a.W * a.ldx * 2;
-        const uintptr_t ptrs = reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.y) |
-                               reinterpret_cast<uintptr_t>(a.w_hi) | reinterpret_cast<uintptr_t>(a.residual);
         const int kt = (g_glds_kt == 64 && a.Cp % 64 == 0) ? 64 : 32;
-        if (g_glds && fast && a.M % (a.P * a.Q) == 0 && a.Ng % 8 == 0 && a.ldy % 8 == 0 &&
-            a.ldx % 8 == 0 && (!a.residual || a.ldr % 8 == 0) && !a.o_mode && a_bytes < (1ll << 31) &&
-            (long long)a.Ng * a.Ktot * 2 < (1ll << 31) && (long long)a.M * a.ldy < (1ll << 31) &&
-            (!a.residual || (long long)a.M * a.ldr < (1ll << 31)) && (ptrs & 15) == 0) {
+        if (glds_form) {
             a.no_tap_skip = g_tap_skip ? 0 : 1;
             a.perm = nullptr;
             a.x_bytes = (uint32_t)a_bytes;
@@ -2763,23 +2776,26 @@ static int up::conv2d_bwd_weight_impl(const up_conv_desc* d, const float* x, con
                           (int64_t)d->N * d->P * d->Q * d->ldy < (1ll << 31);
     if (use_bf16) {
         const int v = (p.bm == 128 && p.bn == 128) ? 16 : (p.bm == 128 && p.bn == 64) ? 17 : (p.bm == 64 && p.bn == 128) ? 18 : 19;
-        ProfScope prof(v, 2.0 * (double)a.M * (double)d->K * (double)d->R * d->S * d->C, st, d->K, a.Ncols, a.M,
+        const long long xb = (long long)d->N * d->H * d->W * d->ldx * 2, dyb = (long long)d->N * d->P * d->Q * d->ldy * 2;
+        const bool glds_form = bf16 == 2 && g_glds && xb < (1ll << 31) && dyb < (1ll << 31) &&
+                               ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+        ProfScope prof(glds_form ? v + 8 : v, 2.0 * (double)a.M * (double)d->K * (double)d->R * d->S * d->C, st, d->K, a.Ncols, a.M,
                        a.nwg);
         a.rect = (g_wgrad_rect && (int64_t)d->N * d->P * d->Q < (1ll << 30)) ? wgrad_rect_device(d, p) : nullptr;
-        const long long xb = (long long)d->N * d->H * d->W * d->ldx * 2, dyb = (long long)d->N * d->P * d->Q * d->ldy * 2;
-        if (bf16 == 2 && g_glds && xb < (1ll << 31) && dyb < (1ll << 31) &&
-            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
+        if (glds_form) {
             // second generation (bf16s_glds.h): [pixel][channel] slices HBM -> LDS directly, transposing fragment reads
             a.x_bytes = (uint32_t)xb;
             a.dy_bytes = (uint32_t)dyb;
-            if (p.bm == 128 && p.bn == 128)
-                hipLaunchKernelGGL((glds::wgrad_glds_kernel<128, 128>), grid, dim3(256), 0, st, a);
-            else if (p.bm == 128 && p.bn == 64)
-                hipLaunchKernelGGL((glds::wgrad_glds_kernel<128, 64>), grid, dim3(256), 0, st, a);
-            else if (p.bm == 64 && p.bn == 128)
-                hipLaunchKernelGGL((glds::wgrad_glds_kernel<64, 128>), grid, dim3(256), 0, st, a);
-            else
-                hipLaunchKernelGGL((glds::wgrad_glds_kernel<64, 64>), grid, dim3(256), 0, st, a);
+            void (*kernel)(WgradArgs);
+#define UP_WG_FORMS(BM_, BN_)                                                                              \
+    (g_wgrad_kp == 32 ? (g_wgrad_st == 3 ? glds::wgrad_glds_kernel<BM_, BN_, 32, 3, 3> : glds::wgrad_glds_kernel<BM_, BN_, 32, 2, 3>) \
+                      : glds::wgrad_glds_kernel<BM_, BN_, 64, 2, 2>)
+            if (p.bm == 128 && p.bn == 128) kernel = UP_WG_FORMS(128, 128);
+            else if (p.bm == 128 && p.bn == 64) kernel = UP_WG_FORMS(128, 64);
+            else if (p.bm == 64 && p.bn == 128) kernel = UP_WG_FORMS(64, 128);
+            else kernel = UP_WG_FORMS(64, 64);
+#undef UP_WG_FORMS
+            hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, a);
         } else if (bf16 == 2) {
             if (p.bm == 128 && p.bn == 128)
                 hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128, true>), grid, dim3(256), 0, st, a);

@@ -42,7 +42,7 @@ class GraphedForward:
         self.warmup = warmup
         # library-owned scratch (K-split partials, tap-sort tables) is keyed by stream and allocated on first use: warm up
         # on the stream the capture will run on, so nothing allocates while capturing
-        self.stream = _capture_stream(self.device)
+        self.stream = torch.cuda.Stream(device=self.device)
         self.static_args = [a.clone() if torch.is_tensor(a) else a for a in example_args]
         self.graph = None
         self.static_out = None
