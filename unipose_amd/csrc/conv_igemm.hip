@@ -1828,7 +1828,7 @@ static int env_int(const char* name, int dflt, int min_ok) {
 }
 static int g_tile_want = env_int("UP_TILE_WANT", 1500, 1);   // A/B in the network: 700 / 1000 / 1500 / 2200 / 4300 -> 70.1 / 69.9 / 69.6 / 69.9 / 69.8 ms
 static int g_tile_want_bf16 = env_int("UP_TILE_WANT_BF16", 500, 1);
-static int g_glds_kt = env_int("UP_GLDS_KT", 32, 32);   // channels per K slice of the direct-to-LDS kernels (64 | 32); 736^2 step (r03_b): register-staged 46.6 ms, 64: 43.6, 32: 41.7, 32 with three stages 42.1
+static int g_glds_kt = env_int("UP_GLDS_KT", 32, 0);   // channels per K slice of the direct-to-LDS kernels (64 | 32); 736^2 step (r03_b): register-staged 46.6 ms, 64: 43.6, 32: 41.7, 32 with three stages 42.1
 static int g_wgrad_kp = env_int("UP_WGRAD_KP", 64, 32);  // pixels per slice of the direct-to-LDS weight gradient (64 | 32)
 static int g_wgrad_st = env_int("UP_WGRAD_ST", 2, 2);   // its LDS stages at 32 pixels per slice (2 | 3)
 static int g_glds_st = env_int("UP_GLDS_ST", 2, 2);    // LDS stages of the 32-channel form (2 | 3)
@@ -2182,7 +2182,7 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "glds_st") && (value == 2 || value == 3)) g_glds_st = value;
     else if (!strcmp(key, "wgrad_kp") && (value == 32 || value == 64)) g_wgrad_kp = value;
     else if (!strcmp(key, "wgrad_st") && (value == 2 || value == 3)) g_wgrad_st = value;
-    else if (!strcmp(key, "glds_kt") && (value == 32 || value == 64)) g_glds_kt = value;
+    else if (!strcmp(key, "glds_kt") && (value == 0 || value == 32 || value == 64)) g_glds_kt = value;
     else if (!strcmp(key, "db_min_k") && value > 0) g_db_min_k = value;
     else if (!strcmp(key, "short_k") && value > 0) g_short_k = value;
     else if (!strcmp(key, "short_k_mult") && value > 0) g_short_k_mult = value;
@@ -2351,7 +2351,18 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
         // second-generation kernel (bf16s_glds.h): operands HBM -> LDS directly, 64-channel slices, 16-byte epilogue stores.
         // Needs 64-channel alignment, 8-channel (16-byte) output rows, 31-bit byte offsets and no strided gather.
         const long long a_bytes = (long long)(a.M / (a.P * a.Q)) * a.H * a.W * a.ldx * 2;
-        const int kt = (g_glds_kt == 64 && a.Cp % 64 == 0) ? 64 : 32;
+        // Slice form per launch (tools/gpu/glds_probe forms, profiles/r03_p_glds_forms.txt): 64-channel slices (two
+        // workgroups per CU, half the barriers) win on long reductions with enough tiles to fill two rounds — 3x3 512->512:
+        // 170 vs 201 us, 1x1 2048->512: 83 vs 97, decoder 3x3 at 92x92: 205 vs 245 — and lose where the launch is one ragged
+        // round of tiles (530 tiles: 58 vs 50 us) or the reduction is short (K <= 512).  glds_kt = 64 forces them everywhere
+        // they fit, 0 applies that rule per launch, 32 (default) keeps 32 everywhere: inside the training step, next to the
+        // weight-gradient stream, the rule measured 39.10 ms against 39.03 ms for plain 32 (r03_q) — the isolated gains do not
+        // survive the co-residency, like most isolated gains before them.
+        int kt = 32;
+        if (a.Cp % 64 == 0) {
+            if (g_glds_kt == 64) kt = 64;
+            else if (g_glds_kt == 0 && a.nwg >= 1000 && (a.Ktot >= 1024 || (BN == 64 && a.Ktot >= 576))) kt = 64;
+        }
         if (glds_form) {
             a.no_tap_skip = g_tap_skip ? 0 : 1;
             a.perm = nullptr;
