@@ -59,9 +59,12 @@ def _merge(st):
 
 
 def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, affine=False, residual=False, relu=False,
-            add=False, seed=0, kt=64, st=2, wkp=64, wst=2):
+            add=False, seed=0, kt=64, st=2, wkp=64, wst=2, split=0, cus=0):
     """forward (+ optional BatchNorm partials / folded epilogue / residual) and data gradient (+ optional addend) of one
-    convolution in bf16 storage: glds = 1 against glds = 0 under the same tile rule."""
+    convolution in bf16 storage: glds = 1 against glds = 0 under the same tile rule.
+    split = 1: the K-split of tail tiles is on in the glds kernels (`cus` shrinks the chip so that a small launch has whole rounds of
+    tiles + a tail); a split tile adds its shares in a different order, so outputs are then compared within fp32 round-off of the
+    reduction instead of exactly."""
     cp, kp = ops.rup32(c), ops.rup32(k)
     x = _nhwc(torch.randn(n, c, h, w, generator=_g(seed)), dev, cp)
     wt = (torch.randn(k, c, r, r, generator=_g(seed + 1)) * (2.0 / (c * r * r)) ** 0.5).to(dev)
@@ -73,7 +76,7 @@ def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, 
         kw["bias"] = torch.randn(k, generator=_g(seed + 4)).to(dev)
     out = {}
     try:
-        _tune(tile_want_bf16=tile_want, glds_kt=kt, glds_st=st, wgrad_kp=wkp, wgrad_st=wst)
+        _tune(tile_want_bf16=tile_want, glds_kt=kt, glds_st=st, wgrad_kp=wkp, wgrad_st=wst, glds_split=split, cu_count=cus, glds_split_q=4, glds_split_maxp=256)
         for mode in (1, 0):
             _tune(glds=mode)
             d0 = ops.make_desc(x, wt, cfg)
@@ -87,9 +90,25 @@ def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, 
             dw, _ = ops.conv_bwd_weight_raw(x, dy, wt.shape, d, False)
             out[mode] = (y, st, dx, dw)
     finally:
-        _tune(glds=1, tile_want_bf16=500, glds_kt=32, glds_st=2, wgrad_kp=64, wgrad_st=2)
+        _tune(glds=1, tile_want_bf16=500, glds_kt=32, glds_st=2, wgrad_kp=64, wgrad_st=2, glds_split=1, cu_count=0, glds_split_q=2, glds_split_maxp=4)
     (y1, s1, dx1, dw1), (y0, s0, dx0, dw0) = out[1], out[0]
     _same(dw1, dw0, "dw")
+    if split:
+        # bf16 outputs of fp32 sums that differ by re-association: at most one bf16 ulp (2^-8 relative) on a few elements
+        for a_, b_, what in ((y1, y0, "y"), (dx1, dx0, "dx")):
+            if a_ is None:
+                continue
+            a_, b_ = a_.float().cpu(), b_.float().cpu()
+            err = (a_ - b_).abs()
+            assert float((err / b_.abs().clamp_min(1e-2)).max()) <= 2.0 ** -7, (what, float(err.max()))
+            assert float((err > 0).float().mean()) < 0.02, (what, "too many elements differ", float((err > 0).float().mean()))
+        if stats:
+            m1, m0 = _merge(s1), _merge(s0)
+            assert torch.equal(m1[0], m0[0]), "BatchNorm counts"
+            for i, what in ((1, "mean"), (2, "M2")):
+                err = float((m1[i] - m0[i]).abs().max() / m0[i].abs().max().clamp_min(1e-30))
+                assert err < 1e-4, (what, err)
+        return y1
     _same(y1, y0, "y")
     if stats:
         # per-tile partials (count, mean, M2): identical when both kernels tile the rows alike; with tap-sorted rows the
@@ -122,6 +141,16 @@ SMALL = [
     dict(n=2, c=64, h=8, w=8, k=64, r=3, stride=1, pad=2, dil=2, tile_want=1, affine=True, relu=True),   # eval, no residual, tap-sorted
     dict(n=2, c=64, h=9, w=9, k=64, r=3, stride=2, pad=1, dil=1, tile_want=1, stats=True),          # stride 2 forward
     dict(n=1, c=192, h=5, w=5, k=64, r=1, stride=1, pad=0, dil=1, tile_want=1),                     # three slices
+]
+
+# K-split tail tiles (chip shrunk to `cus` CUs): whole rounds + tail parts in one launch
+SPLIT = [
+    dict(n=3, c=64, h=7, w=7, k=128, r=3, stride=1, pad=1, dil=1, tile_want=100000, stats=True, cus=4),   # 64x64 tiles: 3 x 2 = 6 tiles = 4 + 2 tails x 2 parts
+    dict(n=2, c=128, h=6, w=6, k=72, r=3, stride=1, pad=1, dil=1, tile_want=1, add=True, cus=0),          # one 128x128 tile, 36 slices -> 18 parts, addend after the merge
+    dict(n=4, c=64, h=7, w=7, k=64, r=3, stride=1, pad=3, dil=3, tile_want=100000, stats=True, cus=3),    # tap-sorted, tiles with different live taps: 4 tiles = 3 + 1 x 3
+    dict(n=2, c=64, h=9, w=9, k=64, r=1, stride=1, pad=0, dil=1, tile_want=100000, stats=True, cus=2),    # 1x1, two slices: 3 tiles = 2 + 1 tail; p = 1 (too short): no split
+    dict(n=1, c=256, h=5, w=5, k=64, r=1, stride=1, pad=0, dil=1, tile_want=1, affine=True, relu=True, residual=True, cus=0),   # 1x1 8 slices -> 4 parts, folded epilogue
+    dict(n=1, c=64, h=5, w=5, k=64, r=3, stride=1, pad=6, dil=6, tile_want=1, stats=True, cus=0),         # only the centre tap lives: 2 live slices under 9 parts -> empty shares
 ]
 
 # the real geometries of BASELINE configs[4] (736x736, B = 16) that carry the step

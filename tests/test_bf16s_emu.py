@@ -72,3 +72,11 @@ def test_glds_kernel_matches_register_staged_kernel(emu_backend, case, form):
     32-channel slices, two and three LDS stages) == the register-staged kernels, element for element: outputs, BatchNorm
     partials, data gradients, weight gradients"""
     gc.conv_ab(emu_backend, kt=form[0], st=form[1], wkp=form[2], wst=form[3], **case)
+
+
+@pytest.mark.parametrize("case", gc.SPLIT, ids=lambda c: "c%d_%dx%d_k%d_r%d_d%d_cus%d" % (c["c"], c["h"], c["w"], c["k"], c["r"], c["dil"], c["cus"]))
+@pytest.mark.parametrize("form", [(64, 2), (32, 2), (32, 3)], ids=lambda f: "kt%d_st%d" % f)
+def test_glds_kernel_tail_split(emu_backend, case, form):
+    """K-split tail tiles of the direct-to-LDS kernels (whole rounds + parts in one launch, tap-sorted tiles, empty shares, folded
+    epilogue and addend after the merge) against the unsplit register-staged kernels"""
+    gc.conv_ab(emu_backend, kt=form[0], st=form[1], split=1, **case)

@@ -61,6 +61,15 @@ def test_glds_kernel_matches_register_staged_kernel(case, form):
     gc.conv_ab(DEV, kt=form[0], st=form[1], wkp=form[2], wst=form[3], **case)
 
 
+@pytest.mark.parametrize("form", [(32, 2), (64, 2), (32, 3)], ids=lambda f: "kt%d_st%d" % f)
+@pytest.mark.parametrize("case", gc.SPLIT + [dict(c, cus=0) for c in gc.FULL[:3]],
+                         ids=lambda c: "n%d_c%d_%dx%d_k%d_r%d_d%d_cus%d" % (c["n"], c["c"], c["h"], c["w"], c["k"], c["r"], c["dil"], c["cus"]))
+def test_glds_kernel_tail_split(case, form):
+    """K-split tail tiles of the direct-to-LDS kernels: small launches on a shrunk chip, and the 530-tile layer3 launches of
+    BASELINE configs[4] on the real one (512 whole tiles + 18 tiles in 14 parts), against the unsplit register-staged kernels"""
+    gc.conv_ab(DEV, kt=form[0], st=form[1], split=1, **case)
+
+
 def _golden_eval(golden_dir, name, size, B):
     from unipose_amd import ops
     g = np.load(os.path.join(golden_dir, name))

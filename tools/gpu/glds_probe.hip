@@ -114,13 +114,13 @@ int main(int argc, char** argv) {
     if (argc > 1 && !strcmp(argv[1], "forms")) {   // which slice form per layer shape?  (64 | 32 channels, 2 | 3 stages)
         std::vector<Variant> v = {
             {"register-staged <128,128> (round 2)", igemm_bf16_kernel<128, 128, 2, false, 32, true>, 128, 128, false},
-            {"glds 128x128 kt32 st2", G(128, 128, 32, 2, 3, 0, 0), 128, 128, false},
+            {"glds 128x128 kt32 st2", G(128, 128, 32, 2, 4, 0, 0), 128, 128, false},
             {"glds 128x128 kt32 st3", G(128, 128, 32, 3, 3, 0, 0), 128, 128, false},
             {"glds 128x128 kt64 st2", G(128, 128, 64, 2, 2, 0, 0), 128, 128, false},
         };
         std::vector<Variant> v64 = {
             {"register-staged <128,64> (round 2)", igemm_bf16_kernel<128, 64, 2, false, 32, true>, 128, 64, false},
-            {"glds 128x64 kt32 st2", G(128, 64, 32, 2, 3, 0, 0), 128, 64, false},
+            {"glds 128x64 kt32 st2", G(128, 64, 32, 2, 4, 0, 0), 128, 64, false},
             {"glds 128x64 kt32 st3", G(128, 64, 32, 3, 3, 0, 0), 128, 64, false},
             {"glds 128x64 kt64 st2", G(128, 64, 64, 2, 2, 0, 0), 128, 64, false},
         };
@@ -139,14 +139,14 @@ int main(int argc, char** argv) {
     }
     std::vector<Variant> v128 = {
         {"register-staged <128,128> (round 2)", igemm_bf16_kernel<128, 128, 2, false, 32, true>, 128, 128, false},
-        {"glds 128x128 kt32 st2", G(128, 128, 32, 2, 3, 0, 0), 128, 128, false},
-        {"glds 128x128 kt32 st2 +stamps", G(128, 128, 32, 2, 3, 0, 1), 128, 128, true},
-        {"glds 128x128 kt32 st2 old epilogue", G(128, 128, 32, 2, 3, 1, 0), 128, 128, false},
+        {"glds 128x128 kt32 st2", G(128, 128, 32, 2, 4, 0, 0), 128, 128, false},
+        {"glds 128x128 kt32 st2 +stamps", G(128, 128, 32, 2, 4, 0, 1), 128, 128, true},
+        {"glds 128x128 kt32 st2 old epilogue", G(128, 128, 32, 2, 4, 1, 0), 128, 128, false},
         {"glds 128x128 kt32 st3", G(128, 128, 32, 3, 3, 0, 0), 128, 128, false},
         {"glds 128x128 kt64 st2", G(128, 128, 64, 2, 2, 0, 0), 128, 128, false},
         {"glds 128x128 kt64 st2 +stamps", G(128, 128, 64, 2, 2, 0, 1), 128, 128, true},
-        {"glds 64x128 kt32 st2", G(64, 128, 32, 2, 3, 0, 0), 64, 128, false},
-        {"glds 128x64 kt32 st2", G(128, 64, 32, 2, 3, 0, 0), 128, 64, false},
+        {"glds 64x128 kt32 st2", G(64, 128, 32, 2, 4, 0, 0), 64, 128, false},
+        {"glds 128x64 kt32 st2", G(128, 64, 32, 2, 4, 0, 0), 128, 64, false},
     };
     shape("layer3 conv3 1x1 256->1024 @46", mk(16, 46, 256, 1024, 1, 0, 1), true, v128);
     shape("layer3 conv1 1x1 1024->256 @46", mk(16, 46, 1024, 256, 1, 0, 1), true, v128);

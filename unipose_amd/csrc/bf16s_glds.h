@@ -45,6 +45,10 @@ __device__ __forceinline__ uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t
 template <int N>
 __device__ __forceinline__ void wait_dma_but() {}
 __device__ __forceinline__ void raw_barrier() { __syncthreads(); }
+__device__ __forceinline__ void sched_fence() {}
+// 16 bytes per lane to / from a split-K share at byte offset `uni` (wave-uniform) + `lane_off`, agent scope
+__device__ __forceinline__ void share_store16(Rsrc r, int lane_off, int uni, const float* v) { memcpy(const_cast<unsigned char*>(r.base) + uni + lane_off, v, 16); }
+__device__ __forceinline__ void share_load16(Rsrc r, int lane_off, int uni, float* v) { memcpy(v, r.base + uni + lane_off, 16); }
 #else
 typedef __amdgpu_buffer_rsrc_t Rsrc;
 __device__ __forceinline__ Rsrc make_rsrc(const void* p, uint32_t bytes) {
@@ -65,6 +69,20 @@ __device__ __forceinline__ void wait_dma_but() { asm volatile("s_waitcnt vmcnt(%
 __device__ __forceinline__ void raw_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+}
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }   // nothing is scheduled across
+// 16 bytes per lane to / from a split-K share at byte offset `uni` (wave-uniform: an SGPR / immediate, no address VGPRs) +
+// `lane_off`; aux bit 4 = sc1: the agent-scope form of a store / load on gfx942+ (write-through to / read from the memory side of
+// the per-XCD L2), what st_agent / ld_agent compile to
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void share_store16(Rsrc r, int lane_off, int uni, const float* v) {
+    u32x4_t u;
+    memcpy(&u, v, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, lane_off, uni, 16);
+}
+__device__ __forceinline__ void share_load16(Rsrc r, int lane_off, int uni, float* v) {
+    const u32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, uni, 16);
+    memcpy(v, &u, 16);
 }
 #endif
 
@@ -337,7 +355,18 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds_kernel(IgemmArgs a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    const int logical = xcd_remap(blockIdx.x, a.nwg);
+    // K-split tail tiles as in igemm_kernel (conv_igemm.hip "tail split"): blocks >= full_blocks reduce a 1 / parts share of
+    // the live slices of tile full_blocks + tail; the last part of a tile adds the published shares and runs the epilogue
+    int logical, part = 0, tail = 0;
+    const bool split = (int)blockIdx.x >= a.full_blocks;
+    if (!split) {
+        logical = xcd_remap(blockIdx.x, a.full_blocks);
+    } else {
+        const int j = (int)blockIdx.x - a.full_blocks;
+        tail = uniform(j / a.parts);
+        part = j - tail * a.parts;
+        logical = a.full_blocks + tail;
+    }
     const int mt = fdiv(logical, a.fNtn);
     const int nt = logical - mt * a.ntn;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -366,7 +395,8 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds_kernel(IgemmArgs a) {
     // 1x1, stride 1, no padding (two thirds of the launches): the source pixel IS the destination pixel, and the first weight
     // slice does not depend on any row set-up: it is on its way before the rows are looked at
     const bool pointwise = a.taps == 1 && a.mul == 1 && a.off0 == 0 && a.off0w == 0 && a.H == a.P && a.W == a.Q;
-    if (pointwise) issueB(0, 0, 0);
+    const bool early_b = pointwise && !split;
+    if (early_b) issueB(0, 0, 0);
 
     int roffA[NA];        // byte offset of (filter tap (0,0), this lane's chunk) of the row in the activation tensor
     unsigned tmA[NA];     // bit t: tap t of the row reads a real pixel (0 for rows >= M)
@@ -423,11 +453,19 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds_kernel(IgemmArgs a) {
         if (live == 0u) live = all_taps;
     }
     const int spt = a.Cp / KT;
-    const int nsl = __builtin_popcount(live) * spt;
+    int nsl = __builtin_popcount(live) * spt;
     unsigned rest = live;
     int tap = __builtin_ctz(rest), cs = 0;
+    if (split) {   // slices [kb, ke) of the tile's live slices
+        const int kb = (int)((long long)nsl * part / a.parts), ke = (int)((long long)nsl * (part + 1) / a.parts);
+        const int skip = kb / spt;
+        for (int t = 0; t < skip; ++t) rest &= rest - 1u;
+        tap = rest ? __builtin_ctz(rest) : 0;
+        cs = kb - skip * spt;
+        nsl = ke - kb;
+    }
 
-    bool b_issued = pointwise;   // the weight slice of the first issue is already on its way
+    bool b_issued = early_b;   // the weight slice of the first issue is already on its way
     auto issue = [&](int stage) {
         unsigned char* const As = smem + stage * G::STAGE;
         const int r = fdiv(tap, a.fS);
@@ -477,7 +515,7 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds_kernel(IgemmArgs a) {
 
     if (DBG && tid == 0) stamp[1] = wall_clock64();
     if constexpr (ST == 2) {
-        issue(0);
+        if (nsl > 0) issue(0);
         for (int it = 0; it < nsl; ++it) {
             wait_dma();
             __syncthreads();   // slice `it` has landed for every wave, and every wave is done with the other stage
@@ -487,7 +525,7 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds_kernel(IgemmArgs a) {
         }
     } else {
         static_assert(ST == 3, "two or three LDS stages");
-        issue(0);
+        if (nsl > 0) issue(0);
         if (nsl > 1) issue(1);
         int cur = 0, nxt = 2;   // stage of slice `it`, stage slice it + 2 goes to
         for (int it = 0; it < nsl; ++it) {
@@ -503,6 +541,57 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds_kernel(IgemmArgs a) {
     }
     __syncthreads();   // every wave is past its last fragment read: the stages become the epilogue image
     if (DBG && tid == 0) stamp[3] = wall_clock64();
+
+    int nmerge = 0;
+    if (split) {
+        // shares are [part][(i*TN+j)*4 + r/4][256 threads][4] floats: 16 bytes per lane and access, 4 KB per wave-level row, with
+        // agent-scope accesses; readers have a higher block index than writers, so the wait cannot dead-lock the dispatch
+        float* pbase = a.partials + (size_t)tail * (a.parts - 1) * (BM * BN);
+        int* flag = a.flags + tail * (a.parts - 1);
+        if (part < a.parts - 1) {
+            const Rsrc rs = make_rsrc(pbase + (size_t)part * (BM * BN), (uint32_t)(BM * BN * 4));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) share_store16(rs, tid * 16, ((i * TN + j) * 4 + q) * 4096, v + 4 * q);
+                }
+            wait_stores();
+            __syncthreads();
+            if (tid == 0) st_agent_flag(flag + part, 1);
+            return;
+        }
+        nmerge = a.parts - 1;
+    }
+    {   // (one loop on the common path, zero trips for a whole tile: a branch around it made the compiler keep two copies of the
+        // accumulators and spill)
+        float* pbase = a.partials + (size_t)tail * (size_t)nmerge * (BM * BN);
+        int* flag = a.flags + tail * nmerge;
+        for (int pp = 0; pp < nmerge; ++pp) {
+            if (tid == 0) spin_until_set(flag + pp);
+            __syncthreads();
+            const Rsrc rs = make_rsrc(pbase + (size_t)pp * (BM * BN), (uint32_t)(BM * BN * 4));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float v[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) share_load16(rs, tid * 16, ((i * TN + j) * 4 + q) * 4096, v + 4 * q);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += v[r];
+                    sched_fence();   // 16 floats in flight, not 64: the merge must not cost the K loop its registers
+                }
+        }
+        if (nmerge) {
+            __syncthreads();
+            if (tid < nmerge) st_agent_flag(flag + tid, 0);   // consumed: ready for the next launch on this stream
+        }
+    }
 
     if constexpr (EPI == 1) {
         igemm_epilogue<BM, BN, PERM, bf16_t>(a, acc, reinterpret_cast<float*>(smem), mt, m0, n0, wm, wn, l31, lh);

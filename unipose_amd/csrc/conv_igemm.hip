@@ -1873,7 +1873,9 @@ struct SplitScratch {
     int* flags = nullptr;
     size_t pfloats = 0, nflags = 0;   // capacity
 };
+static int g_cu_override = 0;   // up_conv_tune("cu_count", n): tests shrink the "chip" so that small launches have whole rounds + a tail
 static int cu_count() {
+    if (g_cu_override > 0) return g_cu_override;
     static const int n = [] {
         if (const char* e = getenv("UP_CU_COUNT")) return atoi(e) > 0 ? atoi(e) : 256;   // tests shrink the "chip"
 #ifndef UP_EMU
@@ -1947,6 +1949,24 @@ static int split_parts(int tiles, int Ktot, size_t slots, bool* all_tiles = null
         }
     }
     return p;
+}
+
+// The same cut for the direct-to-LDS bf16 kernels (bf16s_glds.h).  Measured on the 736^2 B=16 step (r03_s): per launch, exclusive —
+// 530 tiles, K = 1024: 349 -> 414 TF with 14 parts per tail tile; 1060 tiles (q = 4, 7 parts), K = 4608: 879 -> 743 TF (the parts
+// queue behind four whole rounds and the merger waits for them), so only launches of at most g_glds_split_q = 2 whole rounds are
+// cut.  In the whole step the 14-part cut was 0.6 ms SLOWER although the kernels were faster — every cut launch writes
+// 18 x 13 x 64 KB of shares through to memory and reads them back, ~3.4 GB per step —, at most 4 parts per tail tile measured
+// 0.15 ms faster than no cut (40.17 vs 40.32 ms, two alternations), 2 and 8 parts equal to no cut.
+static int g_glds_split = env_int("UP_GLDS_SPLIT", 1, 0);
+static int g_glds_split_q = env_int("UP_GLDS_SPLIT_Q", 2, 0);
+static int g_glds_split_maxp = env_int("UP_GLDS_SPLIT_MAXP", 4, 2);   // (p - 1) x 64 KB of shares per tail tile
+static int glds_split_parts(int tiles, int nk) {
+    const int cus = cu_count(), q = tiles / cus, r = tiles % cus;
+    if (r == 0 || r > cus / 2 || q > g_glds_split_q) return 1;
+    int p = cus / r;
+    if (p > g_glds_split_maxp) p = g_glds_split_maxp;
+    if (p > nk / 2) p = nk / 2;
+    return p < 2 ? 1 : p;
 }
 
 // ---- tap-sorted row order -----------------------------------------------------------------------------
@@ -2180,6 +2200,10 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "bn_rows")) set_bn_rows(value);
     else if (!strcmp(key, "glds")) g_glds = value ? 1 : 0;
     else if (!strcmp(key, "glds_st") && (value == 2 || value == 3)) g_glds_st = value;
+    else if (!strcmp(key, "cu_count") && value >= 0) g_cu_override = value;
+    else if (!strcmp(key, "glds_split")) g_glds_split = value ? 1 : 0;
+    else if (!strcmp(key, "glds_split_q") && value >= 0) g_glds_split_q = value;
+    else if (!strcmp(key, "glds_split_maxp") && value >= 2) g_glds_split_maxp = value;
     else if (!strcmp(key, "wgrad_kp") && (value == 32 || value == 64)) g_wgrad_kp = value;
     else if (!strcmp(key, "wgrad_st") && (value == 2 || value == 3)) g_wgrad_st = value;
     else if (!strcmp(key, "glds_kt") && (value == 0 || value == 32 || value == 64)) g_glds_kt = value;
@@ -2374,8 +2398,25 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
             else if (g_glds_st == 3)
                 kernel = a.perm ? glds::igemm_glds_kernel<BM, BN, true, 32, 3, 3> : glds::igemm_glds_kernel<BM, BN, false, 32, 3, 3>;
             else
-                kernel = a.perm ? glds::igemm_glds_kernel<BM, BN, true, 32, 2, 3> : glds::igemm_glds_kernel<BM, BN, false, 32, 2, 3>;
-            hipLaunchKernelGGL(kernel, dim3(a.nwg), dim3(256), 0, st, a);
+                kernel = a.perm ? glds::igemm_glds_kernel<BM, BN, true, 32, 2, 4> : glds::igemm_glds_kernel<BM, BN, false, 32, 2, 4>;
+            // tail split (see split_parts): 530 tiles on 256 CUs leave 18 CUs with three tiles and the rest with two
+            a.full_blocks = a.nwg;
+            a.parts = 1;
+            int grid = a.nwg;
+            if (g_glds_split && tail_split_enabled()) {
+                SplitScratch* sc = split_scratch(st);
+                const int p = sc ? glds_split_parts(a.nwg, a.Ktot / kt) : 1;
+                const int full = a.nwg / cu_count() * cu_count();
+                const size_t shares = (size_t)(a.nwg - full) * (size_t)(p - 1);
+                if (p > 1 && shares * (size_t)(BM * BN) <= sc->pfloats && shares <= sc->nflags) {
+                    a.full_blocks = full;
+                    a.parts = p;
+                    a.partials = sc->partials;
+                    a.flags = sc->flags;
+                    grid = full + (a.nwg - full) * p;
+                }
+            }
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, st, a);
             return;
         }
         a.fSpt = make_fastdiv(a.Cp / KT);
