@@ -132,7 +132,7 @@ int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const float* w_dg
  * operands (BASELINE config 5 arithmetic).  Weights come as bf16 planes made by up_pack_weights_bf16 in the
  * [rows][R*S][padded channels] order of up_pack_weights.  Requires the padded reduction channel count (Cp forward,
  * Kp backward) to be a multiple of 32; otherwise UP_ERR_UNSUPPORTED (use the fp32 entry points). */
-typedef enum { UP_MATH_F32 = 0, UP_MATH_BF16X3 = 1, UP_MATH_BF16 = 2, UP_MATH_BF16S = 3 } up_math;
+typedef enum { UP_MATH_F32 = 0, UP_MATH_BF16X3 = 1, UP_MATH_BF16 = 2, UP_MATH_BF16S = 3, UP_MATH_BF16S_F32OUT = 4 } up_math;
 int up_pack_weights_bf16(const up_conv_desc* d, const float* w_oihw, uint16_t* fwd_hi, uint16_t* fwd_lo,
                          uint16_t* dgrad_hi, uint16_t* dgrad_lo, void* stream);
 int up_conv2d_fwd_bf16(const up_conv_desc* d, const float* x, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
@@ -157,7 +157,10 @@ int up_conv2d_bwd_weight_bf16(const up_conv_desc* d, const float* x, const float
  * reduction is a whole number of 32-wide K slices); all arithmetic is fp32 (BatchNorm statistics, accumulators) or
  * bf16 MFMA with fp32 accumulation; weights, weight gradients, BatchNorm parameters and the optimizer stay fp32.
  *   - convolutions: up_conv2d_fwd_bf16 / up_conv2d_bwd_data_bf16 with math = UP_MATH_BF16S — x / y / residual / add are
- *     then bf16 tensors passed through the same pointer arguments; up_conv2d_bwd_weight_bf16s below;
+ *     then bf16 tensors passed through the same pointer arguments; up_conv2d_bwd_weight_bf16s below.  up_conv2d_fwd_bf16 also
+ *     takes math = UP_MATH_BF16S_F32OUT: bf16 x, fp32 y (no residual / statistics) — the network's LAST convolution
+ *     (decoder.py:30), so that the heat-maps and the bilinear up-sampling behind them (model/unipose.py:31-32) are not
+ *     rounded to 8-bit mantissas;
  *   - every streaming operator has a `_t` twin taking the element type of its activation tensors (UP_DT_F32 / UP_DT_BF16);
  *     the fp32 entry points above are the `_t` forms with UP_DT_F32.  The max-pool takes two types: it is where the
  *     network leaves the fp32 stem (fp32 in, bf16 out; its backward bf16 in, fp32 out). */

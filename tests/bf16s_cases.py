@@ -191,6 +191,42 @@ def small_ops_case(dev):
     assert xd.grad.dtype == BF and torch.equal(nchw(xd.grad, 17), rb(dy)) and float(xd.grad.float()[..., 17:].abs().max()) == 0
 
 
+def f32_out_case(dev, n=2, c=64, h=9, w=9, k=17, r=1, pad=0, seed=3):
+    """The network's last convolution in bf16 storage writes fp32 (UP_MATH_BF16S_F32OUT): same accumulators as the bf16-output
+    launch (rounding the fp32 result gives the bf16 result exactly), fp32 round-off from torch, gradients flow back as bf16."""
+    x = rb(torch.randn(n, c, h, w, generator=g(seed)))
+    wt = torch.randn(k, c, r, r, generator=g(seed + 1)) * (2.0 / (c * r * r)) ** 0.5
+    b = torch.randn(k, generator=g(seed + 2))
+    cfg = ops.ConvCfg(1, pad, 1)
+    xd = nhwc16(x, dev, pad_to=(c + 31) // 32 * 32).requires_grad_(True)
+    wd = wt.clone().to(dev).requires_grad_(True)
+    bd = b.clone().to(dev).requires_grad_(True)
+    y32 = ops.ConvBias.apply(xd, wd, bd, cfg, False, True)
+    y16 = ops.ConvBias.apply(xd.detach(), wd.detach(), bd.detach(), cfg, False)
+    assert y32.dtype == torch.float32 and y16.dtype == BF and y32.shape == y16.shape
+    assert torch.equal(y32.detach().to(BF).cpu(), y16.cpu())
+    assert float(y32.detach()[..., k:].abs().max()) == 0          # pad channels
+    xr = x.clone().requires_grad_(True)
+    wr = rb(wt).requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=pad)
+    assert rel(nchw(y32, k), yr.detach()) < 2e-6                  # fp32 accumulation of exact bf16 products
+    dy = torch.randn(yr.shape, generator=g(seed + 3))
+    yr.backward(rb(dy))                                           # the gradient is rounded to bf16 on its way back
+    dyd = torch.zeros(y32.shape)
+    dyd[..., :k] = dy.permute(0, 2, 3, 1)
+    y32.backward(dyd.to(dev))
+    assert xd.grad.dtype == BF
+    assert rel(nchw(xd.grad, c), xr.grad) < OUT_TOL
+    assert rel(wd.grad.cpu(), wr.grad) < 1e-5 and rel(bd.grad.cpu(), br.grad) < 1e-5
+    # fp32 tensors: the flag changes nothing
+    xf = torch.zeros(n, h, w, (c + 31) // 32 * 32)
+    xf[..., :c] = x.permute(0, 2, 3, 1)
+    a_ = ops.ConvBias.apply(xf.to(dev), wd.detach(), bd.detach(), cfg, False, True)
+    b_ = ops.ConvBias.apply(xf.to(dev), wd.detach(), bd.detach(), cfg, False, False)
+    assert a_.dtype == torch.float32 and torch.equal(a_.cpu(), b_.cpu())
+
+
 def model_eval_case(dev, K=14, B=1, size=64, tol=5e-2):
     """Whole network in bf16 storage against the fp32 oracle (own tolerance, SURVEY 8d: <= 5e-2 of the map maximum)."""
     import model_cases as mc

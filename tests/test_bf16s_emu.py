@@ -36,6 +36,11 @@ def test_small_ops_bf16_storage(emu_backend):
     bc.small_ops_case(emu_backend)
 
 
+def test_last_convolution_writes_fp32(emu_backend):
+    bc.f32_out_case(emu_backend)
+    bc.f32_out_case(emu_backend, n=1, c=96, h=7, w=6, k=22, r=3, pad=1, seed=9)
+
+
 def test_model_eval_bf16_storage(emu_backend):
     bc.model_eval_case(emu_backend)
 

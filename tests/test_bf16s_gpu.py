@@ -47,6 +47,12 @@ def test_conv_bn_bf16_storage(cfg):
     bc.conv_bn_case(DEV, n, c, h, w, k, r, s, p, d, relu=relu, residual=residual, train=train)
 
 
+def test_last_convolution_writes_fp32():
+    bc.f32_out_case(DEV)
+    bc.f32_out_case(DEV, n=1, c=96, h=7, w=6, k=22, r=3, pad=1, seed=9)
+    bc.f32_out_case(DEV, n=4, c=256, h=92, w=92, k=17, r=1, pad=0, seed=11)      # the decoder's last layer at 736 / 8
+
+
 def test_small_ops_bf16_storage():
     bc.small_ops_case(DEV)
 

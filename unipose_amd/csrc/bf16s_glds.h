@@ -47,8 +47,14 @@ __device__ __forceinline__ void wait_dma_but() {}
 __device__ __forceinline__ void raw_barrier() { __syncthreads(); }
 __device__ __forceinline__ void sched_fence() {}
 // 16 bytes per lane to / from a split-K share at byte offset `uni` (wave-uniform) + `lane_off`, agent scope
-__device__ __forceinline__ void share_store16(Rsrc r, int lane_off, int uni, const float* v) { memcpy(const_cast<unsigned char*>(r.base) + uni + lane_off, v, 16); }
+template <int AUX = 16>
+__device__ __forceinline__ void share_store16(Rsrc r, int lane_off, int uni, float a0, float a1, float a2, float a3) {
+    const float v[4] = {a0, a1, a2, a3};
+    memcpy(const_cast<unsigned char*>(r.base) + uni + lane_off, v, 16);
+}
+template <int AUX = 16>
 __device__ __forceinline__ void share_load16(Rsrc r, int lane_off, int uni, float* v) { memcpy(v, r.base + uni + lane_off, 16); }
+
 #else
 typedef __amdgpu_buffer_rsrc_t Rsrc;
 __device__ __forceinline__ Rsrc make_rsrc(const void* p, uint32_t bytes) {
@@ -75,15 +81,24 @@ __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0
 // `lane_off`; aux bit 4 = sc1: the agent-scope form of a store / load on gfx942+ (write-through to / read from the memory side of
 // the per-XCD L2), what st_agent / ld_agent compile to
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void share_store16(Rsrc r, int lane_off, int uni, const float* v) {
-    u32x4_t u;
-    memcpy(&u, v, 16);
-    __builtin_amdgcn_raw_buffer_store_b128(u, r, lane_off, uni, 16);
+// The data registers of a 16-byte buffer store with an SGPR offset must not be rewritten right behind it: hipcc (ROCm 7.2) treats that
+// form as hazard-free, the first version of this function (a staging array refilled per store: v_perm / v_mov into the same four
+// VGPRs directly behind each store) published a few lanes' NEXT four values on one box in three (tools/gpu/split_stress.py: 30 of 30
+// repetitions wrong on that box, none on the others).  The values are therefore taken from the caller's registers as they are
+// (the accumulators, never written again), and an s_nop follows each store.
+template <int AUX = 16>
+__device__ __forceinline__ void share_store16(Rsrc r, int lane_off, int uni, float a0, float a1, float a2, float a3) {
+    const u32x4_t u = {__builtin_bit_cast(uint32_t, a0), __builtin_bit_cast(uint32_t, a1), __builtin_bit_cast(uint32_t, a2),
+                       __builtin_bit_cast(uint32_t, a3)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, lane_off, uni, AUX);
+    asm volatile("s_nop 1" ::: "memory");
 }
+template <int AUX = 16>
 __device__ __forceinline__ void share_load16(Rsrc r, int lane_off, int uni, float* v) {
-    const u32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, uni, 16);
+    const u32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, uni, AUX);
     memcpy(v, &u, 16);
 }
+
 #endif
 
 #ifdef UP_EMU
@@ -554,11 +569,12 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds_kernel(IgemmArgs a) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    float v[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) share_store16(rs, tid * 16, ((i * TN + j) * 4 + q) * 4096, v + 4 * q);
+                    for (int q = 0; q < 4; ++q) {
+                        const int off = ((i * TN + j) * 4 + q) * 4096;
+                        const float a0 = acc[i][j][4 * q], a1 = acc[i][j][4 * q + 1], a2 = acc[i][j][4 * q + 2], a3 = acc[i][j][4 * q + 3];
+                        share_store16(rs, tid * 16, off, a0, a1, a2, a3);
+                    }
                 }
             wait_stores();
             __syncthreads();
@@ -581,7 +597,10 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds_kernel(IgemmArgs a) {
                 for (int j = 0; j < TN; ++j) {
                     float v[16];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) share_load16(rs, tid * 16, ((i * TN + j) * 4 + q) * 4096, v + 4 * q);
+                    for (int q = 0; q < 4; ++q) {
+                        const int off = ((i * TN + j) * 4 + q) * 4096;
+                        share_load16(rs, tid * 16, off, v + 4 * q);
+                    }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[i][j][r] += v[r];
                     sched_fence();   // 16 floats in flight, not 64: the merge must not cost the K loop its registers

@@ -865,8 +865,11 @@ __device__ __forceinline__ void split_bf16x2(float a0, float a1, uint32_t& hi, u
 // Slice indices past the end are clamped (harmless reloads): the loop body is branch-free.
 // HS: bf16 STORAGE (BASELINE configs[4]): the activation operand, the residual / addend and the output are bf16 in HBM.  A
 // thread stages 16 bytes = 8 channels per row with no conversion at all (the fp32 form: 4 channels + two packs).
-template <int BM, int BN, int MODE, bool SPLIT, int KT = 32, bool HS = false>
+// OF32 (with HS): the OUTPUT is fp32 — the network's last convolution in bf16 storage, whose heat-maps leave the library as fp32
+// (no residual: it would be read with the output's element type).
+template <int BM, int BN, int MODE, bool SPLIT, int KT = 32, bool HS = false, bool OF32 = false>
 __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
+    static_assert(!OF32 || HS, "OF32 is a bf16-storage form");
     static_assert(MODE == 1 || MODE == 2, "bf16 kernels need channel counts that are multiples of the K slice");
     static_assert(!(HS && SPLIT), "split-bf16 is an fp32-storage arithmetic");
     constexpr bool FAST = MODE == 2;
@@ -1087,8 +1090,8 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
         bodyX(kt);
         if (kt + 1 < nk) bodyY(kt + 1);
     }
-    igemm_epilogue<BM, BN, false, std::conditional_t<HS, bf16_t, float>>(a, acc, reinterpret_cast<float*>(smem), mt, m0, n0,
-                                                                         wm, wn, l31, lh);
+    igemm_epilogue<BM, BN, false, std::conditional_t<HS && !OF32, bf16_t, float>>(a, acc, reinterpret_cast<float*>(smem), mt, m0, n0,
+                                                                                  wm, wn, l31, lh);
 }
 
 // OIHW fp32 -> bf16 hi / lo planes in the [rows][tap][channel] order of pack_fwd / pack_dgrad
@@ -2366,7 +2369,9 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
     const int v = 12 + ((BM == 128 && BN == 128) ? 0 : (BM == 64 && BN == 128) ? 1 : (BM == 128 && BN == 64) ? 2 : 3);
     const bool fast = a.taps <= 32 && a.divshift == 0 &&
                       (long long)a.H * a.W * a.ldx * ((long long)a.M / (a.P * a.Q) + 1) < (1ll << 31);
-    const bool glds_form = math == UP_MATH_BF16S && glds_eligible(a, fast);
+    const bool of32 = math == UP_MATH_BF16S_F32OUT;
+    if (of32) math = UP_MATH_BF16S;
+    const bool glds_form = math == UP_MATH_BF16S && !of32 && glds_eligible(a, fast);
     ProfScope prof(glds_form ? v + 8 : v, 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st, a.M, a.Ng, a.Ktot, a.nwg);
     const bool split = math == UP_MATH_BF16X3;
     // K slice: 64 on the 64x64 tile (6 -> 12 MFMAs per wave and barrier) measured no faster than 32 (141.7 vs 145.1 TF)
@@ -2420,7 +2425,11 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
             return;
         }
         a.fSpt = make_fastdiv(a.Cp / KT);
-        if (fast)
+        if (of32 && fast)
+            hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 2, false, KT, true, true>), dim3(a.nwg), dim3(256), 0, st, a);
+        else if (of32)
+            hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 1, false, KT, true, true>), dim3(a.nwg), dim3(256), 0, st, a);
+        else if (fast)
             hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 2, false, KT, true>), dim3(a.nwg), dim3(256), 0, st, a);
         else
             hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 1, false, KT, true>), dim3(a.nwg), dim3(256), 0, st, a);
@@ -2449,8 +2458,11 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
         hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 1, false, KT>), dim3(a.nwg), dim3(256), 0, st, a);
 }
 static int run_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
-    UP_REQUIRE(math == UP_MATH_BF16X3 || math == UP_MATH_BF16 || math == UP_MATH_BF16S, UP_ERR_INVALID,
+    UP_REQUIRE(math == UP_MATH_BF16X3 || math == UP_MATH_BF16 || math == UP_MATH_BF16S || math == UP_MATH_BF16S_F32OUT, UP_ERR_INVALID,
                "bf16 convolution: math mode %d", math);
+    UP_REQUIRE(math != UP_MATH_BF16S_F32OUT || (a.ldx % 8 == 0 && !a.residual && !a.stats && !a.o_mode), UP_ERR_INVALID,
+               "bf16-storage convolution with fp32 output: ldx=%d must be a multiple of 8; no residual, statistics or parity-class output",
+               a.ldx);
     UP_REQUIRE(math != UP_MATH_BF16S || (a.ldx % 8 == 0 && a.ldy % 2 == 0), UP_ERR_INVALID,
                "bf16-storage convolution: ldx=%d must be a multiple of 8 (16-byte rows)", a.ldx);
     UP_REQUIRE(a.Cp % 32 == 0, UP_ERR_UNSUPPORTED, "bf16 convolution: padded channel count %d is not a multiple of 32",

@@ -223,7 +223,7 @@ class Decoder(nn.Module):
         y = ops.ConcatC.apply(320, x, low)      # 256 + 48 = 304 real channels, zero-padded to a multiple of 32
         y = ops.dropout(ops.conv_bn_act(y, lc[0], lc[1], relu=True), lc[3])
         y = ops.dropout(ops.conv_bn_act(y, lc[4], lc[5], relu=True), lc[7])
-        return ops.conv_bias_act(y, lc[8])
+        return ops.conv_bias_act(y, lc[8], out_f32=True)      # heat-maps leave as fp32 in every storage mode
 
 
 def build_decoder(dataset, num_classes, backbone, BatchNorm, bbox=False):

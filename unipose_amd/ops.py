@@ -197,6 +197,7 @@ def _packed(weight: torch.Tensor, d: _C.ConvDesc):
 #      accumulators, weights, weight gradients and the optimizer stay fp32.  The kernels dispatch on the tensor dtype,
 #      the switch only tells the model where to change the element type (modules.ResNet.forward, unipose.forward).
 MATH_F32, MATH_BF16X3, MATH_BF16, MATH_BF16S = 0, 1, 2, 3
+MATH_BF16S_F32OUT = 4        # up_conv2d_fwd_bf16 only: bf16 input, fp32 output (the network's last convolution)
 CONV_MATH = MATH_F32
 _MATH_NAMES = {"f32": 0, "fp32": 0, "bf16x3": 1, "split": 1, "bf16": 2, "bf16s": 3, "bf16_storage": 3}
 
@@ -248,13 +249,15 @@ def packed_dgrad(weight: torch.Tensor, d: _C.ConvDesc) -> torch.Tensor:
 
 
 def conv_fwd_raw(x, weight, cfg, *, scale=None, shift=None, bias=None, residual=None, relu=False, stats=False,
-                 out=None):
-    """One launch of the implicit-GEMM kernel.  Returns (y, desc, stats_tensor|None)."""
+                 out=None, out_f32=False):
+    """One launch of the implicit-GEMM kernel.  Returns (y, desc, stats_tensor|None).
+    out_f32: in bf16 storage, write an fp32 output (no effect on fp32 tensors)."""
     _dev_ok(x, weight, scale, shift, bias, residual)
     d = make_desc(x, weight, cfg, None if out is None else _nhwc_ok(out))
+    out_f32 = out_f32 and x.dtype == torch.bfloat16
     if out is None:
         alloc = torch.zeros if d.ldy != d.K else torch.empty      # pad channels must read as zeros
-        out = alloc((d.N, d.P, d.Q, d.ldy), dtype=x.dtype, device=x.device)
+        out = alloc((d.N, d.P, d.Q, d.ldy), dtype=torch.float32 if out_f32 else x.dtype, device=x.device)
     ep = _C.ConvEpilogue()
     ep.scale, ep.shift, ep.bias = _ptr(scale), _ptr(shift), _ptr(bias)
     ep.residual = _ptr(residual)
@@ -272,12 +275,14 @@ def conv_fwd_raw(x, weight, cfg, *, scale=None, shift=None, bias=None, residual=
         st = torch.empty((tiles, d.K, 3), dtype=torch.float32, device=x.device)
         ep.stats = st.data_ptr()
     if x.dtype == torch.bfloat16:                                  # bf16 storage: the kernels follow the tensor
-        if d.Cp % 32 or (residual is not None and residual.dtype != x.dtype) or out.dtype != x.dtype:
+        if d.Cp % 32 or (residual is not None and residual.dtype != x.dtype) or \
+                out.dtype != (torch.float32 if out_f32 else x.dtype) or (out_f32 and (residual is not None or stats)):
             raise NotImplementedError(f"bf16-storage convolution needs 32-aligned input channels (got {d.Cp}) and bf16 "
-                                      "residual / output tensors")
+                                      "residual / output tensors (fp32 output: no residual, no statistics)")
         wf, _ = _packed_bf16(weight, d)
         _C.check(_C.lib().up_conv2d_fwd_bf16(C.byref(d), x.data_ptr(), wf[0].data_ptr(), wf[1].data_ptr(),
-                                             out.data_ptr(), C.byref(ep), MATH_BF16S, _stream(x)), "conv2d_fwd_bf16s")
+                                             out.data_ptr(), C.byref(ep), MATH_BF16S_F32OUT if out_f32 else MATH_BF16S,
+                                             _stream(x)), "conv2d_fwd_bf16s")
     elif CONV_MATH in (MATH_BF16X3, MATH_BF16, MATH_BF16S) and d.Cp % 32 == 0:
         wf, _ = _packed_bf16(weight, d)
         _C.check(_C.lib().up_conv2d_fwd_bf16(C.byref(d), x.data_ptr(), wf[0].data_ptr(), wf[1].data_ptr(),
@@ -505,8 +510,8 @@ class ConvBias(Function):
     (decoder.py:30, model/uniposeLSTM.py:12-14,30-38,85-89,120-124)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, cfg: ConvCfg, relu: bool):
-        y, d, _ = conv_fwd_raw(x, weight, cfg, bias=bias, relu=relu)
+    def forward(ctx, x, weight, bias, cfg: ConvCfg, relu: bool, out_f32: bool = False):
+        y, d, _ = conv_fwd_raw(x, weight, cfg, bias=bias, relu=relu, out_f32=out_f32)
         if relu and _RELU_TRACE is not None:
             _RELU_TRACE.append(y.detach())
         ctx.d, ctx.relu, ctx.has_bias = d, relu, bias is not None
@@ -518,6 +523,8 @@ class ConvBias(Function):
     def backward(ctx, dy):
         x, weight, y = ctx.saved_tensors
         dy = _dense(dy)
+        if dy.dtype != x.dtype and not ctx.relu:      # fp32 output of a bf16-storage convolution: its gradient goes back to bf16
+            dy = dy.to(x.dtype)
         if ctx.relu:
             if dy.dtype != torch.float32:
                 raise NotImplementedError("conv + bias + ReLU (the ConvLSTM head) has no bf16-storage backward")
@@ -531,7 +538,7 @@ class ConvBias(Function):
             dw, db = conv_bwd_weight(x, dy, weight, ctx.d, ctx.has_bias and ctx.needs_input_grad[2])
         elif ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.reshape(-1, dy.shape[3]).float().sum(0)[:weight.shape[0]]      # fp32 sum for an fp32 bias, also in bf16 storage
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 _BN_GROUPS = {"n": 1}
@@ -767,9 +774,10 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, link_in=None, link_out=No
                            link_in, link_out)
 
 
-def conv_bias_act(x, conv, relu=False):
+def conv_bias_act(x, conv, relu=False, out_f32=False):
+    """out_f32: the network's last convolution — in bf16 storage its output (the heat-maps) is written as fp32"""
     cfg = ConvCfg(conv.stride[0], conv.padding[0], conv.dilation[0])
-    return ConvBias.apply(x, conv.weight, conv.bias, cfg, relu)
+    return ConvBias.apply(x, conv.weight, conv.bias, cfg, relu, out_f32)
 
 
 # --------------------------------------------------------------------------------------------
