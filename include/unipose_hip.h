@@ -105,7 +105,7 @@ int up_conv_split_parts(const up_conv_desc* d);
  * up_conv_wgrad_visits; default on since the round-2 A/B), "lds_swz" (UP_LDS_SWZ: XOR-swizzled unpadded LDS rows).
  * bf16 storage (round 3): "glds" (UP_GLDS: direct-to-LDS kernels of bf16s_glds.h, default 1), "glds_kt" (32 | 64 channels per K slice,
  * 0 = rule per launch), "glds_st" (2 | 3 LDS stages), "glds_split" / "glds_split_q" / "glds_split_maxp" (K-split of the tail tiles of
- * launches with at most q whole rounds of tiles into at most maxp parts; defaults 1 / 2 / 4), "wgrad_kp" (64 | 32 pixels per slice of
+ * launches with at most q whole rounds of tiles into at most maxp parts; defaults 0 (off: batch-size-independent results) / 2 / 4), "wgrad_kp" (64 | 32 pixels per slice of
  * the weight gradient), "wgrad_st", "bn_rows" (row-strided BatchNorm kernels), "cu_count" (tests: pretend the chip has this many CUs
  * when planning splits; 0 = the real count).
  * Change them only between steps: workspace sizes and the BatchNorm partial-row count follow the tile choice. */

@@ -90,7 +90,7 @@ def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, 
             dw, _ = ops.conv_bwd_weight_raw(x, dy, wt.shape, d, False)
             out[mode] = (y, st, dx, dw)
     finally:
-        _tune(glds=1, tile_want_bf16=500, glds_kt=32, glds_st=2, wgrad_kp=64, wgrad_st=2, glds_split=1, cu_count=0, glds_split_q=2, glds_split_maxp=4)
+        _tune(glds=1, tile_want_bf16=500, glds_kt=32, glds_st=2, wgrad_kp=64, wgrad_st=2, glds_split=0, cu_count=0, glds_split_q=2, glds_split_maxp=4)
     (y1, s1, dx1, dw1), (y0, s0, dx0, dw0) = out[1], out[0]
     _same(dw1, dw0, "dw")
     if split:

@@ -97,15 +97,15 @@ def _golden_eval(golden_dir, name, size, B):
 
 
 def test_g10_eval_736_bf16_storage(golden_dir):
-    """configs[4]'s resolution against the genuine reference: own tolerance 5e-2 of the map maximum, argmax
-    agreement reported (and required to be a clear majority)."""
+    """configs[4]'s resolution against the genuine reference: SURVEY 8d allows 5e-2 of the map maximum; with the last convolution and
+    the up-sampling in fp32 (round 3) the measured distance is 1.2e-2 with 94 % of the joint argmaxes identical: held to 2.5e-2 / 85 %."""
     e, agree = _golden_eval(golden_dir, "g10_eval_736.npz", 736, 1)
-    assert e < 5e-2 and agree > 0.8
+    assert e < 2.5e-2 and agree > 0.85
 
 
 def test_g1_eval_368_bf16_storage(golden_dir):
-    e, agree = _golden_eval(golden_dir, "g1_eval_368.npz", 368, 2)
-    assert e < 5e-2 and agree > 0.8
+    e, agree = _golden_eval(golden_dir, "g1_eval_368.npz", 368, 2)      # measured 1.1e-2 / 90 %
+    assert e < 2.5e-2 and agree > 0.85
 
 
 def test_train_step_bf16_storage_vs_oracle():

@@ -44,7 +44,7 @@ def run(c, k, r, pad, kt, reps, q=4, maxp=256, sync=0):
             print(f"  rep {i}: {int(big.sum())} elements off, max {float(err.max()):.3f}, pixels {int(rows.min())}..{int(rows.max())}, "
                   f"channels {int(idx[:, 3].min())}..{int(idx[:, 3].max())}")
     print(f"c={c} k={k} r={r} kt={kt} q={q} maxp={maxp} sync={sync}: {bad} of {reps} repetitions wrong")
-    tune(glds_split=1, glds_split_q=2, glds_split_maxp=4, glds_kt=32)
+    tune(glds_split=0, glds_split_q=2, glds_split_maxp=4, glds_kt=32)
 
 
 if __name__ == "__main__":

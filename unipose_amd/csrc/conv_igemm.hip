@@ -1960,7 +1960,11 @@ static int split_parts(int tiles, int Ktot, size_t slots, bool* all_tiles = null
 // cut.  In the whole step the 14-part cut was 0.6 ms SLOWER although the kernels were faster — every cut launch writes
 // 18 x 13 x 64 KB of shares through to memory and reads them back, ~3.4 GB per step —, at most 4 parts per tail tile measured
 // 0.15 ms faster than no cut (40.17 vs 40.32 ms, two alternations), 2 and 8 parts equal to no cut.
-static int g_glds_split = env_int("UP_GLDS_SPLIT", 1, 0);
+// Default OFF: a cut changes the summation order of the tiles it touches, which tiles those are depends on the batch size, and in
+// bf16 storage a last-bit difference in an accumulator can flip the rounding of a stored activation — the eval forward of a sample
+// would depend on how many other samples share its batch (tests: B = 4 vs B = 16 differ by 9e-3 with the cut, bit-identical without).
+// 0.15 ms of a 40 ms step does not buy that.
+static int g_glds_split = env_int("UP_GLDS_SPLIT", 0, 0);
 static int g_glds_split_q = env_int("UP_GLDS_SPLIT_Q", 2, 0);
 static int g_glds_split_maxp = env_int("UP_GLDS_SPLIT_MAXP", 4, 2);   // (p - 1) x 64 KB of shares per tail tile
 static int glds_split_parts(int tiles, int nk) {
