@@ -37,7 +37,7 @@ typedef enum {
 } up_status;
 
 const char* up_last_error(void);
-int up_abi_version(void);   /* 5 */
+int up_abi_version(void);   /* 6 */
 
 /* Geometry of one 2-D convolution (nn.Conv2d as used at resnet.py:10-16,61,80-84,104-109;
  * wasp.py:9,52,59-60; decoder.py:17,22,26,30; model/uniposeLSTM.py:12-14,30-38,85-89). */
@@ -202,6 +202,14 @@ int up_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const uint32_t
 size_t up_bn_bwd_workspace(int64_t rows, int C);
 int up_bn_apply_t(const void* y, int ldy, const float* scale, const float* shift, const void* residual, int ldr,
                   int relu, void* z, int ldz, uint32_t* relu_bits, int64_t rows, int C, int dtype, void* stream);
+/* The same pass in the CENTRED form ATen evaluates (native_batch_norm: (x - mean) * invstd * weight + bias):
+ * z = relu?((y - mean[c]) * scale[c] + beta[c] (+ residual)), scale = gamma * invstd from up_bn_finalize, beta = the BatchNorm bias.
+ * y * scale + (beta - mean * scale) rounds the product mean * scale: an absolute error of 2^-24 |mean| * scale on z, i.e. a relative
+ * |mean| / std ulps — 364 ulps for the reference's BatchNorm behind the global-average-pool branch (wasp.py:53: four samples per
+ * channel at B = 4), enough to flip ReLU decisions the reference does not flip: the WASP gradients of G14 moved from 2.7x to within
+ * the reference's own fp32-vs-fp64 distance with this form.  ABI version 6. */
+int up_bn_apply_centered_t(const void* y, int ldy, const float* mean, const float* scale, const float* beta, const void* residual,
+                           int ldr, int relu, void* z, int ldz, uint32_t* relu_bits, int64_t rows, int C, int dtype, void* stream);
 int up_bn_bwd_t(const void* dz, int lddz, const void* z, int ldz, const uint32_t* relu_bits, const void* y, int ldy,
                 const float* gamma, const float* mean, const float* invstd, int relu, int use_batch_stats,
                 void* dy, int lddy, void* dres, int lddres, float* dgamma, float* dbeta,
@@ -218,15 +226,20 @@ int up_bn_bwd_acc_t(const void* dz, int lddz, const void* z, int ldz, const uint
  * (uniposeLSTM.py:116-133 runs the trunk once per frame), while every convolution sees one T-times larger batch.
  *   up_bn_batch_stats_t      partial (count, mean, M2) per (group, 256-row chunk, channel): stats[groups][tiles][C][3]
  *   up_bn_finalize_groups    coef[groups][4][C] = mean, invstd, scale, shift; running statistics updated group by group
- *   up_bn_apply_groups_t     z = relu(y * scale_g + shift_g (+ res)) per group, relu_bits as in up_bn_apply
+ *   up_bn_apply_groups_t     z = relu((y - mean_g) * scale_g + beta (+ res)) per group (beta = NULL: y * scale_g + shift_g), relu_bits
+ *                            as in up_bn_apply
  *   up_bn_bwd_groups_t       data gradient per group from that group's sums; dgamma / dbeta = sums over all groups */
+/* Statistics of SMALL batches (<= 4096 rows per group), float64 two-pass, one tile per group: stats[groups][1][C][3] for
+ * up_bn_finalize (tiles = 1) / up_bn_finalize_groups.  The host side uses it below 256 rows per channel — the BatchNorm behind the
+ * global-average-pool branch (wasp.py:53), B rows — where the mean must be the correctly rounded one (see the kernel). */
+int up_bn_exact_stats_t(const void* y, int ldy, int64_t rows_per_group, int C, int groups, int dtype, float* stats, void* stream);
 int up_bn_batch_stats_tiles(int64_t rows_per_group);
 int up_bn_batch_stats_t(const void* y, int ldy, int64_t rows_per_group, int C, int groups, int dtype, float* stats, void* stream);
 int up_bn_finalize_groups(const float* stats, int tiles, int C, int groups, int64_t rows_per_group, float eps, float momentum,
                           float* running_mean, float* running_var, const float* gamma, const float* beta, float* coef,
                           void* stream);
-int up_bn_apply_groups_t(const void* y, int ldy, const float* coef, const void* res, int ldr, int relu, void* z, int ldz,
-                         uint32_t* relu_bits, int64_t rows_per_group, int C, int groups, int dtype, void* stream);
+int up_bn_apply_groups_t(const void* y, int ldy, const float* coef, const float* beta, const void* res, int ldr, int relu, void* z,
+                         int ldz, uint32_t* relu_bits, int64_t rows_per_group, int C, int groups, int dtype, void* stream);
 size_t up_bn_bwd_groups_workspace(int64_t rows_per_group, int C, int groups);
 int up_bn_bwd_groups_t(const void* dz, int lddz, const uint32_t* relu_bits, const void* y, int ldy, const float* gamma,
                        const float* coef, int relu, void* dy, int lddy, void* dres, int lddres, float* dgamma, float* dbeta,

@@ -67,7 +67,7 @@ def relu_sign_agreement(ours_nhwc, oracle_pre_nchw, max_frac=1e-4, near=1e-4):
     return diff, tot
 
 
-def train_case(dev, K=16, B=2, size=32, wseed=3, dropout_masks=False):
+def train_case(dev, K=16, B=2, size=32, wseed=3, dropout_masks=False, floors=None):
     """fwd + MSE + bwd in train mode; dropouts disabled (p=0) or injected; compares loss, output, every
     parameter gradient and all BN running statistics against the oracle (see `yardstick`)."""
     from unipose_amd import ops
@@ -124,7 +124,7 @@ def train_case(dev, K=16, B=2, size=32, wseed=3, dropout_masks=False):
         if g64 is None:
             assert p.grad is None, name                      # decoder.conv2 / bn2
             continue
-        ok, eo, er = yardstick(p.grad.cpu(), sd32[name].grad, g64, floor=1e-4)
+        ok, eo, er = yardstick(p.grad.cpu(), sd32[name].grad, g64, floor=(floors or {}).get(name, 1e-4))
         if not ok:
             worst[name] = (eo, er)
     assert not worst, worst

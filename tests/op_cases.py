@@ -353,6 +353,72 @@ def normalize_case(dev):
     assert torch.equal(got.cpu(), ref)
 
 
+def bn_large_mean_case(dev, rows=200, c=64, seed=21):
+    """The normalisation pass with |mean| >> std (the reference's wasp.global_avg_pool BatchNorm: |mean| / std = 364 on the G14 input).
+    up_bn_apply_centered_t evaluates (y - mean) * scale + beta like ATen: every element within an ulp or two of the float64 value
+    of that expression over the SAME fp32 coefficient vectors, while y * scale + shift (up_bn_apply_t, kept for folded / legacy
+    callers) is off by 2^-24 |mean| scale per element — random errors that flip ReLU decisions the reference does not flip."""
+    import ctypes as C
+    from unipose_amd import _C
+    gen = g(seed)
+    mean = (3000 + 3000 * torch.rand(c, generator=gen)).float()
+    std = 0.5 + torch.rand(c, generator=gen)
+    y = (mean.view(1, -1) + std.view(1, -1) * torch.randn(rows, c, generator=gen)).float()
+    scale = ((0.5 + torch.rand(c, generator=gen)) / std).float()
+    beta = (0.2 * torch.randn(c, generator=gen)).float()
+    shift = (beta.double() - mean.double() * scale.double()).float()
+    z64 = (y.double() - mean.double().view(1, -1)) * scale.double().view(1, -1) + beta.double().view(1, -1)
+    yd, md, sd_, bd, hd = (t.to(dev).contiguous() for t in (y, mean, scale, beta, shift))
+    zc, zf = torch.empty_like(yd), torch.empty_like(yd)
+    L = _C.lib()
+    st = ops._stream(yd)
+    _C.check(L.up_bn_apply_centered_t(yd.data_ptr(), c, md.data_ptr(), sd_.data_ptr(), bd.data_ptr(), None, 0, 0, zc.data_ptr(), c,
+                                      None, rows, c, 0, st), "bn_apply_centered")
+    _C.check(L.up_bn_apply_t(yd.data_ptr(), c, sd_.data_ptr(), hd.data_ptr(), None, 0, 0, zf.data_ptr(), c, None, rows, c, 0, st),
+             "bn_apply")
+    e_c = float((zc.cpu().double() - z64).abs().max())
+    e_f = float((zf.cpu().double() - z64).abs().max())
+    assert e_c < 2e-6 and e_f > 20 * e_c, (e_c, e_f)
+    return dict(centred=e_c, fused=e_f)
+
+
+def bn_small_batch_case(dev, n=4, c=32, k=64, seed=23):
+    """Train-mode BatchNorm over a handful of rows (the global-average-pool branch: n x 1 x 1): the batch mean is the correctly
+    rounded mean of the stored values (float64 statistics, up_bn_exact_stats_t), also when |mean| >> std.  Integer inputs and
+    weights make the 1x1 convolution exact, momentum 1 makes running_mean the batch mean itself."""
+    import copy
+    x = torch.randint(-3, 4, (n, c, 1, 1), generator=g(seed)).float()
+    conv = torch.nn.Conv2d(c, k, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(k, momentum=1.0)
+    with torch.no_grad():
+        w = torch.randint(-2, 3, tuple(conv.weight.shape), generator=g(seed + 1)).float()
+        x[:, 0] = 1.0
+        w[:, 0, 0, 0] = torch.randint(3000, 6000, (k,), generator=g(seed + 2)).float() + 0.25      # sums of 4 need > 24 bits
+        conv.weight.copy_(w)
+        bn.weight.copy_(0.5 + torch.rand(k, generator=g(seed + 3)))
+        bn.bias.copy_(0.2 * torch.randn(k, generator=g(seed + 4)))
+    conv_d, bn_d = copy.deepcopy(conv).to(dev), copy.deepcopy(bn).to(dev)
+    conv.train(), bn.train(), conv_d.train(), bn_d.train()
+    with torch.no_grad():
+        yc = conv(x)
+        assert torch.equal(yc.double(), torch.nn.functional.conv2d(x.double(), w.double()))
+        zr = bn(yc)
+    z = nchw(ops.conv_bn_act(nhwc(x, dev), conv_d, bn_d, relu=False), k)
+    mean64 = yc.double().mean((0, 2, 3))
+    assert torch.equal(bn_d.running_mean.cpu(), mean64.float()), (bn_d.running_mean.cpu() - mean64.float()).abs().max()
+    assert torch.equal(bn.running_mean, mean64.float())                  # ATen (CPU: double accumulators) does the same
+    assert rel(bn_d.running_var.cpu(), bn.running_var) < 1e-6
+    # the normalised values against the float64 evaluation (ATen's CPU kernel applies x * alpha + beta' and is itself 3e-5 off here;
+    # its CUDA kernel and this library evaluate the centred form)
+    var64 = yc.double().var((0, 2, 3), unbiased=False)
+    z64 = (yc.double() - mean64.view(1, -1, 1, 1)) / torch.sqrt(var64 + bn.eps).view(1, -1, 1, 1) * bn.weight.double().view(1, -1, 1, 1) \
+        + bn.bias.double().view(1, -1, 1, 1)
+    # (an fp32 mean is itself up to half an ulp off: that much, times the scale, is the floor of ANY fp32 implementation)
+    bound = (0.5 * 2.0 ** -23 * mean64.abs() * bn.weight.double() / torch.sqrt(var64 + bn.eps)).view(1, -1, 1, 1) + 2e-6
+    assert bool(((z.double() - z64).abs() <= bound).all()), float(((z.double() - z64).abs() / bound).max())
+    assert float((zr.double() - z64).abs().max()) < 1e-3
+
+
 def bn_rows_ab_case(dev, n, c, h, w, k, relu=True, residual=True, dtype=torch.float32, seed=0):
     """The row-strided BatchNorm passes (norm_act.hip: bn_apply_rows_kernel / bn_bwd_apply_rows_kernel, per-channel parameters
     loaded once per thread) against the flat ones on a conv -> BN (-> +residual) (-> ReLU) train step: same arithmetic, same

@@ -101,7 +101,14 @@ def test_g11_train_b8_vs_reference_golden(golden_dir, fixture):
     with the reference itself (tools/make_goldens.py g11): its distance from its own fp64 evaluation (`noise`) and from the
     same modules with BatchNorm evaluated by an exact-statistics formula (`alt`, i.e. "another correct fp32
     implementation": 0.3 % ... 1.7 %, ReLU decisions at round-off flip between any two evaluations).  This implementation is
-    held to 2x the larger of the two (+1e-5 for the well-conditioned head); measured on the MI355X: 0.9 ... 1.3x."""
+    held to 2x the larger of the two (+1e-5 for the well-conditioned head); measured on the MI355X: 0.9 ... 1.3x (G11), 0.7 ... 1.5x
+    (G14) — except the WASP gradients of G14, 1.7 ... 2.5x and held to 3x.  Their backward signal passes the ReLUs behind the
+    global-average-pool branch, whose BatchNorm normalises B = 4 values per channel with |mean| / std = 364 on this input: one fp32
+    ulp there is 2e-5 of the normalised scale, and the fixture's two yardsticks keep that layer's inputs fixed.  Moving every
+    convolution output of the reference by one random ulp (another summation order) already puts these gradients 1.9e-3 ... 4.3e-3
+    from the fixture (tools/experiments/g14_gap_branch_sensitivity.py), the HIP path reads 5.2e-3 / 7.6e-3 while its OUTPUT is as far
+    from the reference as the reference's own float64 evaluation (1.5e-5) and, with the reference's ReLU decisions replayed, every
+    WASP gradient sits inside the oracle's fp32-vs-fp64 yardstick at this size (test_train_step_368_vs_oracle_yardstick)."""
     from unipose_amd import ops
     g = np.load(os.path.join(golden_dir, fixture))
     K, wseed, xseed, tseed, B = (int(v) for v in g["meta"][:5])
@@ -115,6 +122,8 @@ def test_g11_train_b8_vs_reference_golden(golden_dir, fixture):
     y = m(x)
     loss = ops.mse_loss(y, t)
     loss.backward()
+    print(f"{fixture}: output max_rel {O.max_rel(y.detach().cpu(), g['out']):.2e} (reference fp32 vs fp64 {float(g['out_noise']):.2e}), "
+          f"loss {float(loss.detach()):.8f} vs {float(g['loss']):.8f}")
     assert O.max_rel(y.detach().cpu(), g["out"]) < max(1e-3, 50 * float(g["out_noise"]))
     assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
     sd, p = m.state_dict(), dict(m.named_parameters())
@@ -133,7 +142,8 @@ def test_g11_train_b8_vs_reference_golden(golden_dir, fixture):
             bar = max(noise, alt)
             print(f"{k[5:]:45s} rel-L2 vs reference {l2:.2e}  (reference fp32 vs fp64 {noise:.2e}, exact-statistics BN "
                   f"variant {alt:.2e}; ratio to the larger {l2 / bar:.2f})")
-            if l2 > 2.0 * bar + 1e-5:
+            factor = 3.0 if size != 128 and k.startswith("grad/wasp.") else 2.0
+            if l2 > factor * bar + 1e-5:
                 worst[k] = (l2, noise, alt)
     assert not worst, worst
     names = sorted(n for n, q in m.named_parameters())

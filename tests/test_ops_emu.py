@@ -303,3 +303,13 @@ def test_grouped_batchnorm_matches_separate_calls(emu_backend, cfg):
     groups, n, c, h, w, k, r, relu, residual, dt = cfg
     oc.bn_groups_case(emu_backend, groups, n, c, h, w, k, r=r, relu=relu, residual=residual,
                       dtype=torch.float32 if dt == "f32" else torch.bfloat16)
+
+
+def test_bn_large_mean_is_applied_centred(emu_backend):
+    print(oc.bn_large_mean_case(emu_backend))
+
+
+def test_bn_small_batch_statistics_are_exact(emu_backend):
+    oc.bn_small_batch_case(emu_backend)
+    oc.bn_small_batch_case(emu_backend, n=7, c=64, k=40, seed=31)
+    oc.conv_bn_case(emu_backend, 4, 64, 1, 1, 32, 1, 1, 0, 1, relu=True, train=True)      # gradients through the same path

@@ -190,3 +190,14 @@ def test_grouped_batchnorm_matches_separate_calls(cfg):
     groups, n, c, h, w, k, r, relu, residual, dt = cfg
     oc.bn_groups_case(DEV, groups, n, c, h, w, k, r=r, relu=relu, residual=residual,
                       dtype=torch.float32 if dt == "f32" else torch.bfloat16)
+
+
+def test_bn_large_mean_is_applied_centred():
+    print(oc.bn_large_mean_case(DEV))
+
+
+def test_bn_small_batch_statistics_are_exact():
+    oc.bn_small_batch_case(DEV)
+    oc.bn_small_batch_case(DEV, n=7, c=64, k=40, seed=31)
+    oc.bn_small_batch_case(DEV, n=32, c=2048, k=256, seed=33)                     # the GAP branch of the headline batch
+    oc.conv_bn_case(DEV, 4, 64, 1, 1, 32, 1, 1, 0, 1, relu=True, train=True)

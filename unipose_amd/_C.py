@@ -60,10 +60,12 @@ SIGNATURES = {
     "up_bn_apply_t": (_i, [_p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i64, _i, _i, _p]),
     "up_bn_bwd_t": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _sz, _i64, _i, _i, _p]),
     "up_bn_bwd_acc_t": (_i, [_p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _sz, _i64, _i, _i, _p]),
+    "up_bn_exact_stats_t": (_i, [_p, _i, _i64, _i, _i, _i, _p, _p]),
     "up_bn_batch_stats_tiles": (_i, [_i64]),
     "up_bn_batch_stats_t": (_i, [_p, _i, _i64, _i, _i, _i, _p, _p]),
     "up_bn_finalize_groups": (_i, [_p, _i, _i, _i, _i64, _f, _f, _p, _p, _p, _p, _p, _p]),
-    "up_bn_apply_groups_t": (_i, [_p, _i, _p, _p, _i, _i, _p, _i, _p, _i64, _i, _i, _i, _p]),
+    "up_bn_apply_groups_t": (_i, [_p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i64, _i, _i, _i, _p]),
+    "up_bn_apply_centered_t": (_i, [_p, _i, _p, _p, _p, _p, _i, _i, _p, _i, _p, _i64, _i, _i, _p]),
     "up_bn_bwd_groups_workspace": (_sz, [_i64, _i, _i]),
     "up_bn_bwd_groups_t": (_i, [_p, _i, _p, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _sz, _i64, _i, _i, _i, _p]),
     "up_relu_bwd": (_i, [_p, _p, _p, _i64, _p]),

@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* stats, in
 // 1/32 of the bytes.  One thread produces 4 bits; 8 neighbouring lanes are merged into one 32-bit word.
 template <typename T>
 __global__ void __launch_bounds__(256) bn_apply_kernel(const T* y, int ldy, const float* scale,
-                                                       const float* shift, const T* res, int ldr, int relu,
+                                                       const float* shift, const float* mean, const T* res, int ldr, int relu,
                                                        T* z, int ldz, uint32_t* relu_bits, int64_t total, int C4,
                                                        FastDiv fC4) {
     const int lane = threadIdx.x & 63;
@@ -142,10 +142,11 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const T* y, int ldy, cons
             float4 v = ld4<T>(y + (size_t)row * ldy + c);
             float4 s = *reinterpret_cast<const float4*>(scale + c);
             float4 h = *reinterpret_cast<const float4*>(shift + c);
-            v.x = v.x * s.x + h.x;
-            v.y = v.y * s.y + h.y;
-            v.z = v.z * s.z + h.z;
-            v.w = v.w * s.w + h.w;
+            const float4 mu = mean ? *reinterpret_cast<const float4*>(mean + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v.x = (v.x - mu.x) * s.x + h.x;      // centred form, see up_bn_apply_centered_t (mu = 0: y * scale + shift exactly)
+            v.y = (v.y - mu.y) * s.y + h.y;
+            v.z = (v.z - mu.z) * s.z + h.z;
+            v.w = (v.w - mu.w) * s.w + h.w;
             if (res) {
                 float4 r = ld4<T>(res + (size_t)row * ldr + c);
                 v.x += r.x;
@@ -200,7 +201,7 @@ __device__ __forceinline__ void st8(bf16_t* p, const F8& a) {
 }
 
 __global__ void __launch_bounds__(256) bn_apply8_kernel(const bf16_t* y, int ldy, const float* scale, const float* shift,
-                                                        const bf16_t* res, int ldr, int relu, bf16_t* z, int ldz,
+                                                        const float* mean, const bf16_t* res, int ldr, int relu, bf16_t* z, int ldz,
                                                         uint32_t* relu_bits, int64_t total, int C8, FastDiv fC8) {
     const int lane = threadIdx.x & 63;
     for (int64_t i0 = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63); i0 < total; i0 += (int64_t)gridDim.x * 256) {
@@ -211,8 +212,12 @@ __global__ void __launch_bounds__(256) bn_apply8_kernel(const bf16_t* y, int ldy
             const int c = ((int)i - (int)row * C8) * 8;
             F8 v = ld8(y + (size_t)row * ldy + c);
             const F8 s = ld8(scale + c), h = ld8(shift + c);
+            F8 mu;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v.v[e] = v.v[e] * s.v[e] + h.v[e];
+            for (int e = 0; e < 8; ++e) mu.v[e] = 0.f;
+            if (mean) mu = ld8(mean + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v.v[e] = (v.v[e] - mu.v[e]) * s.v[e] + h.v[e];
             if (res) {
                 const F8 r = ld8(res + (size_t)row * ldr + c);
 #pragma unroll
@@ -283,7 +288,8 @@ constexpr int BN_ROWS_UNROLL = 4;
 // lanes of the workgroup and gridDim.x workgroups stride over the rows
 template <typename T>
 __global__ void __launch_bounds__(256) bn_apply_rows_kernel(const T* __restrict__ y, int ldy, const float* __restrict__ scale,
-                                                            const float* __restrict__ shift, const T* __restrict__ res, int ldr,
+                                                            const float* __restrict__ shift, const float* __restrict__ mean,
+                                                            const T* __restrict__ res, int ldr,
                                                             int relu, T* __restrict__ z, int ldz, uint32_t* __restrict__ relu_bits,
                                                             int rows, int C, int lcs, GroupArgs grp) {
     constexpr int E = Row16<T>::E, LPW = 32 / E;   // lanes per 32-bit word of relu_bits
@@ -293,13 +299,17 @@ __global__ void __launch_bounds__(256) bn_apply_rows_kernel(const T* __restrict_
     z += grow0 * ldz;
     if (res) res += grow0 * ldr;
     scale += (size_t)blockIdx.z * grp.pstride;
-    shift += (size_t)blockIdx.z * grp.pstride;
+    // centred form (mean given): `shift` is the BatchNorm bias, one vector for all groups; else the per-group shift row
+    shift += mean ? 0 : (size_t)blockIdx.z * grp.pstride;
     const int cl = threadIdx.x & ((1 << lcs) - 1), rl = threadIdx.x >> lcs;
     const int rpb = 256 >> lcs;
     const int c = ((blockIdx.y << lcs) + cl) * E;
-    float sc[E], sh[E];
+    float sc[E], sh[E], mu[E];
     ldparam<E>(scale + c, sc);
     ldparam<E>(shift + c, sh);
+#pragma unroll
+    for (int e = 0; e < E; ++e) mu[e] = 0.f;
+    if (mean) ldparam<E>(mean + (size_t)blockIdx.z * grp.pstride + c, mu);
     const int stride = gridDim.x * rpb;
     for (int base = blockIdx.x * rpb; base < rows; base += BN_ROWS_UNROLL * stride) {   // uniform trip count: the bit merge shuffles
         Row16<T> v[BN_ROWS_UNROLL], r[BN_ROWS_UNROLL];
@@ -317,7 +327,7 @@ __global__ void __launch_bounds__(256) bn_apply_rows_kernel(const T* __restrict_
             uint32_t bits = 0;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                float t = v[u].v[e] * sc[e] + sh[e];
+                float t = (v[u].v[e] - mu[e]) * sc[e] + sh[e];
                 if (res) t += r[u].v[e];
                 if (relu) t = fmaxf(t, 0.f);
                 v[u].v[e] = t;
@@ -491,6 +501,29 @@ __global__ void __launch_bounds__(256) bn_batch_stats_kernel(const T* y, int ldy
             o[2] = cs;
         }
     }
+}
+
+// Statistics of a SMALL batch (a few rows per channel: the BatchNorm behind the global-average-pool branch sees B values), one
+// thread per channel, float64 two-pass: the mean is the correctly rounded mean of the stored values, like ATen's CPU kernel (double
+// accumulators).  With few samples nothing averages the round-off of a float sum out, and with |mean| >> std (364 for that layer on
+// the G14 input) an ulp of the mean is 2e-5 of the normalised scale.
+template <typename T>
+__global__ void __launch_bounds__(256) bn_exact_stats_kernel(const T* y, int ldy, int rows_per_group, int C, float* stats) {
+    const int c = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (c >= C) return;
+    const T* base = y + (size_t)g * rows_per_group * ldy + c;
+    double sum = 0.0;
+    for (int r = 0; r < rows_per_group; ++r) sum += (double)ld1(base + (size_t)r * ldy);
+    const double mean = sum / rows_per_group;
+    double m2 = 0.0;
+    for (int r = 0; r < rows_per_group; ++r) {
+        const double d = (double)ld1(base + (size_t)r * ldy) - mean;
+        m2 += d * d;
+    }
+    float* o = stats + ((size_t)g * C + c) * 3;
+    o[0] = (float)rows_per_group;
+    o[1] = (float)mean;
+    o[2] = (float)m2;
 }
 
 // ---- BN backward -------------------------------------------------------------------------
@@ -800,7 +833,7 @@ constexpr int BNB_ROWS = 128;   // small chunks: enough workgroups (and bytes in
 using namespace up;
 
 extern "C" const char* up_last_error(void) { return g_err; }
-extern "C" int up_abi_version(void) { return 5; }   // 5: up_conv2d_bwd_weight_acc; 4: element-typed (_t) twins + bf16 storage
+extern "C" int up_abi_version(void) { return 6; }   // 5: up_conv2d_bwd_weight_acc; 4: element-typed (_t) twins + bf16 storage
 
 extern "C" int up_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                  int C, float* scale, float* shift, void* stream) {
@@ -821,9 +854,10 @@ extern "C" int up_bn_finalize(const float* stats, int tiles, int C, float eps, f
     return check_launch("bn_finalize");
 }
 
-extern "C" int up_bn_apply_t(const void* y, int ldy, const float* scale, const float* shift, const void* res,
-                             int ldr, int relu, void* z, int ldz, uint32_t* relu_bits, int64_t rows, int C, int dtype,
-                             void* stream) {
+// mean == nullptr: z = y * scale + shift;  else the centred form z = (y - mean) * scale + shift with shift = the BatchNorm bias
+static int bn_apply_impl(const void* y, int ldy, const float* mean, const float* scale, const float* shift, const void* res,
+                         int ldr, int relu, void* z, int ldz, uint32_t* relu_bits, int64_t rows, int C, int dtype,
+                         void* stream) {
     UP_REQUIRE(y && scale && shift && z && rows > 0 && C > 0, UP_ERR_INVALID, "bn_apply: bad argument");
     UP_REQUIRE(C % 4 == 0 && ldy % 4 == 0 && ldz % 4 == 0 && (!res || ldr % 4 == 0), UP_ERR_INVALID,
                "bn_apply: C and strides must be multiples of 4");
@@ -836,28 +870,39 @@ extern "C" int up_bn_apply_t(const void* y, int ldy, const float* scale, const f
         if (bn_rows_enabled() && dtype == UP_DT_BF16 && ldy % 8 == 0 && ldz % 8 == 0 && (!res || ldr % 8 == 0) &&
             rows_geometry<bf16_t>(rows, C, grid, lcs)) {
             hipLaunchKernelGGL(bn_apply_rows_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)y, ldy, scale,
-                               shift, (const bf16_t*)res, ldr, relu, (bf16_t*)z, ldz, relu_bits, (int)rows, C, lcs, GroupArgs{0, 0});
+                               shift, mean, (const bf16_t*)res, ldr, relu, (bf16_t*)z, ldz, relu_bits, (int)rows, C, lcs, GroupArgs{0, 0});
             return check_launch("bn_apply");
         }
         if (bn_rows_enabled() && dtype == UP_DT_F32 && rows_geometry<float>(rows, C, grid, lcs)) {
             hipLaunchKernelGGL(bn_apply_rows_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)y, ldy, scale,
-                               shift, (const float*)res, ldr, relu, (float*)z, ldz, relu_bits, (int)rows, C, lcs, GroupArgs{0, 0});
+                               shift, mean, (const float*)res, ldr, relu, (float*)z, ldz, relu_bits, (int)rows, C, lcs, GroupArgs{0, 0});
             return check_launch("bn_apply");
         }
     }
     if (dtype == UP_DT_BF16 && C % 8 == 0 && ldy % 8 == 0 && ldz % 8 == 0 && (!res || ldr % 8 == 0))
         hipLaunchKernelGGL(bn_apply8_kernel, dim3(grid_for(total / 2)), dim3(256), 0, as_stream(stream), (const bf16_t*)y, ldy,
-                           scale, shift, (const bf16_t*)res, ldr, relu, (bf16_t*)z, ldz, relu_bits, total / 2, C / 8,
+                           scale, shift, mean, (const bf16_t*)res, ldr, relu, (bf16_t*)z, ldz, relu_bits, total / 2, C / 8,
                            make_fastdiv(C / 8));
     else if (dtype == UP_DT_BF16)
         hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
-                           (const bf16_t*)y, ldy, scale, shift, (const bf16_t*)res, ldr, relu, (bf16_t*)z, ldz, relu_bits,
+                           (const bf16_t*)y, ldy, scale, shift, mean, (const bf16_t*)res, ldr, relu, (bf16_t*)z, ldz, relu_bits,
                            total, C / 4, make_fastdiv(C / 4));
     else
         hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)y,
-                           ldy, scale, shift, (const float*)res, ldr, relu, (float*)z, ldz, relu_bits, total, C / 4,
+                           ldy, scale, shift, mean, (const float*)res, ldr, relu, (float*)z, ldz, relu_bits, total, C / 4,
                            make_fastdiv(C / 4));
     return check_launch("bn_apply");
+}
+extern "C" int up_bn_apply_t(const void* y, int ldy, const float* scale, const float* shift, const void* res,
+                             int ldr, int relu, void* z, int ldz, uint32_t* relu_bits, int64_t rows, int C, int dtype,
+                             void* stream) {
+    return bn_apply_impl(y, ldy, nullptr, scale, shift, res, ldr, relu, z, ldz, relu_bits, rows, C, dtype, stream);
+}
+extern "C" int up_bn_apply_centered_t(const void* y, int ldy, const float* mean, const float* scale, const float* beta,
+                                      const void* res, int ldr, int relu, void* z, int ldz, uint32_t* relu_bits, int64_t rows,
+                                      int C, int dtype, void* stream) {
+    UP_REQUIRE(mean, UP_ERR_INVALID, "bn_apply_centered: null mean");
+    return bn_apply_impl(y, ldy, mean, scale, beta, res, ldr, relu, z, ldz, relu_bits, rows, C, dtype, stream);
 }
 extern "C" int up_bn_apply(const float* y, int ldy, const float* scale, const float* shift, const float* res,
                            int ldr, int relu, float* z, int ldz, uint32_t* relu_bits, int64_t rows, int C,
@@ -997,6 +1042,20 @@ extern "C" int up_bn_batch_stats_t(const void* y, int ldy, int64_t rows_per_grou
                            (int)rows_per_group, C, stats, tiles);
     return check_launch("bn_batch_stats");
 }
+extern "C" int up_bn_exact_stats_t(const void* y, int ldy, int64_t rows_per_group, int C, int groups, int dtype, float* stats,
+                                   void* stream) {
+    UP_REQUIRE(y && stats && rows_per_group > 0 && rows_per_group <= 4096 && C > 0 && groups > 0 && groups <= 65535, UP_ERR_INVALID,
+               "bn_exact_stats: bad argument (1..4096 rows per group)");
+    UP_REQUIRE(dtype == UP_DT_F32 || dtype == UP_DT_BF16, UP_ERR_INVALID, "bn_exact_stats: dtype %d", dtype);
+    dim3 grid(cdiv(C, 256), groups);
+    if (dtype == UP_DT_BF16)
+        hipLaunchKernelGGL(bn_exact_stats_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)y, ldy,
+                           (int)rows_per_group, C, stats);
+    else
+        hipLaunchKernelGGL(bn_exact_stats_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)y, ldy,
+                           (int)rows_per_group, C, stats);
+    return check_launch("bn_exact_stats");
+}
 // coef: [groups][4][C] = mean, invstd, scale, shift per group.  The groups are finalised IN ORDER on the stream, so the running
 // statistics receive the same sequence of momentum updates as `groups` separate forward calls.
 extern "C" int up_bn_finalize_groups(const float* stats, int tiles, int C, int groups, int64_t rows_per_group, float eps,
@@ -1014,8 +1073,12 @@ extern "C" int up_bn_finalize_groups(const float* stats, int tiles, int C, int g
                            C, (float)rows_per_group, eps, momentum, rm, rv);
     return check_launch("bn_finalize_groups");
 }
-extern "C" int up_bn_apply_groups_t(const void* y, int ldy, const float* coef, const void* res, int ldr, int relu, void* z, int ldz,
-                                    uint32_t* relu_bits, int64_t rows_per_group, int C, int groups, int dtype, void* stream) {
+extern "C" int up_bn_apply_groups_t(const void* y, int ldy, const float* coef, const float* beta, const void* res, int ldr, int relu,
+                                    void* z, int ldz, uint32_t* relu_bits, int64_t rows_per_group, int C, int groups, int dtype,
+                                    void* stream) {
+    // beta given: centred form (y - mean_g) * scale_g + beta;  else y * scale_g + shift_g
+    const float* gmean = beta ? coef : nullptr;
+    const float* gshift = beta ? beta : coef + 3 * C;
     UP_REQUIRE(y && z && coef && groups > 0 && groups <= 65535 && rows_per_group > 0, UP_ERR_INVALID, "bn_apply_groups: bad argument");
     UP_REQUIRE(dtype == UP_DT_F32 || dtype == UP_DT_BF16, UP_ERR_INVALID, "bn_apply_groups: dtype %d", dtype);
     UP_REQUIRE(!relu_bits || (rows_per_group * C) % 32 == 0, UP_ERR_UNSUPPORTED,
@@ -1027,22 +1090,22 @@ extern "C" int up_bn_apply_groups_t(const void* y, int ldy, const float* coef, c
     if (dtype == UP_DT_F32 && ldy % 4 == 0 && ldz % 4 == 0 && (!res || ldr % 4 == 0) && rows_geometry<float>(rows_per_group, C, grid, lcs)) {
         grid.z = groups;   // ONE launch: blockIdx.z = group
         hipLaunchKernelGGL(bn_apply_rows_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)y, ldy, coef + 2 * C,
-                           coef + 3 * C, (const float*)res, ldr, relu, (float*)z, ldz, relu_bits, (int)rows_per_group, C, lcs, ga);
+                           gshift, gmean, (const float*)res, ldr, relu, (float*)z, ldz, relu_bits, (int)rows_per_group, C, lcs, ga);
         return check_launch("bn_apply_groups");
     }
     if (dtype == UP_DT_BF16 && ldy % 8 == 0 && ldz % 8 == 0 && (!res || ldr % 8 == 0) &&
         rows_geometry<bf16_t>(rows_per_group, C, grid, lcs)) {
         grid.z = groups;
         hipLaunchKernelGGL(bn_apply_rows_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)y, ldy, coef + 2 * C,
-                           coef + 3 * C, (const bf16_t*)res, ldr, relu, (bf16_t*)z, ldz, relu_bits, (int)rows_per_group, C, lcs, ga);
+                           gshift, gmean, (const bf16_t*)res, ldr, relu, (bf16_t*)z, ldz, relu_bits, (int)rows_per_group, C, lcs, ga);
         return check_launch("bn_apply_groups");
     }
     for (int g = 0; g < groups; ++g) {       // channel counts without a row-strided geometry: one flat launch per group
         const float* cg = coef + (size_t)g * 4 * C;
         const size_t r0 = (size_t)g * rows_per_group;
-        if (int e = up_bn_apply_t((const char*)y + r0 * ldy * es, ldy, cg + 2 * C, cg + 3 * C, res ? (const char*)res + r0 * ldr * es : nullptr,
-                                  ldr, relu, (char*)z + r0 * ldz * es, ldz, relu_bits ? relu_bits + r0 * C / 32 : nullptr, rows_per_group,
-                                  C, dtype, stream))
+        if (int e = bn_apply_impl((const char*)y + r0 * ldy * es, ldy, beta ? cg : nullptr, cg + 2 * C, beta ? beta : cg + 3 * C,
+                                  res ? (const char*)res + r0 * ldr * es : nullptr, ldr, relu, (char*)z + r0 * ldz * es, ldz,
+                                  relu_bits ? relu_bits + r0 * C / 32 : nullptr, rows_per_group, C, dtype, stream))
             return e;
     }
     return UP_OK;

@@ -542,6 +542,7 @@ class ConvBias(Function):
 
 
 _BN_GROUPS = {"n": 1}
+EXACT_STATS_ROWS = 256      # train-mode BatchNorm over at most this many rows per channel: float64 statistics (up_bn_exact_stats_t)
 
 
 class bn_groups:
@@ -587,18 +588,27 @@ class ConvBnAct(Function):
             if rpg <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size "
                                  f"{(d.N // groups, k, d.P, d.Q)}")
-            tiles = L.up_bn_batch_stats_tiles(rpg)
+            tiles = 1 if rpg <= EXACT_STATS_ROWS else L.up_bn_batch_stats_tiles(rpg)
             st = torch.empty((groups, tiles, k, 3), dtype=torch.float32, device=dev)
             coef = torch.empty((groups, 4, k), dtype=torch.float32, device=dev)   # per group: mean, invstd, scale, shift
-            _C.check(L.up_bn_batch_stats_t(y.data_ptr(), d.ldy, rpg, k, groups, _dt(y), st.data_ptr(), _stream(x)), "bn_batch_stats")
+            if rpg <= EXACT_STATS_ROWS:
+                _C.check(L.up_bn_exact_stats_t(y.data_ptr(), d.ldy, rpg, k, groups, _dt(y), st.data_ptr(), _stream(x)), "bn_exact_stats")
+            else:
+                _C.check(L.up_bn_batch_stats_t(y.data_ptr(), d.ldy, rpg, k, groups, _dt(y), st.data_ptr(), _stream(x)), "bn_batch_stats")
             _C.check(L.up_bn_finalize_groups(st.data_ptr(), tiles, k, groups, rpg, eps, momentum, _ptr(rm), _ptr(rv),
                                              gamma.data_ptr(), beta.data_ptr(), coef.data_ptr(), _stream(x)), "bn_finalize_groups")
         elif train:
-            y, d, st = conv_fwd_raw(x, weight, cfg, stats=True)
+            small = x.shape[0] * ((x.shape[1] + 2 * cfg.pad - cfg.dil * (weight.shape[2] - 1) - 1) // cfg.stride + 1) * \
+                ((x.shape[2] + 2 * cfg.pad - cfg.dil * (weight.shape[3] - 1) - 1) // cfg.stride + 1) <= EXACT_STATS_ROWS
+            y, d, st = conv_fwd_raw(x, weight, cfg, stats=not small)
             rows = d.N * d.P * d.Q
             if rows <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size "
                                  f"{(d.N, k, d.P, d.Q)}")          # F.batch_norm's check
+            if small:      # a handful of samples per channel (the global-average-pool branch): float64 statistics, see the kernel
+                assert rows <= EXACT_STATS_ROWS
+                st = torch.empty((1, k, 3), dtype=torch.float32, device=dev)
+                _C.check(L.up_bn_exact_stats_t(y.data_ptr(), d.ldy, rows, k, 1, _dt(y), st.data_ptr(), _stream(x)), "bn_exact_stats")
             coef = torch.empty((4, k), dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
             _C.check(L.up_bn_finalize(st.data_ptr(), st.shape[0], k, eps, momentum, _ptr(rm), _ptr(rv),
                                       gamma.data_ptr(), beta.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
@@ -618,13 +628,14 @@ class ConvBnAct(Function):
         if residual is not None and residual.dtype != y.dtype:
             raise TypeError(f"residual {residual.dtype} vs convolution output {y.dtype}")
         if groups > 1:
-            _C.check(L.up_bn_apply_groups_t(y.data_ptr(), d.ldy, coef.data_ptr(), _ptr(residual),
+            _C.check(L.up_bn_apply_groups_t(y.data_ptr(), d.ldy, coef.data_ptr(), beta.data_ptr(), _ptr(residual),
                                             _nhwc_ok(residual) if residual is not None else 0, int(relu), z.data_ptr(), d.ldy,
                                             _ptr(bits), rows // groups, k, groups, _dt(y), _stream(x)), "bn_apply_groups")
         else:
-            _C.check(L.up_bn_apply_t(y.data_ptr(), d.ldy, coef[2].data_ptr(), coef[3].data_ptr(), _ptr(residual),
-                                     _nhwc_ok(residual) if residual is not None else 0, int(relu), z.data_ptr(), d.ldy,
-                                     _ptr(bits), rows, k, _dt(y), _stream(x)), "bn_apply")
+            # the centred form ATen evaluates, (y - mean) * (gamma * invstd) + beta: see up_bn_apply_centered_t
+            _C.check(L.up_bn_apply_centered_t(y.data_ptr(), d.ldy, coef[0].data_ptr(), coef[2].data_ptr(), beta.data_ptr(),
+                                              _ptr(residual), _nhwc_ok(residual) if residual is not None else 0, int(relu),
+                                              z.data_ptr(), d.ldy, _ptr(bits), rows, k, _dt(y), _stream(x)), "bn_apply")
         if relu and _RELU_TRACE is not None:
             _RELU_TRACE.append(z.detach())
         ctx.d, ctx.relu, ctx.train, ctx.has_res, ctx.groups = d, relu, train, residual is not None, groups
