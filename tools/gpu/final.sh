@@ -1,5 +1,6 @@
 # Round-end measurement set: smoke, default bench line (cpu_baseline, stock_gpu_baseline, alt_math, other_configs), rocprofv3 kernel
-# stats of the bench command in both stream modes, PMC passes; with TESTS=1 also the full -m gpu suite (default + bf16x3 arithmetic).
+# stats of the bench command in both stream modes, PMC passes; with TESTS=1 also the full -m gpu suite (default + bf16x3 arithmetic);
+# LIGHT=1 stops after the kernel statistics.
 cd $GRAFT_REPO_ROOT
 TAG=${1:-r03_z}
 mkdir -p gpurun_out/$TAG
@@ -25,17 +26,19 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG
 UNIPOSE_SYNC_WGRAD=1 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_sync -o bench -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_sync.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_736 -o bench -- python $GRAFT_REPO_ROOT/bench.py --size 736 --batch 16 --math bf16s $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_736.log 2>&1
 UNIPOSE_SYNC_WGRAD=1 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_736x -o bench -- python $GRAFT_REPO_ROOT/bench.py --size 736 --batch 16 --math bf16s $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_736x.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_lstm -o bench -- python $GRAFT_REPO_ROOT/bench.py --model lstm $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_lstm.log 2>&1
+[ -n "$LIGHT" ] || timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_lstm -o bench -- python $GRAFT_REPO_ROOT/bench.py --model lstm $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_lstm.log 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof -name "*.db" | head -1) 4 > gpurun_out/$TAG/kernel_stats.txt 2>&1
 python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof_sync -name "*.db" | head -1) 4 > gpurun_out/$TAG/kernel_stats_exclusive.txt 2>&1
 python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof_736 -name "*.db" | head -1) 4 > gpurun_out/$TAG/kernel_stats_736_bf16s.txt 2>&1
 python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof_736x -name "*.db" | head -1) 4 > gpurun_out/$TAG/kernel_stats_736_bf16s_exclusive.txt 2>&1
-python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof_lstm -name "*.db" | head -1) 4 > gpurun_out/$TAG/kernel_stats_lstm.txt 2>&1
+[ -n "$LIGHT" ] || python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof_lstm -name "*.db" | head -1) 4 > gpurun_out/$TAG/kernel_stats_lstm.txt 2>&1
 find gpurun_out/$TAG -name "*.db" -delete
 head -8 gpurun_out/$TAG/kernel_stats.txt
 head -8 gpurun_out/$TAG/kernel_stats_exclusive.txt
 head -8 gpurun_out/$TAG/kernel_stats_736_bf16s.txt
+# LIGHT=1: bench line + kernel statistics only (the per-shape tables and the counter passes of the round stay those of the last full run)
+[ -n "$LIGHT" ] && exit 0
 UNIPOSE_SYNC_WGRAD=1 UP_PROFILE_CSV=$GRAFT_REPO_ROOT/gpurun_out/$TAG/launches.csv timeout 300 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-stock-baseline --no-alt-math --no-other-configs > gpurun_out/$TAG/bench_csv.log 2>&1
 python tools/gpu/csv_loss.py gpurun_out/$TAG/launches.csv.1 157.3 20 > gpurun_out/$TAG/lost_time_by_shape.txt 2>&1 || python tools/gpu/csv_loss.py gpurun_out/$TAG/launches.csv 157.3 20 > gpurun_out/$TAG/lost_time_by_shape.txt 2>&1
 head -4 gpurun_out/$TAG/lost_time_by_shape.txt
