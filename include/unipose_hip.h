@@ -95,6 +95,9 @@ int up_conv_stats_tiles_math(const up_conv_desc* d, int math);   /* ... the forw
  * each tail tile along K into this many parts (1 = no split), one per CU, and merges them in a fixed order through a
  * per-stream scratch the library allocates on first use (one 128x128 fp32 partial per CU: 16 MB + flags).  UP_TAIL_SPLIT=0 disables it.  Informational. */
 int up_conv_split_parts(const up_conv_desc* d);
+/* Frees the per-stream scratch of a stream the caller retires (no launch or captured graph of that stream may run afterwards);
+ * a stream that never ran a split launch has none: no-op. */
+int up_stream_release(void* stream);
 /* Development knobs (A/B runs inside one process; each also has an environment variable read at load time):
  * "tile_want" (UP_TILE_WANT; "tile_want_bf16" for the plain-bf16 kernels) workgroups a launch should at least have when the tile size is chosen ("short_k" /
  * "short_k_mult": reductions shorter than short_k want short_k_mult / 2 times as many), "db_min_k"

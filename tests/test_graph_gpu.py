@@ -69,3 +69,37 @@ def test_graphed_forward_recapture_follows_new_weights():
         ref = model(x).clone()
     fwd.recapture()
     assert torch.equal(fwd(x), ref) and not torch.equal(ref, before)
+
+
+def test_graphed_forward_close_returns_the_stream_scratch():
+    """Every GraphedForward owns a capture stream, and the library keeps 16 MB of K-split scratch per stream that ran a split
+    launch (B = 1: every small launch is split): close() / deletion hands it back, so building graphs in a loop does not grow."""
+    from model.unipose import unipose
+    from unipose_amd.graph import GraphedForward
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = unipose("MPII", num_classes=16).to(dev).eval()
+    x = torch.randn(1, 3, 128, 128, device=dev)
+    with torch.no_grad():
+        ref = model(x).clone()
+
+    def used():
+        torch.cuda.synchronize()
+        free, total = torch.cuda.mem_get_info(dev)
+        return total - free
+
+    fwd = GraphedForward(model, x)
+    assert torch.equal(fwd(x), ref)
+    fwd.close()
+    fwd.close()                                   # idempotent
+    torch.cuda.empty_cache()
+    base = used()
+    for _ in range(6):
+        fwd = GraphedForward(model, x)
+        assert torch.equal(fwd(x), ref)
+        del fwd
+    torch.cuda.empty_cache()
+    grown = used() - base
+    assert grown < 48 * 2 ** 20, f"{grown / 2 ** 20:.0f} MiB left behind by six graphs"      # 6 x 16 MB would be 96
+    with torch.no_grad():
+        assert torch.equal(model(x), ref)         # the eager path (its own stream scratch) is untouched

@@ -40,6 +40,7 @@ SIGNATURES = {
     "up_conv_stats_tiles": (_i, [_D]),
     "up_conv_stats_tiles_math": (_i, [_D, _i]),
     "up_conv_split_parts": (_i, [_D]),
+    "up_stream_release": (_i, [_p]),
     "up_conv_tune": (_i, [C.c_char_p, _i]),
     "up_conv_wgrad_visits": (_i, [_D, C.POINTER(C.c_double)]),
     "up_conv_tap_visits": (_i, [_D, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

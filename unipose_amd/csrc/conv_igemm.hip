@@ -1892,12 +1892,12 @@ static int cu_count() {
     }();
     return n;
 }
+static std::mutex g_scratch_mu;
+static std::map<hipStream_t, SplitScratch> g_scratch;   // released per stream by up_stream_release
 static SplitScratch* split_scratch(hipStream_t st) {
     // at most one partial per CU and launch; launches on one stream are serialised, so one buffer per stream suffices
-    static std::mutex mu;
-    static std::map<hipStream_t, SplitScratch> table;
-    std::lock_guard<std::mutex> lock(mu);
-    SplitScratch& s = table[st];
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    SplitScratch& s = g_scratch[st];
     if (!s.partials) {
         // tail split: at most one 128x128 partial per CU and launch; the all-tiles split of small launches cuts the same
         // bytes into up to four 64x64 partials per CU, one flag each
@@ -1922,6 +1922,26 @@ static SplitScratch* split_scratch(hipStream_t st) {
     return &s;
 }
 static bool tail_split_enabled() { return g_tail_split != 0; }
+}  // namespace up
+// The library's only per-stream device memory is the K-split scratch above (16 MB + flags, allocated by the first split launch on
+// a stream).  A caller that retires a stream — unipose_amd.graph.GraphedForward owns a private capture stream — hands it back
+// here once nothing that ran (or was captured) on the stream can execute any more.
+extern "C" int up_stream_release(void* stream) {
+    using namespace up;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    auto it = g_scratch.find(as_stream(stream));
+    if (it == g_scratch.end()) return UP_OK;
+#ifdef UP_EMU
+    free(it->second.partials);
+    free(it->second.flags);
+#else
+    if (it->second.partials) (void)hipFree(it->second.partials);
+    if (it->second.flags) (void)hipFree(it->second.flags);
+#endif
+    g_scratch.erase(it);
+    return UP_OK;
+}
+namespace up {
 
 // parts each tail tile is split into (1 = no split) for a launch of `tiles` tiles reducing over Ktot
 // *all_tiles: every tile is split, not only the tail of the launch

@@ -11,23 +11,12 @@ partial exchange of small launches — into a hipGraph (torch.cuda.CUDAGraph on 
 
 The returned tensors are the graph's static output buffers: consume (or clone) them before the next call.  Shapes are fixed
 at capture; the packed weight images the kernels read are captured by address, so call `recapture()` after changing the
-parameters (load_state_dict, an optimizer step).  Inference only (`model.eval()`, `torch.no_grad()`).
+parameters (load_state_dict, an optimizer step).  Inference only (`model.eval()`, `torch.no_grad()`).  `close()` (or deleting the object)
+releases the graph and the library scratch of its private stream.
 
 Reference call sites: the validation / test loops `unipose.py:150-160`, `uniposeLSTM.py:160-190` (one forward per batch).
 """
 import torch
-
-
-_CAPTURE_STREAMS = {}
-
-
-def _capture_stream(dev):
-    """ONE capture stream per device, shared by every GraphedForward: the library keeps per-stream scratch (K-split
-    partials), a private stream per instance would leak one scratch per graph."""
-    st = _CAPTURE_STREAMS.get(dev.index)
-    if st is None:
-        st = _CAPTURE_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
-    return st
 
 
 class GraphedForward:
@@ -73,3 +62,19 @@ class GraphedForward:
                 raise ValueError(f"non-tensor argument {src!r} differs from the captured {dst!r}")
         self.graph.replay()
         return self.static_out
+
+    def close(self):
+        """Drop the graph and hand the private stream's library scratch (K-split partials, 16 MB) back; idempotent."""
+        if getattr(self, "stream", None) is None:
+            return
+        from . import _C
+        self.graph, self.static_out = None, None
+        torch.cuda.synchronize(self.device)
+        _C.lib().up_stream_release(self.stream.cuda_stream)
+        self.stream = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown: the process takes the memory with it
+            pass
