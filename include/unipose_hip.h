@@ -109,7 +109,8 @@ int up_stream_release(void* stream);
  * bf16 storage (round 3): "glds" (UP_GLDS: direct-to-LDS kernels of bf16s_glds.h, default 1), "glds_kt" (32 | 64 channels per K slice,
  * 0 = rule per launch), "glds_st" (2 | 3 LDS stages), "glds_split" / "glds_split_q" / "glds_split_maxp" (K-split of the tail tiles of
  * launches with at most q whole rounds of tiles into at most maxp parts; defaults 0 (off: batch-size-independent results) / 2 / 4), "wgrad_kp" (64 | 32 pixels per slice of
- * the weight gradient), "wgrad_st", "bn_rows" (row-strided BatchNorm kernels), "cu_count" (tests: pretend the chip has this many CUs
+ * the weight gradient), "wgrad_st", "glds_256" (256 x 128 tiles for launches with at least this many of them; 0 = never, the default: measured slower), "bn_rows"
+ * (row-strided BatchNorm kernels), "cu_count" (tests: pretend the chip has this many CUs
  * when planning splits; 0 = the real count).
  * Change them only between steps: workspace sizes and the BatchNorm partial-row count follow the tile choice. */
 int up_conv_tune(const char* key, int value);

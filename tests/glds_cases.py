@@ -59,12 +59,13 @@ def _merge(st):
 
 
 def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, affine=False, residual=False, relu=False,
-            add=False, seed=0, kt=64, st=2, wkp=64, wst=2, split=0, cus=0):
+            add=False, seed=0, kt=64, st=2, wkp=64, wst=2, split=0, cus=0, big=0):
     """forward (+ optional BatchNorm partials / folded epilogue / residual) and data gradient (+ optional addend) of one
     convolution in bf16 storage: glds = 1 against glds = 0 under the same tile rule.
     split = 1: the K-split of tail tiles is on in the glds kernels (`cus` shrinks the chip so that a small launch has whole rounds of
     tiles + a tail); a split tile adds its shares in a different order, so outputs are then compared within fp32 round-off of the
-    reduction instead of exactly."""
+    reduction instead of exactly.
+    big = n: launches that would run at least n 256 x 128 tiles use them (glds_256) instead of 128 x 128 ones."""
     cp, kp = ops.rup32(c), ops.rup32(k)
     x = _nhwc(torch.randn(n, c, h, w, generator=_g(seed)), dev, cp)
     wt = (torch.randn(k, c, r, r, generator=_g(seed + 1)) * (2.0 / (c * r * r)) ** 0.5).to(dev)
@@ -76,7 +77,7 @@ def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, 
         kw["bias"] = torch.randn(k, generator=_g(seed + 4)).to(dev)
     out = {}
     try:
-        _tune(tile_want_bf16=tile_want, glds_kt=kt, glds_st=st, wgrad_kp=wkp, wgrad_st=wst, glds_split=split, cu_count=cus, glds_split_q=4, glds_split_maxp=256)
+        _tune(tile_want_bf16=tile_want, glds_kt=kt, glds_st=st, wgrad_kp=wkp, wgrad_st=wst, glds_split=split, cu_count=cus, glds_split_q=4, glds_split_maxp=256, glds_256=big)
         for mode in (1, 0):
             _tune(glds=mode)
             d0 = ops.make_desc(x, wt, cfg)
@@ -90,7 +91,7 @@ def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, 
             dw, _ = ops.conv_bwd_weight_raw(x, dy, wt.shape, d, False)
             out[mode] = (y, st, dx, dw)
     finally:
-        _tune(glds=1, tile_want_bf16=500, glds_kt=32, glds_st=2, wgrad_kp=64, wgrad_st=2, glds_split=0, cu_count=0, glds_split_q=2, glds_split_maxp=4)
+        _tune(glds=1, tile_want_bf16=500, glds_kt=32, glds_st=2, wgrad_kp=64, wgrad_st=2, glds_split=0, cu_count=0, glds_split_q=2, glds_split_maxp=4, glds_256=0)
     (y1, s1, dx1, dw1), (y0, s0, dx0, dw0) = out[1], out[0]
     _same(dw1, dw0, "dw")
     if split:
@@ -151,6 +152,16 @@ SPLIT = [
     dict(n=2, c=64, h=9, w=9, k=64, r=1, stride=1, pad=0, dil=1, tile_want=100000, stats=True, cus=2),    # 1x1, two slices: 3 tiles = 2 + 1 tail; p = 1 (too short): no split
     dict(n=1, c=256, h=5, w=5, k=64, r=1, stride=1, pad=0, dil=1, tile_want=1, affine=True, relu=True, residual=True, cus=0),   # 1x1 8 slices -> 4 parts, folded epilogue
     dict(n=1, c=64, h=5, w=5, k=64, r=3, stride=1, pad=6, dil=6, tile_want=1, stats=True, cus=0),         # only the centre tap lives: 2 live slices under 9 parts -> empty shares
+]
+
+# 256 x 128 tiles (kt = 32, two stages): ragged last tiles whose second half is partly or wholly past the end, BatchNorm partial rows per
+# 128-row half, tap-sorted rows, folded epilogue with residual (fp32 half-image path), data-gradient addend
+BIG = [
+    dict(n=3, c=64, h=7, w=7, k=128, r=3, stride=1, pad=1, dil=1, tile_want=1, stats=True),                 # 147 rows: one tile, second half 19 rows
+    dict(n=4, c=64, h=14, w=14, k=136, r=1, stride=1, pad=0, dil=1, tile_want=1, stats=True),               # 784 rows: 4 tiles, the last with 16 rows; ragged N
+    dict(n=5, c=64, h=10, w=10, k=128, r=3, stride=1, pad=2, dil=2, tile_want=1, stats=True, add=True),      # 500 rows, tap-sorted, dgrad addend
+    dict(n=2, c=128, h=16, w=16, k=128, r=1, stride=1, pad=0, dil=1, tile_want=1, affine=True, relu=True, residual=True),   # 512 rows = 2 full tiles
+    dict(n=4, c=64, h=8, w=8, k=128, r=3, stride=1, pad=3, dil=3, tile_want=1, affine=True, relu=True),      # 256 rows exactly, eval epilogue
 ]
 
 # the real geometries of BASELINE configs[4] (736x736, B = 16) that carry the step

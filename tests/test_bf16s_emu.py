@@ -85,3 +85,10 @@ def test_glds_kernel_tail_split(emu_backend, case, form):
     """K-split tail tiles of the direct-to-LDS kernels (whole rounds + parts in one launch, tap-sorted tiles, empty shares, folded
     epilogue and addend after the merge) against the unsplit register-staged kernels"""
     gc.conv_ab(emu_backend, kt=form[0], st=form[1], split=1, **case)
+
+
+@pytest.mark.parametrize("case", gc.BIG, ids=lambda c: "n%d_c%d_%dx%d_k%d_r%d_d%d" % (c["n"], c["c"], c["h"], c["w"], c["k"], c["r"], c["dil"]))
+def test_glds_kernel_256_row_tiles(emu_backend, case):
+    """256 x 128 tiles of the direct-to-LDS kernel == the register-staged 128 x 128 kernel, element for element (outputs, per-half
+    BatchNorm partial rows, data gradients)"""
+    gc.conv_ab(emu_backend, kt=32, st=2, big=1, **case)

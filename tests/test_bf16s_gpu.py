@@ -76,6 +76,14 @@ def test_glds_kernel_tail_split(case, form):
     gc.conv_ab(DEV, kt=form[0], st=form[1], split=1, **case)
 
 
+@pytest.mark.parametrize("case", gc.BIG + gc.FULL,
+                         ids=lambda c: "n%d_c%d_%dx%d_k%d_r%d_d%d_t%d" % (c["n"], c["c"], c["h"], c["w"], c["k"], c["r"], c["dil"], c["tile_want"]))
+def test_glds_kernel_256_row_tiles(case):
+    """256 x 128 tiles of the direct-to-LDS kernel (small ragged launches and the layer geometries of configs[4]) == the
+    register-staged 128 x 128 kernel, element for element"""
+    gc.conv_ab(DEV, kt=32, st=2, big=1, **case)
+
+
 def _golden_eval(golden_dir, name, size, B):
     from unipose_amd import ops
     g = np.load(os.path.join(golden_dir, name))

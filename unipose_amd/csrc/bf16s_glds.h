@@ -201,6 +201,23 @@ __device__ __forceinline__ void tile_stats(const IgemmArgs& a, f32x16 (&acc)[BM 
         sm[j] = m1;
         s2[j] = q1;
     }
+    if constexpr (BM == 256) {
+        // 256-row tiles: one partial row per 128-row HALF (the rows of one M-wave), so the statistics tensor keeps the 128-row
+        // granularity the tile rule promises (up_conv_stats_tiles_math) whichever tile the launch ends up with
+        if (lh == 0 && m0 + wm * 128 < a.M) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = ncol0 + j * 32;
+                if (n < a.Ng) {
+                    float* o = a.stats + ((size_t)(2 * mt + wm) * a.Ng + n) * 3;
+                    o[0] = sc[j];
+                    o[1] = sm[j];
+                    o[2] = s2[j];
+                }
+            }
+        }
+        return;
+    }
     if (wm == 1 && lh == 0) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -238,7 +255,7 @@ template <int BM, int BN, bool PERM>
 __device__ __forceinline__ void store_tile(const IgemmArgs& a, f32x16 (&acc)[BM / 64][BN / 64], unsigned char* img_mem, float* xch,
                                            int mt, int m0, int n0, int tid, int wm, int wn, int l31, int lh) {
     constexpr int TM = BM / 64, TN = BN / 64;
-    const bool full = m0 + BM <= a.M;   // uniform
+    const bool full = BM == 256 ? m0 + (wm + 1) * 128 <= a.M : m0 + BM <= a.M;   // uniform (BM = 256: per M-wave, no barrier inside)
     if (a.stats) {
         if (full) tile_stats<BM, BN, true>(a, acc, xch, mt, m0, n0, wm, wn, l31, lh);
         else tile_stats<BM, BN, false>(a, acc, xch, mt, m0, n0, wm, wn, l31, lh);

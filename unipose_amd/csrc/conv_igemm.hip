@@ -1875,6 +1875,7 @@ static int g_glds_kt = env_int("UP_GLDS_KT", 32, 0);   // channels per K slice o
 static int g_wgrad_kp = env_int("UP_WGRAD_KP", 64, 32);  // pixels per slice of the direct-to-LDS weight gradient (64 | 32)
 static int g_wgrad_st = env_int("UP_WGRAD_ST", 2, 2);   // its LDS stages at 32 pixels per slice (2 | 3)
 static int g_glds_st = env_int("UP_GLDS_ST", 2, 2);    // LDS stages of the 32-channel form (2 | 3)
+static int g_glds_256 = env_int("UP_GLDS_256", 0, 0);  // 256 x 128 tiles for launches with at least this many of them (0 = never)
 static int g_glds = env_int("UP_GLDS", 1, 0);   // bf16 storage: direct-to-LDS kernels of bf16s_glds.h (0 = the register-staged round-2 kernels)
 static int g_db_min_k = env_int("UP_DB_MIN_K", 1024, 1);
 static int g_short_k = env_int("UP_SHORT_K", 512, 1);             // reductions shorter than this are epilogue-heavy:
@@ -2267,6 +2268,7 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "bn_rows")) set_bn_rows(value);
     else if (!strcmp(key, "glds")) g_glds = value ? 1 : 0;
     else if (!strcmp(key, "glds_st") && (value == 2 || value == 3)) g_glds_st = value;
+    else if (!strcmp(key, "glds_256") && value >= 0) g_glds_256 = value;
     else if (!strcmp(key, "cu_count") && value >= 0) g_cu_override = value;
     else if (!strcmp(key, "glds_split")) g_glds_split = value ? 1 : 0;
     else if (!strcmp(key, "glds_split_q") && value >= 0) g_glds_split_q = value;
@@ -2462,7 +2464,16 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
             a.x_bytes = (uint32_t)a_bytes;
             if (g_tap_sort && a.taps > 1 && a.taps <= 16 && !a.residual && !a.no_tap_skip) a.perm = tap_sort_perm(a);
             void (*kernel)(IgemmArgs);
-            if (kt == 64)
+            // 256 x 128 tiles (one M-wave = 128 x 64: 6 fragment reads per 8 MFMAs and 24 KB of operands per slice for twice the
+            // FLOP of a 128 x 128 tile: 0.75x the L1 and LDS traffic per FLOP) where the launch still has at least
+            // g_glds_256 of them, i.e. two per CU
+            bool big = false;
+            if constexpr (BM == 128 && BN == 128)
+                big = g_glds_256 > 0 && kt == 32 && g_glds_st == 2 && (long long)cdiv(a.M, 256) * a.ntn >= g_glds_256;
+            if (big) {
+                a.nwg = cdiv(a.M, 256) * a.ntn;
+                kernel = a.perm ? glds::igemm_glds_kernel<256, 128, true, 32, 2, 2> : glds::igemm_glds_kernel<256, 128, false, 32, 2, 2>;
+            } else if (kt == 64)
                 kernel = a.perm ? glds::igemm_glds_kernel<BM, BN, true, 64, 2, 2> : glds::igemm_glds_kernel<BM, BN, false, 64, 2, 2>;
             else if (g_glds_st == 3)
                 kernel = a.perm ? glds::igemm_glds_kernel<BM, BN, true, 32, 3, 3> : glds::igemm_glds_kernel<BM, BN, false, 32, 3, 3>;
@@ -2477,7 +2488,7 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
                 const int p = sc ? glds_split_parts(a.nwg, a.Ktot / kt) : 1;
                 const int full = a.nwg / cu_count() * cu_count();
                 const size_t shares = (size_t)(a.nwg - full) * (size_t)(p - 1);
-                if (p > 1 && shares * (size_t)(BM * BN) <= sc->pfloats && shares <= sc->nflags) {
+                if (p > 1 && shares * (size_t)((big ? 2 : 1) * BM * BN) <= sc->pfloats && shares <= sc->nflags) {
                     a.full_blocks = full;
                     a.parts = p;
                     a.partials = sc->partials;
