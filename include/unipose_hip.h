@@ -114,6 +114,10 @@ int up_stream_release(void* stream);
  * when planning splits; 0 = the real count).
  * Change them only between steps: workspace sizes and the BatchNorm partial-row count follow the tile choice. */
 int up_conv_tune(const char* key, int value);
+/* Diagnostics: fp32 forward / data-gradient launches since load, by kernel family — "igemm" (register-staged igemm_kernel),
+ * "glds32" (f32_glds.h), "glds32_epi1" (of those, with the LDS-transposed epilogue), "glds32_bnred" (with the fused
+ * BatchNorm-backward reduction); -1 for an unknown name.  Tests use it to prove which kernel a case ran on. */
+long long up_conv_counter(const char* name);
 /* Analysis (host only, no launch): share of (row tile, filter tap) pairs the K loop of the forward (data_gradient = 0) or
  * data-gradient launch of `d` visits with its rows in image order and in tap-sorted order ("tap_sort" knob), and the share
  * of (pixel, tap) pairs that touch the image at all (`live`: what a perfect skip would visit).  Aligned fast path only. */
@@ -129,6 +133,22 @@ int up_conv_wgrad_visits(const up_conv_desc* d, double* rect_fraction);
  * instead of by a separate add kernel. */
 int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
                        const float* add, int ld_add, void* stream);
+/* The same launch when dx is dz of the layer z = relu(bn(y) (+ res)) that produced this convolution's input (resnet.py:25-33:
+ * bn1 -> relu -> conv2, bn2 -> relu -> conv3, block output -> next block's conv1): its epilogue also reduces that layer's two
+ * BatchNorm-backward sums per row tile — partial[tile][c] = {sum g, invstd[c] * sum g * (y - mean[c])}, g = dz * [z > 0] — so the
+ * layer's backward (up_bn_bwd_prereduced_t) needs no reduction pass of its own (native_batch_norm_backward's first read of
+ * dz and y).  up_conv2d_bwd_data_tiles(d) = rows of `partial` (0: this launch cannot carry the reduction; use the plain form). */
+typedef struct {
+    const float* y;            /* raw convolution output of the producing layer, [rows][ld]            */
+    const uint32_t* relu_bits; /* sign bits of z (bit row * C + c), NULL when the layer has no ReLU    */
+    const float* mean;         /* [C] batch (or running) mean / 1 / sqrt(var + eps) of that BatchNorm  */
+    const float* invstd;
+    float* partial;            /* out: [up_conv2d_bwd_data_tiles(d)][C][2]                              */
+    int32_t ld, C;             /* pixel stride of y; channels (== d->C of this convolution)             */
+} up_bn_reduce_slot;
+int up_conv2d_bwd_data_tiles(const up_conv_desc* d);
+int up_conv2d_bwd_data_bnred(const up_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
+                             const float* add, int ld_add, const up_bn_reduce_slot* slot, void* stream);
 
 /* bf16-operand variants of the forward / data-gradient convolution (v_mfma_f32_32x32x16_bf16, fp32 accumulate,
  * fp32 activations in HBM).  math = UP_MATH_BF16X3: every operand is carried as hi = bf16(x), lo = bf16(x - hi)
@@ -224,6 +244,12 @@ int up_bn_bwd_acc_t(const void* dz, int lddz, const void* z, int ldz, const uint
                 const float* gamma, const float* mean, const float* invstd, int relu, int use_batch_stats,
                 void* dy, int lddy, void* dres, int lddres, float* dgamma, float* dbeta, float* acc_dgamma, float* acc_dbeta,
                 float* workspace, size_t workspace_bytes, int64_t rows, int C, int dtype, void* stream);
+/* BatchNorm backward whose reduction pass ran inside the data-gradient launch that produced dz (up_conv2d_bwd_data_bnred):
+ * `partial` = that launch's [chunks][C][2] sums; finalize + apply only.  fp32 tensors (dtype = UP_DT_F32). */
+int up_bn_bwd_prereduced_t(const void* dz, int lddz, const uint32_t* relu_bits, const void* y, int ldy, const float* gamma,
+                           const float* mean, const float* invstd, int relu, int use_batch_stats, void* dy, int lddy, void* dres,
+                           int lddres, float* dgamma, float* dbeta, float* acc_dgamma, float* acc_dbeta, float* partial, int chunks,
+                           int64_t rows, int C, int dtype, void* stream);
 
 /* ---- grouped BatchNorm: one tensor holds `groups` row groups of equal size (the T frames of a clip batch, frame-major), each
  * normalised with ITS OWN batch statistics — what `groups` separate module calls do in the reference's video loop

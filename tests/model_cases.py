@@ -316,3 +316,45 @@ def tap_case(dev, golden_file, size, keys, sub, output_stride=16, tol=1e-3):
         _, _, idx = ops.heatmap_argmax(y)
         assert np.array_equal(idx.cpu().numpy(), g["argmax"])            # bit-exact joint index
     return errs
+
+
+def fused_reduce_case(dev, K=16, B=2, size=32, wseed=3, tol=2e-5):
+    """One training step with the BatchNorm-backward reductions fused into the consuming convolutions' data gradients
+    (ops.BnSlot, f32_glds.h BNRED) against the same step with the separate reduce pass: the launch counter proves the fused
+    path ran, every parameter gradient agrees to the round-off of a re-ordered fp32 sum."""
+    from unipose_amd import _C, ops
+    m, _ = build_image_model(K, wseed, dev)
+    m.train()
+    for d in (m.wasp.dropout, m.decoder.last_conv[3], m.decoder.last_conv[7]):
+        d.p = 0.0
+    x = O.synth_input((B, 3, size, size), 13).to(dev)
+    t = O.synth_input((B, K + 1, size // 8, size // 8), 14, "rand").to(dev)
+    cnt = lambda: int(_C.lib().up_conv_counter(b"glds32_bnred"))
+    grads, launches = {}, {}
+    prev = ops.BN_FUSE_REDUCE
+    try:
+        for fuse in (True, False):
+            ops.BN_FUSE_REDUCE = fuse
+            rs = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}
+            m.zero_grad(set_to_none=True)
+            c0 = cnt()
+            loss = ops.mse_loss(m(x), t)
+            loss.backward()
+            ops.wgrad_fence()
+            launches[fuse] = cnt() - c0
+            grads[fuse] = {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}
+            m.load_state_dict({**m.state_dict(), **rs})        # the second step starts from the same running statistics
+    finally:
+        ops.BN_FUSE_REDUCE = prev
+    assert launches[False] == 0, launches
+    # 33 blocks: bn2 in every conv3 launch, bn1 in the stride-1 conv2 launches (31 of 33), bn3 in the conv1 launch of the 29
+    # identity blocks
+    assert launches[True] >= 60, launches
+    assert grads[True].keys() == grads[False].keys()
+    worst = ("", 0.0)
+    for n in grads[True]:
+        e = O.max_rel(grads[True][n], grads[False][n])
+        if e > worst[1]:
+            worst = (n, e)
+    assert worst[1] < tol, worst
+    return launches[True], worst

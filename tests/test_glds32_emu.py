@@ -1,0 +1,25 @@
+"""Exact-fp32 direct-to-LDS kernels (unipose_amd/csrc/f32_glds.h) on the CPU emulator: the same kernel sources, A/B against the
+register-staged igemm_kernel, and the BatchNorm-backward reduction fused into the data gradient against the separate pass."""
+import pytest
+
+import glds32_cases as g32
+
+_id = lambda c: "n%d_c%d_%dx%d_k%d_r%d_d%d_t%d" % (c["n"], c["c"], c["h"], c["w"], c["k"], c["r"], c["dil"], c["tile_want"])
+
+
+@pytest.mark.parametrize("case", g32.SMALL, ids=_id)
+def test_glds32_kernel_matches_register_staged_kernel(emu_backend, case):
+    """outputs, BatchNorm partials and data gradients, element for element, for the three forms (LDS-transposed / dword epilogue,
+    one / two LDS stages)"""
+    g32.conv_ab(emu_backend, **case)
+
+
+@pytest.mark.parametrize("case", g32.SPLIT, ids=_id)
+def test_glds32_kernel_tail_split(emu_backend, case):
+    """K-split tail tiles: same cut, same merge order as igemm_kernel -> equal results"""
+    g32.conv_ab(emu_backend, **case)
+
+
+@pytest.mark.parametrize("case", g32.BNRED, ids=_id)
+def test_bn_backward_reduction_fused_into_data_gradient(emu_backend, case):
+    g32.bnred_case(emu_backend, **case)

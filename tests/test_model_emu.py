@@ -15,6 +15,10 @@ def test_train_dropout_masks_emu(emu_backend):
     mc.train_case(emu_backend, size=32, dropout_masks=True)
 
 
+def test_bn_backward_reduction_fused_into_data_gradients_emu(emu_backend):
+    mc.fused_reduce_case(emu_backend, size=32)
+
+
 def test_second_step_repack_and_counters_emu(emu_backend):
     mc.second_step_case(emu_backend)
 

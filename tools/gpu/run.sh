@@ -8,11 +8,13 @@
 #   prof736      rocprofv3 kernel stats of the 736^2 step, both stream modes
 #   ab368        default fp32 step, two runs (box sanity)
 #   lstm         UniPose-LSTM leg with host / wall split (tools/gpu/steps.py)
+#   abenv368 / csvenv368   the same A/B forms on the headline fp32 step (368^2, B = 32);  tests_glds32  tests/test_glds32_gpu.py
 cd $GRAFT_REPO_ROOT
 TAG=$1; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 B736="--size 736 --batch 16 --math bf16s --no-cpu-baseline --no-stock-baseline --no-alt-math --no-other-configs"
+B368="--no-cpu-baseline --no-stock-baseline --no-alt-math --no-other-configs"
 line() { tail -1 $1 | python -c "
 import sys, json
 try:
@@ -47,6 +49,17 @@ prof736) # rocprofv3 kernel stats of the 736^2 step: default (two streams) and e
   python tools/rocprof_summary.py $(find $OUT/prof_736 -name "*.db" | head -1) 4 > $OUT/kernel_stats_736_bf16s.txt 2>&1
   python tools/rocprof_summary.py $(find $OUT/prof_736x -name "*.db" | head -1) 4 > $OUT/kernel_stats_736_bf16s_exclusive.txt 2>&1
   find $OUT -name "*.db" -delete; head -${HEAD:-30} $OUT/kernel_stats_736_bf16s_exclusive.txt ;;
+abenv368) # VARIANTS="UP_GLDS32=0;UP_GLDS32=1 UP_GLDS32_EPI=0;..."  (the headline fp32 step per variant, REPS alternations, default 2)
+  IFS=';' read -ra VS <<< "$VARIANTS"
+  for rep in $(seq 1 ${REPS:-2}); do for v in "${VS[@]}"; do
+  env $v timeout 300 python bench.py $B368 --steps ${STEPS:-10} --warmup 3 --no-profile > $OUT/abenv368.log 2>&1; line $OUT/abenv368.log "$v"; done; done ;;
+csvenv368) # per-launch CSVs (exclusive stream mode) of the fp32 step for each of VARIANTS, each compared with the first
+  IFS=';' read -ra VS <<< "$VARIANTS"; i=0
+  for v in "${VS[@]}"; do
+  env $v UNIPOSE_SYNC_WGRAD=1 UP_PROFILE_CSV=$GRAFT_REPO_ROOT/$OUT/launches368_v$i.csv timeout 300 python bench.py $B368 --steps 3 --warmup 2 > $OUT/csvenv368_$i.log 2>&1; line $OUT/csvenv368_$i.log "csv $v"
+  if [ $i -gt 0 ]; then echo "== variant $i ($v) vs variant 0 (${VS[0]})"; python tools/gpu/csv_compare.py $(ls $OUT/launches368_v$i.csv* | tail -1) $(ls $OUT/launches368_v0.csv* | tail -1) > $OUT/csv368_compare_$i.txt 2>&1; head -${HEAD:-40} $OUT/csv368_compare_$i.txt; fi
+  i=$((i+1)); done ;;
+tests_glds32) timeout 600 python -m pytest tests/test_glds32_gpu.py -m gpu -q -x --timeout 300 > $OUT/pytest_glds32.log 2>&1; echo "pytest exit $?"; tail -15 $OUT/pytest_glds32.log ;;
 ab368) for rep in 1 2; do timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-stock-baseline --no-alt-math --no-other-configs --no-profile > $OUT/ab368.log 2>&1; line $OUT/ab368.log "fp32"; done ;;
 lstm) timeout 300 python tools/gpu/steps.py --model lstm --batch 8 > $OUT/lstm_steps.log 2>&1; tail -5 $OUT/lstm_steps.log ;;
 *) echo "unknown action $act" ;;

@@ -28,6 +28,14 @@ class ConvEpilogue(C.Structure):
 
 
 _i, _i64, _f, _u64, _sz, _p = C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_size_t, C.c_void_p
+
+
+class BnReduceSlot(C.Structure):
+    """up_bn_reduce_slot"""
+    _fields_ = [("y", C.c_void_p), ("relu_bits", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
+                ("partial", C.c_void_p), ("ld", C.c_int32), ("C", C.c_int32)]
+
+
 _D, _E = C.POINTER(ConvDesc), C.POINTER(ConvEpilogue)
 
 # name -> (restype, argtypes); mirrors include/unipose_hip.h one to one
@@ -42,9 +50,14 @@ SIGNATURES = {
     "up_conv_split_parts": (_i, [_D]),
     "up_stream_release": (_i, [_p]),
     "up_conv_tune": (_i, [C.c_char_p, _i]),
+    "up_conv_counter": (C.c_longlong, [C.c_char_p]),
     "up_conv_wgrad_visits": (_i, [_D, C.POINTER(C.c_double)]),
     "up_conv_tap_visits": (_i, [_D, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "up_conv2d_bwd_data": (_i, [_D, _p, _p, _p, _p, _i, _p]),
+    "up_conv2d_bwd_data_tiles": (_i, [_D]),
+    "up_conv2d_bwd_data_bnred": (_i, [_D, _p, _p, _p, _p, _i, C.POINTER(BnReduceSlot), _p]),
+    "up_bn_bwd_prereduced_t": (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _i64, _i,
+                                    _i, _p]),
     "up_pack_weights_bf16": (_i, [_D, _p, _p, _p, _p, _p, _p]),
     "up_conv2d_fwd_bf16": (_i, [_D, _p, _p, _p, _p, _E, _i, _p]),
     "up_conv2d_bwd_data_bf16": (_i, [_D, _p, _p, _p, _p, _p, _i, _i, _p]),

@@ -39,7 +39,7 @@ namespace up {
 // up_profile_begin() arms it; every igemm/wgrad launch is then bracketed by two hipEvents on the
 // launch stream; up_profile_end() synchronises and returns, per kernel variant, {launches, total ms,
 // total algorithmic flops}.  Off by default: no events, no overhead.
-constexpr int PROF_VARIANTS = 28;
+constexpr int PROF_VARIANTS = 32;
 static const char* const kVariantNames[PROF_VARIANTS] = {
     "igemm_kernel<128,128,aligned>", "igemm_kernel<128,128,generic>", "igemm_kernel<64,128,aligned>",
     "igemm_kernel<64,128,generic>",  "igemm_kernel<128,64,aligned>",  "igemm_kernel<128,64,generic>",
@@ -51,7 +51,9 @@ static const char* const kVariantNames[PROF_VARIANTS] = {
     // bf16 storage, direct-to-LDS generation (bf16s_glds.h)
     "igemm_glds_kernel<128,128> (bf16)", "igemm_glds_kernel<64,128> (bf16)", "igemm_glds_kernel<128,64> (bf16)",
     "igemm_glds_kernel<64,64> (bf16)",   "wgrad_glds_kernel<128,128> (bf16)", "wgrad_glds_kernel<128,64> (bf16)",
-    "wgrad_glds_kernel<64,128> (bf16)",  "wgrad_glds_kernel<64,64> (bf16)"};
+    "wgrad_glds_kernel<64,128> (bf16)",  "wgrad_glds_kernel<64,64> (bf16)",
+    // exact fp32, direct-to-LDS generation (f32_glds.h)
+    "igemm_glds32_kernel<128,128>", "igemm_glds32_kernel<64,128>", "igemm_glds32_kernel<128,64>", "igemm_glds32_kernel<64,64>"};
 #ifndef UP_EMU
 struct ProfRec {
     hipEvent_t a, b;
@@ -131,7 +133,15 @@ struct IgemmArgs {
     // tap-sorted row order (igemm_kernel<..., PERM = true>, see TapSort): GEMM row m is output pixel perm[m]; pixels
     // with the same set of live filter taps are contiguous, so the tile-level tap skipping drops (nearly) every dead tap
     const int* perm;
-    uint32_t x_bytes;   // bf16s_glds.h: bytes of the activation tensor behind x (num_records of its buffer descriptor)
+    uint32_t x_bytes;   // bf16s_glds.h / f32_glds.h: bytes of the activation tensor behind x (num_records of its buffer descriptor)
+    // f32_glds.h, BNRED: the output of this data-gradient launch is dz of the layer z = relu(bn(y) (+ res)); its epilogue also
+    // reduces that layer's BatchNorm-backward sums per row tile: partial[row tile][channel][2] = {sum g, invstd * sum g (y - mean)}
+    const float* bn_y;
+    const uint32_t* bn_bits;   // sign bits of z (bit pixel * bn_C + channel), nullptr: no ReLU
+    const float* bn_mean;
+    const float* bn_invstd;
+    float* bn_partial;
+    int bn_ld, bn_C;
 };
 
 __device__ __forceinline__ void wf_merge(float& n1, float& m1, float& s1, float n2, float m2, float s2) {
@@ -1621,6 +1631,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradArgs a) {
 }
 
 #include "bf16s_glds.h"
+#include "f32_glds.h"
 
 // sum the split-K slabs and scatter into PyTorch OIHW
 // (Measured and removed in round 2: the merge folded into the weight-gradient kernels — every split publishes its slab with
@@ -1877,6 +1888,13 @@ static int g_wgrad_st = env_int("UP_WGRAD_ST", 2, 2);   // its LDS stages at 32 
 static int g_glds_st = env_int("UP_GLDS_ST", 2, 2);    // LDS stages of the 32-channel form (2 | 3)
 static int g_glds_256 = env_int("UP_GLDS_256", 0, 0);  // 256 x 128 tiles for launches with at least this many of them (0 = never)
 static int g_glds = env_int("UP_GLDS", 1, 0);   // bf16 storage: direct-to-LDS kernels of bf16s_glds.h (0 = the register-staged round-2 kernels)
+// fp32 forward / data gradient with operands HBM -> LDS by LDS-DMA (f32_glds.h, round 4): glds32 = 0 keeps the register-staged
+// igemm_kernel; glds32_epi: 1 = LDS-transposed 16-byte-store epilogue, 0 = igemm_epilogue; glds32_st1: reductions shorter than
+// this use ONE LDS stage (16 KB per 64x64 workgroup) instead of two
+static long long g_count_igemm = 0, g_count_glds32 = 0, g_count_glds32_epi1 = 0, g_count_glds32_bnred = 0;   // up_conv_counter
+static int g_glds32 = env_int("UP_GLDS32", 1, 0);
+static int g_glds32_epi = env_int("UP_GLDS32_EPI", 1, 0);
+static int g_glds32_st1 = env_int("UP_GLDS32_ST1", 0, 0);
 static int g_db_min_k = env_int("UP_DB_MIN_K", 1024, 1);
 static int g_short_k = env_int("UP_SHORT_K", 512, 1);             // reductions shorter than this are epilogue-heavy:
 static int g_short_k_mult = env_int("UP_SHORT_K_MULT", 4, 1);     // they want g_short_k_mult / 2 times as many workgroups
@@ -2168,6 +2186,44 @@ static double visited_tap_fraction(const IgemmArgs& a, int bm, bool sorted, doub
     return (double)visited / ((double)tiles * a.taps);
 }
 
+// f32_glds.h: needs the aligned fast path (<= 32 taps, no strided gather), 31-bit BYTE offsets and 16-byte aligned operands
+static bool glds32_eligible(IgemmArgs& a, bool fast) {
+    if (!g_glds32 || !fast || a.Cp % 32 != 0 || a.M % (a.P * a.Q) != 0) return false;
+    const long long a_bytes = (long long)(a.M / (a.P * a.Q)) * a.H * a.W * a.ldx * 4;
+    const uintptr_t ptrs = reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.w);
+    if (a_bytes >= (1ll << 31) || (long long)a.Ng * a.Ktot * 4 >= (1ll << 31) || (ptrs & 15)) return false;
+    a.x_bytes = (uint32_t)a_bytes;
+    return true;
+}
+// the LDS-transposed epilogue stores float4 rows: 4-channel granularity everywhere, linear (or tap-sorted) output rows
+static bool glds32_epi1_ok(const IgemmArgs& a) {
+    const uintptr_t ptrs = reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.residual);
+    return g_glds32_epi && !a.o_mode && a.Ng % 4 == 0 && a.ldy % 4 == 0 && (!a.residual || a.ldr % 4 == 0) && (ptrs & 15) == 0;
+}
+template <int BM, int BN>
+static auto glds32_kernel(const IgemmArgs& a) -> void (*)(IgemmArgs) {
+    constexpr int OCC2 = (BM == 128 && BN == 128) ? 2 : (BM == 64 && BN == 64) ? 4 : 3;
+    const bool epi1 = glds32_epi1_ok(a);
+    const bool bnred = epi1 && a.bn_partial != nullptr;
+    // one LDS stage: 64x64 tiles only (21 KB, six workgroups per CU by registers; the wider tiles gain no workgroup from it)
+    const bool st1 = BM == 64 && BN == 64 && !a.perm && a.Ktot < g_glds32_st1;
+    if (a.perm) {
+        if (bnred) return glds::igemm_glds32_kernel<BM, BN, true, 2, OCC2, 1, true>;
+        if (epi1) return glds::igemm_glds32_kernel<BM, BN, true, 2, OCC2, 1, false>;
+        return glds::igemm_glds32_kernel<BM, BN, true, 2, OCC2, 0, false>;
+    }
+    if constexpr (BM == 64 && BN == 64) {
+        if (st1) {
+            if (bnred) return glds::igemm_glds32_kernel<64, 64, false, 1, 4, 1, true>;
+            if (epi1) return glds::igemm_glds32_kernel<64, 64, false, 1, 5, 1, false>;
+            return glds::igemm_glds32_kernel<64, 64, false, 1, 6, 0, false>;
+        }
+    }
+    if (bnred) return glds::igemm_glds32_kernel<BM, BN, false, 2, OCC2, 1, true>;
+    if (epi1) return glds::igemm_glds32_kernel<BM, BN, false, 2, OCC2, 1, false>;
+    return glds::igemm_glds32_kernel<BM, BN, false, 2, OCC2, 0, false>;
+}
+
 template <int BM, int BN>
 static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     int ntm = cdiv(a.M, BM);
@@ -2176,11 +2232,12 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     a.fNtn = make_fastdiv(a.ntn);
     a.fSpt = make_fastdiv(a.Cp >= 32 ? a.Cp / 32 : 1);
     const int vbase = (BM == 128 && BN == 128) ? 0 : (BM == 64 && BN == 128) ? 2 : (BM == 128 && BN == 64) ? 4 : 6;
-    ProfScope prof(vbase + (aligned ? 0 : 1), 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st, a.M, a.Ng,
-                   a.Ktot, a.nwg);
     // MODE 2 needs <= 32 taps (bit mask), no stride division and 32-bit element offsets
     const bool fast = aligned && a.taps <= 32 && a.divshift == 0 &&
                       (long long)a.H * a.W * a.ldx * ((long long)a.M / (a.P * a.Q) + 1) < (1ll << 31);
+    const bool use32 = glds32_eligible(a, fast);   // direct-to-LDS generation (f32_glds.h)
+    ProfScope prof(use32 ? 28 + vbase / 2 : vbase + (aligned ? 0 : 1), 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st,
+                   a.M, a.Ng, a.Ktot, a.nwg);
     // double-buffered LDS (one barrier per slice) for long reductions.  In isolation it is 3-5 % faster than the
     // single-buffer loop down to K = 256 (probe), but in the network the rule K >= 1024 is 0.5 % faster per step (A/B in
     // one session, 70.55 vs 70.95 ms): the 73 KB footprint leaves less room for the weight-gradient workgroups of
@@ -2229,6 +2286,14 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
             grid = a.full_blocks + (a.nwg - a.full_blocks) * p;
         }
     }
+    if (use32) {
+        kernel = glds32_kernel<BM, BN>(a);
+        ++g_count_glds32;
+        if (glds32_epi1_ok(a)) ++g_count_glds32_epi1;
+        if (glds32_epi1_ok(a) && a.bn_partial) ++g_count_glds32_bnred;
+    } else {
+        ++g_count_igemm;
+    }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, st, a);
 }
 
@@ -2276,6 +2341,9 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "wgrad_kp") && (value == 32 || value == 64)) g_wgrad_kp = value;
     else if (!strcmp(key, "wgrad_st") && (value == 2 || value == 3)) g_wgrad_st = value;
     else if (!strcmp(key, "glds_kt") && (value == 0 || value == 32 || value == 64)) g_glds_kt = value;
+    else if (!strcmp(key, "glds32")) g_glds32 = value ? 1 : 0;
+    else if (!strcmp(key, "glds32_epi")) g_glds32_epi = value ? 1 : 0;
+    else if (!strcmp(key, "glds32_st1") && value >= 0) g_glds32_st1 = value;
     else if (!strcmp(key, "db_min_k") && value > 0) g_db_min_k = value;
     else if (!strcmp(key, "short_k") && value > 0) g_short_k = value;
     else if (!strcmp(key, "short_k_mult") && value > 0) g_short_k_mult = value;
@@ -2288,6 +2356,15 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "wgrad_per_cu") && value > 0) g_wgrad_per_cu = value;
     else UP_REQUIRE(false, UP_ERR_INVALID, "conv_tune: unknown key '%s'", key);
     return UP_OK;
+}
+
+extern "C" long long up_conv_counter(const char* name) {
+    if (!name) return -1;
+    if (!strcmp(name, "igemm")) return g_count_igemm;
+    if (!strcmp(name, "glds32")) return g_count_glds32;
+    if (!strcmp(name, "glds32_epi1")) return g_count_glds32_epi1;
+    if (!strcmp(name, "glds32_bnred")) return g_count_glds32_bnred;
+    return -1;
 }
 
 extern "C" int up_conv_split_parts(const up_conv_desc* d) {
@@ -2629,6 +2706,49 @@ extern "C" int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const 
     }
     run_igemm(a, choose_tile(a.M, a.Ng, a.Ktot), as_stream(stream));
     return check_launch("conv2d_bwd_data");
+}
+
+// Row tiles of the data-gradient launch of `d` when that launch can carry a fused BatchNorm-backward reduction (f32_glds.h BNRED:
+// fp32, stride 1, 32-aligned output channels, 4-aligned input channels, LDS-DMA + LDS-transposed epilogue enabled), else 0.
+extern "C" int up_conv2d_bwd_data_tiles(const up_conv_desc* d) {
+    if (!d || check_desc(d)) return 0;
+    if (!g_glds32 || !g_glds32_epi || d->stride != 1 || d->Kp % 32 != 0 || d->R * d->S > 32 || d->C % 4 != 0 || d->ldx % 4 != 0 ||
+        d->ldy % 4 != 0 || d->Kp < d->K)
+        return 0;
+    const long long M = (long long)d->N * d->H * d->W;
+    if ((long long)d->N * d->P * d->Q * d->ldy * 4 >= (1ll << 31) || (long long)d->C * d->R * d->S * d->Kp * 4 >= (1ll << 31) ||
+        (long long)d->P * d->Q * d->ldy * ((long long)d->N + 1) >= (1ll << 31))
+        return 0;
+    return cdiv(M, choose_tile(M, d->C, d->R * d->S * d->Kp).bm);
+}
+
+// up_conv2d_bwd_data whose output dx is dz of the layer z = relu(bn(y) (+ res)) that produced this convolution's input: the
+// launch's epilogue also writes that layer's BatchNorm-backward partial sums (slot->partial, one row per row tile), which
+// up_bn_bwd_prereduced_t consumes instead of its own reduction pass.
+extern "C" int up_conv2d_bwd_data_bnred(const up_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
+                                        const float* add, int ld_add, const up_bn_reduce_slot* slot, void* stream) {
+    if (int e = check_desc(d)) return e;
+    UP_REQUIRE(dy && w_dgrad && dx && slot, UP_ERR_INVALID, "conv2d_bwd_data_bnred: null pointer");
+    UP_REQUIRE(!add || ld_add >= d->C, UP_ERR_INVALID, "conv2d_bwd_data_bnred: ld_add=%d < C=%d", ld_add, d->C);
+    UP_REQUIRE(slot->y && slot->mean && slot->invstd && slot->partial && slot->C == d->C && slot->ld >= d->C && slot->ld % 4 == 0,
+               UP_ERR_INVALID, "conv2d_bwd_data_bnred: bad slot (C=%d vs %d, ld=%d)", slot->C, d->C, slot->ld);
+    UP_REQUIRE(up_conv2d_bwd_data_tiles(d) > 0, UP_ERR_UNSUPPORTED, "conv2d_bwd_data_bnred: this launch cannot carry the reduction");
+    IgemmArgs a;
+    if (int e = fill_dgrad_args(a, d, dy, w_dgrad, dx)) return e;
+    a.residual = add;
+    a.ldr = ld_add;
+    a.bn_y = slot->y;
+    a.bn_ld = slot->ld;
+    a.bn_C = slot->C;
+    a.bn_bits = slot->relu_bits;
+    a.bn_mean = slot->mean;
+    a.bn_invstd = slot->invstd;
+    a.bn_partial = slot->partial;
+    const uintptr_t ptrs = reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(w_dgrad) | reinterpret_cast<uintptr_t>(dx) |
+                           reinterpret_cast<uintptr_t>(add) | reinterpret_cast<uintptr_t>(slot->y);
+    UP_REQUIRE((ptrs & 15) == 0 && (!add || ld_add % 4 == 0), UP_ERR_UNSUPPORTED, "conv2d_bwd_data_bnred: 16-byte alignment");
+    run_igemm(a, choose_tile(a.M, a.Ng, a.Ktot), as_stream(stream));
+    return check_launch("conv2d_bwd_data_bnred");
 }
 
 extern "C" int up_pack_weights_bf16(const up_conv_desc* d, const float* w, uint16_t* fwd_hi, uint16_t* fwd_lo,

@@ -919,10 +919,13 @@ template <typename T>
 static void launch_bn_bwd(const T* dz, int lddz, const T* z, int ldz, const uint32_t* relu_bits, const T* y, int ldy,
                           const float* gamma, const float* mean, const float* invstd, int relu, int use_batch_stats, T* dy,
                           int lddy, T* dres, int lddres, float* dgamma, float* dbeta, float* acc_dgamma, float* acc_dbeta,
-                          float* workspace, int64_t rows, int C, hipStream_t st) {
-    int chunks = cdiv(rows, BNB_ROWS);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(chunks, cdiv(C, 64)), dim3(256), 0, st, dz, lddz, z, ldz, relu_bits,
-                       y, ldy, mean, invstd, relu, workspace, rows, C, BNB_ROWS, GroupArgs{0, 0});
+                          float* workspace, int64_t rows, int C, hipStream_t st, int prereduced_chunks = 0) {
+    // prereduced_chunks > 0: `workspace` already holds that many rows of partial sums [chunk][C][2] — the data-gradient launch
+    // that produced dz reduced them in its epilogue (f32_glds.h BNRED) — so pass 1 is skipped
+    int chunks = prereduced_chunks > 0 ? prereduced_chunks : cdiv(rows, BNB_ROWS);
+    if (prereduced_chunks <= 0)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(chunks, cdiv(C, 64)), dim3(256), 0, st, dz, lddz, z, ldz, relu_bits,
+                           y, ldy, mean, invstd, relu, workspace, rows, C, BNB_ROWS, GroupArgs{0, 0});
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (const float*)workspace, chunks, C,
                        dgamma, dbeta, acc_dgamma, acc_dbeta, GroupArgs{0, 0});
     int64_t total = rows * (C / 4);
@@ -985,6 +988,25 @@ extern "C" int up_bn_bwd_acc_t(const void* dz, int lddz, const void* z, int ldz,
                              invstd, relu, use_batch_stats, (float*)dy, lddy, (float*)dres, lddres, dgamma, dbeta,
                              acc_dgamma, acc_dbeta, workspace, rows, C, st);
     return check_launch("bn_bwd");
+}
+// BatchNorm backward whose reduction pass already ran inside the data-gradient launch that produced dz
+// (up_conv2d_bwd_data_bnred): `partial` = [chunks][C][2] from that launch; finalize + apply only.
+extern "C" int up_bn_bwd_prereduced_t(const void* dz, int lddz, const uint32_t* relu_bits, const void* y, int ldy,
+                                      const float* gamma, const float* mean, const float* invstd, int relu, int use_batch_stats,
+                                      void* dy, int lddy, void* dres, int lddres, float* dgamma, float* dbeta, float* acc_dgamma,
+                                      float* acc_dbeta, float* partial, int chunks, int64_t rows, int C, int dtype, void* stream) {
+    UP_REQUIRE(!acc_dgamma == !acc_dbeta, UP_ERR_INVALID, "bn_bwd_prereduced: acc_dgamma and acc_dbeta come together");
+    UP_REQUIRE(dz && y && gamma && mean && invstd && dy && dgamma && dbeta && partial && chunks > 0, UP_ERR_INVALID,
+               "bn_bwd_prereduced: null pointer / no partial rows");
+    UP_REQUIRE(!relu || relu_bits, UP_ERR_INVALID, "bn_bwd_prereduced: relu needs the sign bits of the forward output");
+    UP_REQUIRE(C % 4 == 0 && lddz % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && (!dres || lddres % 4 == 0), UP_ERR_INVALID,
+               "bn_bwd_prereduced: C and strides must be multiples of 4");
+    UP_REQUIRE(rows * (C / 4) < (1ll << 31), UP_ERR_UNSUPPORTED, "bn_bwd_prereduced: tensor too large");
+    UP_REQUIRE(dtype == UP_DT_F32, UP_ERR_UNSUPPORTED, "bn_bwd_prereduced: fp32 tensors only (dtype %d)", dtype);
+    launch_bn_bwd<float>((const float*)dz, lddz, (const float*)nullptr, 0, relu_bits, (const float*)y, ldy, gamma, mean, invstd, relu,
+                         use_batch_stats, (float*)dy, lddy, (float*)dres, lddres, dgamma, dbeta, acc_dgamma, acc_dbeta, partial,
+                         rows, C, as_stream(stream), chunks);
+    return check_launch("bn_bwd_prereduced");
 }
 extern "C" int up_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const uint32_t* relu_bits,
                          const float* y, int ldy,

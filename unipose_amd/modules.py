@@ -46,12 +46,24 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         # identity blocks: the gradient of the skip connection joins the data gradient of conv1 inside its kernel
-        link = ops.GradLink() if self.downsample is None and x.requires_grad and torch.is_grad_enabled() else None
-        y = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True, link_in=link)
-        y = ops.conv_bn_act(y, self.conv2, self.bn2, relu=True)
+        grad = torch.is_grad_enabled()
+        link = ops.GradLink() if self.downsample is None and x.requires_grad and grad else None
+        # BatchNorm-backward reductions ride in the data gradient of the consuming convolution (ops.BnSlot): bn1 in conv2's,
+        # bn2 in conv3's, and the previous block's bn3 in this block's conv1 launch when that launch already adds the skip
+        # gradient (identity block) — then the block input has no other gradient path.  The slot of this block's output travels as
+        # an attribute of the output tensor; nobody picks it up unless the next module is an identity Bottleneck.
+        s_in = getattr(x, "_up_bnslot", None) if link is not None else None
+        s1, s2, s3 = (ops.BnSlot(), ops.BnSlot(), ops.BnSlot()) if grad else (None, None, None)
+        if self._forward_hooks or self._forward_pre_hooks:
+            s_in = s3 = None          # a hook may use the block input / output elsewhere: keep autograd's generic path
+        y = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True, link_in=link, slot_in=s_in, slot_out=s1)
+        y = ops.conv_bn_act(y, self.conv2, self.bn2, relu=True, slot_in=s1, slot_out=s2)
         if self.downsample is not None:
             x = ops.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
-        return ops.conv_bn_act(y, self.conv3, self.bn3, relu=True, residual=x, link_out=link)
+        out = ops.conv_bn_act(y, self.conv3, self.bn3, relu=True, residual=x, link_out=link, slot_in=s2, slot_out=s3)
+        if s3 is not None and s3.y is not None:
+            out._up_bnslot = s3
+        return out
 
 
 class ResNet(nn.Module):

@@ -295,8 +295,31 @@ def conv_fwd_raw(x, weight, cfg, *, scale=None, shift=None, bias=None, residual=
     return out, d, st
 
 
-def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev, add=None):
-    """dx = dgrad(dy) (+ add: another gradient of the same input, summed in the kernel epilogue)."""
+class BnSlot:
+    """Hands the BatchNorm-backward REDUCTION of a layer z = relu(bn(y) (+ res)) to the data-gradient launch of the one
+    convolution that consumes z (resnet.py:25-33: bn1 -> relu -> conv2, bn2 -> relu -> conv3, and a block's output into the next
+    identity block's conv1, whose kernel already adds the skip gradient): that launch produces dz and reduces sum(g), sum(g * xhat)
+    per row tile in its epilogue (f32_glds.h BNRED), so the producer's backward runs finalize + apply only.
+    Contract: z has NO other consumer whose gradient autograd would add to dz (the engine may add in place, which no pointer
+    check can see).  The producer fills y / bits / mean / invstd in its forward; the consumer's backward fills partial and dz_ptr;
+    the producer's backward uses them once if dz is that very tensor, else falls back to its own reduction."""
+    __slots__ = ("y", "bits", "mean", "invstd", "C", "partial", "dz_ptr")
+
+    def __init__(self, y=None, bits=None, mean=None, invstd=None, C=0):
+        self.y, self.bits, self.mean, self.invstd, self.C = y, bits, mean, invstd, C
+        self.partial, self.dz_ptr = None, 0
+
+    def clear(self):
+        self.y = self.bits = self.mean = self.invstd = self.partial = None
+        self.dz_ptr = 0
+
+
+BN_FUSE_REDUCE = os.environ.get("UNIPOSE_BN_FUSE_REDUCE", "1") != "0"     # development switch (A/B runs)
+
+
+def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev, add=None, bn_slot=None):
+    """dx = dgrad(dy) (+ add: another gradient of the same input, summed in the kernel epilogue).
+    bn_slot: see BnSlot (fp32, stride 1; a launch that cannot carry the reduction leaves bn_slot.partial None)."""
     n, h, w, cp = x_shape
     alloc = torch.zeros if cp != d.C else torch.empty
     dx = alloc((n, h, w, cp), dtype=dy.dtype, device=dev)
@@ -318,8 +341,22 @@ def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev, add=None):
                                                   _stream(dy)), "conv2d_bwd_data_bf16")
     else:
         wd = packed_dgrad(weight, d)
-        _C.check(_C.lib().up_conv2d_bwd_data(C.byref(dd), dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), _ptr(add),
-                                             ld_add, _stream(dy)), "conv2d_bwd_data")
+        tiles = 0
+        if bn_slot is not None and bn_slot.y is not None and bn_slot.C == d.C == cp and bn_slot.y.dtype == torch.float32 and \
+                bn_slot.y.shape[:3] == (n, h, w):
+            tiles = _C.lib().up_conv2d_bwd_data_tiles(C.byref(dd))
+        if tiles > 0:
+            partial = torch.empty((tiles, d.C, 2), dtype=torch.float32, device=dev)
+            sl = _C.BnReduceSlot()
+            sl.y, sl.relu_bits, sl.mean, sl.invstd = bn_slot.y.data_ptr(), _ptr(bn_slot.bits), bn_slot.mean.data_ptr(), \
+                bn_slot.invstd.data_ptr()
+            sl.partial, sl.ld, sl.C = partial.data_ptr(), _nhwc_ok(bn_slot.y), d.C
+            _C.check(_C.lib().up_conv2d_bwd_data_bnred(C.byref(dd), dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), _ptr(add),
+                                                       ld_add, C.byref(sl), _stream(dy)), "conv2d_bwd_data_bnred")
+            bn_slot.partial, bn_slot.dz_ptr = partial, dx.data_ptr()
+        else:
+            _C.check(_C.lib().up_conv2d_bwd_data(C.byref(dd), dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), _ptr(add),
+                                                 ld_add, _stream(dy)), "conv2d_bwd_data")
     return dx
 
 
@@ -572,7 +609,7 @@ class ConvBnAct(Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, rm, rv, cfg: ConvCfg, relu: bool, train: bool, eps: float,
-                momentum: float, link_in=None, link_out=None):
+                momentum: float, link_in=None, link_out=None, slot_in=None, slot_out=None):
         L = _C.lib()
         dev = x.device
         k = weight.shape[0]
@@ -643,6 +680,16 @@ class ConvBnAct(Function):
         ctx.link_in, ctx.link_out = link_in, link_out
         if link_in is not None:
             link_in.armed = True       # this node will compute a data gradient: the producer may hand over
+        # BatchNorm-backward reduction by the consumer's data gradient (BnSlot): this layer as the producer ...
+        ctx.slot_out = None
+        if slot_out is not None:
+            slot_out.clear()
+            if BN_FUSE_REDUCE and groups == 1 and y.dtype == torch.float32 and d.ldy == k and (bits is not None or not relu) and \
+                    CONV_MATH == MATH_F32:
+                slot_out.y, slot_out.bits, slot_out.mean, slot_out.invstd, slot_out.C = y, bits, coef[0], coef[1], k
+                ctx.slot_out = slot_out
+        # ... and as the consumer of the layer that produced x
+        ctx.slot_in = slot_in if (slot_in is not None and slot_in.y is not None and ctx.needs_input_grad[0]) else None
         ctx.save_for_backward(x, weight, gamma, y, bits, coef)
         return z
 
@@ -681,6 +728,17 @@ class ConvBnAct(Function):
                 _DEFER["bn"][id(gamma)] = (gamma, beta, dgb)
             else:
                 acc = entry[2]
+        so = ctx.slot_out
+        if so is not None and so.partial is not None and so.dz_ptr == dz.data_ptr() and so.y is y:
+            # the data-gradient launch that wrote dz already reduced this layer's sums (BnSlot): finalize + apply
+            partial, so.partial, so.dz_ptr = so.partial, None, 0
+            _C.check(L.up_bn_bwd_prereduced_t(dz.data_ptr(), d.ldy, _ptr(bits), y.data_ptr(), d.ldy, gamma.data_ptr(),
+                                              coef[0].data_ptr(), coef[1].data_ptr(), int(ctx.relu), int(ctx.train), dy.data_ptr(),
+                                              d.ldy, _ptr(dres), d.ldy, dgb[0].data_ptr(), dgb[1].data_ptr(),
+                                              acc[0].data_ptr() if acc is not None else None,
+                                              acc[1].data_ptr() if acc is not None else None, partial.data_ptr(),
+                                              partial.shape[0], rows, k, _dt(y), _stream(x)), "bn_bwd_prereduced")
+            return ConvBnAct._finish_backward(ctx, x, weight, d, dy, dres, dgb, hand_over)
         _C.check(L.up_bn_bwd_acc_t(dz.data_ptr(), d.ldy, None, 0, _ptr(bits), y.data_ptr(), d.ldy, gamma.data_ptr(),
                                    coef[0].data_ptr(), coef[1].data_ptr(), int(ctx.relu), int(ctx.train), dy.data_ptr(),
                                    d.ldy, _ptr(dres), d.ldy, dgb[0].data_ptr(), dgb[1].data_ptr(),
@@ -694,12 +752,15 @@ class ConvBnAct(Function):
         add = None
         if ctx.link_in is not None:
             add, ctx.link_in.grad, ctx.link_in.armed = ctx.link_in.grad, None, False
-        dx = conv_bwd_data_raw(dy, weight, d, x.shape, x.device, add) if ctx.needs_input_grad[0] else add
+        si = ctx.slot_in
+        if si is not None and ctx.link_in is not None and add is None:
+            si = None       # the skip gradient was not handed over: autograd will ADD it to dx, which is then not dz yet
+        dx = conv_bwd_data_raw(dy, weight, d, x.shape, x.device, add, bn_slot=si) if ctx.needs_input_grad[0] else add
         if ctx.link_out is not None and ctx.link_out.armed and dres is not None:
             ctx.link_out.grad, dres = dres, None          # the block's first convolution adds it to ITS dx
         dw = conv_bwd_weight(x, dy, weight, d, False)[0] if ctx.needs_input_grad[1] else None   # frozen weight: no launch
         return dx, dw, (dgb[0] if hand_over else None), (dgb[1] if hand_over else None), dres, None, None, None, None, None, \
-            None, None, None, None
+            None, None, None, None, None, None
 
 
 def conv_bn_act_eval_fused(x, weight, gamma, beta, rm, rv, cfg, relu, residual=None, eps=BN_EPS_DEFAULT):
@@ -756,8 +817,9 @@ class FoldedBatchNorm(torch.nn.Identity):
     convolution's weight and bias (inference export).  No parameters, no buffers, inference only."""
 
 
-def conv_bn_act(x, conv, bn, relu=True, residual=None, link_in=None, link_out=None):
-    """Dispatch on (bn.training, grad mode) exactly like nn.BatchNorm2d would.  link_in / link_out: see GradLink."""
+def conv_bn_act(x, conv, bn, relu=True, residual=None, link_in=None, link_out=None, slot_in=None, slot_out=None):
+    """Dispatch on (bn.training, grad mode) exactly like nn.BatchNorm2d would.  link_in / link_out: see GradLink;
+    slot_in / slot_out: see BnSlot (slot_in: the slot the producer of x filled; slot_out: filled here for x's ONE consumer)."""
     weight, cfg = conv.weight, ConvCfg(conv.stride[0], conv.padding[0], conv.dilation[0])
     if isinstance(bn, FoldedBatchNorm):       # BN-folded network: ONE kernel, conv + bias (+ residual) (+ ReLU) epilogue
         if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
@@ -782,7 +844,7 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, link_in=None, link_out=No
         mom = 0.0
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     return ConvBnAct.apply(x, weight, bn.weight, bn.bias, residual, rm, rv, cfg, relu, train, bn.eps, mom,
-                           link_in, link_out)
+                           link_in, link_out, slot_in, slot_out)
 
 
 def conv_bias_act(x, conv, relu=False, out_f32=False):
