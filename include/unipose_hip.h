@@ -116,7 +116,8 @@ int up_stream_release(void* stream);
 int up_conv_tune(const char* key, int value);
 /* Diagnostics: fp32 forward / data-gradient launches since load, by kernel family — "igemm" (register-staged igemm_kernel),
  * "glds32" (f32_glds.h), "glds32_epi1" (of those, with the LDS-transposed epilogue), "glds32_bnred" (with the fused
- * BatchNorm-backward reduction); -1 for an unknown name.  Tests use it to prove which kernel a case ran on. */
+ * BatchNorm-backward reduction), "wgrad_glds32" / "wgrad_glds32_st1" (fp32 weight-gradient launches on the direct-to-LDS kernel /
+ * of those, the one-stage form); -1 for an unknown name.  Tests use it to prove which kernel a case ran on. */
 long long up_conv_counter(const char* name);
 /* Analysis (host only, no launch): share of (row tile, filter tap) pairs the K loop of the forward (data_gradient = 0) or
  * data-gradient launch of `d` visits with its rows in image order and in tap-sorted order ("tap_sort" knob), and the share

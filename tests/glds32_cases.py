@@ -41,7 +41,7 @@ def _same(a, b, what):
                              f"first at {tuple(int(i) for i in (d > 0).nonzero()[0])}")
 
 
-DEFAULTS = dict(glds32=1, glds32_epi=1, glds32_st1=0, tile_want=1500, cu_count=0)
+DEFAULTS = dict(glds32=1, glds32_epi=1, glds32_st1=0, glds32_wgrad=1, tile_want=1500, cu_count=0)
 
 
 def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, affine=False, residual=False, relu=False,
@@ -66,20 +66,23 @@ def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, 
         dy = _nhwc(torch.randn(n, k, d.P, d.Q, generator=_g(seed + 6)), dev, kp)
         addt = _nhwc(torch.randn(n, c, h, w, generator=_g(seed + 7)), dev, cp) if add else None
         dx = ops.conv_bwd_data_raw(dy, wt, d, x.shape, x.device, add=addt)
-        return y, st, dx
+        dw, _ = ops.conv_bwd_weight_raw(x, dy, wt.shape, d, False)
+        return y, st, dx, dw
 
     cnt = lambda name: int(_C.lib().up_conv_counter(name.encode()))
     try:
-        _tune(tile_want=tile_want, cu_count=cus, glds32=0)
-        c0 = cnt("glds32")
-        y0, s0, dx0 = run()
-        assert cnt("glds32") == c0, "glds32 = 0 still launched the direct-to-LDS kernel"
+        _tune(tile_want=tile_want, cu_count=cus, glds32=0, glds32_wgrad=0)
+        c0, w0 = cnt("glds32"), cnt("wgrad_glds32")
+        y0, s0, dx0, dw0 = run()
+        assert cnt("glds32") == c0 and cnt("wgrad_glds32") == w0, "glds32 = 0 still launched a direct-to-LDS kernel"
         for epi, st1 in forms:
-            _tune(glds32=1, glds32_epi=epi, glds32_st1=st1)
-            c0, e0 = cnt("glds32"), cnt("glds32_epi1")
-            y1, s1, dx1 = run()
+            _tune(glds32=1, glds32_epi=epi, glds32_st1=st1, glds32_wgrad=1)
+            c0, e0, w0 = cnt("glds32"), cnt("glds32_epi1"), cnt("wgrad_glds32")
+            y1, s1, dx1, dw1 = run()
             assert cnt("glds32") > c0, "the case never reached the direct-to-LDS kernel"
+            assert cnt("wgrad_glds32") > w0, "the weight gradient never reached the direct-to-LDS kernel"
             assert epi == 1 or cnt("glds32_epi1") == e0
+            _same(dw1, dw0, "dw " + f"epi={epi} st1={st1}")
             tag = f"epi={epi} st1={st1}"
             _same(y1, y0, "y " + tag)
             if stats:
@@ -177,6 +180,40 @@ SPLIT = [
     dict(n=4, c=64, h=7, w=7, k=64, r=3, stride=1, pad=3, dil=3, tile_want=100000, stats=True, cus=3),    # tap-sorted, tiles with different live taps
     dict(n=1, c=256, h=5, w=5, k=64, r=1, stride=1, pad=0, dil=1, tile_want=1, affine=True, relu=True, residual=True, cus=0),   # 1x1 8 slices, folded epilogue
 ]
+
+# weight gradient only: shapes the convolution cases above do not reach (unaligned channel counts, many taps, stride 2, both
+# stage forms: `cus` shrinks the chip so that the grid exceeds two workgroups per CU -> the one-stage form)
+WGRAD = [
+    dict(n=2, c=3, h=20, w=20, k=64, r=7, stride=2, pad=3, dil=1, cus=0),        # the stem: 3 -> 4 channels, 49 taps, stride 2
+    dict(n=2, c=15, h=9, w=9, k=15, r=3, stride=1, pad=1, dil=1, cus=0),         # ConvLSTM gate: 15 -> 16 channels, K = 15
+    dict(n=1, c=15, h=12, w=12, k=128, r=11, stride=1, pad=5, dil=1, cus=0),     # LSTM head 11x11
+    dict(n=3, c=160, h=7, w=7, k=136, r=3, stride=1, pad=1, dil=1, cus=1),       # several tiles both ways, one-stage form (cus = 1)
+    dict(n=3, c=64, h=23, w=23, k=64, r=3, stride=1, pad=18, dil=18, cus=2),     # live rectangles (WASP d = 18), one-stage form
+    dict(n=4, c=64, h=10, w=10, k=256, r=1, stride=1, pad=0, dil=1, cus=0),      # 1x1, 64-column tiles
+    dict(n=2, c=64, h=9, w=9, k=64, r=3, stride=2, pad=1, dil=1, cus=0),         # stride 2
+]
+
+
+def wgrad_ab(dev, n, c, h, w, k, r, stride, pad, dil, cus=0, seed=0):
+    cp, kp = ops.rup4(c), ops.rup4(k)
+    x = _nhwc(torch.randn(n, c, h, w, generator=_g(seed)), dev, cp)
+    wt = torch.randn(k, c, r, r, generator=_g(seed + 1)).to(dev)
+    d = ops.make_desc(x, wt, ops.ConvCfg(stride, pad, dil))
+    dy = _nhwc(torch.randn(n, k, d.P, d.Q, generator=_g(seed + 6)), dev, kp)
+    cnt = lambda name: int(_C.lib().up_conv_counter(name.encode()))
+    try:
+        _tune(cu_count=cus, glds32_wgrad=0)
+        dw0, _ = ops.conv_bwd_weight_raw(x, dy, wt.shape, d, False)
+        _tune(glds32_wgrad=1)
+        w0, s0 = cnt("wgrad_glds32"), cnt("wgrad_glds32_st1")
+        dw1, _ = ops.conv_bwd_weight_raw(x, dy, wt.shape, d, False)
+        assert cnt("wgrad_glds32") == w0 + 1
+        one_stage = cnt("wgrad_glds32_st1") > s0
+    finally:
+        _tune(**DEFAULTS)
+    _same(dw1, dw0, "dw")
+    return one_stage
+
 
 BNRED = [
     dict(n=2, c=64, h=9, w=9, k=64, r=1, pad=0, dil=1, tile_want=100000),                 # 1x1, ragged last row tile

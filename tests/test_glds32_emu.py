@@ -23,3 +23,12 @@ def test_glds32_kernel_tail_split(emu_backend, case):
 @pytest.mark.parametrize("case", g32.BNRED, ids=_id)
 def test_bn_backward_reduction_fused_into_data_gradient(emu_backend, case):
     g32.bnred_case(emu_backend, **case)
+
+
+_wid = lambda c: "n%d_c%d_%dx%d_k%d_r%d_s%d_d%d_cus%d" % (c["n"], c["c"], c["h"], c["w"], c["k"], c["r"], c["stride"], c["dil"], c["cus"])
+
+
+@pytest.mark.parametrize("case", g32.WGRAD, ids=_wid)
+def test_wgrad_glds32_kernel_matches_register_staged_kernel(emu_backend, case):
+    one_stage = g32.wgrad_ab(emu_backend, **case)
+    assert one_stage == (case["cus"] > 0), "the case was meant for the other stage form"

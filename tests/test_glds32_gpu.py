@@ -30,3 +30,11 @@ def test_glds32_kernel_at_the_layer_geometries_of_the_headline(dev, case):
 @pytest.mark.parametrize("case", g32.BNRED + g32.BNRED_FULL, ids=_id)
 def test_bn_backward_reduction_fused_into_data_gradient(dev, case):
     g32.bnred_case(dev, **case)
+
+
+_wid = lambda c: "n%d_c%d_%dx%d_k%d_r%d_s%d_d%d_cus%d" % (c["n"], c["c"], c["h"], c["w"], c["k"], c["r"], c["stride"], c["dil"], c["cus"])
+
+
+@pytest.mark.parametrize("case", g32.WGRAD, ids=_wid)
+def test_wgrad_glds32_kernel_matches_register_staged_kernel(dev, case):
+    g32.wgrad_ab(dev, **case)

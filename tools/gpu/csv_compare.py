@@ -8,7 +8,7 @@ import sys
 def load(path):
     d = collections.OrderedDict()
     for r in csv.DictReader(open(path)):
-        fam = r["kernel"].split("<")[0].replace("igemm_glds32_kernel", "igemm_kernel")   # the two fp32 generations line up
+        fam = r["kernel"].split("<")[0].replace("igemm_glds32_kernel", "igemm_kernel").replace("wgrad_glds32_kernel", "wgrad_kernel")   # the two fp32 generations line up
         key = (fam, int(r["M"]), int(r["N"]), int(r["K"]))
         e = d.setdefault(key, [0, 0.0, set(), 0.0])
         e[0] += 1

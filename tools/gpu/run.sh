@@ -60,6 +60,14 @@ csvenv368) # per-launch CSVs (exclusive stream mode) of the fp32 step for each o
   if [ $i -gt 0 ]; then echo "== variant $i ($v) vs variant 0 (${VS[0]})"; python tools/gpu/csv_compare.py $(ls $OUT/launches368_v$i.csv* | tail -1) $(ls $OUT/launches368_v0.csv* | tail -1) > $OUT/csv368_compare_$i.txt 2>&1; head -${HEAD:-40} $OUT/csv368_compare_$i.txt; fi
   i=$((i+1)); done ;;
 tests_glds32) timeout 600 python -m pytest tests/test_glds32_gpu.py -m gpu -q -x --timeout 300 > $OUT/pytest_glds32.log 2>&1; echo "pytest exit $?"; tail -15 $OUT/pytest_glds32.log ;;
+prof368) # rocprofv3 kernel stats of the headline fp32 step: default (two streams) and exclusive (UNIPOSE_SYNC_WGRAD=1)
+  ARGS="$B368 --steps 3 --warmup 1 --no-profile"
+  ( cd /tmp && export TMPDIR=/tmp
+    timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof_368 -o bench -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $GRAFT_REPO_ROOT/$OUT/prof_368.log 2>&1
+    UNIPOSE_SYNC_WGRAD=1 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof_368x -o bench -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $GRAFT_REPO_ROOT/$OUT/prof_368x.log 2>&1 )
+  python tools/rocprof_summary.py $(find $OUT/prof_368 -name "*.db" | head -1) 4 > $OUT/kernel_stats.txt 2>&1
+  python tools/rocprof_summary.py $(find $OUT/prof_368x -name "*.db" | head -1) 4 > $OUT/kernel_stats_exclusive.txt 2>&1
+  find $OUT -name "*.db" -delete; head -${HEAD:-30} $OUT/kernel_stats_exclusive.txt ;;
 ab368) for rep in 1 2; do timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-stock-baseline --no-alt-math --no-other-configs --no-profile > $OUT/ab368.log 2>&1; line $OUT/ab368.log "fp32"; done ;;
 lstm) timeout 300 python tools/gpu/steps.py --model lstm --batch 8 > $OUT/lstm_steps.log 2>&1; tail -5 $OUT/lstm_steps.log ;;
 *) echo "unknown action $act" ;;

@@ -39,7 +39,7 @@ namespace up {
 // up_profile_begin() arms it; every igemm/wgrad launch is then bracketed by two hipEvents on the
 // launch stream; up_profile_end() synchronises and returns, per kernel variant, {launches, total ms,
 // total algorithmic flops}.  Off by default: no events, no overhead.
-constexpr int PROF_VARIANTS = 32;
+constexpr int PROF_VARIANTS = 36;
 static const char* const kVariantNames[PROF_VARIANTS] = {
     "igemm_kernel<128,128,aligned>", "igemm_kernel<128,128,generic>", "igemm_kernel<64,128,aligned>",
     "igemm_kernel<64,128,generic>",  "igemm_kernel<128,64,aligned>",  "igemm_kernel<128,64,generic>",
@@ -53,7 +53,8 @@ static const char* const kVariantNames[PROF_VARIANTS] = {
     "igemm_glds_kernel<64,64> (bf16)",   "wgrad_glds_kernel<128,128> (bf16)", "wgrad_glds_kernel<128,64> (bf16)",
     "wgrad_glds_kernel<64,128> (bf16)",  "wgrad_glds_kernel<64,64> (bf16)",
     // exact fp32, direct-to-LDS generation (f32_glds.h)
-    "igemm_glds32_kernel<128,128>", "igemm_glds32_kernel<64,128>", "igemm_glds32_kernel<128,64>", "igemm_glds32_kernel<64,64>"};
+    "igemm_glds32_kernel<128,128>", "igemm_glds32_kernel<64,128>", "igemm_glds32_kernel<128,64>", "igemm_glds32_kernel<64,64>",
+    "wgrad_glds32_kernel<128,128>", "wgrad_glds32_kernel<128,64>", "wgrad_glds32_kernel<64,128>", "wgrad_glds32_kernel<64,64>"};
 #ifndef UP_EMU
 struct ProfRec {
     hipEvent_t a, b;
@@ -1892,9 +1893,11 @@ static int g_glds = env_int("UP_GLDS", 1, 0);   // bf16 storage: direct-to-LDS k
 // igemm_kernel; glds32_epi: 1 = LDS-transposed 16-byte-store epilogue, 0 = igemm_epilogue; glds32_st1: reductions shorter than
 // this use ONE LDS stage (16 KB per 64x64 workgroup) instead of two
 static long long g_count_igemm = 0, g_count_glds32 = 0, g_count_glds32_epi1 = 0, g_count_glds32_bnred = 0;   // up_conv_counter
+static long long g_count_wgrad32 = 0, g_count_wgrad32_st1 = 0;
 static int g_glds32 = env_int("UP_GLDS32", 1, 0);
 static int g_glds32_epi = env_int("UP_GLDS32_EPI", 1, 0);
 static int g_glds32_st1 = env_int("UP_GLDS32_ST1", 0, 0);
+static int g_glds32_wgrad = env_int("UP_GLDS32_WGRAD", 1, 0);   // fp32 weight gradient with LDS-DMA operands (wgrad_glds32_kernel)
 static int g_db_min_k = env_int("UP_DB_MIN_K", 1024, 1);
 static int g_short_k = env_int("UP_SHORT_K", 512, 1);             // reductions shorter than this are epilogue-heavy:
 static int g_short_k_mult = env_int("UP_SHORT_K_MULT", 4, 1);     // they want g_short_k_mult / 2 times as many workgroups
@@ -2344,6 +2347,7 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "glds32")) g_glds32 = value ? 1 : 0;
     else if (!strcmp(key, "glds32_epi")) g_glds32_epi = value ? 1 : 0;
     else if (!strcmp(key, "glds32_st1") && value >= 0) g_glds32_st1 = value;
+    else if (!strcmp(key, "glds32_wgrad")) g_glds32_wgrad = value ? 1 : 0;
     else if (!strcmp(key, "db_min_k") && value > 0) g_db_min_k = value;
     else if (!strcmp(key, "short_k") && value > 0) g_short_k = value;
     else if (!strcmp(key, "short_k_mult") && value > 0) g_short_k_mult = value;
@@ -2364,6 +2368,8 @@ extern "C" long long up_conv_counter(const char* name) {
     if (!strcmp(name, "glds32")) return g_count_glds32;
     if (!strcmp(name, "glds32_epi1")) return g_count_glds32_epi1;
     if (!strcmp(name, "glds32_bnred")) return g_count_glds32_bnred;
+    if (!strcmp(name, "wgrad_glds32")) return g_count_wgrad32;
+    if (!strcmp(name, "wgrad_glds32_st1")) return g_count_wgrad32_st1;
     return -1;
 }
 
@@ -3074,8 +3080,33 @@ static int up::conv2d_bwd_weight_impl(const up_conv_desc* d, const float* x, con
             hipLaunchKernelGGL((wgrad_bf16_kernel<64, 64>), grid, dim3(256), 0, st, a);
     } else {
         const int v = (p.bm == 128 && p.bn == 128) ? 8 : (p.bm == 128 && p.bn == 64) ? 9 : (p.bm == 64 && p.bn == 128) ? 10 : 11;
-        ProfScope prof(v, 2.0 * (double)a.M * (double)d->K * (double)d->R * d->S * d->C, st, d->K, a.Ncols, a.M,
-                       a.nwg);
+        // direct-to-LDS form (f32_glds.h): 31-bit byte offsets, 16-byte aligned operands
+        const long long xb = (long long)d->N * d->H * d->W * d->ldx * 4, dyb = (long long)d->N * d->P * d->Q * d->ldy * 4;
+        bool glds32_form = g_glds32_wgrad && xb < (1ll << 31) && dyb < (1ll << 31) && (int64_t)d->N * d->P * d->Q < (1ll << 30) &&
+                           ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+#ifdef UP_PROBE
+        glds32_form = glds32_form && !g_wgrad_single && !g_wgrad_dbg;
+#endif
+        ProfScope prof(glds32_form ? v + 24 : v, 2.0 * (double)a.M * (double)d->K * (double)d->R * d->S * d->C, st, d->K, a.Ncols,
+                       a.M, a.nwg);
+        if (glds32_form) {
+            a.x_bytes = (uint32_t)xb;
+            a.dy_bytes = (uint32_t)dyb;
+            a.rect = g_wgrad_rect ? wgrad_rect_device(d, p) : nullptr;
+            const bool single = a.nwg > 2 * cu_count();   // (wgrad_kernel's rule: one LDS stage when more than two workgroups per CU queue up)
+            ++g_count_wgrad32;
+            if (single) ++g_count_wgrad32_st1;
+            void (*kernel)(WgradArgs);
+            if (p.bm == 128 && p.bn == 128)
+                kernel = single ? glds::wgrad_glds32_kernel<128, 128, 1, 3> : glds::wgrad_glds32_kernel<128, 128, 2, 2>;
+            else if (p.bm == 128 && p.bn == 64)
+                kernel = single ? glds::wgrad_glds32_kernel<128, 64, 1, 4> : glds::wgrad_glds32_kernel<128, 64, 2, 3>;
+            else if (p.bm == 64 && p.bn == 128)
+                kernel = single ? glds::wgrad_glds32_kernel<64, 128, 1, 4> : glds::wgrad_glds32_kernel<64, 128, 2, 3>;
+            else
+                kernel = single ? glds::wgrad_glds32_kernel<64, 64, 1, 4> : glds::wgrad_glds32_kernel<64, 64, 2, 4>;
+            hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, a);
+        } else
 #ifdef UP_PROBE
         if (g_wgrad_single && !g_wgrad_dbg) {   // the older single-buffer loop, for comparison
             if (p.bm == 128 && p.bn == 128)
