@@ -686,6 +686,50 @@ __device__ __forceinline__ bf16x8 lds_read_tr16x2(const unsigned char* lds, int 
 }
 #endif
 
+#ifndef UP_EMU
+// Transposing fragment reads of wgrad_glds_kernel as inline assembly (see the comment in the kernel): one 16-pixel step of
+// fragments, the reads of a step, and "wait for this step's reads, then its MFMAs".
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+template <int TM, int TN>
+struct TrFrags {
+    s16x4_t alo[TM], ahi[TM], blo[TN], bhi[TN];
+};
+template <int S, int ROWA, int ROWB, int TM, int TN>
+__device__ __forceinline__ void tr16_read_step(TrFrags<TM, TN>& f, uint32_t base, const uint32_t (&adA)[TM], const uint32_t (&adB)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.alo[i]) : "v"(base + adA[i]), "n"(16 * S * ROWA));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.ahi[i]) : "v"(base + adA[i]), "n"((16 * S + 4) * ROWA));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.blo[j]) : "v"(base + adB[j]), "n"(16 * S * ROWB));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.bhi[j]) : "v"(base + adB[j]), "n"((16 * S + 4) * ROWB));
+    }
+}
+template <int S, int NS, int ROWA, int ROWB, int TM, int TN>
+__device__ __forceinline__ void tr16_mfma_step(TrFrags<TM, TN> (&f)[2], uint32_t base, const uint32_t (&adA)[TM], const uint32_t (&adB)[TN],
+                                               f32x16 (&acc)[TM][TN]) {
+    constexpr int b = S & 1;
+    if constexpr (S + 1 < NS) tr16_read_step<S + 1, ROWA, ROWB>(f[b ^ 1], base, adA, adB);
+    constexpr int younger = S + 1 < NS ? 2 * (TM + TN) : 0;
+    // the wait is tied to every fragment register of this step, so no MFMA below can be scheduled in front of it
+#pragma unroll
+    for (int i = 0; i < TM; ++i) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[b].alo[i]), "+v"(f[b].ahi[i]) : "n"(younger));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f[b].blo[j]), "+v"(f[b].bhi[j]) : "n"(younger));
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const bf16x8 af = __builtin_bit_cast(bf16x8, (s16x8_t)__builtin_shufflevector(f[b].alo[i], f[b].ahi[i], 0, 1, 2, 3, 4, 5, 6, 7));
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, (s16x8_t)__builtin_shufflevector(f[b].blo[j], f[b].bhi[j], 0, 1, 2, 3, 4, 5, 6, 7));
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[i][j], 0, 0, 0);
+        }
+}
+#endif
+
 // KP: pixels per K slice (64 | 32), ST: LDS stages (2 | 3, see igemm_glds_kernel), OCC: workgroups per CU the registers allow
 template <int BM, int BN, int KP, int ST>
 struct WGeom {
@@ -756,6 +800,9 @@ __global__ void __launch_bounds__(256, OCC) wgrad_glds_kernel(WgradArgs a) {
     const int rB = fdiv(tapB, a.fS);
     const int dhB = rB * a.dil, dwB = (tapB - rB * a.S) * a.dil;
     const int deltaB = (dhB * a.W + dwB) * a.ldx * 2 + ciB * 2;
+    // columns past the end fail the row test through a huge row offset (with `colokB && ...` in the per-slice predicate the compiler
+    // split every B instruction into two exec-masked halves: the lanes with and without a real column)
+    const int dhT = colokB ? dhB : (1 << 24);
 
     auto fill_table = [&](int sl, int slot) {   // wave 0: one lane per pixel of slice sl
         if (KP < 64 && lane >= KP) return;
@@ -788,8 +835,8 @@ __global__ void __launch_bounds__(256, OCC) wgrad_glds_kernel(WgradArgs a) {
         for (int i = 0; i < NIB; ++i) {
             const int grp = wave + 4 * i;
             const PixRec r = t[grp * RPB + prowB];
-            const int h = r.h0 + dhB, w = r.w0 + dwB;
-            const bool ok = colokB && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+            const int h = r.h0 + dhT, w = r.w0 + dwB;
+            const bool ok = (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
             load16_to_lds(rsB, ok ? (uint32_t)(r.xoff + deltaB) : OOB, Bs + grp * 1024);
         }
     };
@@ -807,6 +854,41 @@ __global__ void __launch_bounds__(256, OCC) wgrad_glds_kernel(WgradArgs a) {
     const int fpix = 8 * (grp16 >> 1) + (jq >> 2);           // + 4 * h + 16 * s
     const int fch = 16 * (grp16 & 1) + 4 * (jq & 3);         // channel inside the 32-wide MFMA tile
 
+#ifndef UP_EMU
+    // Fragment reads as INLINE ASSEMBLY with hand-counted lgkmcnt waits (round 4).  Through the builtin, the compiler's wait-count
+    // pass put an `s_waitcnt vmcnt(0)` in front of the first transposing read of every slice: it sees an LDS access while LDS-DMA
+    // writes are in flight — the NEXT slice, just issued into the other stage — and cannot tell the stages apart (the plain vector
+    // loads of igemm_glds_kernel escape that through their type-based alias info; an intrinsic call carries none).  The kernel
+    // therefore waited for slice it + 1 to land before computing slice it: no load / compute overlap inside a workgroup
+    // (profiles/r03_z_sq_counters: waves waiting on vmcnt, MFMA pipe 22.5 % busy).  The assembler reads are invisible to that
+    // pass; ordering: the reads of 16-pixel step s + 1 are issued before the MFMAs of step s, which wait until only those
+    // 2 (TM + TN) younger reads are outstanding (LDS operations return in order).
+    const int swA0 = CHA == 16 ? 4 * (fpix & 3) : 4 * ((fpix >> 1) & 1);   // (16 s + 4 h is a multiple of 4: the swizzle term is the lane's)
+    const int swB0 = CHB == 16 ? 4 * (fpix & 3) : 4 * ((fpix >> 1) & 1);
+    uint32_t adA[TM], adB[TN];   // byte offset inside a stage of this lane's (s = 0, h = 0) read of every 32-channel block
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ch = wm * (BM / 2) + i * 32 + fch;
+        adA[i] = (uint32_t)(fpix * G::ROWA + (((ch >> 3) ^ swA0) << 4) + (ch & 7) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ch = wn * (BN / 2) + j * 32 + fch;
+        adB[j] = (uint32_t)(G::A_BYTES + fpix * G::ROWB_ + (((ch >> 3) ^ swB0) << 4) + (ch & 7) * 2);
+    }
+    const uint32_t lds0 = (uint32_t)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+    auto mfmas = [&](const unsigned char* As) {
+        constexpr int NS = KP / 16;
+        static_assert(NS <= 4, "at most four 16-pixel steps per slice");
+        const uint32_t base = lds0 + (uint32_t)(As - smem);
+        TrFrags<TM, TN> f[2];
+        tr16_read_step<0, G::ROWA, G::ROWB_>(f[0], base, adA, adB);
+        tr16_mfma_step<0, NS, G::ROWA, G::ROWB_>(f, base, adA, adB, acc);
+        if constexpr (NS > 1) tr16_mfma_step<1, NS, G::ROWA, G::ROWB_>(f, base, adA, adB, acc);
+        if constexpr (NS > 2) tr16_mfma_step<2, NS, G::ROWA, G::ROWB_>(f, base, adA, adB, acc);
+        if constexpr (NS > 3) tr16_mfma_step<3, NS, G::ROWA, G::ROWB_>(f, base, adA, adB, acc);
+    };
+#else
     auto mfmas = [&](const unsigned char* As) {
         const unsigned char* Bs = As + G::A_BYTES;
 #pragma unroll
@@ -843,6 +925,7 @@ __global__ void __launch_bounds__(256, OCC) wgrad_glds_kernel(WgradArgs a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     };
+#endif
     if (nsl > 0) {
         if constexpr (ST == 2) {
             if (wave == 0) fill_table(0, 0);
