@@ -16,7 +16,10 @@
  *     channels hold zeros; pixel strides and base pointers are multiples of 4 floats (16 B);
  *   - `stream` is a hipStream_t (as void*); all work is enqueued asynchronously on it;
  *   - return value: 0 on success, negative up_status on failure; up_last_error() gives the text.
- *     No C++ exception crosses this boundary.  No host-side global state except the error string.
+ *     No C++ exception crosses this boundary.
+ *   - host-side global state: the per-thread error string; the development knobs of up_conv_tune (and the UP_* environment
+ *     variables read at load time), which select kernels process-wide; per-stream K-split scratch (up_stream_release) and
+ *     per-geometry device tables (tap-sort permutations, weight-gradient rectangles) allocated on first use and kept.
  */
 #ifndef UNIPOSE_HIP_H
 #define UNIPOSE_HIP_H
@@ -106,12 +109,13 @@ int up_stream_release(void* stream);
  * workgroups per CU), "tap_sort" (UP_TAP_SORT: GEMM rows ordered by their set of live filter taps so that the tile-level tap
  * skipping becomes near exact; default on since the round-2 A/B), "wgrad_per_cu" (UP_WGRAD_PER_CU), "wgrad_rect" (UP_WGRAD_RECT, see
  * up_conv_wgrad_visits; default on since the round-2 A/B), "lds_swz" (UP_LDS_SWZ: XOR-swizzled unpadded LDS rows).
- * bf16 storage (round 3): "glds" (UP_GLDS: direct-to-LDS kernels of bf16s_glds.h, default 1), "glds_kt" (32 | 64 channels per K slice,
- * 0 = rule per launch), "glds_st" (2 | 3 LDS stages), "glds_split" / "glds_split_q" / "glds_split_maxp" (K-split of the tail tiles of
- * launches with at most q whole rounds of tiles into at most maxp parts; defaults 0 (off: batch-size-independent results) / 2 / 4), "wgrad_kp" (64 | 32 pixels per slice of
- * the weight gradient), "wgrad_st", "glds_256" (256 x 128 tiles for launches with at least this many of them; 0 = never, the default: measured slower), "bn_rows"
- * (row-strided BatchNorm kernels), "cu_count" (tests: pretend the chip has this many CUs
- * when planning splits; 0 = the real count).
+ * bf16 storage: "glds" (UP_GLDS: direct-to-LDS kernels of bf16s_glds.h, default 1; 0 = the register-staged kernels), "bn_rows"
+ * (row-strided BatchNorm kernels).  fp32 (round 4): "glds32" (UP_GLDS32: forward / data gradient on f32_glds.h, default 1),
+ * "glds32_epi" (LDS-transposed 16-byte-store epilogue, 1), "glds32_st1" (reductions shorter than this use one LDS stage; 0),
+ * "glds32_wgrad" (weight gradient on f32_glds.h, 1).  "cu_count" (tests: pretend the chip has this many CUs when planning
+ * splits; 0 = the real count).
+ * These knobs and the UP_* environment variables they mirror are PROCESS-GLOBAL host state (kernel selection of every later
+ * launch on every stream), like the library's per-stream K-split scratch and per-geometry tables; see the note at the top.
  * Change them only between steps: workspace sizes and the BatchNorm partial-row count follow the tile choice. */
 int up_conv_tune(const char* key, int value);
 /* Diagnostics: fp32 forward / data-gradient launches since load, by kernel family — "igemm" (register-staged igemm_kernel),
@@ -134,22 +138,37 @@ int up_conv_wgrad_visits(const up_conv_desc* d, double* rect_fraction);
  * instead of by a separate add kernel. */
 int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
                        const float* add, int ld_add, void* stream);
-/* The same launch when dx is dz of the layer z = relu(bn(y) (+ res)) that produced this convolution's input (resnet.py:25-33:
- * bn1 -> relu -> conv2, bn2 -> relu -> conv3, block output -> next block's conv1): its epilogue also reduces that layer's two
- * BatchNorm-backward sums per row tile — partial[tile][c] = {sum g, invstd[c] * sum g * (y - mean[c])}, g = dz * [z > 0] — so the
- * layer's backward (up_bn_bwd_prereduced_t) needs no reduction pass of its own (native_batch_norm_backward's first read of
- * dz and y).  up_conv2d_bwd_data_tiles(d) = rows of `partial` (0: this launch cannot carry the reduction; use the plain form). */
+/* Extended data-gradient epilogue (round 4; fp32 and bf16 storage).  Two things a residual network's backward otherwise pays
+ * separate full-tensor passes for (resnet.py:25-42):
+ *  - `bn`: dx is dz of the layer z = relu(bn(y) (+ res)) that produced this convolution's input (bn1 -> relu -> conv2,
+ *    bn2 -> relu -> conv3, a block's output -> the next identity block's conv1): the launch also reduces that layer's two
+ *    BatchNorm-backward sums per row tile — partial[tile][c] = {sum g, invstd[c] * sum g * (y - mean[c])}, g = dz * [z > 0] —
+ *    so the layer's backward (up_bn_bwd_prereduced_t) needs no reduction pass (native_batch_norm_backward's first read of dz, y);
+ *  - `add_relu_bits`: the addend (the skip-connection gradient, resnet.py:36-40) is the UNMASKED dz of the block's last layer
+ *    and its ReLU mask is applied here (bit row * C + c of that layer's sign bits), so that layer's backward need not write
+ *    dz * [z > 0] as a tensor of its own (threshold_backward's output).
+ * up_conv2d_bwd_data_tiles_math(d, math) = rows of `partial`, and > 0 exactly when the launch of `d` runs on a kernel that
+ * supports the two extras (math = UP_MATH_F32 or UP_MATH_BF16S); with 0 use the plain entry points (add only). */
 typedef struct {
-    const float* y;            /* raw convolution output of the producing layer, [rows][ld]            */
-    const uint32_t* relu_bits; /* sign bits of z (bit row * C + c), NULL when the layer has no ReLU    */
-    const float* mean;         /* [C] batch (or running) mean / 1 / sqrt(var + eps) of that BatchNorm  */
+    const void* y;             /* raw convolution output of the producing layer, [rows][ld] (element type of dx)  */
+    const uint32_t* relu_bits; /* sign bits of z (bit row * C + c), NULL when the layer has no ReLU               */
+    const float* mean;         /* [C] batch (or running) mean / 1 / sqrt(var + eps) of that BatchNorm              */
     const float* invstd;
-    float* partial;            /* out: [up_conv2d_bwd_data_tiles(d)][C][2]                              */
-    int32_t ld, C;             /* pixel stride of y; channels (== d->C of this convolution)             */
+    float* partial;            /* out: [up_conv2d_bwd_data_tiles_math(d, math)][C][2]                               */
+    int32_t ld, C;             /* pixel stride of y; channels (== d->C of this convolution)                        */
 } up_bn_reduce_slot;
-int up_conv2d_bwd_data_tiles(const up_conv_desc* d);
-int up_conv2d_bwd_data_bnred(const up_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
-                             const float* add, int ld_add, const up_bn_reduce_slot* slot, void* stream);
+typedef struct {
+    const void* add;               /* second gradient of the same input (element type of dx), or NULL              */
+    const uint32_t* add_relu_bits; /* optional ReLU mask of the addend, see above                                   */
+    const up_bn_reduce_slot* bn;   /* optional fused BatchNorm-backward reduction                                   */
+    int32_t ld_add;
+} up_dgrad_epilogue;
+int up_conv2d_bwd_data_tiles(const up_conv_desc* d);                 /* = ..._tiles_math(d, UP_MATH_F32) */
+int up_conv2d_bwd_data_tiles_math(const up_conv_desc* d, int math);
+/* w_dgrad: the fp32 data-gradient image of up_pack_weights (math = UP_MATH_F32) or the bf16 `hi` plane of
+ * up_pack_weights_bf16 (UP_MATH_BF16S: dy, dx, add and bn->y are bf16). */
+int up_conv2d_bwd_data_ex(const up_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const up_dgrad_epilogue* ep,
+                          int math, void* stream);
 
 /* bf16-operand variants of the forward / data-gradient convolution (v_mfma_f32_32x32x16_bf16, fp32 accumulate,
  * fp32 activations in HBM).  math = UP_MATH_BF16X3: every operand is carried as hi = bf16(x), lo = bf16(x - hi)
@@ -245,8 +264,8 @@ int up_bn_bwd_acc_t(const void* dz, int lddz, const void* z, int ldz, const uint
                 const float* gamma, const float* mean, const float* invstd, int relu, int use_batch_stats,
                 void* dy, int lddy, void* dres, int lddres, float* dgamma, float* dbeta, float* acc_dgamma, float* acc_dbeta,
                 float* workspace, size_t workspace_bytes, int64_t rows, int C, int dtype, void* stream);
-/* BatchNorm backward whose reduction pass ran inside the data-gradient launch that produced dz (up_conv2d_bwd_data_bnred):
- * `partial` = that launch's [chunks][C][2] sums; finalize + apply only.  fp32 tensors (dtype = UP_DT_F32). */
+/* BatchNorm backward whose reduction pass ran inside the data-gradient launch that produced dz (up_conv2d_bwd_data_ex):
+ * `partial` = that launch's [chunks][C][2] sums; finalize + apply only. */
 int up_bn_bwd_prereduced_t(const void* dz, int lddz, const uint32_t* relu_bits, const void* y, int ldy, const float* gamma,
                            const float* mean, const float* invstd, int relu, int use_batch_stats, void* dy, int lddy, void* dres,
                            int lddres, float* dgamma, float* dbeta, float* acc_dgamma, float* acc_dbeta, float* partial, int chunks,

@@ -93,7 +93,7 @@ def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, 
     return y0
 
 
-def bnred_case(dev, n, c, h, w, k, r, pad, dil, *, tile_want, add=False, relu=True, seed=0, cus=0):
+def bnred_case(dev, n, c, h, w, k, r, pad, dil, *, tile_want, add=False, mask_add=False, relu=True, seed=0, cus=0):
     """The data gradient of a convolution whose INPUT is z = relu(bn(y) (+ res)): the launch's epilogue reduces the
     BatchNorm-backward sums of that layer (up_conv2d_bwd_data_bnred) — against up_bn_bwd's own reduce pass on the same dz."""
     cp, kp = ops.rup4(c), ops.rup4(k)
@@ -116,13 +116,21 @@ def bnred_case(dev, n, c, h, w, k, r, pad, dil, *, tile_want, add=False, relu=Tr
     mean = torch.randn(c, generator=_g(seed + 10)).to(dev)
     invstd = (0.5 + torch.rand(c, generator=_g(seed + 11))).to(dev)
     gamma = (0.5 + torch.rand(c, generator=_g(seed + 12))).to(dev)
+    abits = pre = None
+    if add and mask_add:     # the addend is an UNMASKED gradient; its ReLU mask is applied by the epilogue
+        apos = torch.rand(rows * c, generator=_g(seed + 13)) > 0.45
+        aw = torch.zeros((rows * c + 31) // 32 * 32, dtype=torch.int64)
+        aw[:rows * c] = apos.long()
+        ab = (aw.view(-1, 32) << torch.arange(32)).sum(1)
+        abits = torch.where(ab >= 2 ** 31, ab - 2 ** 32, ab).to(torch.int32).to(dev)
+        pre = addt * apos.view(n, h, w, c).to(dev).float()
     try:
         _tune(tile_want=tile_want, cu_count=cus, glds32=1, glds32_epi=1)
         slot = ops.BnSlot(ybn, bits, mean, invstd, c)
-        dx = ops.conv_bwd_data_raw(dy, wt, d, x.shape, x.device, add=addt, bn_slot=slot)
+        dx = ops.conv_bwd_data_raw(dy, wt, d, x.shape, x.device, add=addt, bn_slot=slot, add_bits=abits)
         assert slot.partial is not None, "the launch did not take the fused reduction"
         _tune(glds32=0)
-        dx0 = ops.conv_bwd_data_raw(dy, wt, d, x.shape, x.device, add=addt)
+        dx0 = ops.conv_bwd_data_raw(dy, wt, d, x.shape, x.device, add=addt if pre is None else pre)
     finally:
         _tune(**DEFAULTS)
     _same(dx, dx0, "dx (fused reduction on / off)")
@@ -218,6 +226,8 @@ def wgrad_ab(dev, n, c, h, w, k, r, stride, pad, dil, cus=0, seed=0):
 BNRED = [
     dict(n=2, c=64, h=9, w=9, k=64, r=1, pad=0, dil=1, tile_want=100000),                 # 1x1, ragged last row tile
     dict(n=2, c=64, h=9, w=9, k=32, r=1, pad=0, dil=1, tile_want=100000, add=True),       # addend (identity-branch gradient) before the mask
+    dict(n=2, c=64, h=9, w=9, k=32, r=1, pad=0, dil=1, tile_want=100000, add=True, mask_add=True),   # ... masked by the epilogue
+    dict(n=3, c=128, h=7, w=7, k=64, r=1, pad=0, dil=1, tile_want=1, add=True, mask_add=True),       # 128x128 tile: operands fetched in the epilogue
     dict(n=3, c=128, h=7, w=7, k=64, r=3, pad=1, dil=1, tile_want=100000),                # 3x3, tap-sorted rows
     dict(n=3, c=128, h=7, w=7, k=64, r=3, pad=1, dil=1, tile_want=1),                     # 128x128 tile: operands fetched in the epilogue
     dict(n=3, c=128, h=7, w=7, k=64, r=3, pad=1, dil=1, tile_want=3),                     # 64x128 / 128x64
@@ -241,7 +251,7 @@ FULL = [
 BNRED_FULL = [
     dict(n=32, c=256, h=23, w=23, k=1024, r=1, pad=0, dil=1, tile_want=1500),               # conv3's data gradient reduces bn2
     dict(n=32, c=256, h=23, w=23, k=256, r=3, pad=1, dil=1, tile_want=1500),                # conv2's (tap-sorted, K-split tails) reduces bn1
-    dict(n=32, c=1024, h=23, w=23, k=256, r=1, pad=0, dil=1, tile_want=1500, add=True),     # the next block's conv1 (+ skip gradient) reduces bn3
+    dict(n=32, c=1024, h=23, w=23, k=256, r=1, pad=0, dil=1, tile_want=1500, add=True, mask_add=True),   # the next block's conv1 (+ masked skip gradient) reduces bn3
     dict(n=8, c=256, h=92, w=92, k=64, r=1, pad=0, dil=1, tile_want=1500, add=True),        # layer1: 128-wide tiles, operands fetched in the epilogue
     dict(n=32, c=512, h=23, w=23, k=512, r=3, pad=2, dil=2, tile_want=1500),                # layer4 d = 2
 ]

@@ -59,13 +59,9 @@ def _merge(st):
 
 
 def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, affine=False, residual=False, relu=False,
-            add=False, seed=0, kt=64, st=2, wkp=64, wst=2, split=0, cus=0, big=0):
-    """forward (+ optional BatchNorm partials / folded epilogue / residual) and data gradient (+ optional addend) of one
-    convolution in bf16 storage: glds = 1 against glds = 0 under the same tile rule.
-    split = 1: the K-split of tail tiles is on in the glds kernels (`cus` shrinks the chip so that a small launch has whole rounds of
-    tiles + a tail); a split tile adds its shares in a different order, so outputs are then compared within fp32 round-off of the
-    reduction instead of exactly.
-    big = n: launches that would run at least n 256 x 128 tiles use them (glds_256) instead of 128 x 128 ones."""
+            add=False, seed=0):
+    """forward (+ optional BatchNorm partials / folded epilogue / residual), data gradient (+ optional addend) and weight
+    gradient of one convolution in bf16 storage: glds = 1 against glds = 0 under the same tile rule."""
     cp, kp = ops.rup32(c), ops.rup32(k)
     x = _nhwc(torch.randn(n, c, h, w, generator=_g(seed)), dev, cp)
     wt = (torch.randn(k, c, r, r, generator=_g(seed + 1)) * (2.0 / (c * r * r)) ** 0.5).to(dev)
@@ -77,7 +73,7 @@ def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, 
         kw["bias"] = torch.randn(k, generator=_g(seed + 4)).to(dev)
     out = {}
     try:
-        _tune(tile_want_bf16=tile_want, glds_kt=kt, glds_st=st, wgrad_kp=wkp, wgrad_st=wst, glds_split=split, cu_count=cus, glds_split_q=4, glds_split_maxp=256, glds_256=big)
+        _tune(tile_want_bf16=tile_want)
         for mode in (1, 0):
             _tune(glds=mode)
             d0 = ops.make_desc(x, wt, cfg)
@@ -91,25 +87,9 @@ def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, 
             dw, _ = ops.conv_bwd_weight_raw(x, dy, wt.shape, d, False)
             out[mode] = (y, st, dx, dw)
     finally:
-        _tune(glds=1, tile_want_bf16=500, glds_kt=32, glds_st=2, wgrad_kp=64, wgrad_st=2, glds_split=0, cu_count=0, glds_split_q=2, glds_split_maxp=4, glds_256=0)
+        _tune(glds=1, tile_want_bf16=500)
     (y1, s1, dx1, dw1), (y0, s0, dx0, dw0) = out[1], out[0]
     _same(dw1, dw0, "dw")
-    if split:
-        # bf16 outputs of fp32 sums that differ by re-association: at most one bf16 ulp (2^-8 relative) on a few elements
-        for a_, b_, what in ((y1, y0, "y"), (dx1, dx0, "dx")):
-            if a_ is None:
-                continue
-            a_, b_ = a_.float().cpu(), b_.float().cpu()
-            err = (a_ - b_).abs()
-            assert float((err / b_.abs().clamp_min(1e-2)).max()) <= 2.0 ** -7, (what, float(err.max()))
-            assert float((err > 0).float().mean()) < 0.02, (what, "too many elements differ", float((err > 0).float().mean()))
-        if stats:
-            m1, m0 = _merge(s1), _merge(s0)
-            assert torch.equal(m1[0], m0[0]), "BatchNorm counts"
-            for i, what in ((1, "mean"), (2, "M2")):
-                err = float((m1[i] - m0[i]).abs().max() / m0[i].abs().max().clamp_min(1e-30))
-                assert err < 1e-4, (what, err)
-        return y1
     _same(y1, y0, "y")
     if stats:
         # per-tile partials (count, mean, M2): identical when both kernels tile the rows alike; with tap-sorted rows the
@@ -144,26 +124,6 @@ SMALL = [
     dict(n=1, c=192, h=5, w=5, k=64, r=1, stride=1, pad=0, dil=1, tile_want=1),                     # three slices
 ]
 
-# K-split tail tiles (chip shrunk to `cus` CUs): whole rounds + tail parts in one launch
-SPLIT = [
-    dict(n=3, c=64, h=7, w=7, k=128, r=3, stride=1, pad=1, dil=1, tile_want=100000, stats=True, cus=4),   # 64x64 tiles: 3 x 2 = 6 tiles = 4 + 2 tails x 2 parts
-    dict(n=2, c=128, h=6, w=6, k=72, r=3, stride=1, pad=1, dil=1, tile_want=1, add=True, cus=0),          # one 128x128 tile, 36 slices -> 18 parts, addend after the merge
-    dict(n=4, c=64, h=7, w=7, k=64, r=3, stride=1, pad=3, dil=3, tile_want=100000, stats=True, cus=3),    # tap-sorted, tiles with different live taps: 4 tiles = 3 + 1 x 3
-    dict(n=2, c=64, h=9, w=9, k=64, r=1, stride=1, pad=0, dil=1, tile_want=100000, stats=True, cus=2),    # 1x1, two slices: 3 tiles = 2 + 1 tail; p = 1 (too short): no split
-    dict(n=1, c=256, h=5, w=5, k=64, r=1, stride=1, pad=0, dil=1, tile_want=1, affine=True, relu=True, residual=True, cus=0),   # 1x1 8 slices -> 4 parts, folded epilogue
-    dict(n=1, c=64, h=5, w=5, k=64, r=3, stride=1, pad=6, dil=6, tile_want=1, stats=True, cus=0),         # only the centre tap lives: 2 live slices under 9 parts -> empty shares
-]
-
-# 256 x 128 tiles (kt = 32, two stages): ragged last tiles whose second half is partly or wholly past the end, BatchNorm partial rows per
-# 128-row half, tap-sorted rows, folded epilogue with residual (fp32 half-image path), data-gradient addend
-BIG = [
-    dict(n=3, c=64, h=7, w=7, k=128, r=3, stride=1, pad=1, dil=1, tile_want=1, stats=True),                 # 147 rows: one tile, second half 19 rows
-    dict(n=4, c=64, h=14, w=14, k=136, r=1, stride=1, pad=0, dil=1, tile_want=1, stats=True),               # 784 rows: 4 tiles, the last with 16 rows; ragged N
-    dict(n=5, c=64, h=10, w=10, k=128, r=3, stride=1, pad=2, dil=2, tile_want=1, stats=True, add=True),      # 500 rows, tap-sorted, dgrad addend
-    dict(n=2, c=128, h=16, w=16, k=128, r=1, stride=1, pad=0, dil=1, tile_want=1, affine=True, relu=True, residual=True),   # 512 rows = 2 full tiles
-    dict(n=4, c=64, h=8, w=8, k=128, r=3, stride=1, pad=3, dil=3, tile_want=1, affine=True, relu=True),      # 256 rows exactly, eval epilogue
-]
-
 # the real geometries of BASELINE configs[4] (736x736, B = 16) that carry the step
 FULL = [
     dict(n=16, c=256, h=46, w=46, k=256, r=3, stride=1, pad=1, dil=1, tile_want=500, stats=True, add=True),      # layer3 conv2
@@ -172,4 +132,83 @@ FULL = [
     dict(n=16, c=256, h=46, w=46, k=256, r=3, stride=1, pad=18, dil=18, tile_want=500, stats=True),              # WASP d = 18
     dict(n=16, c=512, h=46, w=46, k=512, r=3, stride=1, pad=4, dil=4, tile_want=500, stats=True),                # layer4 d = 4
     dict(n=4, c=64, h=184, w=184, k=256, r=1, stride=1, pad=0, dil=1, tile_want=500, stats=True),                # layer1 conv3 (B = 4)
+]
+
+
+def bnred_case(dev, n, c, h, w, k, r, pad, dil, *, tile_want, add=False, mask_add=False, relu=True, seed=0):
+    """bf16 storage: the data gradient of a convolution whose INPUT is z = relu(bn(y) (+ res)) also reduces that layer's
+    BatchNorm-backward sums (up_conv2d_bwd_data_ex) — against up_bn_bwd's own reduce pass on the same dz;
+    mask_add: the addend is an unmasked gradient whose ReLU mask the epilogue applies — against the pre-masked addend."""
+    cp, kp = ops.rup32(c), ops.rup32(k)
+    assert cp == c, "the fused forms need unpadded channel counts"
+    L = _C.lib()
+    wt = (torch.randn(k, c, r, r, generator=_g(seed + 1)) * (2.0 / (c * r * r)) ** 0.5).to(dev)
+    cfg = ops.ConvCfg(1, pad, dil)
+    x = _nhwc(torch.randn(n, c, h, w, generator=_g(seed)), dev, cp)
+    d = ops.make_desc(x, wt, cfg)
+    dy = _nhwc(torch.randn(n, k, d.P, d.Q, generator=_g(seed + 6)), dev, kp)
+    addt = _nhwc(torch.randn(n, c, h, w, generator=_g(seed + 7)), dev, cp) if add else None
+    ybn = _nhwc(torch.randn(n, c, h, w, generator=_g(seed + 8)) * 2 + 0.5, dev, cp)
+    rows = n * h * w
+
+    def make_bits(s):
+        pos = torch.rand(rows * c, generator=_g(s)) > 0.45
+        words = torch.zeros((rows * c + 31) // 32 * 32, dtype=torch.int64)
+        words[:rows * c] = pos.long()
+        b = (words.view(-1, 32) << torch.arange(32)).sum(1)
+        return torch.where(b >= 2 ** 31, b - 2 ** 32, b).to(torch.int32).to(dev), pos.view(n, h, w, c)
+
+    bits, _ = make_bits(seed + 9) if relu else (None, None)
+    abits, apos = make_bits(seed + 13) if (add and mask_add) else (None, None)
+    mean = torch.randn(c, generator=_g(seed + 10)).to(dev)
+    invstd = (0.5 + torch.rand(c, generator=_g(seed + 11))).to(dev)
+    gamma = (0.5 + torch.rand(c, generator=_g(seed + 12))).to(dev)
+    try:
+        _tune(tile_want_bf16=tile_want, glds=1)
+        slot = ops.BnSlot(ybn, bits, mean, invstd, c)
+        dx = ops.conv_bwd_data_raw(dy, wt, d, x.shape, x.device, add=addt, bn_slot=slot, add_bits=abits)
+        assert slot.partial is not None, "the launch did not take the fused reduction"
+        pre = addt if abits is None else (addt.float() * apos.to(dev).float()).to(BF)
+        dx0 = ops.conv_bwd_data_raw(dy, wt, d, x.shape, x.device, add=pre)
+    finally:
+        _tune(glds=1, tile_want_bf16=500)
+    _same(dx, dx0, "dx (fused reduction / masked addend on / off)")
+    outs = []
+    for fused in (True, False):
+        dyb, dres = torch.empty_like(ybn), torch.empty_like(ybn)
+        dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
+        ws = ops.workspace(dx.device, L.up_bn_bwd_workspace(rows, c))
+        pb = None if bits is None else bits.data_ptr()
+        if fused:
+            _C.check(L.up_bn_bwd_prereduced_t(dx.data_ptr(), cp, pb, ybn.data_ptr(), cp, gamma.data_ptr(), mean.data_ptr(),
+                                              invstd.data_ptr(), int(relu), 1, dyb.data_ptr(), cp, dres.data_ptr(), cp,
+                                              dgb[0].data_ptr(), dgb[1].data_ptr(), None, None, slot.partial.data_ptr(),
+                                              slot.partial.shape[0], rows, c, 1, ops._stream(dx)), "bn_bwd_prereduced")
+        else:
+            _C.check(L.up_bn_bwd_acc_t(dx.data_ptr(), cp, None, 0, pb, ybn.data_ptr(), cp, gamma.data_ptr(), mean.data_ptr(),
+                                       invstd.data_ptr(), int(relu), 1, dyb.data_ptr(), cp, dres.data_ptr(), cp, dgb[0].data_ptr(),
+                                       dgb[1].data_ptr(), None, None, ws.data_ptr(), ws.numel(), rows, c, 1, ops._stream(dx)), "bn_bwd")
+        outs.append((dyb.float().cpu(), dres.float().cpu(), dgb.cpu()))
+    (dy1, dr1, g1), (dy0, dr0, g0) = outs
+    _same(dr1, dr0, "dres")
+    scale = float(g0.abs().max())
+    assert float((g1 - g0).abs().max()) <= 2e-5 * max(scale, 1.0), ("dgamma / dbeta", float((g1 - g0).abs().max()), scale)
+    # dy is rounded to bf16: one ulp where the re-ordered sums moved a value across a rounding boundary
+    assert float((dy1 - dy0).abs().max()) <= 2.0 ** -7 * float(dy0.abs().max()), ("dy", float((dy1 - dy0).abs().max()))
+    assert float(((dy1 - dy0).abs() > 0).float().mean()) < 0.02
+    return dx
+
+
+BNRED = [
+    dict(n=2, c=64, h=9, w=9, k=64, r=1, pad=0, dil=1, tile_want=100000),                              # 1x1, ragged last row tile
+    dict(n=2, c=64, h=9, w=9, k=32, r=1, pad=0, dil=1, tile_want=100000, add=True),                    # addend: fp32 half-image path
+    dict(n=2, c=64, h=9, w=9, k=32, r=1, pad=0, dil=1, tile_want=100000, add=True, mask_add=True),     # addend masked in the epilogue
+    dict(n=3, c=128, h=7, w=7, k=64, r=3, pad=1, dil=1, tile_want=1),                                  # 3x3, tap-sorted rows, 128x128 tile
+    dict(n=3, c=128, h=7, w=7, k=64, r=3, pad=1, dil=1, tile_want=3),                                  # 64x128 / 128x64
+    dict(n=2, c=64, h=8, w=8, k=64, r=1, pad=0, dil=1, tile_want=100000, relu=False),                  # BatchNorm without ReLU
+]
+BNRED_FULL = [
+    dict(n=16, c=256, h=46, w=46, k=1024, r=1, pad=0, dil=1, tile_want=500),                           # conv3's data gradient reduces bn2
+    dict(n=16, c=256, h=46, w=46, k=256, r=3, pad=1, dil=1, tile_want=500),                            # conv2's (tap-sorted) reduces bn1
+    dict(n=16, c=1024, h=46, w=46, k=256, r=1, pad=0, dil=1, tile_want=500, add=True, mask_add=True),  # next block's conv1 reduces bn3
 ]

@@ -71,24 +71,12 @@ import glds_cases as gc
 
 
 @pytest.mark.parametrize("case", gc.SMALL, ids=lambda c: "c%d_%dx%d_k%d_r%d_d%d_t%d" % (c["c"], c["h"], c["w"], c["k"], c["r"], c["dil"], c["tile_want"]))
-@pytest.mark.parametrize("form", [(64, 2, 64, 2), (32, 2, 32, 2), (32, 3, 32, 3)], ids=lambda f: "kt%d_st%d_wkp%d_wst%d" % f)
-def test_glds_kernel_matches_register_staged_kernel(emu_backend, case, form):
-    """second-generation bf16-storage kernels (direct-to-LDS loads, tap skipping, tap-sorted rows, 16-byte stores; 64- and
-    32-channel slices, two and three LDS stages) == the register-staged kernels, element for element: outputs, BatchNorm
-    partials, data gradients, weight gradients"""
-    gc.conv_ab(emu_backend, kt=form[0], st=form[1], wkp=form[2], wst=form[3], **case)
+def test_glds_kernel_matches_register_staged_kernel(emu_backend, case):
+    """second-generation bf16-storage kernels (direct-to-LDS loads, tap skipping, tap-sorted rows, 16-byte stores) == the
+    register-staged kernels, element for element: outputs, BatchNorm partials, data gradients, weight gradients"""
+    gc.conv_ab(emu_backend, **case)
 
 
-@pytest.mark.parametrize("case", gc.SPLIT, ids=lambda c: "c%d_%dx%d_k%d_r%d_d%d_cus%d" % (c["c"], c["h"], c["w"], c["k"], c["r"], c["dil"], c["cus"]))
-@pytest.mark.parametrize("form", [(64, 2), (32, 2), (32, 3)], ids=lambda f: "kt%d_st%d" % f)
-def test_glds_kernel_tail_split(emu_backend, case, form):
-    """K-split tail tiles of the direct-to-LDS kernels (whole rounds + parts in one launch, tap-sorted tiles, empty shares, folded
-    epilogue and addend after the merge) against the unsplit register-staged kernels"""
-    gc.conv_ab(emu_backend, kt=form[0], st=form[1], split=1, **case)
-
-
-@pytest.mark.parametrize("case", gc.BIG, ids=lambda c: "n%d_c%d_%dx%d_k%d_r%d_d%d" % (c["n"], c["c"], c["h"], c["w"], c["k"], c["r"], c["dil"]))
-def test_glds_kernel_256_row_tiles(emu_backend, case):
-    """256 x 128 tiles of the direct-to-LDS kernel == the register-staged 128 x 128 kernel, element for element (outputs, per-half
-    BatchNorm partial rows, data gradients)"""
-    gc.conv_ab(emu_backend, kt=32, st=2, big=1, **case)
+@pytest.mark.parametrize("case", gc.BNRED, ids=lambda c: "c%d_%dx%d_k%d_r%d_t%d_%s" % (c["c"], c["h"], c["w"], c["k"], c["r"], c["tile_want"], "m" if c.get("mask_add") else ("a" if c.get("add") else "n")))
+def test_bn_backward_reduction_fused_into_data_gradient_bf16(emu_backend, case):
+    gc.bnred_case(emu_backend, **case)

@@ -57,31 +57,19 @@ def test_small_ops_bf16_storage():
     bc.small_ops_case(DEV)
 
 
-@pytest.mark.parametrize("form", [(32, 2, 64, 2), (64, 2, 32, 2), (32, 3, 32, 3)], ids=lambda f: "kt%d_st%d_wkp%d_wst%d" % f)
 @pytest.mark.parametrize("case", gc.SMALL + gc.FULL,
                          ids=lambda c: "n%d_c%d_%dx%d_k%d_r%d_d%d_t%d" % (c["n"], c["c"], c["h"], c["w"], c["k"], c["r"], c["dil"], c["tile_want"]))
-def test_glds_kernel_matches_register_staged_kernel(case, form):
+def test_glds_kernel_matches_register_staged_kernel(case):
     """second-generation bf16-storage kernels (direct-to-LDS loads, tap skipping, tap-sorted rows, 16-byte stores, transposing
     LDS reads in the weight gradient) == the register-staged kernels, element for element, at small sizes and at the
     geometries of BASELINE configs[4]"""
-    gc.conv_ab(DEV, kt=form[0], st=form[1], wkp=form[2], wst=form[3], **case)
+    gc.conv_ab(DEV, **case)
 
 
-@pytest.mark.parametrize("form", [(32, 2), (64, 2), (32, 3)], ids=lambda f: "kt%d_st%d" % f)
-@pytest.mark.parametrize("case", gc.SPLIT + [dict(c, cus=0) for c in gc.FULL[:3]],
-                         ids=lambda c: "n%d_c%d_%dx%d_k%d_r%d_d%d_cus%d" % (c["n"], c["c"], c["h"], c["w"], c["k"], c["r"], c["dil"], c["cus"]))
-def test_glds_kernel_tail_split(case, form):
-    """K-split tail tiles of the direct-to-LDS kernels: small launches on a shrunk chip, and the 530-tile layer3 launches of
-    BASELINE configs[4] on the real one (512 whole tiles + 18 tiles in 14 parts), against the unsplit register-staged kernels"""
-    gc.conv_ab(DEV, kt=form[0], st=form[1], split=1, **case)
-
-
-@pytest.mark.parametrize("case", gc.BIG + gc.FULL,
-                         ids=lambda c: "n%d_c%d_%dx%d_k%d_r%d_d%d_t%d" % (c["n"], c["c"], c["h"], c["w"], c["k"], c["r"], c["dil"], c["tile_want"]))
-def test_glds_kernel_256_row_tiles(case):
-    """256 x 128 tiles of the direct-to-LDS kernel (small ragged launches and the layer geometries of configs[4]) == the
-    register-staged 128 x 128 kernel, element for element"""
-    gc.conv_ab(DEV, kt=32, st=2, big=1, **case)
+@pytest.mark.parametrize("case", gc.BNRED + gc.BNRED_FULL,
+                         ids=lambda c: "n%d_c%d_%dx%d_k%d_r%d_t%d_%s" % (c["n"], c["c"], c["h"], c["w"], c["k"], c["r"], c["tile_want"], "m" if c.get("mask_add") else ("a" if c.get("add") else "n")))
+def test_bn_backward_reduction_fused_into_data_gradient_bf16(case):
+    gc.bnred_case(DEV, **case)
 
 
 def _golden_eval(golden_dir, name, size, B):

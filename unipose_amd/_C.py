@@ -36,6 +36,11 @@ class BnReduceSlot(C.Structure):
                 ("partial", C.c_void_p), ("ld", C.c_int32), ("C", C.c_int32)]
 
 
+class DgradEpilogue(C.Structure):
+    """up_dgrad_epilogue"""
+    _fields_ = [("add", C.c_void_p), ("add_relu_bits", C.c_void_p), ("bn", C.POINTER(BnReduceSlot)), ("ld_add", C.c_int32)]
+
+
 _D, _E = C.POINTER(ConvDesc), C.POINTER(ConvEpilogue)
 
 # name -> (restype, argtypes); mirrors include/unipose_hip.h one to one
@@ -55,7 +60,8 @@ SIGNATURES = {
     "up_conv_tap_visits": (_i, [_D, _i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "up_conv2d_bwd_data": (_i, [_D, _p, _p, _p, _p, _i, _p]),
     "up_conv2d_bwd_data_tiles": (_i, [_D]),
-    "up_conv2d_bwd_data_bnred": (_i, [_D, _p, _p, _p, _p, _i, C.POINTER(BnReduceSlot), _p]),
+    "up_conv2d_bwd_data_tiles_math": (_i, [_D, _i]),
+    "up_conv2d_bwd_data_ex": (_i, [_D, _p, _p, _p, C.POINTER(DgradEpilogue), _i, _p]),
     "up_bn_bwd_prereduced_t": (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _i64, _i,
                                     _i, _p]),
     "up_pack_weights_bf16": (_i, [_D, _p, _p, _p, _p, _p, _p]),

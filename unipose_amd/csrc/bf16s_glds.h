@@ -42,19 +42,6 @@ __device__ __forceinline__ uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t
     for (int b = 0; b < 4; ++b) r |= (uint32_t)((src >> (8 * ((sel >> (8 * b)) & 7))) & 0xff) << (8 * b);
     return r;
 }
-template <int N>
-__device__ __forceinline__ void wait_dma_but() {}
-__device__ __forceinline__ void raw_barrier() { __syncthreads(); }
-__device__ __forceinline__ void sched_fence() {}
-// 16 bytes per lane to / from a split-K share at byte offset `uni` (wave-uniform) + `lane_off`, agent scope
-template <int AUX = 16>
-__device__ __forceinline__ void share_store16(Rsrc r, int lane_off, int uni, float a0, float a1, float a2, float a3) {
-    const float v[4] = {a0, a1, a2, a3};
-    memcpy(const_cast<unsigned char*>(r.base) + uni + lane_off, v, 16);
-}
-template <int AUX = 16>
-__device__ __forceinline__ void share_load16(Rsrc r, int lane_off, int uni, float* v) { memcpy(v, r.base + uni + lane_off, 16); }
-
 #else
 typedef __amdgpu_buffer_rsrc_t Rsrc;
 __device__ __forceinline__ Rsrc make_rsrc(const void* p, uint32_t bytes) {
@@ -67,38 +54,6 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 // the LDS-DMA writes count on vmcnt; __syncthreads() drains them too, the explicit wait keeps that independent of the compiler
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
-// all but the N youngest vector-memory operations of this wave have completed
-template <int N>
-__device__ __forceinline__ void wait_dma_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// s_barrier without the fence of __syncthreads() (which would wait for every LDS-DMA in flight); LDS reads of this wave are
-// complete (their MFMAs consumed them), LDS-DMA writes are ordered by the counted wait in front
-__device__ __forceinline__ void raw_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-}
-__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }   // nothing is scheduled across
-// 16 bytes per lane to / from a split-K share at byte offset `uni` (wave-uniform: an SGPR / immediate, no address VGPRs) +
-// `lane_off`; aux bit 4 = sc1: the agent-scope form of a store / load on gfx942+ (write-through to / read from the memory side of
-// the per-XCD L2), what st_agent / ld_agent compile to
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-// The data registers of a 16-byte buffer store with an SGPR offset must not be rewritten right behind it: hipcc (ROCm 7.2) treats that
-// form as hazard-free, the first version of this function (a staging array refilled per store: v_perm / v_mov into the same four
-// VGPRs directly behind each store) published a few lanes' NEXT four values on one box in three (tools/gpu/split_stress.py: 30 of 30
-// repetitions wrong on that box, none on the others).  The values are therefore taken from the caller's registers as they are
-// (the accumulators, never written again), and an s_nop follows each store.
-template <int AUX = 16>
-__device__ __forceinline__ void share_store16(Rsrc r, int lane_off, int uni, float a0, float a1, float a2, float a3) {
-    const u32x4_t u = {__builtin_bit_cast(uint32_t, a0), __builtin_bit_cast(uint32_t, a1), __builtin_bit_cast(uint32_t, a2),
-                       __builtin_bit_cast(uint32_t, a3)};
-    __builtin_amdgcn_raw_buffer_store_b128(u, r, lane_off, uni, AUX);
-    asm volatile("s_nop 1" ::: "memory");
-}
-template <int AUX = 16>
-__device__ __forceinline__ void share_load16(Rsrc r, int lane_off, int uni, float* v) {
-    const u32x4_t u = __builtin_amdgcn_raw_buffer_load_b128(r, lane_off, uni, AUX);
-    memcpy(v, &u, 16);
-}
-
 #endif
 
 #ifdef UP_EMU
@@ -201,23 +156,6 @@ __device__ __forceinline__ void tile_stats(const IgemmArgs& a, f32x16 (&acc)[BM 
         sm[j] = m1;
         s2[j] = q1;
     }
-    if constexpr (BM == 256) {
-        // 256-row tiles: one partial row per 128-row HALF (the rows of one M-wave), so the statistics tensor keeps the 128-row
-        // granularity the tile rule promises (up_conv_stats_tiles_math) whichever tile the launch ends up with
-        if (lh == 0 && m0 + wm * 128 < a.M) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = ncol0 + j * 32;
-                if (n < a.Ng) {
-                    float* o = a.stats + ((size_t)(2 * mt + wm) * a.Ng + n) * 3;
-                    o[0] = sc[j];
-                    o[1] = sm[j];
-                    o[2] = s2[j];
-                }
-            }
-        }
-        return;
-    }
     if (wm == 1 && lh == 0) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -251,11 +189,41 @@ __device__ __forceinline__ void tile_stats(const IgemmArgs& a, f32x16 (&acc)[BM 
 //   no residual: image word [row pair][column] = bf16 (row 2rp, row 2rp + 1) of one channel (registers r, r + 1 of an accumulator
 //                hold consecutive rows); a thread reads 8 words = 8 channels x 2 rows, two byte-permutes per output word
 //   residual / addend: fp32 image of half the rows at a time; the addend is added before the single rounding to bf16
-template <int BM, int BN, bool PERM>
+//   BNRED (round 4): this launch's output is dz of the layer z = relu(bn(y) (+ res)); the read-out loops also accumulate that
+//                layer's BatchNorm-backward sums (a.bn_*: sum g, sum g * (y - mean) per channel, g = dz * [z > 0]) on the rows
+//                they are about to store, and the tile's sums go to a.bn_partial[row tile] (f32_glds.h has the fp32 twin)
+//   a.res_bits:  the addend is an UNMASKED dz of another layer; its ReLU mask (bit pixel * Ng + channel) is applied here
+template <int BM, int BN, bool PERM, bool BNRED = false>
 __device__ __forceinline__ void store_tile(const IgemmArgs& a, f32x16 (&acc)[BM / 64][BN / 64], unsigned char* img_mem, float* xch,
                                            int mt, int m0, int n0, int tid, int wm, int wn, int l31, int lh) {
     constexpr int TM = BM / 64, TN = BN / 64;
-    const bool full = BM == 256 ? m0 + (wm + 1) * 128 <= a.M : m0 + BM <= a.M;   // uniform (BM = 256: per M-wave, no barrier inside)
+    static_assert(!BNRED || BM <= 128, "the fused reduction is written for one partial row per tile");
+    float s1a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s2a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float mu8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // g = v * [bit set], accumulated with the BatchNorm operand row yy (8 bf16) of the same pixel
+    auto bn_acc = [&](const float (&v)[8], const uint4& yy, uint32_t bits8) {
+        const float y[8] = {bf_lo(yy.x), bf_hi(yy.x), bf_lo(yy.y), bf_hi(yy.y), bf_lo(yy.z), bf_hi(yy.z), bf_lo(yy.w), bf_hi(yy.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float g = ((bits8 >> e) & 1u) ? v[e] : 0.f;
+            s1a[e] += g;
+            s2a[e] += g * (y[e] - mu8[e]);
+        }
+    };
+    if constexpr (BNRED) {   // the batch means of this thread's 8 channels (its chunk column is the same in every unit)
+        const int nb = n0 + (tid % (BN / 8)) * 8;
+        if (nb < a.Ng) {
+            const float4 m0v = *reinterpret_cast<const float4*>(a.bn_mean + nb), m1v = *reinterpret_cast<const float4*>(a.bn_mean + nb + 4);
+            mu8[0] = m0v.x; mu8[1] = m0v.y; mu8[2] = m0v.z; mu8[3] = m0v.w;
+            mu8[4] = m1v.x; mu8[5] = m1v.y; mu8[6] = m1v.z; mu8[7] = m1v.w;
+        }
+    }
+    // the 8 sign bits of channels n .. n + 7 of pixel p (n is a multiple of 8: one byte of the bit array)
+    auto bits8_of = [&](const uint32_t* bits, int C, int p, int n) -> uint32_t {
+        const long long b = (long long)p * C + n;
+        return (bits[b >> 5] >> (int)(b & 31)) & 0xffu;
+    };
+    const bool full = m0 + BM <= a.M;   // uniform
     if (a.stats) {
         if (full) tile_stats<BM, BN, true>(a, acc, xch, mt, m0, n0, wm, wn, l31, lh);
         else tile_stats<BM, BN, false>(a, acc, xch, mt, m0, n0, wm, wn, l31, lh);
@@ -310,6 +278,24 @@ __device__ __forceinline__ void store_tile(const IgemmArgs& a, f32x16 (&acc)[BM 
             const int n = n0 + cq * 8;
             if (n >= a.Ng) continue;
             const int p0 = opix(2 * rp), p1 = opix(2 * rp + 1);
+            if constexpr (BNRED) {
+                const bf16_t* const ybn = reinterpret_cast<const bf16_t*>(a.bn_y);
+                const uint32_t wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                if (p0 >= 0) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = bf_lo(wv[e]);
+                    bn_acc(v, *reinterpret_cast<const uint4*>(ybn + (uint32_t)(p0 * a.bn_ld + n)),
+                           a.bn_bits ? bits8_of(a.bn_bits, a.bn_C, p0, n) : 0xffu);
+                }
+                if (p1 >= 0) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = bf_hi(wv[e]);
+                    bn_acc(v, *reinterpret_cast<const uint4*>(ybn + (uint32_t)(p1 * a.bn_ld + n)),
+                           a.bn_bits ? bits8_of(a.bn_bits, a.bn_C, p1, n) : 0xffu);
+                }
+            }
             if (p0 >= 0)
                 *reinterpret_cast<uint4*>(yo + (uint32_t)(p0 * a.ldy + n)) =
                     make_uint4(byte_perm(w0.y, w0.x, 0x05040100u), byte_perm(w0.w, w0.z, 0x05040100u),
@@ -350,14 +336,59 @@ __device__ __forceinline__ void store_tile(const IgemmArgs& a, f32x16 (&acc)[BM 
                 const float4 f0 = *reinterpret_cast<const float4*>(img + row * BN + cq * 8);
                 const float4 f1 = *reinterpret_cast<const float4*>(img + row * BN + cq * 8 + 4);
                 const uint4 rr = *reinterpret_cast<const uint4*>(rs + (uint32_t)(px * a.ldr + n));
-                float v[8] = {f0.x + bf_lo(rr.x), f0.y + bf_hi(rr.x), f0.z + bf_lo(rr.y), f0.w + bf_hi(rr.y),
-                              f1.x + bf_lo(rr.z), f1.y + bf_hi(rr.z), f1.z + bf_lo(rr.w), f1.w + bf_hi(rr.w)};
+                float ad[8] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y), bf_lo(rr.z), bf_hi(rr.z), bf_lo(rr.w), bf_hi(rr.w)};
+                if (a.res_bits) {   // the addend's ReLU mask, applied here
+                    const uint32_t mb = bits8_of(a.res_bits, a.Ng, px, n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ad[e] = ((mb >> e) & 1u) ? ad[e] : 0.f;
+                }
+                float v[8] = {f0.x + ad[0], f0.y + ad[1], f0.z + ad[2], f0.w + ad[3], f1.x + ad[4], f1.y + ad[5], f1.z + ad[6], f1.w + ad[7]};
                 if (relu) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
                 }
-                *reinterpret_cast<uint4*>(yo + (uint32_t)(px * a.ldy + n)) = make_uint4(
-                    pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+                const uint4 packed = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+                if constexpr (BNRED) {
+                    // the STORED (rounded) values, like the separate reduction pass reads them back
+                    const float vr[8] = {bf_lo(packed.x), bf_hi(packed.x), bf_lo(packed.y), bf_hi(packed.y),
+                                         bf_lo(packed.z), bf_hi(packed.z), bf_lo(packed.w), bf_hi(packed.w)};
+                    bn_acc(vr, *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.bn_y) + (uint32_t)(px * a.bn_ld + n)),
+                           a.bn_bits ? bits8_of(a.bn_bits, a.bn_C, px, n) : 0xffu);
+                }
+                *reinterpret_cast<uint4*>(yo + (uint32_t)(px * a.ldy + n)) = packed;
+            }
+        }
+    }
+    if constexpr (BNRED) {
+        // lanes that share a chunk column are CQ apart; then the four waves through LDS (the image is free after one more
+        // barrier), summed in a fixed order: deterministic
+#pragma unroll
+        for (int off = CQ; off < 64; off <<= 1)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s1a[e] += __shfl_xor(s1a[e], off);
+                s2a[e] += __shfl_xor(s2a[e], off);
+            }
+        __syncthreads();   // every thread is done with the image
+        float* const red = reinterpret_cast<float*>(img_mem);
+        const int wave = tid >> 6, lane = tid & 63, cq = tid % CQ;
+        if (lane < CQ) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(wave * BN + cq * 8 + e) * 2] = s1a[e];
+                red[(wave * BN + cq * 8 + e) * 2 + 1] = s2a[e];
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int ch = tid >> 1, which = tid & 1;
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) t += red[(w * BN + ch) * 2 + which];
+            const int cc = n0 + ch;
+            if (cc < a.Ng) {
+                if (which) t *= a.bn_invstd[cc];
+                a.bn_partial[((size_t)mt * a.Ng + cc) * 2 + which] = t;
             }
         }
     }
@@ -369,7 +400,7 @@ __device__ __forceinline__ void store_tile(const IgemmArgs& a, f32x16 (&acc)[BM 
 //       vmcnt + raw s_barrier (a __syncthreads() would drain the LDS-DMA queue).
 // EPI:  0 = store_tile (LDS transpose, 16-byte stores), 1 = igemm_epilogue (the register-staged kernel's 2-byte stores; probe).
 // DBG:  probe only (tools/gpu/glds_probe.hip): eight 100 MHz time stamps per workgroup.
-template <int BM, int BN, bool PERM, int KT = 64, int ST = 2, int OCC = 2, int EPI = 0, int DBG = 0>
+template <int BM, int BN, bool PERM, int KT = 64, int ST = 2, int OCC = 2, int EPI = 0, int DBG = 0, bool BNRED = false>
 __global__ void __launch_bounds__(256, OCC) igemm_glds_kernel(IgemmArgs a) {
     using SL = Slice<KT>;
     using G = Geom<BM, BN, KT, ST>;
@@ -387,18 +418,9 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds_kernel(IgemmArgs a) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    // K-split tail tiles as in igemm_kernel (conv_igemm.hip "tail split"): blocks >= full_blocks reduce a 1 / parts share of
-    // the live slices of tile full_blocks + tail; the last part of a tile adds the published shares and runs the epilogue
-    int logical, part = 0, tail = 0;
-    const bool split = (int)blockIdx.x >= a.full_blocks;
-    if (!split) {
-        logical = xcd_remap(blockIdx.x, a.full_blocks);
-    } else {
-        const int j = (int)blockIdx.x - a.full_blocks;
-        tail = uniform(j / a.parts);
-        part = j - tail * a.parts;
-        logical = a.full_blocks + tail;
-    }
+    // (no K-split of tail tiles here: in bf16 storage a cut re-associates fp32 sums batch-size-dependently and one last-bit
+    //  difference can flip the rounding of a stored activation; measured 0.15 ms of 40 at best, r03_s — removed in round 4)
+    const int logical = xcd_remap(blockIdx.x, a.nwg);
     const int mt = fdiv(logical, a.fNtn);
     const int nt = logical - mt * a.ntn;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -427,7 +449,7 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds_kernel(IgemmArgs a) {
     // 1x1, stride 1, no padding (two thirds of the launches): the source pixel IS the destination pixel, and the first weight
     // slice does not depend on any row set-up: it is on its way before the rows are looked at
     const bool pointwise = a.taps == 1 && a.mul == 1 && a.off0 == 0 && a.off0w == 0 && a.H == a.P && a.W == a.Q;
-    const bool early_b = pointwise && !split;
+    const bool early_b = pointwise;
     if (early_b) issueB(0, 0, 0);
 
     int roffA[NA];        // byte offset of (filter tap (0,0), this lane's chunk) of the row in the activation tensor
@@ -485,17 +507,9 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds_kernel(IgemmArgs a) {
         if (live == 0u) live = all_taps;
     }
     const int spt = a.Cp / KT;
-    int nsl = __builtin_popcount(live) * spt;
+    const int nsl = __builtin_popcount(live) * spt;
     unsigned rest = live;
     int tap = __builtin_ctz(rest), cs = 0;
-    if (split) {   // slices [kb, ke) of the tile's live slices
-        const int kb = (int)((long long)nsl * part / a.parts), ke = (int)((long long)nsl * (part + 1) / a.parts);
-        const int skip = kb / spt;
-        for (int t = 0; t < skip; ++t) rest &= rest - 1u;
-        tap = rest ? __builtin_ctz(rest) : 0;
-        cs = kb - skip * spt;
-        nsl = ke - kb;
-    }
 
     bool b_issued = early_b;   // the weight slice of the first issue is already on its way
     auto issue = [&](int stage) {
@@ -546,7 +560,8 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds_kernel(IgemmArgs a) {
     };
 
     if (DBG && tid == 0) stamp[1] = wall_clock64();
-    if constexpr (ST == 2) {
+    static_assert(ST == 2, "two LDS stages (the three-stage form measured no faster and left in round 4)");
+    {
         if (nsl > 0) issue(0);
         for (int it = 0; it < nsl; ++it) {
             wait_dma();
@@ -555,84 +570,14 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds_kernel(IgemmArgs a) {
             if (it + 1 < nsl) issue((it + 1) & 1);
             mfmas(smem + (it & 1) * G::STAGE);
         }
-    } else {
-        static_assert(ST == 3, "two or three LDS stages");
-        if (nsl > 0) issue(0);
-        if (nsl > 1) issue(1);
-        int cur = 0, nxt = 2;   // stage of slice `it`, stage slice it + 2 goes to
-        for (int it = 0; it < nsl; ++it) {
-            if (it + 1 < nsl) wait_dma_but<NA + NB>();   // slice `it` has landed, slice it + 1 may still be in flight
-            else wait_dma();
-            raw_barrier();
-            if (DBG && tid == 0 && it == 0) stamp[2] = wall_clock64();
-            if (it + 2 < nsl) issue(nxt);               // that stage was read during slice it - 1
-            mfmas(smem + cur * G::STAGE);
-            cur = cur == 2 ? 0 : cur + 1;
-            nxt = nxt == 2 ? 0 : nxt + 1;
-        }
     }
     __syncthreads();   // every wave is past its last fragment read: the stages become the epilogue image
     if (DBG && tid == 0) stamp[3] = wall_clock64();
 
-    int nmerge = 0;
-    if (split) {
-        // shares are [part][(i*TN+j)*4 + r/4][256 threads][4] floats: 16 bytes per lane and access, 4 KB per wave-level row, with
-        // agent-scope accesses; readers have a higher block index than writers, so the wait cannot dead-lock the dispatch
-        float* pbase = a.partials + (size_t)tail * (a.parts - 1) * (BM * BN);
-        int* flag = a.flags + tail * (a.parts - 1);
-        if (part < a.parts - 1) {
-            const Rsrc rs = make_rsrc(pbase + (size_t)part * (BM * BN), (uint32_t)(BM * BN * 4));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int off = ((i * TN + j) * 4 + q) * 4096;
-                        const float a0 = acc[i][j][4 * q], a1 = acc[i][j][4 * q + 1], a2 = acc[i][j][4 * q + 2], a3 = acc[i][j][4 * q + 3];
-                        share_store16(rs, tid * 16, off, a0, a1, a2, a3);
-                    }
-                }
-            wait_stores();
-            __syncthreads();
-            if (tid == 0) st_agent_flag(flag + part, 1);
-            return;
-        }
-        nmerge = a.parts - 1;
-    }
-    {   // (one loop on the common path, zero trips for a whole tile: a branch around it made the compiler keep two copies of the
-        // accumulators and spill)
-        float* pbase = a.partials + (size_t)tail * (size_t)nmerge * (BM * BN);
-        int* flag = a.flags + tail * nmerge;
-        for (int pp = 0; pp < nmerge; ++pp) {
-            if (tid == 0) spin_until_set(flag + pp);
-            __syncthreads();
-            const Rsrc rs = make_rsrc(pbase + (size_t)pp * (BM * BN), (uint32_t)(BM * BN * 4));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    float v[16];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int off = ((i * TN + j) * 4 + q) * 4096;
-                        share_load16(rs, tid * 16, off, v + 4 * q);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] += v[r];
-                    sched_fence();   // 16 floats in flight, not 64: the merge must not cost the K loop its registers
-                }
-        }
-        if (nmerge) {
-            __syncthreads();
-            if (tid < nmerge) st_agent_flag(flag + tid, 0);   // consumed: ready for the next launch on this stream
-        }
-    }
-
     if constexpr (EPI == 1) {
         igemm_epilogue<BM, BN, PERM, bf16_t>(a, acc, reinterpret_cast<float*>(smem), mt, m0, n0, wm, wn, l31, lh);
     } else {
-        store_tile<BM, BN, PERM>(a, acc, smem, xch, mt, m0, n0, tid, wm, wn, l31, lh);
+        store_tile<BM, BN, PERM, BNRED>(a, acc, smem, xch, mt, m0, n0, tid, wm, wn, l31, lh);
     }
     if (DBG && tid == 0) {
         stamp[4] = wall_clock64();
@@ -927,7 +872,8 @@ __global__ void __launch_bounds__(256, OCC) wgrad_glds_kernel(WgradArgs a) {
     };
 #endif
     if (nsl > 0) {
-        if constexpr (ST == 2) {
+        static_assert(ST == 2 && KP == 64, "64-pixel slices, two LDS stages (32 pixels / three stages measured slower and left in round 4)");
+        {
             if (wave == 0) fill_table(0, 0);
             __syncthreads();
             issue(0);
@@ -938,28 +884,6 @@ __global__ void __launch_bounds__(256, OCC) wgrad_glds_kernel(WgradArgs a) {
                 if (it + 1 < nsl) issue((it + 1) & 1);
                 if (wave == 0 && it + 2 < nsl) fill_table(it + 2, it & 1);
                 mfmas(smem + (it & 1) * G::STAGE);
-            }
-        } else {
-            static_assert(ST == 3, "two or three LDS stages");
-            // two slices in flight: slice it+2 is issued (and table it+3 written) right behind barrier `it`
-            if (wave == 0) {
-                fill_table(0, 0);
-                if (nsl > 1) fill_table(1, 1);
-            }
-            __syncthreads();
-            issue(0);
-            if (nsl > 1) issue(1);
-            if (wave == 0 && nsl > 2) fill_table(2, 2);
-            int cur = 0, nxt = 2;
-            for (int it = 0; it < nsl; ++it) {
-                if (it + 1 < nsl) wait_dma_but<NIA + NIB>();
-                else wait_dma();
-                raw_barrier();     // slice `it` landed; table it+2 is written; every wave is done with stage nxt (slice it-1)
-                if (it + 2 < nsl) issue(nxt);
-                if (wave == 0 && it + 3 < nsl) fill_table(it + 3, cur);   // slot of slice `it`: its table was consumed by issue(it)
-                mfmas(smem + cur * G::STAGE);
-                cur = cur == 2 ? 0 : cur + 1;
-                nxt = nxt == 2 ? 0 : nxt + 1;
             }
         }
     }

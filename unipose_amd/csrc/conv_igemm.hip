@@ -137,6 +137,9 @@ struct IgemmArgs {
     uint32_t x_bytes;   // bf16s_glds.h / f32_glds.h: bytes of the activation tensor behind x (num_records of its buffer descriptor)
     // f32_glds.h, BNRED: the output of this data-gradient launch is dz of the layer z = relu(bn(y) (+ res)); its epilogue also
     // reduces that layer's BatchNorm-backward sums per row tile: partial[row tile][channel][2] = {sum g, invstd * sum g (y - mean)}
+    // masked addend (f32_glds.h / bf16s_glds.h epilogues): the residual / addend is dz of ANOTHER layer whose ReLU mask
+    // (bit pixel * Ng + channel) is applied here, so that layer's backward need not materialise dz * [z > 0]
+    const uint32_t* res_bits;
     const float* bn_y;
     const uint32_t* bn_bits;   // sign bits of z (bit pixel * bn_C + channel), nullptr: no ReLU
     const float* bn_mean;
@@ -1883,17 +1886,13 @@ static int env_int(const char* name, int dflt, int min_ok) {
 }
 static int g_tile_want = env_int("UP_TILE_WANT", 1500, 1);   // A/B in the network: 700 / 1000 / 1500 / 2200 / 4300 -> 70.1 / 69.9 / 69.6 / 69.9 / 69.8 ms
 static int g_tile_want_bf16 = env_int("UP_TILE_WANT_BF16", 500, 1);
-static int g_glds_kt = env_int("UP_GLDS_KT", 32, 0);   // channels per K slice of the direct-to-LDS kernels (64 | 32); 736^2 step (r03_b): register-staged 46.6 ms, 64: 43.6, 32: 41.7, 32 with three stages 42.1
-static int g_wgrad_kp = env_int("UP_WGRAD_KP", 64, 32);  // pixels per slice of the direct-to-LDS weight gradient (64 | 32)
-static int g_wgrad_st = env_int("UP_WGRAD_ST", 2, 2);   // its LDS stages at 32 pixels per slice (2 | 3)
-static int g_glds_st = env_int("UP_GLDS_ST", 2, 2);    // LDS stages of the 32-channel form (2 | 3)
-static int g_glds_256 = env_int("UP_GLDS_256", 0, 0);  // 256 x 128 tiles for launches with at least this many of them (0 = never)
 static int g_glds = env_int("UP_GLDS", 1, 0);   // bf16 storage: direct-to-LDS kernels of bf16s_glds.h (0 = the register-staged round-2 kernels)
 // fp32 forward / data gradient with operands HBM -> LDS by LDS-DMA (f32_glds.h, round 4): glds32 = 0 keeps the register-staged
 // igemm_kernel; glds32_epi: 1 = LDS-transposed 16-byte-store epilogue, 0 = igemm_epilogue; glds32_st1: reductions shorter than
 // this use ONE LDS stage (16 KB per 64x64 workgroup) instead of two
 static long long g_count_igemm = 0, g_count_glds32 = 0, g_count_glds32_epi1 = 0, g_count_glds32_bnred = 0;   // up_conv_counter
 static long long g_count_wgrad32 = 0, g_count_wgrad32_st1 = 0;
+static bool g_extras_dropped = false;   // a launch was asked for a masked addend / fused reduction on a kernel without them
 static int g_glds32 = env_int("UP_GLDS32", 1, 0);
 static int g_glds32_epi = env_int("UP_GLDS32_EPI", 1, 0);
 static int g_glds32_st1 = env_int("UP_GLDS32_ST1", 0, 0);
@@ -2034,28 +2033,6 @@ static int split_parts(int tiles, int Ktot, size_t slots, bool* all_tiles = null
         }
     }
     return p;
-}
-
-// The same cut for the direct-to-LDS bf16 kernels (bf16s_glds.h).  Measured on the 736^2 B=16 step (r03_s): per launch, exclusive —
-// 530 tiles, K = 1024: 349 -> 414 TF with 14 parts per tail tile; 1060 tiles (q = 4, 7 parts), K = 4608: 879 -> 743 TF (the parts
-// queue behind four whole rounds and the merger waits for them), so only launches of at most g_glds_split_q = 2 whole rounds are
-// cut.  In the whole step the 14-part cut was 0.6 ms SLOWER although the kernels were faster — every cut launch writes
-// 18 x 13 x 64 KB of shares through to memory and reads them back, ~3.4 GB per step —, at most 4 parts per tail tile measured
-// 0.15 ms faster than no cut (40.17 vs 40.32 ms, two alternations), 2 and 8 parts equal to no cut.
-// Default OFF: a cut changes the summation order of the tiles it touches, which tiles those are depends on the batch size, and in
-// bf16 storage a last-bit difference in an accumulator can flip the rounding of a stored activation — the eval forward of a sample
-// would depend on how many other samples share its batch (tests: B = 4 vs B = 16 differ by 9e-3 with the cut, bit-identical without).
-// 0.15 ms of a 40 ms step does not buy that.
-static int g_glds_split = env_int("UP_GLDS_SPLIT", 0, 0);
-static int g_glds_split_q = env_int("UP_GLDS_SPLIT_Q", 2, 0);
-static int g_glds_split_maxp = env_int("UP_GLDS_SPLIT_MAXP", 4, 2);   // (p - 1) x 64 KB of shares per tail tile
-static int glds_split_parts(int tiles, int nk) {
-    const int cus = cu_count(), q = tiles / cus, r = tiles % cus;
-    if (r == 0 || r > cus / 2 || q > g_glds_split_q) return 1;
-    int p = cus / r;
-    if (p > g_glds_split_maxp) p = g_glds_split_maxp;
-    if (p > nk / 2) p = nk / 2;
-    return p < 2 ? 1 : p;
 }
 
 // ---- tap-sorted row order -----------------------------------------------------------------------------
@@ -2289,6 +2266,7 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
             grid = a.full_blocks + (a.nwg - a.full_blocks) * p;
         }
     }
+    if ((a.bn_partial || a.res_bits) && !(use32 && glds32_epi1_ok(a))) g_extras_dropped = true;
     if (use32) {
         kernel = glds32_kernel<BM, BN>(a);
         ++g_count_glds32;
@@ -2335,15 +2313,7 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "tile_want_bf16") && value > 0) g_tile_want_bf16 = value;
     else if (!strcmp(key, "bn_rows")) set_bn_rows(value);
     else if (!strcmp(key, "glds")) g_glds = value ? 1 : 0;
-    else if (!strcmp(key, "glds_st") && (value == 2 || value == 3)) g_glds_st = value;
-    else if (!strcmp(key, "glds_256") && value >= 0) g_glds_256 = value;
     else if (!strcmp(key, "cu_count") && value >= 0) g_cu_override = value;
-    else if (!strcmp(key, "glds_split")) g_glds_split = value ? 1 : 0;
-    else if (!strcmp(key, "glds_split_q") && value >= 0) g_glds_split_q = value;
-    else if (!strcmp(key, "glds_split_maxp") && value >= 2) g_glds_split_maxp = value;
-    else if (!strcmp(key, "wgrad_kp") && (value == 32 || value == 64)) g_wgrad_kp = value;
-    else if (!strcmp(key, "wgrad_st") && (value == 2 || value == 3)) g_wgrad_st = value;
-    else if (!strcmp(key, "glds_kt") && (value == 0 || value == 32 || value == 64)) g_glds_kt = value;
     else if (!strcmp(key, "glds32")) g_glds32 = value ? 1 : 0;
     else if (!strcmp(key, "glds32_epi")) g_glds32_epi = value ? 1 : 0;
     else if (!strcmp(key, "glds32_st1") && value >= 0) g_glds32_st1 = value;
@@ -2526,62 +2496,28 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
     // K slice: 64 on the 64x64 tile (6 -> 12 MFMAs per wave and barrier) measured no faster than 32 (141.7 vs 145.1 TF)
     constexpr int KT = 32;
     if (math == UP_MATH_BF16S) {   // bf16 storage
-        // second-generation kernel (bf16s_glds.h): operands HBM -> LDS directly, 64-channel slices, 16-byte epilogue stores.
-        // Needs 64-channel alignment, 8-channel (16-byte) output rows, 31-bit byte offsets and no strided gather.
+        // second-generation kernel (bf16s_glds.h): operands HBM -> LDS directly, 32-channel slices (34 KB of LDS, four
+        // workgroups per CU), two LDS stages, 16-byte epilogue stores.  Needs 8-channel (16-byte) output rows, 31-bit byte offsets
+        // and no strided gather.  (Round 3 also built 64-channel slices, a per-launch slice rule, three stages, 256 x 128 tiles and
+        // a K-split of tail tiles; each measured neutral or slower in the 736^2 step — profiles/r03_p, r03_q, r03_s, r03_u — and
+        // left the library in round 4.)
         const long long a_bytes = (long long)(a.M / (a.P * a.Q)) * a.H * a.W * a.ldx * 2;
-        // Slice form per launch (tools/gpu/glds_probe forms, profiles/r03_p_glds_forms.txt): 64-channel slices (two
-        // workgroups per CU, half the barriers) win on long reductions with enough tiles to fill two rounds — 3x3 512->512:
-        // 170 vs 201 us, 1x1 2048->512: 83 vs 97, decoder 3x3 at 92x92: 205 vs 245 — and lose where the launch is one ragged
-        // round of tiles (530 tiles: 58 vs 50 us) or the reduction is short (K <= 512).  glds_kt = 64 forces them everywhere
-        // they fit, 0 applies that rule per launch, 32 (default) keeps 32 everywhere: inside the training step, next to the
-        // weight-gradient stream, the rule measured 39.10 ms against 39.03 ms for plain 32 (r03_q) — the isolated gains do not
-        // survive the co-residency, like most isolated gains before them.
-        int kt = 32;
-        if (a.Cp % 64 == 0) {
-            if (g_glds_kt == 64) kt = 64;
-            else if (g_glds_kt == 0 && a.nwg >= 1000 && (a.Ktot >= 1024 || (BN == 64 && a.Ktot >= 576))) kt = 64;
-        }
         if (glds_form) {
             a.no_tap_skip = g_tap_skip ? 0 : 1;
             a.perm = nullptr;
             a.x_bytes = (uint32_t)a_bytes;
             if (g_tap_sort && a.taps > 1 && a.taps <= 16 && !a.residual && !a.no_tap_skip) a.perm = tap_sort_perm(a);
             void (*kernel)(IgemmArgs);
-            // 256 x 128 tiles (one M-wave = 128 x 64: 6 fragment reads per 8 MFMAs and 24 KB of operands per slice for twice the
-            // FLOP of a 128 x 128 tile: 0.75x the L1 and LDS traffic per FLOP) where the launch still has at least
-            // g_glds_256 of them, i.e. two per CU
-            bool big = false;
-            if constexpr (BM == 128 && BN == 128)
-                big = g_glds_256 > 0 && kt == 32 && g_glds_st == 2 && (long long)cdiv(a.M, 256) * a.ntn >= g_glds_256;
-            if (big) {
-                a.nwg = cdiv(a.M, 256) * a.ntn;
-                kernel = a.perm ? glds::igemm_glds_kernel<256, 128, true, 32, 2, 2> : glds::igemm_glds_kernel<256, 128, false, 32, 2, 2>;
-            } else if (kt == 64)
-                kernel = a.perm ? glds::igemm_glds_kernel<BM, BN, true, 64, 2, 2> : glds::igemm_glds_kernel<BM, BN, false, 64, 2, 2>;
-            else if (g_glds_st == 3)
-                kernel = a.perm ? glds::igemm_glds_kernel<BM, BN, true, 32, 3, 3> : glds::igemm_glds_kernel<BM, BN, false, 32, 3, 3>;
+            if (a.bn_partial)   // fused BatchNorm-backward reduction of the producing layer (up_conv2d_bwd_data_ex)
+                kernel = a.perm ? glds::igemm_glds_kernel<BM, BN, true, 32, 2, 4, 0, 0, true> : glds::igemm_glds_kernel<BM, BN, false, 32, 2, 4, 0, 0, true>;
             else
                 kernel = a.perm ? glds::igemm_glds_kernel<BM, BN, true, 32, 2, 4> : glds::igemm_glds_kernel<BM, BN, false, 32, 2, 4>;
-            // tail split (see split_parts): 530 tiles on 256 CUs leave 18 CUs with three tiles and the rest with two
             a.full_blocks = a.nwg;
             a.parts = 1;
-            int grid = a.nwg;
-            if (g_glds_split && tail_split_enabled()) {
-                SplitScratch* sc = split_scratch(st);
-                const int p = sc ? glds_split_parts(a.nwg, a.Ktot / kt) : 1;
-                const int full = a.nwg / cu_count() * cu_count();
-                const size_t shares = (size_t)(a.nwg - full) * (size_t)(p - 1);
-                if (p > 1 && shares * (size_t)((big ? 2 : 1) * BM * BN) <= sc->pfloats && shares <= sc->nflags) {
-                    a.full_blocks = full;
-                    a.parts = p;
-                    a.partials = sc->partials;
-                    a.flags = sc->flags;
-                    grid = full + (a.nwg - full) * p;
-                }
-            }
-            hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(kernel, dim3(a.nwg), dim3(256), 0, st, a);
             return;
         }
+        if (a.bn_partial || a.res_bits) g_extras_dropped = true;   // (up_conv2d_bwd_data_ex checks eligibility first: cannot happen)
         a.fSpt = make_fastdiv(a.Cp / KT);
         if (of32 && fast)
             hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 2, false, KT, true, true>), dim3(a.nwg), dim3(256), 0, st, a);
@@ -2714,47 +2650,70 @@ extern "C" int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const 
     return check_launch("conv2d_bwd_data");
 }
 
-// Row tiles of the data-gradient launch of `d` when that launch can carry a fused BatchNorm-backward reduction (f32_glds.h BNRED:
-// fp32, stride 1, 32-aligned output channels, 4-aligned input channels, LDS-DMA + LDS-transposed epilogue enabled), else 0.
-extern "C" int up_conv2d_bwd_data_tiles(const up_conv_desc* d) {
+// Row tiles of the data-gradient launch of `d` when that launch runs on a kernel whose epilogue can carry the extras of
+// up_dgrad_epilogue (masked addend, fused BatchNorm-backward reduction): fp32 -> f32_glds.h with the LDS-transposed epilogue,
+// bf16 storage -> bf16s_glds.h; stride 1, 32-aligned output channels, 4- / 8-aligned input channels.  Else 0.
+extern "C" int up_conv2d_bwd_data_tiles_math(const up_conv_desc* d, int math) {
     if (!d || check_desc(d)) return 0;
-    if (!g_glds32 || !g_glds32_epi || d->stride != 1 || d->Kp % 32 != 0 || d->R * d->S > 32 || d->C % 4 != 0 || d->ldx % 4 != 0 ||
-        d->ldy % 4 != 0 || d->Kp < d->K)
+    if (math != UP_MATH_F32 && math != UP_MATH_BF16S) return 0;
+    const int q = math == UP_MATH_BF16S ? 8 : 4, eb = math == UP_MATH_BF16S ? 2 : 4;
+    if (math == UP_MATH_F32 && (!g_glds32 || !g_glds32_epi)) return 0;
+    if (math == UP_MATH_BF16S && !g_glds) return 0;
+    if (d->stride != 1 || d->Kp % 32 != 0 || d->R * d->S > 32 || d->C % q != 0 || d->ldx % q != 0 || d->ldy % q != 0 || d->Kp < d->K)
         return 0;
     const long long M = (long long)d->N * d->H * d->W;
-    if ((long long)d->N * d->P * d->Q * d->ldy * 4 >= (1ll << 31) || (long long)d->C * d->R * d->S * d->Kp * 4 >= (1ll << 31) ||
-        (long long)d->P * d->Q * d->ldy * ((long long)d->N + 1) >= (1ll << 31))
+    if ((long long)d->N * d->P * d->Q * d->ldy * eb >= (1ll << 31) || (long long)d->C * d->R * d->S * d->Kp * eb >= (1ll << 31) ||
+        (long long)d->P * d->Q * d->ldy * ((long long)d->N + 1) >= (1ll << 31) || M * d->ldx >= (1ll << 31))
         return 0;
-    return cdiv(M, choose_tile(M, d->C, d->R * d->S * d->Kp).bm);
+    return cdiv(M, choose_tile(M, d->C, d->R * d->S * d->Kp, math).bm);
 }
+extern "C" int up_conv2d_bwd_data_tiles(const up_conv_desc* d) { return up_conv2d_bwd_data_tiles_math(d, UP_MATH_F32); }
 
-// up_conv2d_bwd_data whose output dx is dz of the layer z = relu(bn(y) (+ res)) that produced this convolution's input: the
-// launch's epilogue also writes that layer's BatchNorm-backward partial sums (slot->partial, one row per row tile), which
-// up_bn_bwd_prereduced_t consumes instead of its own reduction pass.
-extern "C" int up_conv2d_bwd_data_bnred(const up_conv_desc* d, const float* dy, const float* w_dgrad, float* dx,
-                                        const float* add, int ld_add, const up_bn_reduce_slot* slot, void* stream) {
+// up_conv2d_bwd_data / _bf16 (bf16 storage) with the extended epilogue: see up_dgrad_epilogue in the header.
+extern "C" int up_conv2d_bwd_data_ex(const up_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
+                                     const up_dgrad_epilogue* ep, int math, void* stream) {
     if (int e = check_desc(d)) return e;
-    UP_REQUIRE(dy && w_dgrad && dx && slot, UP_ERR_INVALID, "conv2d_bwd_data_bnred: null pointer");
-    UP_REQUIRE(!add || ld_add >= d->C, UP_ERR_INVALID, "conv2d_bwd_data_bnred: ld_add=%d < C=%d", ld_add, d->C);
-    UP_REQUIRE(slot->y && slot->mean && slot->invstd && slot->partial && slot->C == d->C && slot->ld >= d->C && slot->ld % 4 == 0,
-               UP_ERR_INVALID, "conv2d_bwd_data_bnred: bad slot (C=%d vs %d, ld=%d)", slot->C, d->C, slot->ld);
-    UP_REQUIRE(up_conv2d_bwd_data_tiles(d) > 0, UP_ERR_UNSUPPORTED, "conv2d_bwd_data_bnred: this launch cannot carry the reduction");
+    UP_REQUIRE(dy && w_dgrad && dx && ep, UP_ERR_INVALID, "conv2d_bwd_data_ex: null pointer");
+    UP_REQUIRE(math == UP_MATH_F32 || math == UP_MATH_BF16S, UP_ERR_INVALID, "conv2d_bwd_data_ex: math %d (fp32 or bf16 storage)", math);
+    UP_REQUIRE(!ep->add || ep->ld_add >= d->C, UP_ERR_INVALID, "conv2d_bwd_data_ex: ld_add=%d < C=%d", ep->ld_add, d->C);
+    UP_REQUIRE(!ep->add_relu_bits || ep->add, UP_ERR_INVALID, "conv2d_bwd_data_ex: add_relu_bits without an addend");
+    const up_bn_reduce_slot* slot = ep->bn;
+    const int q = math == UP_MATH_BF16S ? 8 : 4;
+    UP_REQUIRE(!slot || (slot->y && slot->mean && slot->invstd && slot->partial && slot->C == d->C && slot->ld >= d->C && slot->ld % q == 0),
+               UP_ERR_INVALID, "conv2d_bwd_data_ex: bad BatchNorm slot (C=%d vs %d, ld=%d)", slot ? slot->C : 0, d->C, slot ? slot->ld : 0);
+    UP_REQUIRE(!(slot || ep->add_relu_bits) || up_conv2d_bwd_data_tiles_math(d, math) > 0, UP_ERR_UNSUPPORTED,
+               "conv2d_bwd_data_ex: this launch cannot carry a masked addend / a fused reduction (up_conv2d_bwd_data_tiles_math = 0)");
     IgemmArgs a;
-    if (int e = fill_dgrad_args(a, d, dy, w_dgrad, dx)) return e;
-    a.residual = add;
-    a.ldr = ld_add;
-    a.bn_y = slot->y;
-    a.bn_ld = slot->ld;
-    a.bn_C = slot->C;
-    a.bn_bits = slot->relu_bits;
-    a.bn_mean = slot->mean;
-    a.bn_invstd = slot->invstd;
-    a.bn_partial = slot->partial;
+    if (int e = fill_dgrad_args(a, d, static_cast<const float*>(dy), static_cast<const float*>(w_dgrad), static_cast<float*>(dx))) return e;
+    a.residual = static_cast<const float*>(ep->add);
+    a.ldr = ep->ld_add;
+    a.res_bits = ep->add_relu_bits;
+    if (slot) {
+        a.bn_y = static_cast<const float*>(slot->y);
+        a.bn_ld = slot->ld;
+        a.bn_C = slot->C;
+        a.bn_bits = slot->relu_bits;
+        a.bn_mean = slot->mean;
+        a.bn_invstd = slot->invstd;
+        a.bn_partial = slot->partial;
+    }
     const uintptr_t ptrs = reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(w_dgrad) | reinterpret_cast<uintptr_t>(dx) |
-                           reinterpret_cast<uintptr_t>(add) | reinterpret_cast<uintptr_t>(slot->y);
-    UP_REQUIRE((ptrs & 15) == 0 && (!add || ld_add % 4 == 0), UP_ERR_UNSUPPORTED, "conv2d_bwd_data_bnred: 16-byte alignment");
-    run_igemm(a, choose_tile(a.M, a.Ng, a.Ktot), as_stream(stream));
-    return check_launch("conv2d_bwd_data_bnred");
+                           reinterpret_cast<uintptr_t>(ep->add) | (slot ? reinterpret_cast<uintptr_t>(slot->y) : 0);
+    UP_REQUIRE(!(slot || ep->add_relu_bits) || ((ptrs & 15) == 0 && (!ep->add || ep->ld_add % q == 0)), UP_ERR_UNSUPPORTED,
+               "conv2d_bwd_data_ex: 16-byte alignment");
+    g_extras_dropped = false;
+    if (math == UP_MATH_BF16S) {
+        UP_REQUIRE(!s2_decomposed(d->stride, d->dil) || !(slot || ep->add_relu_bits), UP_ERR_UNSUPPORTED, "conv2d_bwd_data_ex: stride 2");
+        a.w = nullptr;
+        a.w_hi = static_cast<const uint16_t*>(w_dgrad);
+        a.w_lo = nullptr;
+        if (int e = run_igemm_bf16(a, math, as_stream(stream))) return e;
+    } else {
+        UP_REQUIRE(!s2_decomposed(d->stride, d->dil), UP_ERR_UNSUPPORTED, "conv2d_bwd_data_ex: stride-2 convolutions use up_conv2d_bwd_data");
+        run_igemm(a, choose_tile(a.M, a.Ng, a.Ktot), as_stream(stream));
+    }
+    UP_REQUIRE(!g_extras_dropped, UP_ERR_UNSUPPORTED, "conv2d_bwd_data_ex: the launch ran on a kernel without the requested epilogue extras");
+    return check_launch("conv2d_bwd_data_ex");
 }
 
 extern "C" int up_pack_weights_bf16(const up_conv_desc* d, const float* w, uint16_t* fwd_hi, uint16_t* fwd_lo,
@@ -3052,14 +3011,10 @@ static int up::conv2d_bwd_weight_impl(const up_conv_desc* d, const float* x, con
             a.x_bytes = (uint32_t)xb;
             a.dy_bytes = (uint32_t)dyb;
             void (*kernel)(WgradArgs);
-#define UP_WG_FORMS(BM_, BN_)                                                                              \
-    (g_wgrad_kp == 32 ? (g_wgrad_st == 3 ? glds::wgrad_glds_kernel<BM_, BN_, 32, 3, 3> : glds::wgrad_glds_kernel<BM_, BN_, 32, 2, 3>) \
-                      : glds::wgrad_glds_kernel<BM_, BN_, 64, 2, 2>)
-            if (p.bm == 128 && p.bn == 128) kernel = UP_WG_FORMS(128, 128);
-            else if (p.bm == 128 && p.bn == 64) kernel = UP_WG_FORMS(128, 64);
-            else if (p.bm == 64 && p.bn == 128) kernel = UP_WG_FORMS(64, 128);
-            else kernel = UP_WG_FORMS(64, 64);
-#undef UP_WG_FORMS
+            if (p.bm == 128 && p.bn == 128) kernel = glds::wgrad_glds_kernel<128, 128, 64, 2, 2>;
+            else if (p.bm == 128 && p.bn == 64) kernel = glds::wgrad_glds_kernel<128, 64, 64, 2, 2>;
+            else if (p.bm == 64 && p.bn == 128) kernel = glds::wgrad_glds_kernel<64, 128, 64, 2, 2>;
+            else kernel = glds::wgrad_glds_kernel<64, 64, 64, 2, 2>;
             hipLaunchKernelGGL(kernel, grid, dim3(256), 0, st, a);
         } else if (bf16 == 2) {
             if (p.bm == 128 && p.bn == 128)

@@ -55,7 +55,7 @@ struct Epi32 {
     static_assert(!PF || UNITS_PF == UNITS, "prefetch holds every unit of the thread");
 
     float4 res[PF ? UNITS : 1], yb[PF ? UNITS : 1], pmu;
-    uint32_t bw[PF ? UNITS : 1];
+    uint32_t bw[PF ? UNITS : 1], rw[PF ? UNITS : 1];   // sign-bit nibbles: of the layer being reduced / of the layer the addend belongs to
     float pis;           // 1 / std of the column this thread finishes (BNRED)
     int pix[UNITS];      // destination pixel of each unit (-1: row past the end)
 
@@ -69,9 +69,9 @@ struct Epi32 {
         }
     }
     // bit mask of the 4 channels n..n+3 of pixel p in the ReLU sign bits of the layer being reduced
-    static __device__ __forceinline__ uint32_t bits_word(const IgemmArgs& a, int p, int n) {
-        const long long quad = ((long long)p * a.bn_C + n) >> 2;
-        return a.bn_bits[quad >> 3] >> (4 * (int)(quad & 7));
+    static __device__ __forceinline__ uint32_t bits_word(const uint32_t* bits, int C, int p, int n) {
+        const long long quad = ((long long)p * C + n) >> 2;
+        return bits[quad >> 3] >> (4 * (int)(quad & 7));
     }
     __device__ __forceinline__ void prefetch(const IgemmArgs& a, int n0, int tid) {
         if constexpr (PF) {
@@ -82,6 +82,13 @@ struct Epi32 {
 #pragma unroll
                 for (int k = 0; k < UNITS; ++k)
                     res[k] = *reinterpret_cast<const float4*>(a.residual + (size_t)(pix[k] >= 0 ? pix[k] : 0) * a.ldr + nn);
+                if (a.res_bits) {   // the addend is dz * [z > 0] of another layer, masked here instead of materialised there
+#pragma unroll
+                    for (int k = 0; k < UNITS; ++k) rw[k] = bits_word(a.res_bits, a.Ng, pix[k] >= 0 ? pix[k] : 0, nn);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < UNITS; ++k) rw[k] = 0xfu;
+                }
             }
             if constexpr (BNRED) {
                 pmu = *reinterpret_cast<const float4*>(a.bn_mean + nn);
@@ -92,7 +99,7 @@ struct Epi32 {
                     yb[k] = *reinterpret_cast<const float4*>(a.bn_y + (size_t)(pix[k] >= 0 ? pix[k] : 0) * a.bn_ld + nn);
                 if (a.bn_bits) {
 #pragma unroll
-                    for (int k = 0; k < UNITS; ++k) bw[k] = bits_word(a, pix[k] >= 0 ? pix[k] : 0, nn);
+                    for (int k = 0; k < UNITS; ++k) bw[k] = bits_word(a.bn_bits, a.bn_C, pix[k] >= 0 ? pix[k] : 0, nn);
                 } else {
 #pragma unroll
                     for (int k = 0; k < UNITS; ++k) bw[k] = 0xfu;
@@ -209,20 +216,24 @@ struct Epi32 {
 #pragma unroll
         for (int c0 = 0; c0 < UNITS; c0 += CHK) {
             float4 v[CHK], rr[CHK], yy[CHK];
-            uint32_t w[CHK];
+            uint32_t w[CHK], rm[CHK];
 #pragma unroll
             for (int u = 0; u < CHK; ++u) {
                 const int k = c0 + u;
                 const int p = pix[k] >= 0 ? pix[k] : 0;
                 if constexpr (PF) {
                     rr[u] = res[k];
+                    rm[u] = rw[k];
                     yy[u] = yb[k];
                     w[u] = bw[k];
                 } else {
-                    if (a.residual) rr[u] = *reinterpret_cast<const float4*>(a.residual + (size_t)p * a.ldr + nn);
+                    if (a.residual) {
+                        rr[u] = *reinterpret_cast<const float4*>(a.residual + (size_t)p * a.ldr + nn);
+                        rm[u] = a.res_bits ? bits_word(a.res_bits, a.Ng, p, nn) : 0xfu;
+                    }
                     if constexpr (BNRED) {
                         yy[u] = *reinterpret_cast<const float4*>(a.bn_y + (size_t)p * a.bn_ld + nn);
-                        w[u] = a.bn_bits ? bits_word(a, p, nn) : 0xfu;
+                        w[u] = a.bn_bits ? bits_word(a.bn_bits, a.bn_C, p, nn) : 0xfu;
                     }
                 }
             }
@@ -231,10 +242,10 @@ struct Epi32 {
 #pragma unroll
             for (int u = 0; u < CHK; ++u) {
                 if (a.residual) {
-                    v[u].x += rr[u].x;
-                    v[u].y += rr[u].y;
-                    v[u].z += rr[u].z;
-                    v[u].w += rr[u].w;
+                    v[u].x += (rm[u] & 1u) ? rr[u].x : 0.f;
+                    v[u].y += (rm[u] & 2u) ? rr[u].y : 0.f;
+                    v[u].z += (rm[u] & 4u) ? rr[u].z : 0.f;
+                    v[u].w += (rm[u] & 8u) ? rr[u].w : 0.f;
                 }
                 if (relu) {
                     v[u].x = fmaxf(v[u].x, 0.f);

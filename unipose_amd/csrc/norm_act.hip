@@ -990,7 +990,7 @@ extern "C" int up_bn_bwd_acc_t(const void* dz, int lddz, const void* z, int ldz,
     return check_launch("bn_bwd");
 }
 // BatchNorm backward whose reduction pass already ran inside the data-gradient launch that produced dz
-// (up_conv2d_bwd_data_bnred): `partial` = [chunks][C][2] from that launch; finalize + apply only.
+// (up_conv2d_bwd_data_ex): `partial` = [chunks][C][2] from that launch; finalize + apply only.
 extern "C" int up_bn_bwd_prereduced_t(const void* dz, int lddz, const uint32_t* relu_bits, const void* y, int ldy,
                                       const float* gamma, const float* mean, const float* invstd, int relu, int use_batch_stats,
                                       void* dy, int lddy, void* dres, int lddres, float* dgamma, float* dbeta, float* acc_dgamma,
@@ -1002,10 +1002,15 @@ extern "C" int up_bn_bwd_prereduced_t(const void* dz, int lddz, const uint32_t* 
     UP_REQUIRE(C % 4 == 0 && lddz % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && (!dres || lddres % 4 == 0), UP_ERR_INVALID,
                "bn_bwd_prereduced: C and strides must be multiples of 4");
     UP_REQUIRE(rows * (C / 4) < (1ll << 31), UP_ERR_UNSUPPORTED, "bn_bwd_prereduced: tensor too large");
-    UP_REQUIRE(dtype == UP_DT_F32, UP_ERR_UNSUPPORTED, "bn_bwd_prereduced: fp32 tensors only (dtype %d)", dtype);
-    launch_bn_bwd<float>((const float*)dz, lddz, (const float*)nullptr, 0, relu_bits, (const float*)y, ldy, gamma, mean, invstd, relu,
-                         use_batch_stats, (float*)dy, lddy, (float*)dres, lddres, dgamma, dbeta, acc_dgamma, acc_dbeta, partial,
-                         rows, C, as_stream(stream), chunks);
+    UP_REQUIRE(dtype == UP_DT_F32 || dtype == UP_DT_BF16, UP_ERR_INVALID, "bn_bwd_prereduced: dtype %d", dtype);
+    if (dtype == UP_DT_BF16)
+        launch_bn_bwd<bf16_t>((const bf16_t*)dz, lddz, (const bf16_t*)nullptr, 0, relu_bits, (const bf16_t*)y, ldy, gamma, mean, invstd,
+                              relu, use_batch_stats, (bf16_t*)dy, lddy, (bf16_t*)dres, lddres, dgamma, dbeta, acc_dgamma, acc_dbeta,
+                              partial, rows, C, as_stream(stream), chunks);
+    else
+        launch_bn_bwd<float>((const float*)dz, lddz, (const float*)nullptr, 0, relu_bits, (const float*)y, ldy, gamma, mean, invstd, relu,
+                             use_batch_stats, (float*)dy, lddy, (float*)dres, lddres, dgamma, dbeta, acc_dgamma, acc_dbeta, partial,
+                             rows, C, as_stream(stream), chunks);
     return check_launch("bn_bwd_prereduced");
 }
 extern "C" int up_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const uint32_t* relu_bits,

@@ -314,12 +314,28 @@ class BnSlot:
         self.dz_ptr = 0
 
 
-BN_FUSE_REDUCE = os.environ.get("UNIPOSE_BN_FUSE_REDUCE", "1") != "0"     # development switch (A/B runs)
+BN_FUSE_REDUCE = os.environ.get("UNIPOSE_BN_FUSE_REDUCE", "1") != "0"     # development switches (A/B runs)
+MASKED_ADDEND = os.environ.get("UNIPOSE_MASKED_ADDEND", "1") != "0"
 
 
-def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev, add=None, bn_slot=None):
+def dgrad_extras_tiles(d: _C.ConvDesc, x_shape, dtype) -> int:
+    """Row tiles of the data-gradient launch of `d` if its kernel supports the extended epilogue (masked addend, fused
+    BatchNorm-backward reduction: up_conv2d_bwd_data_ex), else 0."""
+    if dtype == torch.bfloat16:
+        math = MATH_BF16S
+    elif dtype == torch.float32 and CONV_MATH == MATH_F32:
+        math = MATH_F32
+    else:
+        return 0
+    dd = _C.ConvDesc.from_buffer_copy(d)
+    dd.ldx = x_shape[3]
+    return _C.lib().up_conv2d_bwd_data_tiles_math(C.byref(dd), math)
+
+
+def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev, add=None, bn_slot=None, add_bits=None):
     """dx = dgrad(dy) (+ add: another gradient of the same input, summed in the kernel epilogue).
-    bn_slot: see BnSlot (fp32, stride 1; a launch that cannot carry the reduction leaves bn_slot.partial None)."""
+    bn_slot: see BnSlot (stride 1; a launch that cannot carry the reduction leaves bn_slot.partial None).
+    add_bits: ReLU sign bits applied to `add` in the epilogue (the caller made sure with dgrad_extras_tiles that the launch can)."""
     n, h, w, cp = x_shape
     alloc = torch.zeros if cp != d.C else torch.empty
     dx = alloc((n, h, w, cp), dtype=dy.dtype, device=dev)
@@ -327,6 +343,36 @@ def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev, add=None, bn_slo
     dd.ldx = cp
     dd.ldy = _nhwc_ok(dy)
     ld_add = _nhwc_ok(add) if add is not None else 0
+    # extended epilogue (masked addend / fused BatchNorm-backward reduction): fp32 and bf16 storage
+    ex_math = MATH_BF16S if dy.dtype == torch.bfloat16 else (MATH_F32 if CONV_MATH == MATH_F32 else -1)
+    tiles = 0
+    want_slot = bn_slot is not None and bn_slot.y is not None and bn_slot.C == d.C == cp and bn_slot.y.dtype == dy.dtype and \
+        bn_slot.y.shape[:3] == (n, h, w)
+    if (want_slot or add_bits is not None) and ex_math >= 0:
+        tiles = _C.lib().up_conv2d_bwd_data_tiles_math(C.byref(dd), ex_math)
+    if add_bits is not None and tiles <= 0:
+        raise _C.UniPoseHipError("conv_bwd_data_raw: this launch cannot mask its addend (check dgrad_extras_tiles first)")
+    if tiles > 0:
+        ep = _C.DgradEpilogue()
+        ep.add, ep.add_relu_bits, ep.ld_add = _ptr(add), _ptr(add_bits), ld_add
+        if want_slot:
+            partial = torch.empty((tiles, d.C, 2), dtype=torch.float32, device=dev)
+            sl = _C.BnReduceSlot()
+            sl.y, sl.relu_bits, sl.mean, sl.invstd = bn_slot.y.data_ptr(), _ptr(bn_slot.bits), bn_slot.mean.data_ptr(), \
+                bn_slot.invstd.data_ptr()
+            sl.partial, sl.ld, sl.C = partial.data_ptr(), _nhwc_ok(bn_slot.y), d.C
+            ep.bn = C.pointer(sl)
+        if ex_math == MATH_BF16S:
+            if d.Kp % 32 or (add is not None and add.dtype != dy.dtype):
+                raise NotImplementedError("bf16-storage data gradient needs 32-aligned output channels and a bf16 addend")
+            wimg = _packed_bf16(weight, d)[1][0]
+        else:
+            wimg = packed_dgrad(weight, d)
+        _C.check(_C.lib().up_conv2d_bwd_data_ex(C.byref(dd), dy.data_ptr(), wimg.data_ptr(), dx.data_ptr(), C.byref(ep), ex_math,
+                                                _stream(dy)), "conv2d_bwd_data_ex")
+        if want_slot:
+            bn_slot.partial, bn_slot.dz_ptr = partial, dx.data_ptr()
+        return dx
     if dy.dtype == torch.bfloat16:
         if d.Kp % 32 or (add is not None and add.dtype != dy.dtype):
             raise NotImplementedError("bf16-storage data gradient needs 32-aligned output channels and a bf16 addend")
@@ -341,22 +387,8 @@ def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev, add=None, bn_slo
                                                   _stream(dy)), "conv2d_bwd_data_bf16")
     else:
         wd = packed_dgrad(weight, d)
-        tiles = 0
-        if bn_slot is not None and bn_slot.y is not None and bn_slot.C == d.C == cp and bn_slot.y.dtype == torch.float32 and \
-                bn_slot.y.shape[:3] == (n, h, w):
-            tiles = _C.lib().up_conv2d_bwd_data_tiles(C.byref(dd))
-        if tiles > 0:
-            partial = torch.empty((tiles, d.C, 2), dtype=torch.float32, device=dev)
-            sl = _C.BnReduceSlot()
-            sl.y, sl.relu_bits, sl.mean, sl.invstd = bn_slot.y.data_ptr(), _ptr(bn_slot.bits), bn_slot.mean.data_ptr(), \
-                bn_slot.invstd.data_ptr()
-            sl.partial, sl.ld, sl.C = partial.data_ptr(), _nhwc_ok(bn_slot.y), d.C
-            _C.check(_C.lib().up_conv2d_bwd_data_bnred(C.byref(dd), dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), _ptr(add),
-                                                       ld_add, C.byref(sl), _stream(dy)), "conv2d_bwd_data_bnred")
-            bn_slot.partial, bn_slot.dz_ptr = partial, dx.data_ptr()
-        else:
-            _C.check(_C.lib().up_conv2d_bwd_data(C.byref(dd), dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), _ptr(add),
-                                                 ld_add, _stream(dy)), "conv2d_bwd_data")
+        _C.check(_C.lib().up_conv2d_bwd_data(C.byref(dd), dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), _ptr(add),
+                                             ld_add, _stream(dy)), "conv2d_bwd_data")
     return dx
 
 
@@ -366,11 +398,16 @@ class GradLink:
     launches the add of the two gradients of the block input (resnet.py:36-40).  The last stage always runs its
     backward first (its input depends on the first stage's output); a link that is not picked up — the first stage
     needs no input gradient — is returned through autograd as usual."""
-    __slots__ = ("grad", "armed")
+    __slots__ = ("grad", "armed", "bits", "masked_ok")
 
     def __init__(self):
         self.grad = None
         self.armed = False
+        # masked hand-over (round 4): when the first convolution's data-gradient kernel can apply a ReLU mask to its addend
+        # (masked_ok, set by that convolution's forward), the last stage hands over its UNMASKED dz plus its sign bits instead
+        # of writing dz * [z > 0] as a tensor of its own
+        self.bits = None
+        self.masked_ok = False
 
 
 def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws_tag: str = "main", out=None):
@@ -680,12 +717,13 @@ class ConvBnAct(Function):
         ctx.link_in, ctx.link_out = link_in, link_out
         if link_in is not None:
             link_in.armed = True       # this node will compute a data gradient: the producer may hand over
+            link_in.masked_ok = MASKED_ADDEND and dgrad_extras_tiles(d, x.shape, x.dtype) > 0
         # BatchNorm-backward reduction by the consumer's data gradient (BnSlot): this layer as the producer ...
         ctx.slot_out = None
         if slot_out is not None:
             slot_out.clear()
-            if BN_FUSE_REDUCE and groups == 1 and y.dtype == torch.float32 and d.ldy == k and (bits is not None or not relu) and \
-                    CONV_MATH == MATH_F32:
+            if BN_FUSE_REDUCE and groups == 1 and d.ldy == k and (bits is not None or not relu) and \
+                    ((y.dtype == torch.float32 and CONV_MATH == MATH_F32) or y.dtype == torch.bfloat16):
                 slot_out.y, slot_out.bits, slot_out.mean, slot_out.invstd, slot_out.C = y, bits, coef[0], coef[1], k
                 ctx.slot_out = slot_out
         # ... and as the consumer of the layer that produced x
@@ -703,7 +741,11 @@ class ConvBnAct(Function):
         rows = d.N * d.P * d.Q
         fresh = torch.empty_like if d.ldy == k else torch.zeros_like         # pad channels meet zero weights: keep them finite
         dy = fresh(y)
-        dres = fresh(y) if ctx.has_res else None
+        # the skip gradient dz * [z > 0]: not materialised when the block's first convolution masks its addend itself
+        lo = ctx.link_out
+        masked = ctx.has_res and lo is not None and lo.armed and lo.masked_ok and ctx.relu and bits is not None and ctx.groups == 1 \
+            and d.ldy == k
+        dres = fresh(y) if ctx.has_res and not masked else None
         dgb = torch.empty((2, k), dtype=torch.float32, device=x.device)
         if dz.dtype != y.dtype:
             raise TypeError(f"gradient {dz.dtype} vs saved convolution output {y.dtype}")
@@ -738,25 +780,31 @@ class ConvBnAct(Function):
                                               acc[0].data_ptr() if acc is not None else None,
                                               acc[1].data_ptr() if acc is not None else None, partial.data_ptr(),
                                               partial.shape[0], rows, k, _dt(y), _stream(x)), "bn_bwd_prereduced")
-            return ConvBnAct._finish_backward(ctx, x, weight, d, dy, dres, dgb, hand_over)
+            return ConvBnAct._finish_backward(ctx, x, weight, d, dy, dres, dgb, hand_over, (dz, bits) if masked else None)
         _C.check(L.up_bn_bwd_acc_t(dz.data_ptr(), d.ldy, None, 0, _ptr(bits), y.data_ptr(), d.ldy, gamma.data_ptr(),
                                    coef[0].data_ptr(), coef[1].data_ptr(), int(ctx.relu), int(ctx.train), dy.data_ptr(),
                                    d.ldy, _ptr(dres), d.ldy, dgb[0].data_ptr(), dgb[1].data_ptr(),
                                    acc[0].data_ptr() if acc is not None else None,
                                    acc[1].data_ptr() if acc is not None else None, ws.data_ptr(),
                                    ws.numel(), rows, k, _dt(y), _stream(x)), "bn_bwd")
-        return ConvBnAct._finish_backward(ctx, x, weight, d, dy, dres, dgb, hand_over)
+        return ConvBnAct._finish_backward(ctx, x, weight, d, dy, dres, dgb, hand_over, (dz, bits) if masked else None)
 
     @staticmethod
-    def _finish_backward(ctx, x, weight, d, dy, dres, dgb, hand_over):
-        add = None
+    def _finish_backward(ctx, x, weight, d, dy, dres, dgb, hand_over, masked_skip=None):
+        add = add_bits = None
         if ctx.link_in is not None:
-            add, ctx.link_in.grad, ctx.link_in.armed = ctx.link_in.grad, None, False
+            li = ctx.link_in
+            add, add_bits, li.grad, li.bits, li.armed = li.grad, li.bits, None, None, False
         si = ctx.slot_in
         if si is not None and ctx.link_in is not None and add is None:
             si = None       # the skip gradient was not handed over: autograd will ADD it to dx, which is then not dz yet
-        dx = conv_bwd_data_raw(dy, weight, d, x.shape, x.device, add, bn_slot=si) if ctx.needs_input_grad[0] else add
-        if ctx.link_out is not None and ctx.link_out.armed and dres is not None:
+        if ctx.needs_input_grad[0]:
+            dx = conv_bwd_data_raw(dy, weight, d, x.shape, x.device, add, bn_slot=si, add_bits=add_bits)
+        else:
+            dx = add if add_bits is None else None      # (armed links belong to nodes that compute a data gradient)
+        if masked_skip is not None:                       # unmasked dz + sign bits: the first convolution masks
+            ctx.link_out.grad, ctx.link_out.bits = masked_skip
+        elif ctx.link_out is not None and ctx.link_out.armed and dres is not None:
             ctx.link_out.grad, dres = dres, None          # the block's first convolution adds it to ITS dx
         dw = conv_bwd_weight(x, dy, weight, d, False)[0] if ctx.needs_input_grad[1] else None   # frozen weight: no launch
         return dx, dw, (dgb[0] if hand_over else None), (dgb[1] if hand_over else None), dres, None, None, None, None, None, \
