@@ -374,7 +374,9 @@ def main():
                     help="run the gradient exchange (RCCL all-reduce, buckets, hooks) even with one rank")
     ap.add_argument("--overlap", action="store_true",
                     help="bucketed gradient exchange launched during backward (one hook per 32 MB bucket) instead of one flat "
-                         "all-reduce after it")
+                         "all-reduce after it; the default for --math bf16s, whose step (< 40 ms) is short enough for the flat "
+                         "190 MB exchange to show (--no-overlap switches it off)")
+    ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the extra split-bf16 timing loop")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the BASELINE configs[3] (LSTM) and configs[4] (736x736 bf16) legs appended at N=1")
@@ -457,6 +459,7 @@ def main():
     # default: ONE flat all-reduce after backward (190 MB: ~1-2 ms on xGMI against a 66 ms fp32 step); --overlap: 32 MB
     # buckets launched during backward by one hook per bucket (unipose_amd/dist.py)
     reducer = None
+    args.overlap = (args.overlap or args.math == "bf16s") and not args.no_overlap
     if use_dist:
         reducer = GradAllReducer(model, bucket_bytes=(32 << 20) if args.overlap else (256 << 20), force=args.force_dp,
                                  overlap=args.overlap)

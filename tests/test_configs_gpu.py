@@ -317,12 +317,37 @@ def test_one_rank_rccl_gradient_exchange():
             return (time.perf_counter() - t0) / n
 
         steps(2, True), steps(2, False)
-        with_x = min(steps(4, True), steps(4, True))
-        without = min(steps(4, False), steps(4, False))
-        print(f"1-rank RCCL exchange: {with_x * 1e3:.2f} ms/step vs {without * 1e3:.2f} ms/step without "
+        with_x = min(steps(4, True), steps(4, True), steps(4, True))
+        without = min(steps(4, False), steps(4, False), steps(4, False))
+        print(f"1-rank RCCL exchange (fp32, flat): {with_x * 1e3:.2f} ms/step vs {without * 1e3:.2f} ms/step without "
               f"({100 * (with_x / without - 1):+.1f} %)")
-        assert with_x < 1.20 * without
+        # round 4: the weight gradients are written straight into the exchange buffer (no 190 MB gather copy), so what is left
+        # is RCCL's one-rank AVG kernel: VERDICT r3 asks for < 2 % on the fp32 step
+        assert with_x < 1.02 * without
         reducer.close()
+
+        # bf16 storage (configs[4] geometry at B = 8): bucketed exchange launched during backward (bench.py's default for this
+        # arithmetic), held to 4 %
+        ops.set_conv_math("bf16s")
+        try:
+            del m, opt, x, t
+            torch.cuda.empty_cache()
+            B, S = 8, 736
+            m, _ = mc.build_image_model(K, 3, DEV)
+            m.train()
+            x = O.synth_input((B, 3, S, S), 83).to(DEV)
+            t = O.synth_input((B, K + 1, S // 8, S // 8), 84, "rand").to(DEV)
+            reducer = GradAllReducer(m, bucket_bytes=32 << 20, force=True, overlap=True)
+            opt = torch.optim.Adam(m.parameters(), lr=1e-6, fused=True)
+            steps(4, True), steps(2, False)                      # plain exchange, calibration, buckets in hand-out order
+            with_x = min(steps(4, True), steps(4, True), steps(4, True))
+            without = min(steps(4, False), steps(4, False), steps(4, False))
+            print(f"1-rank RCCL exchange (bf16 storage, overlapped buckets): {with_x * 1e3:.2f} ms/step vs {without * 1e3:.2f} "
+                  f"ms/step without ({100 * (with_x / without - 1):+.1f} %)")
+            assert with_x < 1.04 * without
+            reducer.close()
+        finally:
+            ops.set_conv_math("f32")
     finally:
         if created:
             dist.destroy_process_group()

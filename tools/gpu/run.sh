@@ -68,6 +68,14 @@ prof368) # rocprofv3 kernel stats of the headline fp32 step: default (two stream
   python tools/rocprof_summary.py $(find $OUT/prof_368 -name "*.db" | head -1) 4 > $OUT/kernel_stats.txt 2>&1
   python tools/rocprof_summary.py $(find $OUT/prof_368x -name "*.db" | head -1) 4 > $OUT/kernel_stats_exclusive.txt 2>&1
   find $OUT -name "*.db" -delete; head -${HEAD:-30} $OUT/kernel_stats_exclusive.txt ;;
+proflstm) # rocprofv3 kernel stats of the UniPose-LSTM step (K = 13, B = 8, T = 5), both stream modes
+  ARGS="--model lstm --batch 8 --num-classes 13 $B368 --steps 3 --warmup 1 --no-profile"
+  ( cd /tmp && export TMPDIR=/tmp
+    timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof_lstm -o bench -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $GRAFT_REPO_ROOT/$OUT/prof_lstm.log 2>&1
+    UNIPOSE_SYNC_WGRAD=1 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof_lstmx -o bench -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $GRAFT_REPO_ROOT/$OUT/prof_lstmx.log 2>&1 )
+  python tools/rocprof_summary.py $(find $OUT/prof_lstm -name "*.db" | head -1) 4 > $OUT/kernel_stats_lstm.txt 2>&1
+  python tools/rocprof_summary.py $(find $OUT/prof_lstmx -name "*.db" | head -1) 4 > $OUT/kernel_stats_lstm_exclusive.txt 2>&1
+  find $OUT -name "*.db" -delete; tail -2 $OUT/prof_lstm.log | cut -c1-300; head -${HEAD:-30} $OUT/kernel_stats_lstm_exclusive.txt ;;
 ab368) for rep in 1 2; do timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-stock-baseline --no-alt-math --no-other-configs --no-profile > $OUT/ab368.log 2>&1; line $OUT/ab368.log "fp32"; done ;;
 lstm) timeout 300 python tools/gpu/steps.py --model lstm --batch 8 > $OUT/lstm_steps.log 2>&1; tail -5 $OUT/lstm_steps.log ;;
 *) echo "unknown action $act" ;;

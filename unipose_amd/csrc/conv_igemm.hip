@@ -2118,15 +2118,11 @@ static const int* tap_sort_perm(const IgemmArgs& a) {
     std::lock_guard<std::mutex> lock(mu);
     auto it = table.find(key);
     if (it != table.end()) return it->second;
-    if (table.size() >= 1024) {   // variable-size inference: bound the per-geometry tables (in-flight launches finish first)
-#ifndef UP_EMU
-        (void)hipDeviceSynchronize();
-        for (auto& kv : table) (void)hipFree(kv.second);
-#else
-        for (auto& kv : table) free(kv.second);
-#endif
-        table.clear();
-    }
+    // Variable-size inference: the per-geometry tables are bounded by REFUSING new entries, never by freeing old ones — a captured
+    // hipGraph (unipose_amd.graph.GraphedForward) carries a.perm as a raw device pointer in its kernel arguments, and a
+    // hipDeviceSynchronize / hipFree here would also break a capture in progress.  A geometry beyond the bound
+    // keeps the image order (correct, only the tile-level tap skipping is less sharp).
+    if (table.size() >= 1024) return nullptr;
     const std::vector<int> perm = tap_sort_order(a, tap_masks(a));
     int* dev = nullptr;
     if ((int)perm.size() == a.M) {
@@ -2878,15 +2874,7 @@ static const int* wgrad_rect_device(const up_conv_desc* d, const WgradPlan& p) {
     std::lock_guard<std::mutex> lock(mu);
     auto it = table.find(key);
     if (it != table.end()) return it->second;
-    if (table.size() >= 1024) {   // bound the per-geometry tables (see tap_sort_perm)
-#ifndef UP_EMU
-        (void)hipDeviceSynchronize();
-        for (auto& kv : table) (void)hipFree(kv.second);
-#else
-        for (auto& kv : table) free(kv.second);
-#endif
-        table.clear();
-    }
+    if (table.size() >= 1024) return nullptr;   // bounded by refusing new entries (see tap_sort_perm): the plain reduction range
     std::vector<int> tab;
     int* dev = nullptr;
     if (wgrad_rect_table(d, p, tab) < 0.999) {   // every tile sees the whole image (1x1, unpadded): keep the plain form

@@ -53,6 +53,8 @@ class GradAllReducer:
         (profiles/README.md), so the un-overlapped form is the faster one for this model.
         overlap=True: bucketed exchange launched during backward from one hook per BUCKET (see _build)."""
         self.overlap = overlap
+        self.direct_write = os.environ.get("UNIPOSE_DP_DIRECT", "1") != "0"   # development switch (A/B runs)
+        self._dest = {}
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())
@@ -93,6 +95,11 @@ class GradAllReducer:
                 cur, size = [], 0
         if cur:
             self.buckets.append(_Bucket(cur))
+        # convolution weights get their gradient written straight into the bucket (no gather copy)
+        self._dest = {id(p): (b, i) for b in self.buckets for i, p in enumerate(b.params) if p.dim() == 4}
+        if self.buckets and self.buckets[0].buf.is_cuda and self.direct_write:
+            from . import ops
+            ops.set_grad_destinations(self._destination)
 
     def _build(self):
         live = [p for p in reversed(self.params) if p.grad is not None]
@@ -107,17 +114,31 @@ class GradAllReducer:
             self._calibrating = True
 
     def _launch(self, b, side_stream: bool):
-        """copy the bucket's gradients into its flat buffer and start the collective"""
-        grads = [q.grad for q in b.params]
+        """gather the bucket's gradients into its flat buffer — those that were not written there in the first place, see
+        ops.set_grad_destinations — and start the collective"""
+        pairs = [(v, q.grad) for v, q in zip(b.views, b.params) if q.grad.data_ptr() != v.data_ptr()]
         main, side = self._streams(b.buf.device) if side_stream else (None, None)
         if side is not None:
             side.wait_stream(main)                 # BN / bias gradients come from the main stream
             with torch.cuda.stream(side):
-                torch._foreach_copy_(b.views, grads)
+                if pairs:
+                    torch._foreach_copy_([v for v, _ in pairs], [g for _, g in pairs])
                 b.work = self._reduce(b.buf)
         else:
-            torch._foreach_copy_(b.views, grads)
+            if pairs:
+                torch._foreach_copy_([v for v, _ in pairs], [g for _, g in pairs])
             b.work = self._reduce(b.buf)
+
+    def _destination(self, p):
+        """fresh view of the bucket memory behind parameter p (ops.set_grad_destinations), None for unknown parameters"""
+        hit = self._dest.get(id(p))
+        if hit is None:
+            return None
+        b, i = hit
+        if b.work is not None:                     # (the bucket is in flight: cannot happen for a first gradient)
+            return None
+        v = b.views[i]
+        return v.view(v.shape)                     # a new tensor object: autograd may adopt it as .grad without a copy
 
     def _tail_hook(self, bi):
         def hook(_p):
@@ -139,6 +160,16 @@ class GradAllReducer:
                 seen.add(id(p))
                 order.append(p)
         order += [p for b in self.buckets for p in b.params if id(p) not in seen]
+        # every rank must cut the same buckets: rank 0's order wins (the orders agree unless the graphs differ)
+        if dist.is_initialized() and self.world > 1:
+            index = {id(p): i for i, p in enumerate(self.params)}
+            idx = torch.tensor([index[id(p)] for p in order], dtype=torch.int64, device=order[0].device)
+            n = torch.tensor([idx.numel()], dtype=torch.int64, device=idx.device)
+            dist.broadcast(n, 0, group=self.group)
+            if int(n.item()) != idx.numel():
+                raise RuntimeError("data-parallel ranks disagree on the set of parameters that receive gradients")
+            dist.broadcast(idx, 0, group=self.group)
+            order = [self.params[i] for i in idx.tolist()]
         self._make_buckets(order)
         self._handles = [b.params[-1].register_post_accumulate_grad_hook(self._tail_hook(bi))
                          for bi, b in enumerate(self.buckets)]
@@ -190,6 +221,11 @@ class GradAllReducer:
         for h in self._handles:
             h.remove()
         self._handles = []
+        if self._dest:
+            from . import ops
+            if ops._GRAD_DEST["fn"] == self._destination:
+                ops.set_grad_destinations(None)
+            self._dest = {}
 
 
 def shard_seed(base: int, rank: int) -> int:

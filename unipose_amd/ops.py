@@ -410,9 +410,12 @@ class GradLink:
         self.masked_ok = False
 
 
-def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws_tag: str = "main", out=None):
+def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws_tag: str = "main", out=None, accumulate=None):
     """dw (and db) of one convolution.  `out`: an existing fp32 gradient buffer the result is ADDED to by the split-K reduce
-    pass itself (up_conv2d_bwd_weight_acc, accumulate = 1): the sum over the uses of a shared weight without an add kernel."""
+    pass itself (up_conv2d_bwd_weight_acc, accumulate = 1): the sum over the uses of a shared weight without an add kernel;
+    with accumulate=False `out` is simply the destination (a slice of a gradient-exchange bucket, see set_grad_destinations)."""
+    if accumulate is None:
+        accumulate = out is not None
     dd = _C.ConvDesc.from_buffer_copy(d)
     dd.ldx = _nhwc_ok(x)
     dd.ldy = _nhwc_ok(dy)
@@ -429,10 +432,10 @@ def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws
         # the 15-channel ConvLSTM convolutions stay on the exact fp32 MFMA in every pass
         bf = CONV_MATH in (MATH_BF16, MATH_BF16S) and (WGRAD_BF16_ANY_WIDTH or (dd.Cp % 32 == 0 and dd.Kp % 32 == 0))
         math = MATH_BF16 if bf else MATH_F32
-    if out is not None and want_bias:
+    if accumulate and want_bias:
         raise ValueError("accumulating weight gradient: the bias gradient is not accumulated here")
     _C.check(_C.lib().up_conv2d_bwd_weight_acc(C.byref(dd), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(),
-                                               ws.numel(), math, int(out is not None), _stream(x)), "conv2d_bwd_weight")
+                                               ws.numel(), math, int(bool(accumulate)), _stream(x)), "conv2d_bwd_weight")
     return dw, db
 
 
@@ -486,10 +489,21 @@ class deferred_wgrad:
         return False
 
 
+_GRAD_DEST = {"fn": None}
+
+
+def set_grad_destinations(fn):
+    """Data-parallel gradient exchange (unipose_amd.dist): `fn(weight)` returns a FRESH view of the exchange bucket's memory for
+    that parameter (or None).  The weight-gradient reduce pass then writes the gradient there directly, autograd installs that
+    view as ``weight.grad``, and the bucket needs no gather copy before its all-reduce (190 MB per step otherwise).  None switches
+    it off.  Only the first gradient of a weight in a backward pass is redirected; re-used weights keep the normal path."""
+    _GRAD_DEST["fn"] = fn
+
+
 def _side_stream(dev):
     st = _SIDE.get(dev.index)
     if st is None:
-        st = torch.cuda.Stream(device=dev)
+        st = torch.cuda.Stream(device=dev, priority=int(os.environ.get("UNIPOSE_SIDE_PRIO", "0")))
         _SIDE[dev.index] = st
     return st
 
@@ -550,7 +564,10 @@ def conv_bwd_weight(x, dy, weight, d, want_bias):
             for t in (x, dy):
                 t.record_stream(side)
             return None, None
-        dw, db = conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias, ws_tag="side")
+        dst = None
+        if _GRAD_DEST["fn"] is not None and not defer and weight.grad is None and id(weight) not in _PASS["seen"]:
+            dst = _GRAD_DEST["fn"](weight)
+        dw, db = conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias, ws_tag="side", out=dst, accumulate=False)
         if defer:
             _DEFER["acc"][id(weight)] = (weight, dw)
             for t in (x, dy):

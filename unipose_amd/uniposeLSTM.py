@@ -70,12 +70,15 @@ class unipose(nn.Module):
                 return self._trunk(input[:, iter])
         # the cache holds a reference to the clip tensor itself: "same object, same version" cannot be faked by a recycled
         # id / address.  A caller that passes a different tensor for a later frame simply gets the per-frame trunk.
-        hit = self._frames is not None and self._frames[0] is input and self._frames[1] == (input._version, self.training,
-                                                                                             torch.is_grad_enabled())
+        # ... and the key carries the in-place version of the trunk's first and last weight: an optimizer step or a
+        # load_state_dict between two frames of a clip (both bump every parameter) makes the later frames miss
+        key = (input._version, self.training, torch.is_grad_enabled(), self.backbone.conv1.weight._version,
+               self.decoder.last_conv[8].weight._version)
+        hit = self._frames is not None and self._frames[0] is input and self._frames[1] == key
         if iter == 0:
             xa = input.transpose(0, 1).reshape(T * b, *input.shape[2:])      # frame-major: BatchNorm group g = frame g
             with ops.bn_groups(T if self.training else 1), ops.bn_counters(self):
-                self._frames = (input, (input._version, self.training, torch.is_grad_enabled()), self._trunk(xa))
+                self._frames = (input, key, self._trunk(xa))
         elif not hit:
             self._frames = None
             with ops.bn_counters(self):
@@ -84,6 +87,10 @@ class unipose(nn.Module):
         if iter == T - 1:
             self._frames = None                                     # the clip is served: nothing outlives the unroll
         return x
+
+    def train(self, mode: bool = True):
+        self._frames = None          # a clip that was not served to its last frame must not outlive a mode switch
+        return super().train(mode)
 
     def _state(self, t, like, b):
         """(C,h,w) zeros from the first call, or the (B,C,h,w) tensor returned by the previous one."""
