@@ -268,13 +268,16 @@ def lstm_head(sd: SD, hide):
 
 
 def unipose_lstm_forward(sd: SD, frames, centermap, it: int, prev_hide, prev_cell,
-                         train: bool = False, drop_masks: Optional[dict] = None):
+                         train: bool = False, drop_masks: Optional[dict] = None, p_drop=(0.5, 0.5, 0.1)):
     """uniposeLSTM.unipose.forward, model/uniposeLSTM.py:98-147, with the state generalised
-    from the hard-wired batch 1 (:99-104) to (B,15,H/8,W/8).  `previous` is unused there."""
+    from the hard-wired batch 1 (:99-104) to (B,15,H/8,W/8).  `previous` is unused there.
+    p_drop: the three dropout rates (waspVideo.py:48, decoder.py:24,28), like unipose_forward's — (0, 0, 0) for comparisons
+    with a model whose dropouts are switched off (round 4: the training comparisons of the video model passed the default
+    rates with no masks before, i.e. compared against an oracle that dropped activations at random)."""
     x = frames[:, it]
     f, low = backbone(sd, x, train)
-    f = wasp(sd, f, train, drop_masks, video=True)
-    y = decoder(sd, f, low, train, drop_masks)
+    f = wasp(sd, f, train, drop_masks, video=True, p_drop=p_drop[0])
+    y = decoder(sd, f, low, train, drop_masks, p_drop=p_drop[1:])
     c = F.avg_pool2d(centermap[:, it], 9, 8, 1)
     z = torch.cat((y, c), dim=1)
     if it == 0:

@@ -91,6 +91,18 @@ def test_g5_lstm_368_vs_reference_golden(golden_dir, batch_frames):
             assert float(heat.min()) >= 0.0                             # final ReLU
 
 
+@pytest.mark.parametrize("batch_frames", [False, True], ids=["per_frame", "batched_frames"])
+def test_g15_lstm_train_368_vs_reference_golden(golden_dir, batch_frames):
+    """UniPose-LSTM TRAINING (five-frame unroll, summed loss, one backward) against the genuine reference's own train step"""
+    worst = mc.g15_case(DEV, os.path.join(golden_dir, "g15_lstm_train_368.npz"), batch_frames)
+    print("g15 worst gradient distance / bound:", worst)
+
+
+def test_bn_backward_reduction_fused_into_data_gradients_gpu():
+    launches, worst = mc.fused_reduce_case(DEV, B=8, size=128)
+    print("fused BatchNorm-backward reductions per step:", launches, "worst gradient distance fused vs separate:", worst)
+
+
 def test_g4_train_128_vs_reference_golden(golden_dir):
     """Reference train step at 128x128, B=2, dropouts off: loss / output / gradients / running stats."""
     from unipose_amd import ops

@@ -512,6 +512,66 @@ def g13_bf16_yardstick():
     save("g13_bf16_yardstick_b8_128.npz", loss=np.array(losses["fp32"]), **arrs, meta=np.array([K, 7, 43, 44, B]))
 
 
+def g15_lstm_train():
+    """G15: UniPose-LSTM TRAINING against the genuine reference: K=13, B=1 (the reference hard-wires its state
+    to batch 1), T=5 frames at 368x368, train mode (legal at B=1: the video WASP has no BatchNorm behind its global-average
+    pool, waspVideo.py:56-59), the three dropouts at p=0, the loop of uniposeLSTM.py:116-133 — summed MSE over the frames, ONE
+    backward.  Stored: per-frame heat-maps, the loss, sampled gradients (ConvLSTM cells, head, trunk), all gradient norms, running
+    statistics after the five calls, and per gradient the reference's own fp32-vs-fp64 distance (`noise/`), the yardstick of G11."""
+    K, T = 13, 5
+    x = O.synth_input((1, T, 3, 368, 368), 71)
+    cm = O.synth_input((1, T, 1, 368, 368), 72, "rand")
+    t = O.synth_input((1, T, K + 1, 46, 46), 73, "rand")
+    res = {}
+    sd = O.synth_state_dict(K, 6, lstm=True)     # (made under the float32 default: the generator's stream depends on the dtype)
+    for dt in (torch.float32, torch.float64):
+        m = RefUniPoseLSTM(num_classes=K)
+        assert not (set(m.state_dict()) ^ set(sd))
+        m.load_state_dict(sd)
+        torch.set_default_dtype(dt)          # the reference creates its state tensors with torch.zeros(...) (uniposeLSTM.py:99-104)
+        try:
+            m = m.to(dt).train()
+            m.wasp.dropout.p = 0.0
+            m.decoder.last_conv[3].p = 0.0
+            m.decoder.last_conv[7].p = 0.0
+            heat = torch.zeros(K + 1, 46, 46)
+            cell = torch.zeros(15, 46, 46)
+            hide = torch.zeros(15, 46, 46)
+            loss, heats = 0.0, []
+            for j in range(T):
+                heat, cell, hide = m(x.to(dt), cm.to(dt), j, heat, hide, cell)
+                loss = loss + torch.nn.MSELoss()(heat, t[:, j].to(dt))
+                heats.append(heat.detach())
+            loss.backward()
+            res[dt] = (m, torch.stack(heats), loss.detach())
+        finally:
+            torch.set_default_dtype(torch.float32)
+    m, heats, loss = res[torch.float32]
+    m64, heats64, loss64 = res[torch.float64]
+    g, g64 = dict(m.named_parameters()), dict(m64.named_parameters())
+    keys = ["lstm_0.conv_g_lstm.weight", "lstm_0.conv_o_lstm.bias", "lstm.conv_gx_lstm.weight", "lstm.conv_fh_lstm.weight",
+            "lstm.conv_ih_lstm.bias", "conv1.weight", "conv2.weight", "conv3.weight", "conv4.weight", "conv5.weight", "conv5.bias",
+            "backbone.conv1.weight", "backbone.layer3.5.bn2.weight", "backbone.layer3.11.conv1.weight", "wasp.conv2.weight",
+            "wasp.global_avg_pool.1.weight", "decoder.last_conv.8.weight"]
+    arrs = {}
+    for k in keys:
+        a, a64 = g[k].grad, g64[k].grad
+        arrs["noise/" + k] = np.array(float((a.double() - a64).norm() / a64.norm()))
+        a = a.numpy()
+        arrs["grad/" + k] = a[::SUB, ::SUB] if a.size > 100_000 else a
+    names = sorted(g)
+    arrs["grad_norms"] = np.array([g[k].grad.double().norm().item() if g[k].grad is not None else -1.0 for k in names])
+    sdm = m.state_dict()
+    for k in ("backbone.bn1", "backbone.layer3.5.bn2", "wasp.bn1", "decoder.last_conv.5"):
+        arrs["rm/" + k] = sdm[k + ".running_mean"].numpy()
+        arrs["rv/" + k] = sdm[k + ".running_var"].numpy()
+    arrs["nbt/backbone.bn1"] = np.array(int(sdm["backbone.bn1.num_batches_tracked"]))
+    print("g15 fp32-vs-fp64 heat-maps", O.max_rel(heats, heats64.float()), "loss", float(loss), float(loss64))
+    print("g15 gradient noise (rel L2, fp32 vs fp64 reference):", {k: round(float(arrs["noise/" + k]), 6) for k in keys})
+    save("g15_lstm_train_368.npz", heat=heats.numpy(), heat_noise=np.array(O.max_rel(heats, heats64.float())),
+         loss=np.array(loss.item()), loss64=np.array(loss64.item()), **arrs, meta=np.array([K, 6, 71, 72, 73, T]))
+
+
 def g0_keys():
     """G0: the reference's state_dict contract (names, shapes, dtypes, order) for both models."""
     import json
@@ -525,9 +585,9 @@ def g0_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     fns = dict(g0=g0_keys, g1=g1_eval_full, g2=g2_taps, g4=g4_train, g5=g5_lstm, g6=g6_argmax, g7=g7_accuracy,
                g8=g8_targets, g9=g9_multi_person, g10=g10_eval_736, g11=g11_train_b8, g12=g12_eval_os8, g13=g13_bf16_yardstick,
-               g14=g14_train_368)
+               g14=g14_train_368, g15=g15_lstm_train)
     for w in which:
         fns[w]()
