@@ -360,7 +360,7 @@ def fused_reduce_case(dev, K=16, B=2, size=32, wseed=3, tol=2e-5):
     return launches[True], worst
 
 
-def g15_case(dev, path, batch_frames, slack=3.0, floor=5e-3):
+def g15_case(dev, path, batch_frames, slack=2.0, floor=5e-3):
     """UniPose-LSTM TRAINING against the genuine reference (G15: K=13, B=1, T=5 at 368x368, train mode, dropouts off, summed MSE,
     one backward): per-frame heat-maps, loss, sampled gradients at `slack` x the reference's own fp32-vs-fp64 distance (+ floor:
     a fp32 BatchNorm that is not bitwise ATen's sits a few 1e-3 from it at 529 samples per channel, see G11's `alt/` yardstick),
@@ -412,9 +412,10 @@ def g15_case(dev, path, batch_frames, slack=3.0, floor=5e-3):
     names = sorted(grads)
     ours = np.array([grads[k].double().norm().item() if grads[k] is not None else -1.0 for k in names])
     ref = g["grad_norms"]
-    live = ref > 1e-12
+    live = ref > 1e-6 * ref.max()        # (the pooled branch's weight has a gradient of round-off size in the reference itself)
     assert ((ours >= 0) == (ref >= 0)).all()
-    assert float(np.abs(ours[live] / ref[live] - 1).max()) < 5e-2, float(np.abs(ours[live] / ref[live] - 1).max())
+    dev_ = np.abs(ours[live] / ref[live] - 1)
+    assert float(dev_.max()) < 5e-2, (names[int(np.flatnonzero(live)[int(dev_.argmax())])], float(dev_.max()))
     sd = m.state_dict()
     for k in [k[3:] for k in g.files if k.startswith("rm/")]:
         assert O.max_rel(sd[k + ".running_mean"].cpu(), torch.from_numpy(g["rm/" + k])) < 1e-4, k

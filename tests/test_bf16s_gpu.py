@@ -104,12 +104,6 @@ def test_g1_eval_368_bf16_storage(golden_dir):
     assert e < 2.5e-2 and agree > 0.85
 
 
-def test_train_step_bf16_storage_vs_oracle():
-    """B = 8 at 128x128 (8x8 top maps, 512 samples per channel): better conditioned than the emulator's case."""
-    c = bc.model_train_case(DEV, K=16, B=8, size=128, cos_min=0.6, cos_head=0.95)
-    print("worst gradient cosine", c)
-
-
 def test_736_b16_train_step_bf16_storage():
     """configs[4] at full size in bf16 storage: finite loss / gradients for every trained parameter, the saved activations
     really are bf16 (memory of the step), per-sample independence of the eval forward, argmax agrees with torch."""
