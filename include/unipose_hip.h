@@ -101,18 +101,16 @@ int up_conv_split_parts(const up_conv_desc* d);
 /* Frees the per-stream scratch of a stream the caller retires (no launch or captured graph of that stream may run afterwards);
  * a stream that never ran a split launch has none: no-op. */
 int up_stream_release(void* stream);
-/* Development knobs (A/B runs inside one process; each also has an environment variable read at load time):
- * "tile_want" (UP_TILE_WANT; "tile_want_bf16" for the plain-bf16 kernels) workgroups a launch should at least have when the tile size is chosen ("short_k" /
- * "short_k_mult": reductions shorter than short_k want short_k_mult / 2 times as many), "db_min_k"
- * (UP_DB_MIN_K) shortest reduction that uses the double-buffered K loop, "tail_split" (UP_TAIL_SPLIT), "tap_skip"
- * (UP_TAP_SKIP), "split_per_cu" (UP_SPLIT_PER_CU: launches with fewer tiles than CUs split every tile along K up to this many
- * workgroups per CU), "tap_sort" (UP_TAP_SORT: GEMM rows ordered by their set of live filter taps so that the tile-level tap
- * skipping becomes near exact; default on since the round-2 A/B), "wgrad_per_cu" (UP_WGRAD_PER_CU), "wgrad_rect" (UP_WGRAD_RECT, see
- * up_conv_wgrad_visits; default on since the round-2 A/B), "lds_swz" (UP_LDS_SWZ: XOR-swizzled unpadded LDS rows).
+/* Development knobs (A/B runs inside one process; each also has an environment variable read at load time).  Twelve keys
+ * (round 4 removed the ones whose question is settled: short_k, short_k_mult, db_min_k, wgrad_per_cu, tap_skip, lds_swz and
+ * the bf16 forms that lost in round 3):
+ * "tile_want" (UP_TILE_WANT; "tile_want_bf16" for the plain-bf16 kernels) workgroups a launch should at least have when the tile
+ * size is chosen, "tail_split" (UP_TAIL_SPLIT), "split_per_cu" (UP_SPLIT_PER_CU: launches with fewer tiles than CUs split every tile
+ * along K up to this many workgroups per CU), "tap_sort" (UP_TAP_SORT: GEMM rows ordered by their set of live filter taps so that
+ * the tile-level tap skipping becomes near exact), "wgrad_rect" (UP_WGRAD_RECT, see up_conv_wgrad_visits).
  * bf16 storage: "glds" (UP_GLDS: direct-to-LDS kernels of bf16s_glds.h, default 1; 0 = the register-staged kernels), "bn_rows"
  * (row-strided BatchNorm kernels).  fp32 (round 4): "glds32" (UP_GLDS32: forward / data gradient on f32_glds.h, default 1),
- * "glds32_epi" (LDS-transposed 16-byte-store epilogue, 1), "glds32_st1" (reductions shorter than this use one LDS stage; 0),
- * "glds32_wgrad" (weight gradient on f32_glds.h, 1).  "cu_count" (tests: pretend the chip has this many CUs when planning
+ * "glds32_epi" (LDS-transposed 16-byte-store epilogue, 1), "glds32_wgrad" (weight gradient on f32_glds.h, 1).  "cu_count" (tests: pretend the chip has this many CUs when planning
  * splits; 0 = the real count).
  * These knobs and the UP_* environment variables they mirror are PROCESS-GLOBAL host state (kernel selection of every later
  * launch on every stream), like the library's per-stream K-split scratch and per-geometry tables; see the note at the top.

@@ -41,13 +41,13 @@ def _same(a, b, what):
                              f"first at {tuple(int(i) for i in (d > 0).nonzero()[0])}")
 
 
-DEFAULTS = dict(glds32=1, glds32_epi=1, glds32_st1=0, glds32_wgrad=1, tile_want=1500, cu_count=0)
+DEFAULTS = dict(glds32=1, glds32_epi=1, glds32_wgrad=1, tile_want=1500, cu_count=0)
 
 
 def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, affine=False, residual=False, relu=False,
-            add=False, seed=0, cus=0, forms=((1, 0), (0, 0), (1, 100000))):
+            add=False, seed=0, cus=0, forms=(1, 0)):
     """forward (+ optional BatchNorm partials / folded epilogue / residual) and data gradient (+ optional addend) of one fp32
-    convolution: every glds32 form in `forms` = (glds32_epi, glds32_st1) against glds32 = 0 under the same tile rule.
+    convolution: both epilogue forms (`forms` = glds32_epi values) against glds32 = 0 under the same tile rule.
     `cus` shrinks the chip so that a small launch has whole rounds of tiles + K-split tail tiles."""
     cp, kp = ops.rup4(c), ops.rup4(k)
     x = _nhwc(torch.randn(n, c, h, w, generator=_g(seed)), dev, cp)
@@ -75,15 +75,15 @@ def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, 
         c0, w0 = cnt("glds32"), cnt("wgrad_glds32")
         y0, s0, dx0, dw0 = run()
         assert cnt("glds32") == c0 and cnt("wgrad_glds32") == w0, "glds32 = 0 still launched a direct-to-LDS kernel"
-        for epi, st1 in forms:
-            _tune(glds32=1, glds32_epi=epi, glds32_st1=st1, glds32_wgrad=1)
+        for epi in forms:
+            _tune(glds32=1, glds32_epi=epi, glds32_wgrad=1)
             c0, e0, w0 = cnt("glds32"), cnt("glds32_epi1"), cnt("wgrad_glds32")
             y1, s1, dx1, dw1 = run()
             assert cnt("glds32") > c0, "the case never reached the direct-to-LDS kernel"
             assert cnt("wgrad_glds32") > w0, "the weight gradient never reached the direct-to-LDS kernel"
             assert epi == 1 or cnt("glds32_epi1") == e0
-            _same(dw1, dw0, "dw " + f"epi={epi} st1={st1}")
-            tag = f"epi={epi} st1={st1}"
+            _same(dw1, dw0, "dw " + f"epi={epi}")
+            tag = f"epi={epi}"
             _same(y1, y0, "y " + tag)
             if stats:
                 _same(s1, s0, "BatchNorm partials " + tag)

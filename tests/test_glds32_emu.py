@@ -9,8 +9,8 @@ _id = lambda c: "n%d_c%d_%dx%d_k%d_r%d_d%d_t%d" % (c["n"], c["c"], c["h"], c["w"
 
 @pytest.mark.parametrize("case", g32.SMALL, ids=_id)
 def test_glds32_kernel_matches_register_staged_kernel(emu_backend, case):
-    """outputs, BatchNorm partials and data gradients, element for element, for the three forms (LDS-transposed / dword epilogue,
-    one / two LDS stages)"""
+    """outputs, BatchNorm partials, data gradients and weight gradients, element for element, for both epilogue forms
+    (LDS-transposed 16-byte stores / dword stores)"""
     g32.conv_ab(emu_backend, **case)
 
 

@@ -175,8 +175,8 @@ def test_tap_sort_model_gpu(tap_sort):
 
 
 def test_random_knob_combinations_emu(emu_backend):
-    """Random geometries x random combinations of every run-time kernel switch (tap_sort, wgrad_rect, tail_split,
-    lds_swz): forward, data gradient, weight gradient and BatchNorm statistics stay within the
+    """Random geometries x random combinations of every run-time kernel switch (tap_sort, wgrad_rect, tail_split, and the
+    three direct-to-LDS fp32 switches): forward, data gradient, weight gradient and BatchNorm statistics stay within the
     operator tolerances.  (The same generator ran over several hundred cases when the switches were written.)"""
     import random
     from unipose_amd import _C
@@ -194,7 +194,8 @@ def test_random_knob_combinations_emu(emu_backend):
             if h + 2 * pad < dil * (r - 1) + 1 or w + 2 * pad < dil * (r - 1) + 1:
                 continue
             for key, val in (("tap_sort", rnd.randint(0, 1)), ("wgrad_rect", rnd.randint(0, 1)),
-                             ("tail_split", rnd.randint(0, 1)), ("lds_swz", rnd.randint(0, 1))):
+                             ("tail_split", rnd.randint(0, 1)), ("glds32", rnd.randint(0, 1)), ("glds32_epi", rnd.randint(0, 1)),
+                             ("glds32_wgrad", rnd.randint(0, 1))):
                 _C.check(lib.up_conv_tune(key.encode(), val), key)
             if done % 3 == 2 and r == 3 and stride == 1:
                 oc.conv_bn_case(emu_backend, n, c, h, w, k, r, stride, dil, dil, relu=rnd.random() < 0.5,
@@ -204,5 +205,5 @@ def test_random_knob_combinations_emu(emu_backend):
                              relu=rnd.random() < 0.3, seed=done)
             done += 1
     finally:
-        for key, val in (("tap_sort", 1), ("wgrad_rect", 1), ("tail_split", 1), ("lds_swz", 1)):
+        for key, val in (("tap_sort", 1), ("wgrad_rect", 1), ("tail_split", 1), ("glds32", 1), ("glds32_epi", 1), ("glds32_wgrad", 1)):
             lib.up_conv_tune(key.encode(), val)

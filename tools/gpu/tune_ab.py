@@ -1,6 +1,6 @@
 """In-process A/B of run-time knobs (up_conv_tune) on the BASELINE configs[1] training step:
 the model is built once, variants are timed interleaved.  A variant is 'name=value+name=value' ('base' = defaults).
-    python tools/gpu/tune_ab.py --rounds 3 --steps 5 base db_min_k=100000+tail_split=0 tile_want=1000"""
+    python tools/gpu/tune_ab.py --rounds 3 --steps 5 base glds32=0+tail_split=0 tile_want=1000"""
 import argparse
 import json
 import os
@@ -12,8 +12,8 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch  # noqa: E402
 
-DEFAULTS = {"short_k": 512, "short_k_mult": 4, "tile_want": 1500, "tile_want_bf16": 500, "db_min_k": 1024, "tail_split": 1, "split_per_cu": 2, "tap_skip": 1, "tap_sort": 1,
-            "wgrad_rect": 1, "wgrad_per_cu": 2, "lds_swz": 1}
+DEFAULTS = {"tile_want": 1500, "tile_want_bf16": 500, "tail_split": 1, "split_per_cu": 2, "tap_sort": 1, "wgrad_rect": 1,
+            "glds": 1, "glds32": 1, "glds32_epi": 1, "glds32_wgrad": 1, "bn_rows": 1}
 # (round 2, profiles/r02_a_knob_ab.txt: occ64, wgrad_single and the high-priority main stream measured no gain and were removed)
 
 

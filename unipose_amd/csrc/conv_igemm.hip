@@ -1888,21 +1888,20 @@ static int g_tile_want = env_int("UP_TILE_WANT", 1500, 1);   // A/B in the netwo
 static int g_tile_want_bf16 = env_int("UP_TILE_WANT_BF16", 500, 1);
 static int g_glds = env_int("UP_GLDS", 1, 0);   // bf16 storage: direct-to-LDS kernels of bf16s_glds.h (0 = the register-staged round-2 kernels)
 // fp32 forward / data gradient with operands HBM -> LDS by LDS-DMA (f32_glds.h, round 4): glds32 = 0 keeps the register-staged
-// igemm_kernel; glds32_epi: 1 = LDS-transposed 16-byte-store epilogue, 0 = igemm_epilogue; glds32_st1: reductions shorter than
-// this use ONE LDS stage (16 KB per 64x64 workgroup) instead of two
+// igemm_kernel; glds32_epi: 1 = LDS-transposed 16-byte-store epilogue, 0 = igemm_epilogue
 static long long g_count_igemm = 0, g_count_glds32 = 0, g_count_glds32_epi1 = 0, g_count_glds32_bnred = 0;   // up_conv_counter
 static long long g_count_wgrad32 = 0, g_count_wgrad32_st1 = 0;
 static bool g_extras_dropped = false;   // a launch was asked for a masked addend / fused reduction on a kernel without them
 static int g_glds32 = env_int("UP_GLDS32", 1, 0);
 static int g_glds32_epi = env_int("UP_GLDS32_EPI", 1, 0);
-static int g_glds32_st1 = env_int("UP_GLDS32_ST1", 0, 0);
+
 static int g_glds32_wgrad = env_int("UP_GLDS32_WGRAD", 1, 0);   // fp32 weight gradient with LDS-DMA operands (wgrad_glds32_kernel)
-static int g_db_min_k = env_int("UP_DB_MIN_K", 1024, 1);
-static int g_short_k = env_int("UP_SHORT_K", 512, 1);             // reductions shorter than this are epilogue-heavy:
-static int g_short_k_mult = env_int("UP_SHORT_K_MULT", 4, 1);     // they want g_short_k_mult / 2 times as many workgroups
+static int g_db_min_k = 1024;   // (settled in round 1/2; no longer a run-time knob)
+static int g_short_k = 512;            // reductions shorter than this are epilogue-heavy:
+static int g_short_k_mult = 4;         // they want g_short_k_mult / 2 times as many workgroups (r04_d sweep: 2 / 4 / 8 within noise)
 static int g_tail_split = env_int("UP_TAIL_SPLIT", 1, 0);
-static int g_tap_skip = env_int("UP_TAP_SKIP", 1, 0);
-static int g_wgrad_per_cu = env_int("UP_WGRAD_PER_CU", 2, 1);   // workgroups per CU a weight-gradient launch aims for
+static int g_tap_skip = 1;   // (tile-level tap skipping: on since round 1; the probe build switches it for its WASP report)
+static int g_wgrad_per_cu = 2;   // workgroups per CU a weight-gradient launch aims for (r04_d: 1 -> +0.7 ms, 3 -> +1.1 ms per step)
 static int g_wgrad_rect = env_int("UP_WGRAD_RECT", 1, 0);      // weight-gradient reduction over live rectangles (see WgradRectKey); on since r02_a (-0.65 ms per step)
 static int cu_count();
 // Largest tile that still yields ~6 workgroups per CU (the tail split evens out the remainder).  Short reductions
@@ -2046,7 +2045,6 @@ static int split_parts(int tiles, int Ktot, size_t slots, bool* all_tiles = null
 // kept on the device.  Knob "tap_sort" (UP_TAP_SORT).  Measured (profiles/r02_a_*): WASP d = 12 / 18 forward 0.166 -> 0.099 /
 // 0.157 -> 0.093 ms, whole step -0.45 ms: on by default.
 static int g_tap_sort = env_int("UP_TAP_SORT", 1, 0);
-static int g_lds_swz = env_int("UP_LDS_SWZ", 1, 0);   // XOR-swizzled, unpadded LDS rows in the double-buffered fp32 kernels (see SWZ); -0.55 ms per step (r02_i)
 struct TapSortKey {
     int M, H, W, P, Q, taps, S, mul, off0, off0w, tapstep;
     bool operator<(const TapSortKey& o) const { return memcmp(this, &o, sizeof(*this)) < 0; }
@@ -2181,19 +2179,12 @@ static auto glds32_kernel(const IgemmArgs& a) -> void (*)(IgemmArgs) {
     constexpr int OCC2 = (BM == 128 && BN == 128) ? 2 : (BM == 64 && BN == 64) ? 4 : 3;
     const bool epi1 = glds32_epi1_ok(a);
     const bool bnred = epi1 && a.bn_partial != nullptr;
-    // one LDS stage: 64x64 tiles only (21 KB, six workgroups per CU by registers; the wider tiles gain no workgroup from it)
-    const bool st1 = BM == 64 && BN == 64 && !a.perm && a.Ktot < g_glds32_st1;
+    // (a one-stage form — 21 KB of LDS, six 64x64 workgroups per CU — for reductions shorter than 1024 measured 0.4 ms per step
+    //  SLOWER than two stages at four per CU, profiles/r04_a_*, and is not instantiated)
     if (a.perm) {
         if (bnred) return glds::igemm_glds32_kernel<BM, BN, true, 2, OCC2, 1, true>;
         if (epi1) return glds::igemm_glds32_kernel<BM, BN, true, 2, OCC2, 1, false>;
         return glds::igemm_glds32_kernel<BM, BN, true, 2, OCC2, 0, false>;
-    }
-    if constexpr (BM == 64 && BN == 64) {
-        if (st1) {
-            if (bnred) return glds::igemm_glds32_kernel<64, 64, false, 1, 4, 1, true>;
-            if (epi1) return glds::igemm_glds32_kernel<64, 64, false, 1, 5, 1, false>;
-            return glds::igemm_glds32_kernel<64, 64, false, 1, 6, 0, false>;
-        }
     }
     if (bnred) return glds::igemm_glds32_kernel<BM, BN, false, 2, OCC2, 1, true>;
     if (epi1) return glds::igemm_glds32_kernel<BM, BN, false, 2, OCC2, 1, false>;
@@ -2228,16 +2219,14 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     if (g_tap_sort && fast && a.taps > 1 && a.taps <= 16 && !a.residual && !a.o_mode && !a.no_tap_skip &&
         a.M % (a.P * a.Q) == 0)
         a.perm = tap_sort_perm(a);
-    if (g_lds_swz && a.perm && db)
+    // (the register-staged MODE 2 forms are the fallback of the direct-to-LDS kernels — glds32 = 0, unaligned pointers,
+    //  >= 2^31 bytes — and the A/B partner of their tests; the double-buffered ones always use the XOR-swizzled LDS rows)
+    if (a.perm && db)
         kernel = igemm_kernel<BM, BN, 2, DB_VARIANT, 32, true, true>;
-    else if (g_lds_swz && fast && db)
+    else if (fast && db)
         kernel = igemm_kernel<BM, BN, 2, DB_VARIANT, 32, false, true>;
-    else if (a.perm && db)
-        kernel = igemm_kernel<BM, BN, 2, DB_VARIANT, 32, true>;
     else if (a.perm)
         kernel = igemm_kernel<BM, BN, 2, 64, 32, true>;
-    else if (fast && db)
-        kernel = igemm_kernel<BM, BN, 2, DB_VARIANT>;
     else if (fast)
         kernel = igemm_kernel<BM, BN, 2, 64>;
     else if (aligned)
@@ -2312,18 +2301,11 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "cu_count") && value >= 0) g_cu_override = value;
     else if (!strcmp(key, "glds32")) g_glds32 = value ? 1 : 0;
     else if (!strcmp(key, "glds32_epi")) g_glds32_epi = value ? 1 : 0;
-    else if (!strcmp(key, "glds32_st1") && value >= 0) g_glds32_st1 = value;
     else if (!strcmp(key, "glds32_wgrad")) g_glds32_wgrad = value ? 1 : 0;
-    else if (!strcmp(key, "db_min_k") && value > 0) g_db_min_k = value;
-    else if (!strcmp(key, "short_k") && value > 0) g_short_k = value;
-    else if (!strcmp(key, "short_k_mult") && value > 0) g_short_k_mult = value;
     else if (!strcmp(key, "tail_split")) g_tail_split = value ? 1 : 0;
     else if (!strcmp(key, "split_per_cu") && value > 0) g_split_per_cu = value;
-    else if (!strcmp(key, "tap_skip")) g_tap_skip = value ? 1 : 0;
     else if (!strcmp(key, "tap_sort")) g_tap_sort = value ? 1 : 0;
-    else if (!strcmp(key, "lds_swz")) g_lds_swz = value ? 1 : 0;
     else if (!strcmp(key, "wgrad_rect")) g_wgrad_rect = value ? 1 : 0;
-    else if (!strcmp(key, "wgrad_per_cu") && value > 0) g_wgrad_per_cu = value;
     else UP_REQUIRE(false, UP_ERR_INVALID, "conv_tune: unknown key '%s'", key);
     return UP_OK;
 }
