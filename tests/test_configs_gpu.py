@@ -9,14 +9,16 @@
   reference itself has on that input (`noise/*` in the fixture = its distance from an fp64 evaluation).
 """
 import os
+import sys
 import time
 
 import numpy as np
 import pytest
 import torch
 
-import model_cases as mc
-from oracle import unipose_oracle as O
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # (run as a script by the RCCL test's child)
+import model_cases as mc  # noqa: E402
+from oracle import unipose_oracle as O  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
@@ -257,8 +259,23 @@ def test_backward_exception_does_not_lose_the_wgrad_fence():
         assert torch.equal(g, got[n]), n
 
 
-@pytest.mark.timeout(300)
+@pytest.mark.timeout(400)
 def test_one_rank_rccl_gradient_exchange():
+    """The exchange test below in a FRESH process.  ROCm maps HIP streams round-robin onto a fixed number of hardware queues
+    (DESIGN 6); in a process that has already run the rest of the suite (private capture streams, side streams) RCCL's streams
+    and the weight-gradient side stream can land on one queue, and the measured cost of the exchange is then that
+    serialisation (+10 % in the full suite, +1 % alone) — not what a training process sees."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rccl-child"], env=env, capture_output=True, text=True,
+                       timeout=380)
+    print(r.stdout[-2000:])
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "1-rank RCCL exchange (bf16 storage" in r.stdout
+
+
+def _one_rank_rccl_gradient_exchange():
     """configs[2]'s per-GPU leg on a 1-GPU box: a ONE-rank RCCL group, GradAllReducer(force=True) — the gradients are
     unchanged by the exchange (the AVG of one rank), param.grad becomes a view of the flat buffer, the three gradient-less
     parameters are left out.  The cost of the exchange is measured and printed (B=32, 368x368): with ONE rank RCCL's AVG
@@ -403,3 +420,10 @@ def test_deferred_wgrad_matches_autograd_accumulation():
         worst = max(float((got[n] - ref[n]).abs().max() / (ref[n].abs().max() + 1e-30)) for n in ref)
         print(f"deferred vs engine accumulation (grads kept: {keep}): worst max-rel difference {worst:.2e}")
         assert worst < 1e-5
+
+
+if __name__ == "__main__":
+    import sys
+    if "--rccl-child" in sys.argv:
+        _one_rank_rccl_gradient_exchange()
+        print("rccl child ok")
