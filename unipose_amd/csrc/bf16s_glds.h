@@ -267,8 +267,28 @@ __device__ __forceinline__ void store_tile(const IgemmArgs& a, f32x16 (&acc)[BM 
                     const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     img[(row >> 1) * BN + wn * (BN / 2) + j * 32 + l31] = pack_bf16x2(v0, v1);
                 }
-        __syncthreads();
         constexpr int UNITS = (BM / 2) * CQ / 256;   // (row pair, chunk) units per thread
+        // BNRED: the operands of the fused reduction (16 bytes of y and the 8 sign bits per row) are requested HERE, before the
+        // barrier, so that their latency overlaps the image write and the barrier instead of sitting in front of every unit
+        // (the first version loaded them inside the loop below: the fused launches lost what the removed pass had cost)
+        uint4 ya[BNRED ? UNITS : 1], yb[BNRED ? UNITS : 1];
+        uint32_t ba[BNRED ? UNITS : 1], bb[BNRED ? UNITS : 1];
+        if constexpr (BNRED) {
+            const int nq = n0 + (tid % CQ) * 8;
+            const int nn = nq < a.Ng ? nq : 0;
+            const bf16_t* const ybn = reinterpret_cast<const bf16_t*>(a.bn_y);
+#pragma unroll
+            for (int k = 0; k < UNITS; ++k) {
+                const int rp = (k * 256 + tid) / CQ;
+                const int q0 = opix(2 * rp), q1 = opix(2 * rp + 1);
+                const int r0 = q0 >= 0 ? q0 : 0, r1 = q1 >= 0 ? q1 : 0;
+                ya[k] = *reinterpret_cast<const uint4*>(ybn + (uint32_t)(r0 * a.bn_ld + nn));
+                yb[k] = *reinterpret_cast<const uint4*>(ybn + (uint32_t)(r1 * a.bn_ld + nn));
+                ba[k] = a.bn_bits ? bits8_of(a.bn_bits, a.bn_C, r0, nn) : 0xffu;
+                bb[k] = a.bn_bits ? bits8_of(a.bn_bits, a.bn_C, r1, nn) : 0xffu;
+            }
+        }
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < UNITS; ++k) {
             const int u = k * 256 + tid;
@@ -279,21 +299,18 @@ __device__ __forceinline__ void store_tile(const IgemmArgs& a, f32x16 (&acc)[BM 
             if (n >= a.Ng) continue;
             const int p0 = opix(2 * rp), p1 = opix(2 * rp + 1);
             if constexpr (BNRED) {
-                const bf16_t* const ybn = reinterpret_cast<const bf16_t*>(a.bn_y);
                 const uint32_t wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
                 if (p0 >= 0) {
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = bf_lo(wv[e]);
-                    bn_acc(v, *reinterpret_cast<const uint4*>(ybn + (uint32_t)(p0 * a.bn_ld + n)),
-                           a.bn_bits ? bits8_of(a.bn_bits, a.bn_C, p0, n) : 0xffu);
+                    bn_acc(v, ya[k], ba[k]);
                 }
                 if (p1 >= 0) {
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = bf_hi(wv[e]);
-                    bn_acc(v, *reinterpret_cast<const uint4*>(ybn + (uint32_t)(p1 * a.bn_ld + n)),
-                           a.bn_bits ? bits8_of(a.bn_bits, a.bn_C, p1, n) : 0xffu);
+                    bn_acc(v, yb[k], bb[k]);
                 }
             }
             if (p0 >= 0)
@@ -312,6 +329,24 @@ __device__ __forceinline__ void store_tile(const IgemmArgs& a, f32x16 (&acc)[BM 
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             if (half) __syncthreads();   // the first half has been read
+            // the addend rows of this half (and the operands of the fused reduction) are requested before the image write
+            uint4 radd[UNITS], ybn4[BNRED ? UNITS : 1];
+            uint32_t rmask[UNITS], bmask[BNRED ? UNITS : 1];
+            {
+                const int nq = n0 + (tid % CQ) * 8;
+                const int nn = nq < a.Ng ? nq : 0;
+#pragma unroll
+                for (int k = 0; k < UNITS; ++k) {
+                    const int q = opix(half * (BM / 2) + (k * 256 + tid) / CQ);
+                    const int r = q >= 0 ? q : 0;
+                    radd[k] = *reinterpret_cast<const uint4*>(rs + (uint32_t)(r * a.ldr + nn));
+                    rmask[k] = a.res_bits ? bits8_of(a.res_bits, a.Ng, r, nn) : 0xffu;
+                    if constexpr (BNRED) {
+                        ybn4[k] = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.bn_y) + (uint32_t)(r * a.bn_ld + nn));
+                        bmask[k] = a.bn_bits ? bits8_of(a.bn_bits, a.bn_C, r, nn) : 0xffu;
+                    }
+                }
+            }
             if (wm == half) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -335,10 +370,10 @@ __device__ __forceinline__ void store_tile(const IgemmArgs& a, f32x16 (&acc)[BM 
                 if (n >= a.Ng || px < 0) continue;
                 const float4 f0 = *reinterpret_cast<const float4*>(img + row * BN + cq * 8);
                 const float4 f1 = *reinterpret_cast<const float4*>(img + row * BN + cq * 8 + 4);
-                const uint4 rr = *reinterpret_cast<const uint4*>(rs + (uint32_t)(px * a.ldr + n));
+                const uint4 rr = radd[k];
                 float ad[8] = {bf_lo(rr.x), bf_hi(rr.x), bf_lo(rr.y), bf_hi(rr.y), bf_lo(rr.z), bf_hi(rr.z), bf_lo(rr.w), bf_hi(rr.w)};
-                if (a.res_bits) {   // the addend's ReLU mask, applied here
-                    const uint32_t mb = bits8_of(a.res_bits, a.Ng, px, n);
+                {   // the addend's ReLU mask (all ones without one), applied here
+                    const uint32_t mb = rmask[k];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) ad[e] = ((mb >> e) & 1u) ? ad[e] : 0.f;
                 }
@@ -352,8 +387,7 @@ __device__ __forceinline__ void store_tile(const IgemmArgs& a, f32x16 (&acc)[BM 
                     // the STORED (rounded) values, like the separate reduction pass reads them back
                     const float vr[8] = {bf_lo(packed.x), bf_hi(packed.x), bf_lo(packed.y), bf_hi(packed.y),
                                          bf_lo(packed.z), bf_hi(packed.z), bf_lo(packed.w), bf_hi(packed.w)};
-                    bn_acc(vr, *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.bn_y) + (uint32_t)(px * a.bn_ld + n)),
-                           a.bn_bits ? bits8_of(a.bn_bits, a.bn_C, px, n) : 0xffu);
+                    bn_acc(vr, ybn4[k], bmask[k]);
                 }
                 *reinterpret_cast<uint4*>(yo + (uint32_t)(px * a.ldy + n)) = packed;
             }

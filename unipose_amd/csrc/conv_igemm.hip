@@ -2486,8 +2486,9 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
             a.x_bytes = (uint32_t)a_bytes;
             if (g_tap_sort && a.taps > 1 && a.taps <= 16 && !a.residual && !a.no_tap_skip) a.perm = tap_sort_perm(a);
             void (*kernel)(IgemmArgs);
+            constexpr int BNRED_OCC = 3;   // (the prefetched reduction operands need ~150 VGPRs: three workgroups per CU, no spills)
             if (a.bn_partial)   // fused BatchNorm-backward reduction of the producing layer (up_conv2d_bwd_data_ex)
-                kernel = a.perm ? glds::igemm_glds_kernel<BM, BN, true, 32, 2, 4, 0, 0, true> : glds::igemm_glds_kernel<BM, BN, false, 32, 2, 4, 0, 0, true>;
+                kernel = a.perm ? glds::igemm_glds_kernel<BM, BN, true, 32, 2, BNRED_OCC, 0, 0, true> : glds::igemm_glds_kernel<BM, BN, false, 32, 2, BNRED_OCC, 0, 0, true>;
             else
                 kernel = a.perm ? glds::igemm_glds_kernel<BM, BN, true, 32, 2, 4> : glds::igemm_glds_kernel<BM, BN, false, 32, 2, 4>;
             a.full_blocks = a.nwg;
