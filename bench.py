@@ -10,7 +10,7 @@ One process per GPU (RCCL via torch.distributed "nccl"); the batch is sharded (w
 images per GPU), weights are replicated, gradients are all-reduced once per step (unipose_amd/dist.py).
 A step = zero_grad -> forward -> MSE -> backward -> gradient all-reduce -> Adam, exactly the loop of
 the reference's Trainer.training (unipose.py:100-131) with synthetic inputs already resident in HBM.
-Rank 0 prints ONE JSON line.  `roofline` is measured live: on every 4th step of the timed region each
+Rank 0 prints ONE JSON line.  `roofline` is measured live: on every 5th step of the timed region each
 MFMA convolution launch is bracketed by hipEvents on its stream (up_profile_begin/enable/end in the C ABI).
 `cpu_baseline` times the CPU oracle (a torch-CPU restatement of the reference graph, pinned to the
 reference by tests/golden) on this box's host cores on a bounded sample; `stock_gpu_baseline` times the same graph on
@@ -34,6 +34,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+PROFILE_EVERY = 5                   # steps of the timed region between two launch-by-launch bracketed ones
 F32_MFMA_PEAK_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA (32x32x16)
 FLOP_PER_IMAGE_FWD_BWD = 187.7e9    # 3 x 31.279 GMAC x 2 at 368x368, K=16
@@ -504,8 +505,8 @@ def main():
     xch["on"] = True
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if profile:        # every 4th step of the timed region is bracketed launch by launch (the events cost ~3 % of a step)
-            _C.lib().up_profile_enable(1 if i % 4 == 0 else 0)
+        if profile:        # every 5th step of the timed region is bracketed launch by launch (~1.7 ms per bracketed step:
+            _C.lib().up_profile_enable(1 if i % PROFILE_EVERY == 0 else 0)      # events are recycled, round 4; 62.8 vs 62.3 ms at every 4th)
         loss = step()
     fence()
     dt = time.perf_counter() - t0
@@ -546,7 +547,7 @@ def main():
                         "top_by_time": top_by_time(rows),
                         "all_mfma_kernels": {"achieved": round(tot_fl / tot_ms, 2),
                                              "frac": round(tot_fl / tot_ms / F32_MFMA_PEAK_TFLOPS, 4),
-                                             "ms_per_step": round(tot_ms / ((args.steps + 3) // 4), 3)},
+                                             "ms_per_step": round(tot_ms / ((args.steps + PROFILE_EVERY - 1) // PROFILE_EVERY), 3)},
                         "by_kernel": [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()
                                        if k != "peak_tflops"} for r in rows]}
             # HBM traffic of the dominant kernel: PMC counters need their own rocprofv3 passes (profiles/pmc_traffic.json

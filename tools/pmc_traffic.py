@@ -10,10 +10,15 @@ import sys
 
 
 def bench_name(k):
-    m = re.match(r"(?:void )?up::(wgrad_kernel|igemm_kernel|igemm_bf16_kernel)<(\d+), (\d+)(?:, (\d+))?", k)
+    m = re.match(r"(?:void )?up::(?:glds::)?(wgrad_kernel|igemm_kernel|igemm_bf16_kernel|igemm_glds32_kernel|wgrad_glds32_kernel|"
+                 r"igemm_glds_kernel|wgrad_glds_kernel)<(\d+), (\d+)(?:, (\d+))?", k)
     if not m:
         return None
     kind, bm, bn, mode = m.groups()
+    if kind in ("igemm_glds32_kernel", "wgrad_glds32_kernel"):        # round 4: the names of bench.py's profile variants
+        return f"{kind}<{bm},{bn}>"
+    if kind in ("igemm_glds_kernel", "wgrad_glds_kernel"):
+        return f"{kind}<{bm},{bn}> (bf16)"
     if kind == "wgrad_kernel":
         return f"wgrad_kernel<{bm},{bn}>"
     if kind == "igemm_kernel":
