@@ -1022,6 +1022,132 @@ extern "C" int up_bn_bwd(const float* dz, int lddz, const float* z, int ldz, con
                        lddres, dgamma, dbeta, workspace, workspace_bytes, rows, C, UP_DT_F32, stream);
 }
 
+// Grouped BatchNorm with up to BN_MAXG groups, ONE launch (round 4): a workgroup per channel merges the partials of every group —
+// thread t takes row tiles t, t + 256, ... of each group, all loads of a round in flight together; the merge tree over LDS handles
+// the groups side by side — writes coef[g] = mean, invstd, scale, shift per group and applies the groups' momentum updates to the
+// running statistics in order, from the merged (count, M2) themselves (the two-launch form recovered the variance from invstd:
+// 1 / invstd^2 - eps cancels for constant channels).  Same per-group merge order as bn_finalize_kernel.
+constexpr int BN_MAXG = 8;
+__global__ void __launch_bounds__(256) bn_finalize_allgroups_kernel(const float* stats, int tiles, int C, int groups, float eps, float mom,
+                                                                    float* rm, float* rv, const float* gamma, const float* beta,
+                                                                    float* coef) {
+    __shared__ float red[256][BN_MAXG][3];
+    const int c = blockIdx.x, t0 = threadIdx.x;
+    float n[BN_MAXG], m[BN_MAXG], q[BN_MAXG];
+#pragma unroll
+    for (int g = 0; g < BN_MAXG; ++g) n[g] = m[g] = q[g] = 0.f;
+    for (int t = t0; t < tiles; t += 256) {
+        float a0[BN_MAXG], a1[BN_MAXG], a2[BN_MAXG];
+#pragma unroll
+        for (int g = 0; g < BN_MAXG; ++g) {
+            const float* s = stats + (((size_t)(g < groups ? g : 0) * tiles + t) * C + c) * 3;
+            a0[g] = g < groups ? s[0] : 0.f;
+            a1[g] = s[1];
+            a2[g] = s[2];
+        }
+#pragma unroll
+        for (int g = 0; g < BN_MAXG; ++g) wf_merge3(n[g], m[g], q[g], a0[g], a1[g], a2[g]);
+    }
+#pragma unroll
+    for (int g = 0; g < BN_MAXG; ++g) {
+        red[t0][g][0] = n[g];
+        red[t0][g][1] = m[g];
+        red[t0][g][2] = q[g];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (t0 < off) {
+#pragma unroll
+            for (int g = 0; g < BN_MAXG; ++g) {
+                wf_merge3(n[g], m[g], q[g], red[t0 + off][g][0], red[t0 + off][g][1], red[t0 + off][g][2]);
+                red[t0][g][0] = n[g];
+                red[t0][g][1] = m[g];
+                red[t0][g][2] = q[g];
+            }
+        }
+        __syncthreads();
+    }
+    if (t0 == 0) {
+        float rmean = rm ? rm[c] : 0.f, rvar = rv ? rv[c] : 0.f;
+#pragma unroll
+        for (int g = 0; g < BN_MAXG; ++g) {
+            if (g >= groups) break;
+            const float var = q[g] / n[g];
+            const float is = 1.0f / sqrtf(var + eps);
+            float* cg = coef + (size_t)g * 4 * C;
+            cg[c] = m[g];
+            cg[C + c] = is;
+            const float sc = gamma[c] * is;
+            cg[2 * C + c] = sc;
+            cg[3 * C + c] = beta[c] - m[g] * sc;
+            const float unb = n[g] > 1.f ? q[g] / (n[g] - 1.f) : var;
+            rmean = (1.f - mom) * rmean + mom * m[g];
+            rvar = (1.f - mom) * rvar + mom * unb;
+        }
+        if (rm) {
+            rm[c] = rmean;
+            rv[c] = rvar;
+        }
+    }
+}
+// backward twin: per-group sums of the chunk partials (gsum[g] = dgamma | dbeta of group g, what the data gradient of that
+// group needs) and their totals over the groups (the parameter gradients), one launch
+__global__ void __launch_bounds__(256) bn_bwd_finalize_allgroups_kernel(const float* partial, int chunks, int C, int groups, float* gsum,
+                                                                        float* dgamma, float* dbeta) {
+    __shared__ float red[256][BN_MAXG][2];
+    const int c = blockIdx.x, t0 = threadIdx.x;
+    float a[BN_MAXG], b[BN_MAXG];
+#pragma unroll
+    for (int g = 0; g < BN_MAXG; ++g) a[g] = b[g] = 0.f;
+    for (int t = t0; t < chunks; t += 256) {
+        float va[BN_MAXG], vb[BN_MAXG];
+#pragma unroll
+        for (int g = 0; g < BN_MAXG; ++g) {
+            const float* v = partial + (((size_t)(g < groups ? g : 0) * chunks + t) * C + c) * 2;
+            va[g] = g < groups ? v[0] : 0.f;
+            vb[g] = g < groups ? v[1] : 0.f;
+        }
+#pragma unroll
+        for (int g = 0; g < BN_MAXG; ++g) {
+            a[g] += va[g];
+            b[g] += vb[g];
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < BN_MAXG; ++g) {
+        red[t0][g][0] = a[g];
+        red[t0][g][1] = b[g];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (t0 < off) {
+#pragma unroll
+            for (int g = 0; g < BN_MAXG; ++g) {
+                a[g] += red[t0 + off][g][0];
+                b[g] += red[t0 + off][g][1];
+                red[t0][g][0] = a[g];
+                red[t0][g][1] = b[g];
+            }
+        }
+        __syncthreads();
+    }
+    if (t0 == 0) {
+        float ta = 0.f, tb = 0.f;
+#pragma unroll
+        for (int g = 0; g < BN_MAXG; ++g) {
+            if (g >= groups) break;
+            gsum[(size_t)g * 2 * C + C + c] = a[g];      // dbeta of the group (sum g): layout of bn_bwd_finalize_kernel's outputs
+            gsum[(size_t)g * 2 * C + c] = b[g];          // dgamma of the group (sum g * xhat)
+            ta += b[g];
+            tb += a[g];
+        }
+        dgamma[c] = ta;
+        dbeta[c] = tb;
+    }
+}
+
 // running statistics after `groups` batches, in order (one thread per channel): the momentum updates of `groups` module calls
 __global__ void __launch_bounds__(256) bn_running_groups_kernel(const float* coef, int groups, int C, float n, float eps, float mom,
                                                                 float* rm, float* rv) {
@@ -1093,6 +1219,11 @@ extern "C" int up_bn_finalize_groups(const float* stats, int tiles, int C, int g
     UP_REQUIRE((rm == nullptr) == (rv == nullptr), UP_ERR_INVALID, "bn_finalize_groups: running stats must come in pairs");
     // every group's partials are merged by its own workgroups (grid C x groups); the running statistics then take the groups'
     // momentum updates in order (the unbiased variance is recovered from invstd: var = 1 / invstd^2 - eps)
+    if (groups <= BN_MAXG) {   // one launch: coefficients of every group + the running statistics
+        hipLaunchKernelGGL(bn_finalize_allgroups_kernel, dim3(C), dim3(256), 0, as_stream(stream), stats, tiles, C, groups, eps,
+                           momentum, rm, rv, gamma, beta, coef);
+        return check_launch("bn_finalize_groups");
+    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C, groups), dim3(256), 0, as_stream(stream), stats, tiles, C, eps, momentum,
                        (float*)nullptr, (float*)nullptr, gamma, beta, coef, coef + C, coef + 2 * C, coef + 3 * C, GroupArgs{4 * C, 0});
     if (rm)
@@ -1156,9 +1287,14 @@ static bool launch_bn_bwd_groups(const T* dz, int lddz, const uint32_t* relu_bit
     const GroupArgs ga{4 * C, 2 * C};
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(chunks, cdiv(C, 64), groups), dim3(256), 0, st, dz, lddz, (const T*)nullptr, 0,
                        relu_bits, y, ldy, coef, coef + C, relu, partial, rows, C, BNB_ROWS, ga);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C, groups), dim3(256), 0, st, (const float*)partial, chunks, C, gsum, gsum + C,
-                       (float*)nullptr, (float*)nullptr, ga);
-    hipLaunchKernelGGL(bn_sum_groups_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)gsum, groups, C, dgamma, dbeta);
+    if (groups <= BN_MAXG) {
+        hipLaunchKernelGGL(bn_bwd_finalize_allgroups_kernel, dim3(C), dim3(256), 0, st, (const float*)partial, chunks, C, groups, gsum,
+                           dgamma, dbeta);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C, groups), dim3(256), 0, st, (const float*)partial, chunks, C, gsum, gsum + C,
+                           (float*)nullptr, (float*)nullptr, ga);
+        hipLaunchKernelGGL(bn_sum_groups_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)gsum, groups, C, dgamma, dbeta);
+    }
     grid.z = groups;
     hipLaunchKernelGGL(bn_bwd_apply_rows_kernel<T>, grid, dim3(256), 0, st, dz, lddz, (const T*)nullptr, 0, relu_bits, y, ldy, gamma,
                        coef, coef + C, (const float*)gsum, (const float*)(gsum + C), relu, 1, 1.0f / (float)rows, dy, lddy, dres, lddres,
