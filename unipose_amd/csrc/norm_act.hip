@@ -344,7 +344,12 @@ __global__ void __launch_bounds__(256) bn_apply_rows_kernel(const T* __restrict_
     }
 }
 
-template <typename T>
+// Per-channel factors folded once per thread into (k, a, b, mean): dy = k * g + a + (y - mean) * b with k = gamma * invstd,
+// a = -k * dbeta / m, b = -k * invstd * dgamma / m.  UNROLL rows in flight per thread; the register budget matters more than
+// the depth here: this pass runs beside the weight-gradient kernels of the side stream (two workgroups of ~170 VGPRs per
+// SIMD pair), and what is left of the register file decides how many of its waves fit next to them.  ZPATH: ReLU decisions
+// taken from the stored output z (no bit mask recorded).
+template <typename T, int UNROLL, bool ZPATH>
 __global__ void __launch_bounds__(256) bn_bwd_apply_rows_kernel(const T* __restrict__ dz, int lddz, const T* __restrict__ z, int ldz,
                                                                 const uint32_t* __restrict__ bits, const T* __restrict__ y, int ldy,
                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -357,7 +362,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_rows_kernel(const T* __restr
     dz += grow0 * lddz;
     y += grow0 * ldy;
     dy += grow0 * lddy;
-    if (z) z += grow0 * ldz;
+    if (ZPATH) z += grow0 * ldz;
     if (dres) dres += grow0 * lddres;
     mean += (size_t)blockIdx.z * grp.pstride;
     invstd += (size_t)blockIdx.z * grp.pstride;
@@ -366,57 +371,71 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_rows_kernel(const T* __restr
     const int cl = threadIdx.x & ((1 << lcs) - 1), rl = threadIdx.x >> lcs;
     const int rpb = 256 >> lcs;
     const int c = ((blockIdx.y << lcs) + cl) * E;
-    float is[E], ga[E], mu[E], dg[E], db[E];
-    ldparam<E>(invstd + c, is);
-    ldparam<E>(gamma + c, ga);
-    ldparam<E>(mean + c, mu);
-    ldparam<E>(dgamma + c, dg);
-    ldparam<E>(dbeta + c, db);
-    const int stride = gridDim.x * rpb;
-    for (int base = blockIdx.x * rpb + rl; base < rows; base += BN_ROWS_UNROLL * stride) {
-        Row16<T> g[BN_ROWS_UNROLL], yv[BN_ROWS_UNROLL], zz[BN_ROWS_UNROLL];
-        uint32_t mk[BN_ROWS_UNROLL];
+    float kk[E], aa[E], bb[E], mu[E];
+    {
+        float is[E], t[E];
+        ldparam<E>(invstd + c, is);
+        ldparam<E>(gamma + c, kk);
+        ldparam<E>(mean + c, mu);
 #pragma unroll
-        for (int u = 0; u < BN_ROWS_UNROLL; ++u) {
+        for (int e = 0; e < E; ++e) kk[e] *= is[e];
+        ldparam<E>(dbeta + c, t);
+#pragma unroll
+        for (int e = 0; e < E; ++e) aa[e] = use_batch ? -kk[e] * t[e] * inv_m : 0.f;
+        ldparam<E>(dgamma + c, t);
+#pragma unroll
+        for (int e = 0; e < E; ++e) bb[e] = use_batch ? -kk[e] * is[e] * t[e] * inv_m : 0.f;
+    }
+    const int stride = gridDim.x * rpb;
+    for (int base = blockIdx.x * rpb + rl; base < rows; base += UNROLL * stride) {
+        Row16<T> g[UNROLL], yv[UNROLL], zz[ZPATH ? UNROLL : 1];
+        uint32_t mk[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
             const int row = base + u * stride;
             const int rr = row < rows ? row : rows - 1;
             g[u] = ld16(dz + (size_t)rr * lddz + c);
             yv[u] = ld16(y + (size_t)rr * ldy + c);
             mk[u] = 0xffffffffu;
-            if (relu) {
-                if (bits) {
-                    const int64_t b = (grow0 + rr) * C + c;
-                    mk[u] = bits[b >> 5] >> (int)(b & 31);
-                } else {
-                    zz[u] = ld16(z + (size_t)rr * ldz + c);
-                }
+            if (ZPATH) {
+                zz[u] = ld16(z + (size_t)rr * ldz + c);
+            } else if (relu) {
+                const int64_t b = (grow0 + rr) * C + c;
+                mk[u] = bits[b >> 5] >> (int)(b & 31);
             }
         }
 #pragma unroll
-        for (int u = 0; u < BN_ROWS_UNROLL; ++u) {
+        for (int u = 0; u < UNROLL; ++u) {
             const int row = base + u * stride;
             if (row >= rows) continue;
             Row16<T> o;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 float ge = g[u].v[e];
-                if (relu) {
-                    const bool pos = bits ? ((mk[u] >> e) & 1u) != 0u : zz[u].v[e] > 0.f;
-                    if (!pos) ge = 0.f;
-                }
+                const bool pos = ZPATH ? zz[ZPATH ? u : 0].v[e] > 0.f : ((mk[u] >> e) & 1u) != 0u;
+                if (!pos) ge = 0.f;
                 g[u].v[e] = ge;
-                const float k = ga[e] * is[e];
-                if (use_batch) {
-                    const float xh = (yv[u].v[e] - mu[e]) * is[e];
-                    o.v[e] = k * (ge - db[e] * inv_m - xh * dg[e] * inv_m);
-                } else {
-                    o.v[e] = k * ge;
-                }
+                o.v[e] = kk[e] * ge + (aa[e] + (yv[u].v[e] - mu[e]) * bb[e]);
             }
             if (dres) st16(dres + (size_t)row * lddres + c, g[u]);
             st16(dy + (size_t)row * lddy + c, o);
         }
     }
+}
+template <typename T>
+static void launch_bn_bwd_apply_rows(dim3 grid, hipStream_t st, const T* dz, int lddz, const T* z, int ldz, const uint32_t* bits,
+                                     const T* y, int ldy, const float* gamma, const float* mean, const float* invstd,
+                                     const float* dgamma, const float* dbeta, int relu, int use_batch, float inv_m, T* dy, int lddy,
+                                     T* dres, int lddres, int rows, int C, int lcs, GroupArgs grp) {
+    // rows in flight per thread: 1 for fp32 (38 VGPRs: four waves per SIMD still fit beside two weight-gradient workgroups;
+    // 368^2 B = 32 step 62.3 -> 61.75 ms against 2 or 4, same-session A/B), 2 for bf16 (no difference measured at 736^2)
+    constexpr int U = sizeof(T) == 4 ? 1 : 2;
+    if (relu && !bits)
+        hipLaunchKernelGGL((bn_bwd_apply_rows_kernel<T, U, true>), grid, dim3(256), 0, st, dz, lddz, z, ldz, bits, y, ldy, gamma, mean,
+                           invstd, dgamma, dbeta, relu, use_batch, inv_m, dy, lddy, dres, lddres, rows, C, lcs, grp);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_rows_kernel<T, U, false>), grid, dim3(256), 0, st, dz, lddz, z, ldz, bits, y, ldy, gamma, mean,
+                           invstd, dgamma, dbeta, relu, use_batch, inv_m, dy, lddy, dres, lddres, rows, C, lcs, grp);
 }
 // launch geometry of the row-strided kernels, or false when the channel-group count is not a power of two (>= 8)
 template <typename T>
@@ -579,18 +598,21 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* dz, int ldd
             s2[3] += g.w * (yy.w - mu.w);
         };
         int64_t r = r0 + rl;
-        for (; r + 48 < r1; r += 64) {   // four rows (8 x 16-byte loads + the mask words) in flight per thread
-            float4 g[4], yv[4], zv[4];
+        // rows in flight per thread (2 x 16-byte loads + the mask word each): four, or two in fp32 where this pass shares the
+        // CUs with the side stream's weight-gradient workgroups and the register count decides how many of its waves fit
+        constexpr int U = sizeof(T) == 4 ? 2 : 4;
+        for (; r + 16 * (U - 1) < r1; r += 16 * U) {
+            float4 g[U], yv[U], zv[U];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 g[u] = ld4<T>(dz + (r + 16 * u) * lddz + c);
                 yv[u] = ld4<T>(y + (r + 16 * u) * ldy + c);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < U; ++u)
                 zv[u] = relu ? relu_mask4(bits, bq0 + (r + 16 * u) * (C >> 2) + (c >> 2), z, (r + 16 * u) * ldz + c) : g[u];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc(g[u], zv[u], yv[u]);
+            for (int u = 0; u < U; ++u) acc(g[u], zv[u], yv[u]);
         }
         for (; r < r1; r += 16) {
             float4 ga = ld4<T>(dz + r * lddz + c);
@@ -935,9 +957,9 @@ static void launch_bn_bwd(const T* dz, int lddz, const T* z, int ldz, const uint
         constexpr int E = 16 / (int)sizeof(T);
         if (bn_rows_enabled() && lddz % E == 0 && ldy % E == 0 && lddy % E == 0 && (!relu || relu_bits || ldz % E == 0) &&
             (!dres || lddres % E == 0) && rows_geometry<T>(rows, C, grid, lcs)) {
-            hipLaunchKernelGGL(bn_bwd_apply_rows_kernel<T>, grid, dim3(256), 0, st, dz, lddz, z, ldz, relu_bits, y, ldy, gamma, mean,
-                               invstd, (const float*)dgamma, (const float*)dbeta, relu, use_batch_stats, 1.0f / (float)rows, dy,
-                               lddy, dres, lddres, (int)rows, C, lcs, GroupArgs{0, 0});
+            launch_bn_bwd_apply_rows<T>(grid, st, dz, lddz, z, ldz, relu_bits, y, ldy, gamma, mean, invstd, (const float*)dgamma,
+                                        (const float*)dbeta, relu, use_batch_stats, 1.0f / (float)rows, dy, lddy, dres, lddres,
+                                        (int)rows, C, lcs, GroupArgs{0, 0});
             return;
         }
     }
@@ -1296,9 +1318,8 @@ static bool launch_bn_bwd_groups(const T* dz, int lddz, const uint32_t* relu_bit
         hipLaunchKernelGGL(bn_sum_groups_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)gsum, groups, C, dgamma, dbeta);
     }
     grid.z = groups;
-    hipLaunchKernelGGL(bn_bwd_apply_rows_kernel<T>, grid, dim3(256), 0, st, dz, lddz, (const T*)nullptr, 0, relu_bits, y, ldy, gamma,
-                       coef, coef + C, (const float*)gsum, (const float*)(gsum + C), relu, 1, 1.0f / (float)rows, dy, lddy, dres, lddres,
-                       (int)rows, C, lcs, ga);
+    launch_bn_bwd_apply_rows<T>(grid, st, dz, lddz, (const T*)nullptr, 0, relu_bits, y, ldy, gamma, coef, coef + C, (const float*)gsum,
+                                (const float*)(gsum + C), relu, 1, 1.0f / (float)rows, dy, lddy, dres, lddres, (int)rows, C, lcs, ga);
     return true;
 }
 }  // namespace up
