@@ -5,9 +5,26 @@ import torch
 from oracle import unipose_oracle as O
 
 
+_SKELETONS = {}
+
+
+def skeleton(kind, K, **kw):
+    """A drop-in model on the CPU with its constructor's random initialisation (0.6 s of the constructor, about to be overwritten
+    by a state dict anyway): built once per (kind, K, options) and deep-copied per test."""
+    import copy
+    key = (kind, K, tuple(sorted(kw.items())))
+    if key not in _SKELETONS:
+        if kind == "lstm":
+            from model.uniposeLSTM import unipose_lstm
+            _SKELETONS[key] = unipose_lstm(num_classes=K, **kw)
+        else:
+            from model.unipose import unipose
+            _SKELETONS[key] = unipose("LSP", num_classes=K, **kw)
+    return copy.deepcopy(_SKELETONS[key])
+
+
 def build_image_model(K, wseed, dev):
-    from model.unipose import unipose
-    m = unipose("LSP", num_classes=K)
+    m = skeleton("image", K)
     sd = O.synth_state_dict(K, wseed)
     m.load_state_dict(sd)
     return m.to(dev), sd
@@ -142,7 +159,7 @@ def lstm_case(dev, K=13, B=1, size=32, T=3, wseed=4, tol=1e-3, train=False, defe
     tolerance per frame.  train: summed MSE, ONE backward through all frames (BPTT), fp64 yardstick."""
     from model.uniposeLSTM import unipose_lstm
     from unipose_amd import ops
-    m = unipose_lstm(num_classes=K)
+    m = skeleton("lstm", K)
     sd = O.synth_state_dict(K, wseed, lstm=True)
     m.load_state_dict(sd)
     m = m.to(dev)
@@ -276,7 +293,7 @@ def tap_case(dev, golden_file, size, keys, sub, output_stride=16, tol=1e-3):
     from unipose_amd import ops
     g = np.load(golden_file)
     K, wseed, xseed = (int(v) for v in g["meta"])
-    m = unipose("LSP", num_classes=K, output_stride=output_stride)
+    m = skeleton("image", K, output_stride=output_stride)
     m.load_state_dict(O.synth_state_dict(K, wseed))
     m = m.to(dev).eval()
     taps = {}
@@ -370,7 +387,7 @@ def g15_case(dev, path, batch_frames, slack=2.0, floor=5e-3):
     from unipose_amd import ops
     g = np.load(path)
     K, wseed, xs, cs, ts, T = (int(v) for v in g["meta"])
-    m = unipose_lstm(num_classes=K)
+    m = skeleton("lstm", K)
     m.load_state_dict(O.synth_state_dict(K, wseed, lstm=True))
     m = m.to(dev).train()
     m.batch_frames = batch_frames

@@ -141,18 +141,19 @@ def test_train_step_vs_oracle_yardstick():
 
 
 def test_train_step_368_vs_oracle_yardstick():
-    """The headline resolution (23x23 / 46x46 maps: the dilated WASP branches have all their live taps, unlike at 128x128), B = 4, with
+    """The headline resolution (23x23 / 46x46 maps: the dilated WASP branches have all their live taps, unlike at 128x128), B = 2
+    (the time of this test is the float64 oracle on the host; the genuine reference's B = 4 gradients at this size are G14), with
     the HIP path's ReLU decisions replayed in the oracle: every gradient inside the oracle's own fp32-vs-fp64 yardstick.  The stem's
     weight gradient gets a floor of 5e-3: it is a sum of 135 424 products per weight and image that cancel to a small value (the
     BatchNorm in front makes the gradient map sum to zero per channel) and lands 2.3e-3 from float64 where ATen's CPU kernel lands
     7e-5; float64 sums in the BatchNorm backward in front of it did not move it (measured, round 3), so it is the round-off of the
     weight-gradient reduction itself — and small against the 6e-3 by which any two evaluations differ once ReLU decisions are
     free (G14: reference fp32 vs fp64 6.4e-3, this path vs the reference 7.6e-3)."""
-    mc.train_case(DEV, K=16, B=4, size=368, floors={"backbone.conv1.weight": 5e-3})
+    mc.train_case(DEV, K=16, B=2, size=368, floors={"backbone.conv1.weight": 5e-3})
 
 
 def test_train_step_dropout_masks():
-    mc.train_case(DEV, K=16, B=2, size=96, dropout_masks=True)
+    mc.train_case(DEV, K=16, B=2, size=64, dropout_masks=True)
 
 
 def test_eval_vs_oracle_odd_sizes():
@@ -161,12 +162,14 @@ def test_eval_vs_oracle_odd_sizes():
 
 
 def test_lstm_train_bptt_vs_oracle():
-    mc.lstm_case(DEV, size=96, T=3, B=2, train=True)
+    # two frames: the initial-state path and one recurrent step; three frames (every weight summed over three uses) run in the
+    # batched-frames test below and, per frame, on the emulator (the time of these tests is the float64 oracle on the host)
+    mc.lstm_case(DEV, size=64, T=2, B=2, train=True)
 
 
 def test_lstm_train_bptt_batched_frames_vs_oracle():
     """trunk once on all T frames with per-frame BatchNorm statistics (ops.bn_groups): same yardsticks as the per-frame form"""
-    mc.lstm_case(DEV, size=96, T=3, B=2, train=True, deferred=True, batch_frames=True)
+    mc.lstm_case(DEV, size=64, T=3, B=2, train=True, deferred=True, batch_frames=True)
 
 
 def test_lstm_batch_generalisation():

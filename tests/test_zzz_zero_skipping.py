@@ -164,14 +164,14 @@ def test_wgrad_rect_gpu(wgrad_rect, tap_sort):
                 (2, 128, 92, 92, 128, 3, 2, 1, 1, False, False), (2, 3, 96, 96, 64, 7, 2, 3, 1, False, False)]:
         n, c, h, w, k, r, s, p, d, bias, relu = cfg
         oc.conv_case(dev, n, c, h, w, k, r, s, p, d, bias=bias, relu=relu)
-    mc.train_case(dev, size=128, B=4)
+    mc.train_case(dev, size=96, B=2)
 
 
 @pytest.mark.gpu
 def test_tap_sort_model_gpu(tap_sort):
     dev = torch.device("cuda:0")
     assert mc.eval_case(dev, size=368, B=1, K=16, tol=1e-4) < 1e-4           # 23x23 top maps: the real WASP geometry
-    mc.train_case(dev, size=96, B=4)
+    mc.train_case(dev, size=96, B=2)
 
 
 def test_random_knob_combinations_emu(emu_backend):

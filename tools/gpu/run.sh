@@ -24,7 +24,7 @@ for act in "$@"; do
 case $act in
 tr16) ./tools/gpu/tr16_probe > $OUT/tr16.txt 2>&1; echo "tr16 exit $?"; head -20 $OUT/tr16.txt ;;
 tests_bf16s) timeout 900 python -m pytest tests/test_bf16s_gpu.py -m gpu -q --timeout 600 > $OUT/pytest_bf16s.log 2>&1; echo "pytest exit $?"; tail -15 $OUT/pytest_bf16s.log ;;
-tests_all) timeout 1500 python -m pytest tests -m gpu -q --timeout 600 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -15 $OUT/pytest_gpu.log ;;
+tests_all) timeout 1500 python -m pytest tests -m gpu -q --timeout 600 --durations=40 > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -${TAILN:-15} $OUT/pytest_gpu.log ;;
 ab736) for rep in 1 2; do for g in 1 0; do
   UP_GLDS=$g timeout 300 python bench.py $B736 --steps 8 --warmup 3 --no-profile > $OUT/ab736_$g.log 2>&1; line $OUT/ab736_$g.log "glds=$g"; done; done ;;
 csv736) for g in 1 0; do
