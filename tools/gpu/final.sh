@@ -2,7 +2,7 @@
 # stats of the bench command in both stream modes, PMC passes; with TESTS=1 also the full -m gpu suite (default + bf16x3 arithmetic);
 # LIGHT=1 stops after the kernel statistics.
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r03_z}
+TAG=${1:-r04_z}
 mkdir -p gpurun_out/$TAG
 # the measured binary is the tree's: the stamp next to the shipped library names the sha256 of the sources it was built from
 python -c "
@@ -27,12 +27,14 @@ UNIPOSE_SYNC_WGRAD=1 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO
 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_736 -o bench -- python $GRAFT_REPO_ROOT/bench.py --size 736 --batch 16 --math bf16s $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_736.log 2>&1
 UNIPOSE_SYNC_WGRAD=1 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_736x -o bench -- python $GRAFT_REPO_ROOT/bench.py --size 736 --batch 16 --math bf16s $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_736x.log 2>&1
 [ -n "$LIGHT" ] || timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_lstm -o bench -- python $GRAFT_REPO_ROOT/bench.py --model lstm $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_lstm.log 2>&1
+[ -n "$LIGHT" ] || UNIPOSE_SYNC_WGRAD=1 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_lstmx -o bench -- python $GRAFT_REPO_ROOT/bench.py --model lstm $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_lstmx.log 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof -name "*.db" | head -1) 4 > gpurun_out/$TAG/kernel_stats.txt 2>&1
 python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof_sync -name "*.db" | head -1) 4 > gpurun_out/$TAG/kernel_stats_exclusive.txt 2>&1
 python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof_736 -name "*.db" | head -1) 4 > gpurun_out/$TAG/kernel_stats_736_bf16s.txt 2>&1
 python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof_736x -name "*.db" | head -1) 4 > gpurun_out/$TAG/kernel_stats_736_bf16s_exclusive.txt 2>&1
 [ -n "$LIGHT" ] || python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof_lstm -name "*.db" | head -1) 4 > gpurun_out/$TAG/kernel_stats_lstm.txt 2>&1
+[ -n "$LIGHT" ] || python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof_lstmx -name "*.db" | head -1) 4 > gpurun_out/$TAG/kernel_stats_lstm_exclusive.txt 2>&1
 find gpurun_out/$TAG -name "*.db" -delete
 head -8 gpurun_out/$TAG/kernel_stats.txt
 head -8 gpurun_out/$TAG/kernel_stats_exclusive.txt
@@ -43,11 +45,14 @@ UNIPOSE_SYNC_WGRAD=1 UP_PROFILE_CSV=$GRAFT_REPO_ROOT/gpurun_out/$TAG/launches.cs
 python tools/gpu/csv_loss.py gpurun_out/$TAG/launches.csv.1 157.3 20 > gpurun_out/$TAG/lost_time_by_shape.txt 2>&1 || python tools/gpu/csv_loss.py gpurun_out/$TAG/launches.csv 157.3 20 > gpurun_out/$TAG/lost_time_by_shape.txt 2>&1
 head -4 gpurun_out/$TAG/lost_time_by_shape.txt
 bash tools/gpu/pmc.sh $TAG
+# whole-step A/B of the round-4 switches (fp32 headline step, alternating, two rounds): fused BatchNorm-backward reduction, masked
+# skip-gradient addend, direct-to-LDS forward / data gradient, direct-to-LDS weight gradient
+VARIANTS="A=default;UNIPOSE_BN_FUSE_REDUCE=0;UNIPOSE_MASKED_ADDEND=0;UP_GLDS32_WGRAD=0;UP_GLDS32=0 UP_GLDS32_WGRAD=0" REPS=2 bash tools/gpu/run.sh $TAG abenv368 > gpurun_out/$TAG/knob_ab.txt 2>&1; cat gpurun_out/$TAG/knob_ab.txt
 UNIPOSE_SYNC_WGRAD=1 UP_PROFILE_CSV=$GRAFT_REPO_ROOT/gpurun_out/$TAG/launches_736.csv timeout 300 python bench.py --size 736 --batch 16 --math bf16s --steps 4 --warmup 2 --no-cpu-baseline --no-stock-baseline --no-alt-math --no-other-configs > gpurun_out/$TAG/bench_csv_736.log 2>&1
 python tools/gpu/csv_loss.py $(ls gpurun_out/$TAG/launches_736.csv* | tail -1) 2500 24 > gpurun_out/$TAG/lost_time_by_shape_736.txt 2>&1; head -3 gpurun_out/$TAG/lost_time_by_shape_736.txt
 bash tools/gpu/pmc_sq.sh ${TAG}_736 --size 736 --batch 16 --math bf16s
 if [ -n "$TESTS" ]; then
-timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > gpurun_out/$TAG/pytest_gpu.log 2>&1; echo "pytest exit $?"
+timeout 1200 python -m pytest tests -m gpu -q --timeout 600 --durations=15 > gpurun_out/$TAG/pytest_gpu.log 2>&1; echo "pytest exit $?"
 tail -2 gpurun_out/$TAG/pytest_gpu.log
 UNIPOSE_CONV_MATH=bf16x3 timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -m gpu -q --timeout 600 > gpurun_out/$TAG/pytest_gpu_bf16x3.log 2>&1; echo "pytest(bf16x3 default) exit $?"
 tail -2 gpurun_out/$TAG/pytest_gpu_bf16x3.log
