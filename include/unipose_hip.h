@@ -40,7 +40,7 @@ typedef enum {
 } up_status;
 
 const char* up_last_error(void);
-int up_abi_version(void);   /* 6 */
+int up_abi_version(void);   /* 7 */
 
 /* Geometry of one 2-D convolution (nn.Conv2d as used at resnet.py:10-16,61,80-84,104-109;
  * wasp.py:9,52,59-60; decoder.py:17,22,26,30; model/uniposeLSTM.py:12-14,30-38,85-89). */
