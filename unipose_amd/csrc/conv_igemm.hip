@@ -1924,9 +1924,6 @@ static int cu_count();
 //  larger tiles: 736^2 B=16 step in bf16 storage 52.0 ms at 1500, 49.0-49.5 ms anywhere in 300..1000, profiles/r02_t)
 static TileChoice choose_tile(int64_t M, int Ng, int Ktot, int math = 0) {
     const int cands[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
-    static const int force = env_int("UP_TILE_FORCE", 0, 0);   // EXPERIMENT: 1..4 = cands[force-1] wherever it is legal
-    if (force >= 1 && force <= 4 && math < UP_MATH_BF16 && !(Ng <= 64 && cands[force - 1][1] == 128))
-        return {cands[force - 1][0], cands[force - 1][1]};
     const int base_want = math >= UP_MATH_BF16 ? g_tile_want_bf16 : g_tile_want;   // workgroups a launch should at least have
     const int64_t want = Ktot < g_short_k ? (int64_t)g_short_k_mult * base_want / 2 : base_want;
     for (auto& c : cands) {
