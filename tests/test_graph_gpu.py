@@ -103,3 +103,33 @@ def test_graphed_forward_close_returns_the_stream_scratch():
     assert grown < 48 * 2 ** 20, f"{grown / 2 ** 20:.0f} MiB left behind by six graphs"      # 6 x 16 MB would be 96
     with torch.no_grad():
         assert torch.equal(model(x), ref)         # the eager path (its own stream scratch) is untouched
+
+
+def test_two_live_graphs_on_one_stream_handle_share_the_scratch():
+    """torch's stream pool is 32 entries round-robin: after 32 more `torch.cuda.Stream()`s a new GraphedForward gets the handle of a
+    live one.  Closing either must not free the K-split scratch the other's captured graph has baked in."""
+    from model.unipose import unipose
+    from unipose_amd.graph import GraphedForward
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = unipose("MPII", num_classes=16).to(dev).eval()
+    x = torch.randn(1, 3, 128, 128, device=dev)
+    with torch.no_grad():
+        ref = model(x).clone()
+    first = GraphedForward(model, x)
+    handle = first.stream.cuda_stream
+    twin = None
+    keep = [torch.cuda.Stream(device=dev) for _ in range(31)]      # 31 plain streams: the next one closes the 32-entry round
+    for _ in range(40):                              # (walk on with whole graphs should the pool be laid out differently)
+        g = GraphedForward(model, x, warmup=1)
+        if g.stream.cuda_stream == handle:
+            twin = g
+            break
+        g.close()
+    del keep
+    assert twin is not None, "the stream pool never repeated a handle"
+    assert torch.equal(twin(x), ref)
+    twin.close()                                     # must NOT release the scratch `first` replays with
+    for _ in range(3):
+        assert torch.equal(first(x), ref)
+    first.close()

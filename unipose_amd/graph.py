@@ -12,11 +12,35 @@ partial exchange of small launches — into a hipGraph (torch.cuda.CUDAGraph on 
 The returned tensors are the graph's static output buffers: consume (or clone) them before the next call.  Shapes are fixed
 at capture; the packed weight images the kernels read are captured by address, so call `recapture()` after changing the
 parameters (load_state_dict, an optimizer step).  Inference only (`model.eval()`, `torch.no_grad()`).  `close()` (or deleting the object)
-releases the graph and the library scratch of its private stream.
+releases the graph and — once no other live graph shares the stream handle — the library scratch of its private stream.
 
 Reference call sites: the validation / test loops `unipose.py:150-160`, `uniposeLSTM.py:160-190` (one forward per batch).
 """
+import collections
+import threading
+
 import torch
+
+# torch hands out stream handles from a 32-entry round-robin pool per device, so two live GraphedForward objects can hold the
+# SAME hipStream_t; the library keys its K-split scratch by that handle and a captured graph has the scratch baked in by
+# address.  The scratch is therefore released only when the LAST graph captured on a handle closes (ADVICE r3).
+_stream_users = collections.Counter()
+_stream_users_lock = threading.Lock()
+
+
+def _acquire_stream(handle):
+    with _stream_users_lock:
+        _stream_users[handle] += 1
+
+
+def _release_stream(handle):
+    """True when no other live graph was captured on this handle (the caller may free the library scratch)."""
+    with _stream_users_lock:
+        _stream_users[handle] -= 1
+        if _stream_users[handle] > 0:
+            return False
+        del _stream_users[handle]
+        return True
 
 
 class GraphedForward:
@@ -32,6 +56,7 @@ class GraphedForward:
         # library-owned scratch (K-split partials, tap-sort tables) is keyed by stream and allocated on first use: warm up
         # on the stream the capture will run on, so nothing allocates while capturing
         self.stream = torch.cuda.Stream(device=self.device)
+        _acquire_stream((self.device.index, self.stream.cuda_stream))
         self.static_args = [a.clone() if torch.is_tensor(a) else a for a in example_args]
         self.graph = None
         self.static_out = None
@@ -70,7 +95,8 @@ class GraphedForward:
         from . import _C
         self.graph, self.static_out = None, None
         torch.cuda.synchronize(self.device)
-        _C.lib().up_stream_release(self.stream.cuda_stream)
+        if _release_stream((self.device.index, self.stream.cuda_stream)):
+            _C.lib().up_stream_release(self.stream.cuda_stream)
         self.stream = None
 
     def __del__(self):
