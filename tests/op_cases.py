@@ -528,3 +528,38 @@ def bn_groups_case(dev, groups, n, c, h, w, k, r=1, relu=True, residual=False, d
     bad = {k_: v for k_, v in errs.items() if not v < (tol if not bf else 2e-3 if k_ in ("rm", "rv") else 3e-2)}
     assert not bad, (bad, errs)
     return errs
+
+
+def bn_group_stats_case(dev, groups, rows, c, seed=0, momentum=0.1, eps=1e-5):
+    """up_bn_batch_stats_t + up_bn_finalize_groups on their own at a row count that gives the finalize kernel several rounds of
+    tiles per lane (rows / 256 > 128) — the network-sized cases have 17: per-group mean / invstd / scale / shift against float64,
+    running statistics after `groups` momentum updates in group order."""
+    from unipose_amd import _C
+    L = _C.lib()
+    gen = torch.Generator().manual_seed(seed)
+    y = (3.0 + 2.0 * torch.randn(groups * rows, c, generator=gen)) * (0.5 + torch.rand(c, generator=gen))
+    y[rows:2 * rows] += 1.5                                      # groups differ
+    gamma, beta = 0.5 + torch.rand(c, generator=gen), 0.2 * torch.randn(c, generator=gen)
+    rm0, rv0 = 0.1 * torch.randn(c, generator=gen), 0.5 + torch.rand(c, generator=gen)
+    yd, gd, bd = y.to(dev), gamma.to(dev), beta.to(dev)
+    rm, rv = rm0.clone().to(dev), rv0.clone().to(dev)
+    tiles = L.up_bn_batch_stats_tiles(rows)
+    st = torch.empty((groups, tiles, c, 3), dtype=torch.float32, device=dev)
+    coef = torch.empty((groups, 4, c), dtype=torch.float32, device=dev)
+    _C.check(L.up_bn_batch_stats_t(yd.data_ptr(), c, rows, c, groups, 0, st.data_ptr(), ops._stream(yd)), "bn_batch_stats")
+    _C.check(L.up_bn_finalize_groups(st.data_ptr(), tiles, c, groups, rows, eps, momentum, rm.data_ptr(), rv.data_ptr(),
+                                     gd.data_ptr(), bd.data_ptr(), coef.data_ptr(), ops._stream(yd)), "bn_finalize_groups")
+    y64 = y.double().view(groups, rows, c)
+    mean, var = y64.mean(1), y64.var(1, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + eps)
+    co = coef.cpu().double()
+    assert float((co[:, 0] - mean).abs().max()) < 2e-6 * float(mean.abs().max())
+    assert float((co[:, 1] / invstd - 1).abs().max()) < 5e-6
+    assert float((co[:, 2] / (gamma.double() * invstd) - 1).abs().max()) < 5e-6
+    assert float((co[:, 3] - (beta.double() - mean * gamma.double() * invstd)).abs().max()) < 2e-5
+    erm, erv = rm0.double(), rv0.double()
+    for g in range(groups):
+        erm = (1 - momentum) * erm + momentum * mean[g]
+        erv = (1 - momentum) * erv + momentum * var[g] * rows / (rows - 1)
+    assert float((rm.cpu().double() - erm).abs().max()) < 2e-6
+    assert float((rv.cpu().double() / erv - 1).abs().max()) < 5e-6

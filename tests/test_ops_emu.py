@@ -305,6 +305,11 @@ def test_grouped_batchnorm_matches_separate_calls(emu_backend, cfg):
                       dtype=torch.float32 if dt == "f32" else torch.bfloat16)
 
 
+@pytest.mark.parametrize("groups,rows,c", [(3, 40000, 8), (5, 17 * 256 - 7, 12), (8, 300, 4)])
+def test_grouped_statistics_and_finalize_many_tiles(emu_backend, groups, rows, c):
+    oc.bn_group_stats_case(emu_backend, groups, rows, c)
+
+
 def test_bn_large_mean_is_applied_centred(emu_backend):
     print(oc.bn_large_mean_case(emu_backend))
 

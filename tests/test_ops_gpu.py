@@ -192,6 +192,11 @@ def test_grouped_batchnorm_matches_separate_calls(cfg):
                       dtype=torch.float32 if dt == "f32" else torch.bfloat16)
 
 
+@pytest.mark.parametrize("groups,rows,c", [(3, 40000, 8), (5, 4232, 256), (8, 67712, 64)])
+def test_grouped_statistics_and_finalize_many_tiles(groups, rows, c):
+    oc.bn_group_stats_case(DEV, groups, rows, c)
+
+
 def test_bn_large_mean_is_applied_centred():
     print(oc.bn_large_mean_case(DEV))
 

@@ -483,13 +483,12 @@ __global__ void __launch_bounds__(256) bn_batch_stats_kernel(const T* y, int ldy
     float n = 0.f, sh[4] = {0.f, 0.f, 0.f, 0.f}, s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
         const T* base = y + (size_t)g * rows_per_group * ldy + c;
-        for (int r = r0 + rl; r < r1; r += 16) {
-            const float4 v = ld4<T>(base + (size_t)r * ldy);
+        // shift = the chunk's first row (the same line for all 16 row lanes), so the row loop has no first-iteration branch and
+        // four rows are in flight per thread (the loop was one dependent load per iteration: 17 us for a 4 us read, r04_z)
+        const float4 s0 = ld4<T>(base + (size_t)r0 * ldy);
+        sh[0] = s0.x, sh[1] = s0.y, sh[2] = s0.z, sh[3] = s0.w;
+        auto acc = [&](const float4& v) {
             const float x[4] = {v.x, v.y, v.z, v.w};
-            if (n == 0.f) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sh[e] = x[e];
-            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float d = x[e] - sh[e];
@@ -497,7 +496,16 @@ __global__ void __launch_bounds__(256) bn_batch_stats_kernel(const T* y, int ldy
                 q[e] += d * d;
             }
             n += 1.f;
+        };
+        int r = r0 + rl;
+        for (; r + 48 < r1; r += 64) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = ld4<T>(base + (size_t)(r + 16 * u) * ldy);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc(v[u]);
         }
+        for (; r < r1; r += 16) acc(ld4<T>(base + (size_t)r * ldy));
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -1044,51 +1052,49 @@ extern "C" int up_bn_bwd(const float* dz, int lddz, const float* z, int ldz, con
                        lddres, dgamma, dbeta, workspace, workspace_bytes, rows, C, UP_DT_F32, stream);
 }
 
-// Grouped BatchNorm with up to BN_MAXG groups, ONE launch (round 4): a workgroup per channel merges the partials of every group —
-// thread t takes row tiles t, t + 256, ... of each group, all loads of a round in flight together; the merge tree over LDS handles
-// the groups side by side — writes coef[g] = mean, invstd, scale, shift per group and applies the groups' momentum updates to the
-// running statistics in order, from the merged (count, M2) themselves (the two-launch form recovered the variance from invstd:
-// 1 / invstd^2 - eps cancels for constant channels).  Same per-group merge order as bn_finalize_kernel.
+// Grouped BatchNorm with up to BN_MAXG groups, ONE launch (round 4): a workgroup per channel merges the partials of every group
+// (one wave per group, see the kernel), writes coef[g] = mean, invstd, scale, shift per group and applies the groups' momentum
+// updates to the running statistics in order, from the merged (count, M2) themselves (the two-launch form recovered the variance
+// from invstd: 1 / invstd^2 - eps cancels for constant channels).
 constexpr int BN_MAXG = 8;
 __global__ void __launch_bounds__(256) bn_finalize_allgroups_kernel(const float* stats, int tiles, int C, int groups, float eps, float mom,
                                                                     float* rm, float* rv, const float* gamma, const float* beta,
                                                                     float* coef) {
-    __shared__ float red[256][BN_MAXG][3];
-    const int c = blockIdx.x, t0 = threadIdx.x;
-    float n[BN_MAXG], m[BN_MAXG], q[BN_MAXG];
-#pragma unroll
-    for (int g = 0; g < BN_MAXG; ++g) n[g] = m[g] = q[g] = 0.f;
-    for (int t = t0; t < tiles; t += 256) {
-        float a0[BN_MAXG], a1[BN_MAXG], a2[BN_MAXG];
-#pragma unroll
-        for (int g = 0; g < BN_MAXG; ++g) {
-            const float* s = stats + (((size_t)(g < groups ? g : 0) * tiles + t) * C + c) * 3;
-            a0[g] = g < groups ? s[0] : 0.f;
-            a1[g] = s[1];
-            a2[g] = s[2];
+    // one workgroup per channel; wave w merges groups w and w + 4: its 64 lanes stride over the group's tiles (two in flight per
+    // lane), then a six-level shuffle merge — no LDS tree and no barrier inside the reduction (the 8-level tree over 8 groups took
+    // 17 us per launch, 112 launches per UniPose-LSTM step on the forward's critical path)
+    __shared__ float fin[BN_MAXG][3];
+    const int c = blockIdx.x, t0 = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int g = wave; g < groups; g += 4) {
+        float gn = 0.f, gm = 0.f, gq = 0.f;
+        const float* s = stats + ((size_t)g * tiles * C + c) * 3;
+        for (int t = lane; t < tiles; t += 128) {
+            const int t2 = t + 64;
+            const float* s1 = s + (size_t)t * C * 3;
+            const float* s2 = s + (size_t)(t2 < tiles ? t2 : t) * C * 3;
+            const float a0 = s1[0], a1 = s1[1], a2 = s1[2];
+            const float b0 = t2 < tiles ? s2[0] : 0.f, b1 = s2[1], b2 = s2[2];
+            wf_merge3(gn, gm, gq, a0, a1, a2);
+            wf_merge3(gn, gm, gq, b0, b1, b2);
         }
 #pragma unroll
-        for (int g = 0; g < BN_MAXG; ++g) wf_merge3(n[g], m[g], q[g], a0[g], a1[g], a2[g]);
-    }
-#pragma unroll
-    for (int g = 0; g < BN_MAXG; ++g) {
-        red[t0][g][0] = n[g];
-        red[t0][g][1] = m[g];
-        red[t0][g][2] = q[g];
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float n2 = __shfl_down(gn, off), m2 = __shfl_down(gm, off), q2 = __shfl_down(gq, off);
+            if (lane + off < 64) wf_merge3(gn, gm, gq, n2, m2, q2);
+        }
+        if (lane == 0) {
+            fin[g][0] = gn;
+            fin[g][1] = gm;
+            fin[g][2] = gq;
+        }
     }
     __syncthreads();
+    float n[BN_MAXG], m[BN_MAXG], q[BN_MAXG];
 #pragma unroll
-    for (int off = 128; off >= 1; off >>= 1) {
-        if (t0 < off) {
-#pragma unroll
-            for (int g = 0; g < BN_MAXG; ++g) {
-                wf_merge3(n[g], m[g], q[g], red[t0 + off][g][0], red[t0 + off][g][1], red[t0 + off][g][2]);
-                red[t0][g][0] = n[g];
-                red[t0][g][1] = m[g];
-                red[t0][g][2] = q[g];
-            }
-        }
-        __syncthreads();
+    for (int g = 0; g < BN_MAXG; ++g) {
+        n[g] = g < groups ? fin[g][0] : 0.f;
+        m[g] = g < groups ? fin[g][1] : 0.f;
+        q[g] = g < groups ? fin[g][2] : 0.f;
     }
     if (t0 == 0) {
         float rmean = rm ? rm[c] : 0.f, rvar = rv ? rv[c] : 0.f;
