@@ -354,11 +354,13 @@ def fused_reduce_case(dev, K=16, B=2, size=32, wseed=3, tol=2e-5):
             ops.BN_FUSE_REDUCE = fuse
             rs = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}
             m.zero_grad(set_to_none=True)
-            c0 = cnt()
+            c0, u0 = cnt(), ops.HOST_COUNTERS["bn_prereduced"]
             loss = ops.mse_loss(m(x), t)
             loss.backward()
             ops.wgrad_fence()
             launches[fuse] = cnt() - c0
+            # every fused launch's sums are USED by the producing layer's backward (address and version of dz as the launch left them)
+            assert ops.HOST_COUNTERS["bn_prereduced"] - u0 == launches[fuse], (ops.HOST_COUNTERS["bn_prereduced"] - u0, launches[fuse])
             grads[fuse] = {n: p.grad.detach().cpu().clone() for n, p in m.named_parameters() if p.grad is not None}
             m.load_state_dict({**m.state_dict(), **rs})        # the second step starts from the same running statistics
     finally:
@@ -438,4 +440,49 @@ def g15_case(dev, path, batch_frames, slack=2.0, floor=5e-3):
         assert O.max_rel(sd[k + ".running_mean"].cpu(), torch.from_numpy(g["rm/" + k])) < 1e-4, k
         assert O.max_rel(sd[k + ".running_var"].cpu(), torch.from_numpy(g["rv/" + k])) < 1e-4, k
     assert int(sd["backbone.bn1.num_batches_tracked"]) == int(g["nbt/backbone.bn1"]) == T
+    return worst
+
+
+def tapped_block_output_case(dev, planes=32, B=2, size=12, tol=2e-5):
+    """Two identity Bottlenecks in a row with the tensor BETWEEN them also feeding the loss (a tap without a hook): the second
+    block's conv1 launch reduces the first block's bn3 sums from ITS data gradient, but autograd adds the tap's gradient to that
+    tensor afterwards (in place or into a new one) — the first block must notice (address + version of dz) and reduce again.
+    Gradients with the fused reduction on equal those with it off; an untapped run proves the fused path is otherwise taken."""
+    from unipose_amd import _C, ops
+    from unipose_amd.modules import Bottleneck
+    torch.manual_seed(5)
+    b1, b2 = Bottleneck(4 * planes, planes).to(dev).train(), Bottleneck(4 * planes, planes).to(dev).train()
+    x0 = torch.randn(B, size, size, 4 * planes)
+    w0 = torch.randn(B, size, size, 4 * planes)
+    cnt = lambda: int(_C.lib().up_conv_counter(b"glds32_bnred"))
+
+    def run(fuse, tapped):
+        prev, ops.BN_FUSE_REDUCE = ops.BN_FUSE_REDUCE, fuse
+        try:
+            for b in (b1, b2):
+                b.zero_grad(set_to_none=True)
+            x = x0.clone().to(dev).requires_grad_(True)         # the modules' activations are NHWC tensors
+            c0 = cnt()
+            t = b1(x)
+            out = b2(t)
+            loss = out.sum() + ((t * w0.to(dev)).sum() if tapped else 0.0)
+            loss.backward()
+            ops.wgrad_fence()
+            g = {f"b{i}.{n}": p.grad.detach().cpu().clone() for i, b in ((1, b1), (2, b2)) for n, p in b.named_parameters()}
+            g["x"] = x.grad.detach().cpu().clone()
+            return g, cnt() - c0
+        finally:
+            ops.BN_FUSE_REDUCE = prev
+
+    g_ref, n_ref = run(False, True)
+    u0 = ops.HOST_COUNTERS["bn_prereduced"]
+    g_fused, n_fused = run(True, True)
+    used = ops.HOST_COUNTERS["bn_prereduced"] - u0
+    # five fused launches (b1: conv2, conv3; b2: conv1 for b1.bn3, conv2, conv3), four of them usable: b1.bn3's dz got the tap's gradient
+    assert n_ref == 0 and n_fused == 5 and used == 4, (n_ref, n_fused, used)
+    u0 = ops.HOST_COUNTERS["bn_prereduced"]
+    _, n_plain = run(True, False)
+    assert n_plain == 5 and ops.HOST_COUNTERS["bn_prereduced"] - u0 == 5
+    worst = max((O.max_rel(g_fused[k], g_ref[k]), k) for k in g_ref)
+    assert worst[0] < tol, worst
     return worst

@@ -19,6 +19,10 @@ def test_bn_backward_reduction_fused_into_data_gradients_emu(emu_backend):
     mc.fused_reduce_case(emu_backend, size=32)
 
 
+def test_tap_between_blocks_falls_back_to_the_separate_reduction_emu(emu_backend):
+    print(mc.tapped_block_output_case(emu_backend))
+
+
 def test_second_step_repack_and_counters_emu(emu_backend):
     mc.second_step_case(emu_backend)
 

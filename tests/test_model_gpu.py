@@ -98,6 +98,10 @@ def test_g15_lstm_train_368_vs_reference_golden(golden_dir, batch_frames):
     print("g15 worst gradient distance / bound:", worst)
 
 
+def test_tap_between_blocks_falls_back_to_the_separate_reduction_gpu():
+    print(mc.tapped_block_output_case(DEV, planes=64, B=4, size=23))
+
+
 def test_bn_backward_reduction_fused_into_data_gradients_gpu():
     launches, worst = mc.fused_reduce_case(DEV, B=8, size=128)
     print("fused BatchNorm-backward reductions per step:", launches, "worst gradient distance fused vs separate:", worst)

@@ -26,6 +26,11 @@ def _kaiming_all(module: nn.Module):
             nn.init.zeros_(m.bias)
 
 
+# (module-wide hooks registered through torch.nn.modules.module.register_module_forward_hook see every block's output too)
+_GLOBAL_FWD_HOOKS = getattr(torch.nn.modules.module, "_global_forward_hooks", {})
+_GLOBAL_PRE_HOOKS = getattr(torch.nn.modules.module, "_global_forward_pre_hooks", {})
+
+
 class Bottleneck(nn.Module):
     """resnet.py:5-42.  Three fused conv+BN(+ReLU) stages; the residual add and the last ReLU ride in
     the third stage's apply pass (train) or convolution epilogue (inference)."""
@@ -54,7 +59,7 @@ class Bottleneck(nn.Module):
         # an attribute of the output tensor; nobody picks it up unless the next module is an identity Bottleneck.
         s_in = getattr(x, "_up_bnslot", None) if link is not None else None
         s1, s2, s3 = (ops.BnSlot(), ops.BnSlot(), ops.BnSlot()) if grad else (None, None, None)
-        if self._forward_hooks or self._forward_pre_hooks:
+        if self._forward_hooks or self._forward_pre_hooks or _GLOBAL_FWD_HOOKS or _GLOBAL_PRE_HOOKS:
             s_in = s3 = None          # a hook may use the block input / output elsewhere: keep autograd's generic path
         y = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True, link_in=link, slot_in=s_in, slot_out=s1)
         y = ops.conv_bn_act(y, self.conv2, self.bn2, relu=True, slot_in=s1, slot_out=s2)

@@ -300,20 +300,26 @@ class BnSlot:
     convolution that consumes z (resnet.py:25-33: bn1 -> relu -> conv2, bn2 -> relu -> conv3, and a block's output into the next
     identity block's conv1, whose kernel already adds the skip gradient): that launch produces dz and reduces sum(g), sum(g * xhat)
     per row tile in its epilogue (f32_glds.h BNRED), so the producer's backward runs finalize + apply only.
-    Contract: z has NO other consumer whose gradient autograd would add to dz (the engine may add in place, which no pointer
-    check can see).  The producer fills y / bits / mean / invstd in its forward; the consumer's backward fills partial and dz_ptr;
-    the producer's backward uses them once if dz is that very tensor, else falls back to its own reduction."""
-    __slots__ = ("y", "bits", "mean", "invstd", "C", "partial", "dz_ptr")
+    The wiring assumes z has no other consumer; should one exist after all (a tap taken between two blocks without a hook), autograd
+    adds its gradient to dz either into a new tensor (another address) or IN PLACE (same address, but the tensor's version counter
+    moves — the kernels' raw writes never touch it), so the producer's backward uses the sums only if dz has the address AND the
+    version the consumer's launch left, else it falls back to its own reduction.  The producer fills y / bits / mean / invstd in
+    its forward; the consumer's backward fills partial, dz_ptr and dz_version."""
+    __slots__ = ("y", "bits", "mean", "invstd", "C", "partial", "dz_ptr", "dz_version")
 
     def __init__(self, y=None, bits=None, mean=None, invstd=None, C=0):
         self.y, self.bits, self.mean, self.invstd, self.C = y, bits, mean, invstd, C
-        self.partial, self.dz_ptr = None, 0
+        self.partial, self.dz_ptr, self.dz_version = None, 0, -1
 
     def clear(self):
         self.y = self.bits = self.mean = self.invstd = self.partial = None
-        self.dz_ptr = 0
+        self.dz_ptr, self.dz_version = 0, -1
+
+    def matches(self, dz, y):
+        return self.partial is not None and self.dz_ptr == dz.data_ptr() and self.dz_version == dz._version and self.y is y
 
 
+HOST_COUNTERS = {"bn_prereduced": 0}     # how often a BatchNorm backward really started from a consumer's sums (tests)
 BN_FUSE_REDUCE = os.environ.get("UNIPOSE_BN_FUSE_REDUCE", "1") != "0"     # development switches (A/B runs)
 MASKED_ADDEND = os.environ.get("UNIPOSE_MASKED_ADDEND", "1") != "0"
 
@@ -371,7 +377,7 @@ def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev, add=None, bn_slo
         _C.check(_C.lib().up_conv2d_bwd_data_ex(C.byref(dd), dy.data_ptr(), wimg.data_ptr(), dx.data_ptr(), C.byref(ep), ex_math,
                                                 _stream(dy)), "conv2d_bwd_data_ex")
         if want_slot:
-            bn_slot.partial, bn_slot.dz_ptr = partial, dx.data_ptr()
+            bn_slot.partial, bn_slot.dz_ptr, bn_slot.dz_version = partial, dx.data_ptr(), dx._version
         return dx
     if dy.dtype == torch.bfloat16:
         if d.Kp % 32 or (add is not None and add.dtype != dy.dtype):
@@ -788,9 +794,10 @@ class ConvBnAct(Function):
             else:
                 acc = entry[2]
         so = ctx.slot_out
-        if so is not None and so.partial is not None and so.dz_ptr == dz.data_ptr() and so.y is y:
+        if so is not None and so.matches(dz, y):
             # the data-gradient launch that wrote dz already reduced this layer's sums (BnSlot): finalize + apply
-            partial, so.partial, so.dz_ptr = so.partial, None, 0
+            partial, so.partial, so.dz_ptr, so.dz_version = so.partial, None, 0, -1
+            HOST_COUNTERS["bn_prereduced"] += 1
             _C.check(L.up_bn_bwd_prereduced_t(dz.data_ptr(), d.ldy, _ptr(bits), y.data_ptr(), d.ldy, gamma.data_ptr(),
                                               coef[0].data_ptr(), coef[1].data_ptr(), int(ctx.relu), int(ctx.train), dy.data_ptr(),
                                               d.ldy, _ptr(dres), d.ldy, dgb[0].data_ptr(), dgb[1].data_ptr(),
