@@ -77,9 +77,10 @@ def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, 
         assert cnt("glds32") == c0 and cnt("wgrad_glds32") == w0, "glds32 = 0 still launched a direct-to-LDS kernel"
         for epi in forms:
             _tune(glds32=1, glds32_epi=epi, glds32_wgrad=1)
-            c0, e0, w0 = cnt("glds32"), cnt("glds32_epi1"), cnt("wgrad_glds32")
+            c0, e0, w0, wide0 = cnt("glds32"), cnt("glds32_epi1"), cnt("wgrad_glds32"), cnt("glds32_wide")
             y1, s1, dx1, dw1 = run()
             assert cnt("glds32") > c0, "the case never reached the direct-to-LDS kernel"
+            assert (cnt("glds32_wide") - wide0 == cnt("glds32") - c0) == (r * r > 32), "filters of more than 32 taps take the WIDE form, nothing else does"
             assert cnt("wgrad_glds32") > w0, "the weight gradient never reached the direct-to-LDS kernel"
             assert epi == 1 or cnt("glds32_epi1") == e0
             _same(dw1, dw0, "dw " + f"epi={epi}")
@@ -189,6 +190,16 @@ SPLIT = [
     dict(n=1, c=256, h=5, w=5, k=64, r=1, stride=1, pad=0, dil=1, tile_want=1, affine=True, relu=True, residual=True, cus=0),   # 1x1 8 slices, folded epilogue
 ]
 
+# more than 32 filter taps: the WIDE form of the forward / data-gradient kernel (separable row / column masks, every tap visited)
+# against the register-staged per-slice-tap path.  32-aligned input AND output channels (the data gradient's input is dy).
+WIDE = [
+    dict(n=1, c=32, h=12, w=12, k=64, r=11, stride=1, pad=5, dil=1, tile_want=1),                          # the video head's 11x11: 121 taps
+    dict(n=2, c=64, h=9, w=9, k=32, r=7, stride=1, pad=3, dil=1, tile_want=100000, add=True),              # 49 taps, two slices per tap, addend
+    dict(n=1, c=32, h=10, w=10, k=128, r=11, stride=1, pad=5, dil=1, tile_want=1, affine=True, relu=True),   # folded epilogue (inference head)
+    dict(n=2, c=32, h=8, w=8, k=32, r=7, stride=1, pad=6, dil=2, tile_want=1, stats=True),                  # dilated 7x7: dead rows / columns
+    dict(n=2, c=32, h=9, w=9, k=128, r=7, stride=1, pad=3, dil=1, tile_want=100000, cus=4),                 # K-split tail tiles over 49 x 1 slices
+]
+
 # weight gradient only: shapes the convolution cases above do not reach (unaligned channel counts, many taps, stride 2, both
 # stage forms: `cus` shrinks the chip so that the grid exceeds two workgroups per CU -> the one-stage form)
 WGRAD = [
@@ -237,6 +248,7 @@ BNRED = [
 
 # the real geometries of BASELINE configs[1] (368x368, B = 32) that carry the step (tile rule of the library: tile_want = 1500)
 FULL = [
+    dict(n=8, c=128, h=46, w=46, k=128, r=11, stride=1, pad=5, dil=1, tile_want=1500),                  # UniPose-LSTM head conv2 / conv3 at B = 8 (WIDE form)
     dict(n=32, c=256, h=23, w=23, k=256, r=3, stride=1, pad=1, dil=1, tile_want=1500, stats=True),      # layer3 conv2: 1060 tiles = 4 rounds + 36 K-split tails, tap-sorted
     dict(n=32, c=1024, h=23, w=23, k=256, r=1, stride=1, pad=0, dil=1, tile_want=1500, stats=True, add=True),   # layer3 conv1 (+ skip gradient in its data gradient)
     dict(n=32, c=256, h=23, w=23, k=1024, r=1, stride=1, pad=0, dil=1, tile_want=1500, stats=True),     # layer3 conv3: short reduction, 4240 tiles

@@ -20,6 +20,12 @@ def test_glds32_kernel_tail_split(emu_backend, case):
     g32.conv_ab(emu_backend, **case)
 
 
+@pytest.mark.parametrize("case", g32.WIDE, ids=_id)
+def test_glds32_kernel_filters_of_more_than_32_taps(emu_backend, case):
+    """the WIDE form (11x11 video head, 7x7): equal to the register-staged per-slice-tap kernel, element for element"""
+    g32.conv_ab(emu_backend, **case)
+
+
 @pytest.mark.parametrize("case", g32.BNRED, ids=_id)
 def test_bn_backward_reduction_fused_into_data_gradient(emu_backend, case):
     g32.bnred_case(emu_backend, **case)

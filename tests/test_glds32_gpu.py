@@ -17,7 +17,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("case", g32.SMALL + g32.SPLIT, ids=_id)
+@pytest.mark.parametrize("case", g32.SMALL + g32.SPLIT + g32.WIDE, ids=_id)
 def test_glds32_kernel_matches_register_staged_kernel(dev, case):
     g32.conv_ab(dev, **case)
 

@@ -1903,7 +1903,7 @@ static int g_glds = env_int("UP_GLDS", 1, 0);   // bf16 storage: direct-to-LDS k
 // fp32 forward / data gradient with operands HBM -> LDS by LDS-DMA (f32_glds.h, round 4): glds32 = 0 keeps the register-staged
 // igemm_kernel; glds32_epi: 1 = LDS-transposed 16-byte-store epilogue, 0 = igemm_epilogue
 static long long g_count_igemm = 0, g_count_glds32 = 0, g_count_glds32_epi1 = 0, g_count_glds32_bnred = 0;   // up_conv_counter
-static long long g_count_wgrad32 = 0, g_count_wgrad32_st1 = 0;
+static long long g_count_wgrad32 = 0, g_count_wgrad32_st1 = 0, g_count_glds32_wide = 0;
 static bool g_extras_dropped = false;   // a launch was asked for a masked addend / fused reduction on a kernel without them
 static int g_glds32 = env_int("UP_GLDS32", 1, 0);
 static int g_glds32_epi = env_int("UP_GLDS32_EPI", 1, 0);
@@ -2205,6 +2205,13 @@ static auto glds32_kernel(const IgemmArgs& a) -> void (*)(IgemmArgs) {
 }
 
 template <int BM, int BN>
+static auto glds32_wide_kernel(const IgemmArgs& a) -> void (*)(IgemmArgs) {
+    constexpr int OCC2 = (BM == 128 && BN == 128) ? 2 : (BM == 64 && BN == 64) ? 4 : 3;
+    if (glds32_epi1_ok(a)) return glds::igemm_glds32_kernel<BM, BN, false, 2, OCC2, 1, false, true>;
+    return glds::igemm_glds32_kernel<BM, BN, false, 2, OCC2, 0, false, true>;
+}
+
+template <int BM, int BN>
 static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     int ntm = cdiv(a.M, BM);
     a.ntn = cdiv(a.Ng, BN);
@@ -2215,7 +2222,10 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     // MODE 2 needs <= 32 taps (bit mask), no stride division and 32-bit element offsets
     const bool fast = aligned && a.taps <= 32 && a.divshift == 0 &&
                       (long long)a.H * a.W * a.ldx * ((long long)a.M / (a.P * a.Q) + 1) < (1ll << 31);
-    const bool use32 = glds32_eligible(a, fast);   // direct-to-LDS generation (f32_glds.h)
+    // filters of more than 32 taps (the video head's 11x11): the direct-to-LDS kernel's WIDE form (separable row / column masks)
+    const bool wide = aligned && a.taps > 32 && a.S <= 16 && a.taps / a.S <= 16 && a.divshift == 0 &&
+                      (long long)a.H * a.W * a.ldx * ((long long)a.M / (a.P * a.Q) + 1) < (1ll << 31);
+    const bool use32 = glds32_eligible(a, fast || wide);   // direct-to-LDS generation (f32_glds.h)
     ProfScope prof(use32 ? 28 + vbase / 2 : vbase + (aligned ? 0 : 1), 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st,
                    a.M, a.Ng, a.Ktot, a.nwg);
     // double-buffered LDS (one barrier per slice) for long reductions.  In isolation it is 3-5 % faster than the
@@ -2264,10 +2274,11 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
             grid = a.full_blocks + (a.nwg - a.full_blocks) * p;
         }
     }
-    if ((a.bn_partial || a.res_bits) && !(use32 && glds32_epi1_ok(a))) g_extras_dropped = true;
+    if ((a.bn_partial || a.res_bits) && !(use32 && glds32_epi1_ok(a) && !(wide && a.bn_partial))) g_extras_dropped = true;
     if (use32) {
-        kernel = glds32_kernel<BM, BN>(a);
+        kernel = wide ? glds32_wide_kernel<BM, BN>(a) : glds32_kernel<BM, BN>(a);
         ++g_count_glds32;
+        if (wide) ++g_count_glds32_wide;
         if (glds32_epi1_ok(a)) ++g_count_glds32_epi1;
         if (glds32_epi1_ok(a) && a.bn_partial) ++g_count_glds32_bnred;
     } else {
@@ -2327,6 +2338,7 @@ extern "C" long long up_conv_counter(const char* name) {
     if (!name) return -1;
     if (!strcmp(name, "igemm")) return g_count_igemm;
     if (!strcmp(name, "glds32")) return g_count_glds32;
+    if (!strcmp(name, "glds32_wide")) return g_count_glds32_wide;
     if (!strcmp(name, "glds32_epi1")) return g_count_glds32_epi1;
     if (!strcmp(name, "glds32_bnred")) return g_count_glds32_bnred;
     if (!strcmp(name, "wgrad_glds32")) return g_count_wgrad32;

@@ -313,11 +313,16 @@ struct Epi32 {
 // flight during the MFMAs; 1: single stage, 16 KB per 64x64 workgroup — the co-resident workgroups hide the load).
 // EPI: 0 = igemm_epilogue (dword stores from the accumulator layout), 1 = Epi32 (LDS-transposed, 16-byte stores).
 // BNRED (EPI 1): BatchNorm-backward sums of the producing layer in the epilogue (a.bn_*).
-template <int BM, int BN, bool PERM, int ST = 2, int OCC = 4, int EPI = 1, bool BNRED = false>
+// WIDE: filters of more than 32 taps (the video head's 11x11, uniposeLSTM.py:43-45).  The per-row validity is kept separably —
+//       bit r: filter row r reads a real pixel row, bit 16 + s: filter column s a real column (R, S <= 16) — instead of one bit per
+//       tap, every tap is visited (no tile-level skipping: with pad = 5 on 46x46 maps nearly every tap is live for some row of a
+//       tile), no tap-sorted rows.  Same slice order (tap-major, 32 channels per slice) as the register-staged per-slice-tap path.
+template <int BM, int BN, bool PERM, int ST = 2, int OCC = 4, int EPI = 1, bool BNRED = false, bool WIDE = false>
 __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
     using G = GeomF<BM, BN, ST>;
     static_assert(ST == 1 || ST == 2, "one or two LDS stages");
     static_assert(!BNRED || EPI == 1, "the fused reduction lives in the LDS-transposed epilogue");
+    static_assert(!WIDE || (!PERM && !BNRED), "the > 32-tap form has no tap-sorted rows and no fused reduction");
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int NA = BM / (4 * G::RPI), NB = BN / (4 * G::RPI);   // LDS-DMA instructions per wave, slice and operand
     constexpr int UNITS = BM * BN / 1024;
@@ -395,7 +400,11 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
             for (int r = 0; r < R; ++r) hm |= ((unsigned)(hb + r * a.tapstep) < (unsigned)a.H) ? (1u << r) : 0u;
             for (int s = 0; s < a.S; ++s) wmk |= ((unsigned)(wb + s * a.tapstep) < (unsigned)a.W) ? (1u << s) : 0u;
             mk = 0u;
-            for (int r = 0; r < R; ++r) mk |= ((hm >> r) & 1u) ? (wmk << (r * a.S)) : 0u;
+            if constexpr (WIDE) {
+                mk = hm | (wmk << 16);
+            } else {
+                for (int r = 0; r < R; ++r) mk |= ((hm >> r) & 1u) ? (wmk << (r * a.S)) : 0u;
+            }
         }
         if (m >= a.M) mk = 0u;
         roffA[i] = src * a.ldx * 4 + ((slot ^ G::swz(row)) << 4);
@@ -405,23 +414,29 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
     // the K loop visits the slices of the filter taps that are live for at least one row of the tile
     const unsigned all_taps = a.taps >= 32 ? 0xffffffffu : ((1u << a.taps) - 1u);
     unsigned live = all_taps;
-    if (a.taps > 1 && !a.no_tap_skip) {
+    if constexpr (!WIDE) {
+        if (a.taps > 1 && !a.no_tap_skip) {
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) tile_taps |= __shfl_xor(tile_taps, off);
-        if (lane == 0) wmask[wave] = tile_taps;
-        __syncthreads();
-        live = (unsigned)uniform((int)(wmask[0] | wmask[1] | wmask[2] | wmask[3]));
-        if (live == 0u) live = all_taps;
+            for (int off = 32; off >= 1; off >>= 1) tile_taps |= __shfl_xor(tile_taps, off);
+            if (lane == 0) wmask[wave] = tile_taps;
+            __syncthreads();
+            live = (unsigned)uniform((int)(wmask[0] | wmask[1] | wmask[2] | wmask[3]));
+            if (live == 0u) live = all_taps;
+        }
     }
     const int spt = a.Cp / 32;
-    int nsl = __builtin_popcount(live) * spt;
+    int nsl = (WIDE ? a.taps : __builtin_popcount(live)) * spt;
     unsigned rest = live;
-    int tap = __builtin_ctz(rest), cs = 0;
+    int tap = WIDE ? 0 : __builtin_ctz(rest), cs = 0;
     if (split) {   // slices [kb, ke) of the tile's live slices
         const int kb = (int)((long long)nsl * part / a.parts), ke = (int)((long long)nsl * (part + 1) / a.parts);
         const int skip = kb / spt;
-        for (int t = 0; t < skip; ++t) rest &= rest - 1u;
-        tap = rest ? __builtin_ctz(rest) : 0;
+        if constexpr (WIDE) {
+            tap = skip;
+        } else {
+            for (int t = 0; t < skip; ++t) rest &= rest - 1u;
+            tap = rest ? __builtin_ctz(rest) : 0;
+        }
         cs = kb - skip * spt;
         nsl = ke - kb;
     }
@@ -434,15 +449,19 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
         const int delta = ((r * a.tapstep) * a.W + sx * a.tapstep) * a.ldx * 4 + cs * G::ROWB;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const bool ok = (tmA[i] >> tap) & 1u;
+            const bool ok = WIDE ? (((tmA[i] >> r) & (tmA[i] >> (16 + sx))) & 1u) != 0u : ((tmA[i] >> tap) & 1u) != 0u;
             load16_to_lds(rsA, ok ? (uint32_t)(roffA[i] + delta) : OOB, As + (wave + 4 * i) * 1024);
         }
         if (!b_issued) issueB(stage, tap, cs);
         b_issued = false;
         if (++cs == spt) {   // next live tap
             cs = 0;
-            rest &= rest - 1u;
-            tap = rest ? __builtin_ctz(rest) : 0;
+            if constexpr (WIDE) {
+                ++tap;
+            } else {
+                rest &= rest - 1u;
+                tap = rest ? __builtin_ctz(rest) : 0;
+            }
         }
     };
 
