@@ -486,3 +486,86 @@ def tapped_block_output_case(dev, planes=32, B=2, size=12, tol=2e-5):
     worst = max((O.max_rel(g_fused[k], g_ref[k]), k) for k in g_ref)
     assert worst[0] < tol, worst
     return worst
+
+
+def projection_block_case(dev, inplanes=64, planes=32, stride=2, dilation=1, B=2, size=10, tol=5e-5):
+    """A projection Bottleneck (resnet.py:22-42 with `downsample`): the block input feeds conv1 and the down-sampling convolution;
+    the latter's data gradient is handed to conv1's launch (ops.GradLink via link_dx) instead of autograd adding the two.  Against
+    the same block written with torch.nn.functional on the CPU in float64: output, input gradient, every parameter gradient; the
+    host counter proves the hand-over happened, a run with the input ALSO feeding the loss directly (a third gradient path that
+    autograd must still add) proves nothing is lost."""
+    import torch.nn.functional as F
+    from unipose_amd import ops
+    from unipose_amd.modules import Bottleneck
+    torch.manual_seed(11)
+    ds = torch.nn.Sequential(torch.nn.Conv2d(inplanes, 4 * planes, 1, stride=stride, bias=False), torch.nn.BatchNorm2d(4 * planes))
+    blk = Bottleneck(inplanes, planes, stride=stride, dilation=dilation, downsample=ds)
+    with torch.no_grad():
+        for mod in blk.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.normal_(0, 0.2)
+    ref = {n: p.detach().double().clone().requires_grad_(True) for n, p in blk.named_parameters()}
+    x0 = torch.randn(B, size, size, inplanes)
+    g0 = torch.randn(B, (size - 1) // stride + 1, (size - 1) // stride + 1, 4 * planes)
+    w0 = torch.randn_like(x0)
+    blk = blk.to(dev).train()
+
+    def bn(t, pre):
+        return F.batch_norm(t, None, None, ref[pre + ".weight"], ref[pre + ".bias"], True, 0.0, 1e-5)
+
+    for extra in (False, True):
+        blk.zero_grad(set_to_none=True)
+        for p in ref.values():
+            p.grad = None
+        x = x0.clone().to(dev).requires_grad_(True)
+        h0 = ops.HOST_COUNTERS["dx_handed_over"]
+        out = blk(x)
+        loss = (out * g0.to(dev)).sum() + ((x * w0.to(dev)).sum() if extra else 0.0)
+        loss.backward()
+        ops.wgrad_fence()
+        assert ops.HOST_COUNTERS["dx_handed_over"] == h0 + (1 if ops.DX_HANDOVER else 0)
+        xr = x0.double().permute(0, 3, 1, 2).clone().requires_grad_(True)
+        y = F.relu(bn(F.conv2d(xr, ref["conv1.weight"]), "bn1"))
+        y = F.relu(bn(F.conv2d(y, ref["conv2.weight"], stride=stride, padding=dilation, dilation=dilation), "bn2"))
+        y = bn(F.conv2d(y, ref["conv3.weight"]), "bn3")
+        r = bn(F.conv2d(xr, ref["downsample.0.weight"], stride=stride), "downsample.1")
+        outr = F.relu(y + r)
+        lr = (outr * g0.double().permute(0, 3, 1, 2)).sum() + ((xr * w0.double().permute(0, 3, 1, 2)).sum() if extra else 0.0)
+        lr.backward()
+        assert O.max_rel(out.detach().cpu().permute(0, 3, 1, 2), outr.detach().float()) < tol
+        errs = {"x": O.max_rel(x.grad.cpu().permute(0, 3, 1, 2), xr.grad.float())}
+        for n, p in blk.named_parameters():
+            errs[n] = O.max_rel(p.grad.cpu(), ref[n].grad.float())
+        worst = max((e, n) for n, e in errs.items())
+        assert worst[0] < tol, (extra, {n: f"{e:.1e}" for n, e in errs.items()})
+    return worst
+
+
+def projection_block_ab_case(dev, inplanes, planes, stride, dilation, B, size):
+    """The same projection block at network size: hand-over on against off (autograd adds the two data gradients of the block
+    input).  Both add the same two fp32 tensors element by element, so every gradient is EQUAL; a float64 reference is no yardstick
+    at this size (a ReLU decision of the block output within round-off of zero moves a bias gradient by 1 %)."""
+    from unipose_amd import ops
+    from unipose_amd.modules import Bottleneck
+    torch.manual_seed(11)
+    ds = torch.nn.Sequential(torch.nn.Conv2d(inplanes, 4 * planes, 1, stride=stride, bias=False), torch.nn.BatchNorm2d(4 * planes))
+    blk = Bottleneck(inplanes, planes, stride=stride, dilation=dilation, downsample=ds).to(dev).train()
+    x0 = torch.randn(B, size, size, inplanes)
+    g0 = torch.randn(B, (size - 1) // stride + 1, (size - 1) // stride + 1, 4 * planes).to(dev)
+    res = {}
+    prev = ops.DX_HANDOVER
+    try:
+        for on in (True, False):
+            ops.DX_HANDOVER = on
+            blk.zero_grad(set_to_none=True)
+            x = x0.clone().to(dev).requires_grad_(True)
+            h0 = ops.HOST_COUNTERS["dx_handed_over"]
+            (blk(x) * g0).sum().backward()
+            ops.wgrad_fence()
+            assert ops.HOST_COUNTERS["dx_handed_over"] == h0 + (1 if on else 0)
+            res[on] = {"x": x.grad.detach().clone(), **{n: p.grad.detach().clone() for n, p in blk.named_parameters()}}
+    finally:
+        ops.DX_HANDOVER = prev
+    for n in res[True]:
+        assert torch.equal(res[True][n], res[False][n]), n

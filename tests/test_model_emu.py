@@ -23,6 +23,18 @@ def test_tap_between_blocks_falls_back_to_the_separate_reduction_emu(emu_backend
     print(mc.tapped_block_output_case(emu_backend))
 
 
+import pytest
+
+
+@pytest.mark.parametrize("stride,dilation", [(2, 1), (1, 1), (1, 2)])
+def test_projection_block_hands_its_data_gradient_to_conv1_emu(emu_backend, stride, dilation):
+    print(mc.projection_block_case(emu_backend, stride=stride, dilation=dilation))
+
+
+def test_projection_block_hand_over_equals_autograd_add_emu(emu_backend):
+    mc.projection_block_ab_case(emu_backend, 64, 32, 2, 1, B=2, size=10)
+
+
 def test_second_step_repack_and_counters_emu(emu_backend):
     mc.second_step_case(emu_backend)
 

@@ -98,6 +98,15 @@ def test_g15_lstm_train_368_vs_reference_golden(golden_dir, batch_frames):
     print("g15 worst gradient distance / bound:", worst)
 
 
+@pytest.mark.parametrize("stride,dilation,inplanes,planes,size", [(2, 1, 256, 128, 46), (1, 1, 64, 64, 23), (1, 2, 1024, 512, 23)])
+def test_projection_block_hands_its_data_gradient_to_conv1_gpu(stride, dilation, inplanes, planes, size):
+    mc.projection_block_ab_case(DEV, inplanes, planes, stride, dilation, B=4, size=size)
+
+
+def test_projection_block_vs_float64_gpu():
+    print(mc.projection_block_case(DEV, stride=2))          # the emulator's small case (few ReLU decisions near zero)
+
+
 def test_tap_between_blocks_falls_back_to_the_separate_reduction_gpu():
     print(mc.tapped_block_output_case(DEV, planes=64, B=4, size=23))
 

@@ -61,10 +61,14 @@ class Bottleneck(nn.Module):
         s1, s2, s3 = (ops.BnSlot(), ops.BnSlot(), ops.BnSlot()) if grad else (None, None, None)
         if self._forward_hooks or self._forward_pre_hooks or _GLOBAL_FWD_HOOKS or _GLOBAL_PRE_HOOKS:
             s_in = s3 = None          # a hook may use the block input / output elsewhere: keep autograd's generic path
-        y = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True, link_in=link, slot_in=s_in, slot_out=s1)
+        # projection blocks: x feeds conv1 AND the down-sampling convolution; the latter's data gradient (computed first: its
+        # node is younger) rides into conv1's data-gradient epilogue instead of autograd adding the two (a 277 MB add at layer2.0)
+        link_ds = ops.GradLink() if self.downsample is not None and x.requires_grad and grad else None
+        y = ops.conv_bn_act(x, self.conv1, self.bn1, relu=True, link_in=link if link is not None else link_ds, slot_in=s_in,
+                            slot_out=s1)
         y = ops.conv_bn_act(y, self.conv2, self.bn2, relu=True, slot_in=s1, slot_out=s2)
         if self.downsample is not None:
-            x = ops.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False)
+            x = ops.conv_bn_act(x, self.downsample[0], self.downsample[1], relu=False, link_dx=link_ds)
         out = ops.conv_bn_act(y, self.conv3, self.bn3, relu=True, residual=x, link_out=link, slot_in=s2, slot_out=s3)
         if s3 is not None and s3.y is not None:
             out._up_bnslot = s3

@@ -319,9 +319,11 @@ class BnSlot:
         return self.partial is not None and self.dz_ptr == dz.data_ptr() and self.dz_version == dz._version and self.y is y
 
 
-HOST_COUNTERS = {"bn_prereduced": 0}     # how often a BatchNorm backward really started from a consumer's sums (tests)
+# tests: how often a BatchNorm backward really started from a consumer's sums / a projection's data gradient rode in conv1's launch
+HOST_COUNTERS = {"bn_prereduced": 0, "dx_handed_over": 0}
 BN_FUSE_REDUCE = os.environ.get("UNIPOSE_BN_FUSE_REDUCE", "1") != "0"     # development switches (A/B runs)
 MASKED_ADDEND = os.environ.get("UNIPOSE_MASKED_ADDEND", "1") != "0"
+DX_HANDOVER = os.environ.get("UNIPOSE_DX_HANDOVER", "1") != "0"           # projection blocks: downsample's dx rides in conv1's launch
 
 
 def dgrad_extras_tiles(d: _C.ConvDesc, x_shape, dtype) -> int:
@@ -669,7 +671,7 @@ class ConvBnAct(Function):
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, rm, rv, cfg: ConvCfg, relu: bool, train: bool, eps: float,
-                momentum: float, link_in=None, link_out=None, slot_in=None, slot_out=None):
+                momentum: float, link_in=None, link_out=None, slot_in=None, slot_out=None, link_dx=None):
         L = _C.lib()
         dev = x.device
         k = weight.shape[0]
@@ -742,6 +744,9 @@ class ConvBnAct(Function):
             link_in.armed = True       # this node will compute a data gradient: the producer may hand over
             link_in.masked_ok = MASKED_ADDEND and dgrad_extras_tiles(d, x.shape, x.dtype) > 0
         # BatchNorm-backward reduction by the consumer's data gradient (BnSlot): this layer as the producer ...
+        # link_dx: this node's OWN data gradient is handed to the node behind the link (the block's first convolution, which reads
+        # the same x: resnet.py:36-37 downsample(x) next to conv1(x)) instead of to autograd, whose engine would add the two
+        ctx.link_dx = link_dx if (DX_HANDOVER and link_dx is not None and ctx.needs_input_grad[0]) else None
         ctx.slot_out = None
         if slot_out is not None:
             slot_out.clear()
@@ -826,13 +831,17 @@ class ConvBnAct(Function):
             dx = conv_bwd_data_raw(dy, weight, d, x.shape, x.device, add, bn_slot=si, add_bits=add_bits)
         else:
             dx = add if add_bits is None else None      # (armed links belong to nodes that compute a data gradient)
+        ld = ctx.link_dx
+        if ld is not None and ld.armed and dx is not None and ld.grad is None:
+            ld.grad, dx = dx, None                        # the consumer has not run yet (it disarms the link when it does): it adds
+            HOST_COUNTERS["dx_handed_over"] += 1
         if masked_skip is not None:                       # unmasked dz + sign bits: the first convolution masks
             ctx.link_out.grad, ctx.link_out.bits = masked_skip
         elif ctx.link_out is not None and ctx.link_out.armed and dres is not None:
             ctx.link_out.grad, dres = dres, None          # the block's first convolution adds it to ITS dx
         dw = conv_bwd_weight(x, dy, weight, d, False)[0] if ctx.needs_input_grad[1] else None   # frozen weight: no launch
         return dx, dw, (dgb[0] if hand_over else None), (dgb[1] if hand_over else None), dres, None, None, None, None, None, \
-            None, None, None, None, None, None
+            None, None, None, None, None, None, None
 
 
 def conv_bn_act_eval_fused(x, weight, gamma, beta, rm, rv, cfg, relu, residual=None, eps=BN_EPS_DEFAULT):
@@ -889,7 +898,7 @@ class FoldedBatchNorm(torch.nn.Identity):
     convolution's weight and bias (inference export).  No parameters, no buffers, inference only."""
 
 
-def conv_bn_act(x, conv, bn, relu=True, residual=None, link_in=None, link_out=None, slot_in=None, slot_out=None):
+def conv_bn_act(x, conv, bn, relu=True, residual=None, link_in=None, link_out=None, slot_in=None, slot_out=None, link_dx=None):
     """Dispatch on (bn.training, grad mode) exactly like nn.BatchNorm2d would.  link_in / link_out: see GradLink;
     slot_in / slot_out: see BnSlot (slot_in: the slot the producer of x filled; slot_out: filled here for x's ONE consumer)."""
     weight, cfg = conv.weight, ConvCfg(conv.stride[0], conv.padding[0], conv.dilation[0])
@@ -916,7 +925,7 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, link_in=None, link_out=No
         mom = 0.0
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     return ConvBnAct.apply(x, weight, bn.weight, bn.bias, residual, rm, rv, cfg, relu, train, bn.eps, mom,
-                           link_in, link_out, slot_in, slot_out)
+                           link_in, link_out, slot_in, slot_out, link_dx)
 
 
 def conv_bias_act(x, conv, relu=False, out_f32=False):
