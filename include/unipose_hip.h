@@ -147,6 +147,14 @@ int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const float* w_dg
  *    dz * [z > 0] as a tensor of its own (threshold_backward's output).
  * up_conv2d_bwd_data_tiles_math(d, math) = rows of `partial`, and > 0 exactly when the launch of `d` runs on a kernel that
  * supports the two extras (math = UP_MATH_F32 or UP_MATH_BF16S); with 0 use the plain entry points (add only). */
+/* Row groups (ABI 8): `groups` equal batches stacked along N that must keep separate BatchNorm statistics (the frames of the video
+ * model's batched trunk).  Every group is tiled on its own, so no row tile straddles two groups and stats is
+ * [groups][up_conv_stats_tiles_grouped(d, groups)][K][3] — the layout up_bn_finalize_groups merges; no extra pass over y
+ * (up_bn_batch_stats_t) is needed.  fp32 only, direct-to-LDS kernel with the LDS-transposed epilogue: up_conv_stats_tiles_grouped
+ * returns 0 and up_conv2d_fwd_grouped UP_ERR_UNSUPPORTED (nothing launched) otherwise. */
+int up_conv_stats_tiles_grouped(const up_conv_desc* d, int groups);
+int up_conv2d_fwd_grouped(const up_conv_desc* d, const float* x, const float* w_fwd, float* y, float* stats, int groups, void* stream);
+
 typedef struct {
     const void* y;             /* raw convolution output of the producing layer, [rows][ld] (element type of dx)  */
     const uint32_t* relu_bits; /* sign bits of z (bit row * C + c), NULL when the layer has no ReLU               */

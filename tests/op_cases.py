@@ -458,7 +458,8 @@ def bn_rows_ab_case(dev, n, c, h, w, k, relu=True, residual=True, dtype=torch.fl
             assert err < tol, (what, err)
 
 
-def bn_groups_case(dev, groups, n, c, h, w, k, r=1, relu=True, residual=False, dtype=torch.float32, seed=0, tol=5e-5):
+def bn_groups_case(dev, groups, n, c, h, w, k, r=1, relu=True, residual=False, dtype=torch.float32, seed=0, tol=5e-5,
+                   grouped_fwd=False):
     """conv -> BatchNorm inside ops.bn_groups(G) on a batch of G*n images (group-major) against G separate train-mode calls
     of torch's conv + BatchNorm on the G sub-batches with the SAME modules: outputs, data / residual gradients per group,
     parameter gradients summed over the groups, running statistics after G sequential momentum updates, the batch counter."""
@@ -504,8 +505,15 @@ def bn_groups_case(dev, groups, n, c, h, w, k, r=1, relu=True, residual=False, d
         return o.to(dtype).to(dev)
     xd = to_dev(x, c).requires_grad_(True)
     rd = to_dev(res, k).requires_grad_(True) if residual else None
-    with ops.bn_groups(groups):
-        y = ops.conv_bn_act(xd, conv_d, bn_d, relu=relu, residual=rd)
+    from unipose_amd import _C
+    g0 = int(_C.lib().up_conv_counter(b"glds32_grouped"))
+    prev, ops.GROUPED_TILES = ops.GROUPED_TILES, grouped_fwd        # forward statistics from per-group tiles (off by default)
+    try:
+        with ops.bn_groups(groups):
+            y = ops.conv_bn_act(xd, conv_d, bn_d, relu=relu, residual=rd)
+    finally:
+        ops.GROUPED_TILES = prev
+    took_grouped_tiles = int(_C.lib().up_conv_counter(b"glds32_grouped")) > g0
     yo = nchw(y, k)
     yr_fwd = F.relu(yr) if relu else yr
     if relu:
@@ -527,6 +535,7 @@ def bn_groups_case(dev, groups, n, c, h, w, k, r=1, relu=True, residual=False, d
     # bf16 storage: the group statistics are taken from the STORED (rounded) convolution output
     bad = {k_: v for k_, v in errs.items() if not v < (tol if not bf else 2e-3 if k_ in ("rm", "rv") else 3e-2)}
     assert not bad, (bad, errs)
+    errs["grouped_tiles"] = took_grouped_tiles
     return errs
 
 

@@ -301,8 +301,23 @@ def test_grouped_batchnorm_matches_separate_calls(emu_backend, cfg):
     """ops.bn_groups(G): one convolution over G*n images, BatchNorm statistics / running updates / gradients of G calls"""
     import torch
     groups, n, c, h, w, k, r, relu, residual, dt = cfg
-    oc.bn_groups_case(emu_backend, groups, n, c, h, w, k, r=r, relu=relu, residual=residual,
-                      dtype=torch.float32 if dt == "f32" else torch.bfloat16)
+    e = oc.bn_groups_case(emu_backend, groups, n, c, h, w, k, r=r, relu=relu, residual=residual,
+                          dtype=torch.float32 if dt == "f32" else torch.bfloat16)
+    assert not e["grouped_tiles"]        # <= 256 rows per group: float64 statistics from y, plain tiling
+
+
+@pytest.mark.parametrize("cfg", [
+    (3, 2, 32, 13, 11, 32, 1, True, False),      # 286 rows per group = 4 tiles of 64 + 30 rows: a plain tiling would straddle
+    (2, 3, 32, 10, 10, 64, 3, True, True),       # 3x3: tap-sorted rows inside every group, residual
+    (5, 1, 64, 17, 16, 128, 1, False, True),     # five groups of ONE image (272 rows), no ReLU, two K slices
+    (2, 2, 32, 12, 12, 136, 3, True, False),     # N = 136: ragged column tile; 288 rows per group
+])
+def test_grouped_batchnorm_tiles_per_group(emu_backend, cfg):
+    """more than 256 rows per group in fp32: every group is tiled on its own by the direct-to-LDS kernel (up_conv2d_fwd_grouped), the
+    epilogue's Welford partials are per group and the extra statistics pass over y is gone — same checks against G torch calls"""
+    groups, n, c, h, w, k, r, relu, residual = cfg
+    e = oc.bn_groups_case(emu_backend, groups, n, c, h, w, k, r=r, relu=relu, residual=residual, grouped_fwd=True)
+    assert e["grouped_tiles"]
 
 
 @pytest.mark.parametrize("groups,rows,c", [(3, 40000, 8), (5, 17 * 256 - 7, 12), (8, 300, 4)])

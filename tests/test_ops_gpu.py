@@ -188,8 +188,11 @@ def test_bn_row_strided_passes_match_flat_passes(cfg):
 ])
 def test_grouped_batchnorm_matches_separate_calls(cfg):
     groups, n, c, h, w, k, r, relu, residual, dt = cfg
-    oc.bn_groups_case(DEV, groups, n, c, h, w, k, r=r, relu=relu, residual=residual,
-                      dtype=torch.float32 if dt == "f32" else torch.bfloat16)
+    for fwd in (False, True):
+        e = oc.bn_groups_case(DEV, groups, n, c, h, w, k, r=r, relu=relu, residual=residual,
+                              dtype=torch.float32 if dt == "f32" else torch.bfloat16, grouped_fwd=fwd)
+        # fp32 with 4-aligned output channels: every group tiled on its own (4232 rows per group = 66 tiles of 64 + 8 rows)
+        assert e["grouped_tiles"] == (fwd and dt == "f32" and k % 4 == 0)
 
 
 @pytest.mark.parametrize("groups,rows,c", [(3, 40000, 8), (5, 4232, 256), (8, 67712, 64)])

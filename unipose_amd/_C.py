@@ -62,6 +62,8 @@ SIGNATURES = {
     "up_conv2d_bwd_data_tiles": (_i, [_D]),
     "up_conv2d_bwd_data_tiles_math": (_i, [_D, _i]),
     "up_conv2d_bwd_data_ex": (_i, [_D, _p, _p, _p, C.POINTER(DgradEpilogue), _i, _p]),
+    "up_conv_stats_tiles_grouped": (_i, [_D, _i]),
+    "up_conv2d_fwd_grouped": (_i, [_D, _p, _p, _p, _p, _i, _p]),
     "up_bn_bwd_prereduced_t": (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _i64, _i,
                                     _i, _p]),
     "up_pack_weights_bf16": (_i, [_D, _p, _p, _p, _p, _p, _p]),

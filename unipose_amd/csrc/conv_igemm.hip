@@ -159,6 +159,13 @@ struct IgemmArgs {
     const float* bn_invstd;
     float* bn_partial;
     int bn_ld, bn_C;
+    // row GROUPS (f32_glds.h; the video model's batched trunk, ops.bn_groups): the M rows are `M / grp_rows` groups of grp_rows
+    // rows (the frames of a clip batch) and every group is tiled on its own — tile mt = (group mt / grp_tiles, tile mt % grp_tiles
+    // of that group), rows past the group's end masked — so that no row tile straddles two groups and the per-tile BatchNorm
+    // partials (forward statistics, fused backward sums) belong to ONE group.  grp_rows = 0: one group, tiles over all M rows.
+    // bn_grp_stride: floats between two groups' bn_mean / bn_invstd vectors.
+    int grp_rows, grp_tiles, bn_grp_stride;
+    FastDiv fGrpTiles;
 };
 
 __device__ __forceinline__ void wf_merge(float& n1, float& m1, float& s1, float n2, float m2, float s2) {
@@ -1903,7 +1910,7 @@ static int g_glds = env_int("UP_GLDS", 1, 0);   // bf16 storage: direct-to-LDS k
 // fp32 forward / data gradient with operands HBM -> LDS by LDS-DMA (f32_glds.h, round 4): glds32 = 0 keeps the register-staged
 // igemm_kernel; glds32_epi: 1 = LDS-transposed 16-byte-store epilogue, 0 = igemm_epilogue
 static long long g_count_igemm = 0, g_count_glds32 = 0, g_count_glds32_epi1 = 0, g_count_glds32_bnred = 0;   // up_conv_counter
-static long long g_count_wgrad32 = 0, g_count_wgrad32_st1 = 0, g_count_glds32_wide = 0;
+static long long g_count_wgrad32 = 0, g_count_wgrad32_st1 = 0, g_count_glds32_wide = 0, g_count_glds32_grouped = 0;
 static bool g_extras_dropped = false;   // a launch was asked for a masked addend / fused reduction on a kernel without them
 static int g_glds32 = env_int("UP_GLDS32", 1, 0);
 static int g_glds32_epi = env_int("UP_GLDS32_EPI", 1, 0);
@@ -2211,9 +2218,15 @@ static auto glds32_wide_kernel(const IgemmArgs& a) -> void (*)(IgemmArgs) {
     return glds::igemm_glds32_kernel<BM, BN, false, 2, OCC2, 0, false, true>;
 }
 
+static bool g_group_refused = false;   // a launch asked for row groups on a kernel without them (nothing was launched)
 template <int BM, int BN>
 static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     int ntm = cdiv(a.M, BM);
+    if (a.grp_rows) {   // row groups: every group tiled on its own (IgemmArgs)
+        a.grp_tiles = cdiv(a.grp_rows, BM);
+        a.fGrpTiles = make_fastdiv(a.grp_tiles);
+        ntm = (a.M / a.grp_rows) * a.grp_tiles;
+    }
     a.ntn = cdiv(a.Ng, BN);
     a.nwg = ntm * a.ntn;
     a.fNtn = make_fastdiv(a.ntn);
@@ -2226,6 +2239,10 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     const bool wide = aligned && a.taps > 32 && a.S <= 16 && a.taps / a.S <= 16 && a.divshift == 0 &&
                       (long long)a.H * a.W * a.ldx * ((long long)a.M / (a.P * a.Q) + 1) < (1ll << 31);
     const bool use32 = glds32_eligible(a, fast || wide);   // direct-to-LDS generation (f32_glds.h)
+    if (a.grp_rows && !(use32 && !wide && glds32_epi1_ok(a) && a.grp_rows % (a.P * a.Q) == 0)) {
+        g_group_refused = true;   // only f32_glds.h's LDS-transposed epilogue knows row groups
+        return;
+    }
     ProfScope prof(use32 ? 28 + vbase / 2 : vbase + (aligned ? 0 : 1), 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st,
                    a.M, a.Ng, a.Ktot, a.nwg);
     // double-buffered LDS (one barrier per slice) for long reductions.  In isolation it is 3-5 % faster than the
@@ -2240,8 +2257,15 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     a.no_tap_skip = g_tap_skip ? 0 : 1;
     a.perm = nullptr;
     if (g_tap_sort && fast && a.taps > 1 && a.taps <= 16 && !a.residual && !a.o_mode && !a.no_tap_skip &&
-        a.M % (a.P * a.Q) == 0)
-        a.perm = tap_sort_perm(a);
+        a.M % (a.P * a.Q) == 0) {
+        if (a.grp_rows) {   // the permutation of ONE group (what a call on that group alone uses), applied group by group
+            IgemmArgs ag = a;
+            ag.M = a.grp_rows;
+            a.perm = tap_sort_perm(ag);
+        } else {
+            a.perm = tap_sort_perm(a);
+        }
+    }
     // (the register-staged MODE 2 forms are the fallback of the direct-to-LDS kernels — glds32 = 0, unaligned pointers,
     //  >= 2^31 bytes — and the A/B partner of their tests; the double-buffered ones always use the XOR-swizzled LDS rows)
     if (a.perm && db)
@@ -2279,6 +2303,7 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
         kernel = wide ? glds32_wide_kernel<BM, BN>(a) : glds32_kernel<BM, BN>(a);
         ++g_count_glds32;
         if (wide) ++g_count_glds32_wide;
+        if (a.grp_rows) ++g_count_glds32_grouped;
         if (glds32_epi1_ok(a)) ++g_count_glds32_epi1;
         if (glds32_epi1_ok(a) && a.bn_partial) ++g_count_glds32_bnred;
     } else {
@@ -2339,6 +2364,7 @@ extern "C" long long up_conv_counter(const char* name) {
     if (!strcmp(name, "igemm")) return g_count_igemm;
     if (!strcmp(name, "glds32")) return g_count_glds32;
     if (!strcmp(name, "glds32_wide")) return g_count_glds32_wide;
+    if (!strcmp(name, "glds32_grouped")) return g_count_glds32_grouped;
     if (!strcmp(name, "glds32_epi1")) return g_count_glds32_epi1;
     if (!strcmp(name, "glds32_bnred")) return g_count_glds32_bnred;
     if (!strcmp(name, "wgrad_glds32")) return g_count_wgrad32;
@@ -2434,6 +2460,46 @@ extern "C" int up_conv2d_fwd(const up_conv_desc* d, const float* x, const float*
     if (int e = fill_fwd_args(a, d, x, w_fwd, y, ep)) return e;
     run_igemm(a, choose_tile(a.M, a.Ng, a.Ktot), as_stream(stream));
     return check_launch("conv2d_fwd");
+}
+
+// Row groups (the video model's batched trunk: `groups` frames stacked along N, BatchNorm statistics per frame).  Every group is
+// tiled on its own, so stats is [groups][up_conv_stats_tiles_grouped][K][3] — exactly what up_bn_finalize_groups merges — and no
+// extra pass over y is needed.  0 / UP_ERR_UNSUPPORTED when the launch cannot run on the direct-to-LDS fp32 kernel with the
+// LDS-transposed epilogue (the caller then keeps up_conv2d_fwd + up_bn_batch_stats_t).
+static bool grouped_ok(const up_conv_desc* d, int groups, bool data_gradient) {
+    if (!d || check_desc(d) || groups < 1 || d->N % groups) return false;
+    if (!g_glds32 || !g_glds32_epi) return false;
+    const int cin = data_gradient ? d->Kp : d->Cp, nout = data_gradient ? d->C : d->K, ldo = data_gradient ? d->ldx : d->ldy;
+    if (cin % 32 || d->R * d->S > 32 || nout % 4 || ldo % 4 || (data_gradient && d->stride != 1)) return false;
+    const long long in_elems = data_gradient ? (long long)d->N * d->P * d->Q * d->ldy : (long long)d->N * d->H * d->W * d->ldx;
+    const long long per_img = data_gradient ? (long long)d->P * d->Q * d->ldy : (long long)d->H * d->W * d->ldx;
+    if (in_elems * 4 >= (1ll << 31) || per_img * ((long long)d->N + 1) >= (1ll << 31) ||
+        (long long)nout * d->R * d->S * cin * 4 >= (1ll << 31))
+        return false;
+    return true;
+}
+extern "C" int up_conv_stats_tiles_grouped(const up_conv_desc* d, int groups) {
+    if (!grouped_ok(d, groups, false)) return 0;
+    const int64_t M = (int64_t)d->N * d->P * d->Q;
+    return cdiv(M / groups, choose_tile(M, d->K, d->R * d->S * d->Cp).bm);
+}
+extern "C" int up_conv2d_fwd_grouped(const up_conv_desc* d, const float* x, const float* w_fwd, float* y, float* stats, int groups,
+                                     void* stream) {
+    if (int e = check_desc(d)) return e;
+    UP_REQUIRE(x && w_fwd && y && stats, UP_ERR_INVALID, "conv2d_fwd_grouped: null pointer");
+    UP_REQUIRE(grouped_ok(d, groups, false), UP_ERR_UNSUPPORTED, "conv2d_fwd_grouped: this convolution cannot be tiled per group "
+               "(up_conv_stats_tiles_grouped = 0)");
+    IgemmArgs a;
+    up_conv_epilogue ep;
+    memset(&ep, 0, sizeof(ep));
+    ep.stats = stats;
+    if (int e = fill_fwd_args(a, d, x, w_fwd, y, &ep)) return e;
+    a.grp_rows = groups > 1 ? a.M / groups : 0;
+    g_group_refused = false;
+    run_igemm(a, choose_tile(a.M, a.Ng, a.Ktot), as_stream(stream));
+    UP_REQUIRE(!g_group_refused, UP_ERR_UNSUPPORTED, "conv2d_fwd_grouped: the launch did not qualify for the direct-to-LDS kernel "
+               "(pointer alignment); nothing was launched");
+    return check_launch("conv2d_fwd_grouped");
 }
 
 namespace up {

@@ -59,12 +59,17 @@ struct Epi32 {
     float pis;           // 1 / std of the column this thread finishes (BNRED)
     int pix[UNITS];      // destination pixel of each unit (-1: row past the end)
 
-    __device__ __forceinline__ void rows(const IgemmArgs& a, int m0, int tid) {
+    int m_end;           // first row past this tile's group (= a.M without row groups)
+    int gmean;           // offset of the tile's group in bn_mean / bn_invstd
+
+    __device__ __forceinline__ void rows(const IgemmArgs& a, int m0, int tid, int m_end_, int gbase, int grp) {
+        m_end = m_end_;
+        gmean = grp * a.bn_grp_stride;
 #pragma unroll
         for (int k = 0; k < UNITS; ++k) {
             const int m = m0 + tid / CQ + k * RSTEP;
             int p = -1;
-            if (m < a.M) p = PERM ? a.perm[m] : m;
+            if (m < m_end) p = PERM ? gbase + a.perm[m - gbase] : m;
             pix[k] = p;
         }
     }
@@ -91,9 +96,9 @@ struct Epi32 {
                 }
             }
             if constexpr (BNRED) {
-                pmu = *reinterpret_cast<const float4*>(a.bn_mean + nn);
+                pmu = *reinterpret_cast<const float4*>(a.bn_mean + gmean + nn);
                 const int cc = n0 + (tid >> 1);
-                pis = a.bn_invstd[tid < 2 * BN && cc < a.Ng ? cc : 0];
+                pis = a.bn_invstd[gmean + (tid < 2 * BN && cc < a.Ng ? cc : 0)];
 #pragma unroll
                 for (int k = 0; k < UNITS; ++k)
                     yb[k] = *reinterpret_cast<const float4*>(a.bn_y + (size_t)(pix[k] >= 0 ? pix[k] : 0) * a.bn_ld + nn);
@@ -126,7 +131,7 @@ struct Epi32 {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                        if (m < a.M) {
+                        if (m < m_end) {
                             cnt += 1.f;
                             sum += acc[i][j][r];
                         }
@@ -138,7 +143,7 @@ struct Epi32 {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int m = mrow0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                        if (m < a.M) {
+                        if (m < m_end) {
                             const float d = acc[i][j][r] - mean;
                             q += d * d;
                         }
@@ -211,7 +216,7 @@ struct Epi32 {
         const bool relu = a.relu != 0;
         float s1a[4] = {0.f, 0.f, 0.f, 0.f}, s2a[4] = {0.f, 0.f, 0.f, 0.f};
         float4 mu = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (BNRED) mu = PF ? pmu : *reinterpret_cast<const float4*>(a.bn_mean + nn);
+        if constexpr (BNRED) mu = PF ? pmu : *reinterpret_cast<const float4*>(a.bn_mean + gmean + nn);
         constexpr int CHK = UNITS < 4 ? UNITS : 4;
 #pragma unroll
         for (int c0 = 0; c0 < UNITS; c0 += CHK) {
@@ -301,7 +306,7 @@ struct Epi32 {
                 }
                 const int cc = n0 + ch;
                 if (cc < a.Ng) {
-                    if (which) t *= PF ? pis : a.bn_invstd[cc];
+                    if (which) t *= PF ? pis : a.bn_invstd[gmean + cc];
                     a.bn_partial[((size_t)mt * a.Ng + cc) * 2 + which] = t;
                 }
             }
@@ -349,7 +354,14 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
     }
     const int mt = fdiv(logical, a.fNtn);
     const int nt = logical - mt * a.ntn;
-    const int m0 = mt * BM, n0 = nt * BN;
+    int m0 = mt * BM, m_end = a.M, gbase = 0, grp = 0;
+    const int n0 = nt * BN;
+    if (a.grp_rows) {   // row groups (see IgemmArgs): tile mt % grp_tiles of group mt / grp_tiles
+        grp = fdiv(mt, a.fGrpTiles);
+        gbase = grp * a.grp_rows;
+        m0 = gbase + (mt - grp * a.grp_tiles) * BM;
+        m_end = gbase + a.grp_rows;
+    }
 
     // this lane's rows of the operand tiles: row (wave + 4 i) * RPI + lane / CH, 16-byte slot lane % CH
     const int rsub = lane / G::CH, slot = lane % G::CH;
@@ -382,8 +394,8 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
     for (int i = 0; i < NA; ++i) {
         const int row = (wave + 4 * i) * G::RPI + rsub;
         const int m = m0 + row;
-        int pix = m < a.M ? m : a.M - 1;
-        if constexpr (PERM) pix = a.perm[pix];
+        int pix = m < m_end ? m : m_end - 1;
+        if constexpr (PERM) pix = gbase + a.perm[pix - gbase];
         unsigned mk;
         int src;   // source pixel of filter tap (0,0)
         if (pointwise) {
@@ -406,7 +418,7 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
                 for (int r = 0; r < R; ++r) mk |= ((hm >> r) & 1u) ? (wmk << (r * a.S)) : 0u;
             }
         }
-        if (m >= a.M) mk = 0u;
+        if (m >= m_end) mk = 0u;
         roffA[i] = src * a.ldx * 4 + ((slot ^ G::swz(row)) << 4);
         tmA[i] = mk;
         tile_taps |= mk;
@@ -515,7 +527,7 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
     E epi;
     const bool finisher = !split || part == a.parts - 1;   // this workgroup runs the epilogue
     if constexpr (EPI == 1) {
-        if (finisher) epi.rows(a, m0, tid);
+        if (finisher) epi.rows(a, m0, tid, m_end, gbase, grp);
     }
     if constexpr (ST == 2) {
         if (nsl > 0) issue(0);

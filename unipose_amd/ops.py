@@ -295,6 +295,32 @@ def conv_fwd_raw(x, weight, cfg, *, scale=None, shift=None, bias=None, residual=
     return out, d, st
 
 
+# Forward statistics from per-group tiles (up_conv2d_fwd_grouped) instead of the extra pass over y: built, correct, and OFF —
+# the Welford epilogue on 112 launches + 1.3 % tile padding cost 2.4 ms of kernel time for the 1.7 ms pass they remove
+# (UniPose-LSTM step 103.4 -> 104.0 ms, profiles/r04_experiments.txt).  The per-group tiling itself is what the data gradient uses.
+GROUPED_TILES = os.environ.get("UNIPOSE_GROUPED_TILES", "0") != "0"
+
+
+def conv_fwd_grouped_raw(x, weight, cfg, groups):
+    """Forward convolution over `groups` equal batches stacked along N with every group tiled on its own (up_conv2d_fwd_grouped):
+    returns (y, desc, stats[groups][tiles][K][3]) or None when the launch cannot be tiled per group (the caller then uses
+    conv_fwd_raw + up_bn_batch_stats_t)."""
+    if not GROUPED_TILES or x.dtype != torch.float32 or CONV_MATH != MATH_F32:
+        return None
+    _dev_ok(x, weight)
+    d = make_desc(x, weight, cfg)
+    tiles = _C.lib().up_conv_stats_tiles_grouped(C.byref(d), groups)
+    if tiles <= 0:
+        return None
+    alloc = torch.zeros if d.ldy != d.K else torch.empty      # pad channels must read as zeros
+    out = alloc((d.N, d.P, d.Q, d.ldy), dtype=x.dtype, device=x.device)
+    st = torch.empty((groups, tiles, d.K, 3), dtype=torch.float32, device=x.device)
+    wp = packed_fwd(weight, d)
+    _C.check(_C.lib().up_conv2d_fwd_grouped(C.byref(d), x.data_ptr(), wp.data_ptr(), out.data_ptr(), st.data_ptr(), groups,
+                                            _stream(x)), "conv2d_fwd_grouped")
+    return out, d, st
+
+
 class BnSlot:
     """Hands the BatchNorm-backward REDUCTION of a layer z = relu(bn(y) (+ res)) to the data-gradient launch of the one
     convolution that consumes z (resnet.py:25-33: bn1 -> relu -> conv2, bn2 -> relu -> conv3, and a block's output into the next
@@ -681,19 +707,27 @@ class ConvBnAct(Function):
             # tile of the convolution may straddle two frames, so its epilogue partials cannot be used)
             if x.shape[0] % groups:
                 raise ValueError(f"batch {x.shape[0]} is not a multiple of {groups} BatchNorm groups")
-            y, d, _ = conv_fwd_raw(x, weight, cfg)
+            d0 = make_desc(x, weight, cfg)
+            # (a few rows per channel — the branch behind the global average pool — get float64 statistics from y, below)
+            fused = conv_fwd_grouped_raw(x, weight, cfg, groups) if (d0.N * d0.P * d0.Q) // groups > EXACT_STATS_ROWS else None
+            if fused is not None:                 # every group tiled on its own: the epilogue's partials ARE per group
+                y, d, st = fused
+                tiles = st.shape[1]
+            else:
+                y, d, _ = conv_fwd_raw(x, weight, cfg)
             rows = d.N * d.P * d.Q
             rpg = rows // groups
             if rpg <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size "
                                  f"{(d.N // groups, k, d.P, d.Q)}")
-            tiles = 1 if rpg <= EXACT_STATS_ROWS else L.up_bn_batch_stats_tiles(rpg)
-            st = torch.empty((groups, tiles, k, 3), dtype=torch.float32, device=dev)
             coef = torch.empty((groups, 4, k), dtype=torch.float32, device=dev)   # per group: mean, invstd, scale, shift
-            if rpg <= EXACT_STATS_ROWS:
-                _C.check(L.up_bn_exact_stats_t(y.data_ptr(), d.ldy, rpg, k, groups, _dt(y), st.data_ptr(), _stream(x)), "bn_exact_stats")
-            else:
-                _C.check(L.up_bn_batch_stats_t(y.data_ptr(), d.ldy, rpg, k, groups, _dt(y), st.data_ptr(), _stream(x)), "bn_batch_stats")
+            if fused is None:
+                tiles = 1 if rpg <= EXACT_STATS_ROWS else L.up_bn_batch_stats_tiles(rpg)
+                st = torch.empty((groups, tiles, k, 3), dtype=torch.float32, device=dev)
+                if rpg <= EXACT_STATS_ROWS:
+                    _C.check(L.up_bn_exact_stats_t(y.data_ptr(), d.ldy, rpg, k, groups, _dt(y), st.data_ptr(), _stream(x)), "bn_exact_stats")
+                else:
+                    _C.check(L.up_bn_batch_stats_t(y.data_ptr(), d.ldy, rpg, k, groups, _dt(y), st.data_ptr(), _stream(x)), "bn_batch_stats")
             _C.check(L.up_bn_finalize_groups(st.data_ptr(), tiles, k, groups, rpg, eps, momentum, _ptr(rm), _ptr(rv),
                                              gamma.data_ptr(), beta.data_ptr(), coef.data_ptr(), _stream(x)), "bn_finalize_groups")
         elif train:
