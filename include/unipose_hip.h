@@ -40,7 +40,7 @@ typedef enum {
 } up_status;
 
 const char* up_last_error(void);
-int up_abi_version(void);   /* 7 */
+int up_abi_version(void);   /* 8 */
 
 /* Geometry of one 2-D convolution (nn.Conv2d as used at resnet.py:10-16,61,80-84,104-109;
  * wasp.py:9,52,59-60; decoder.py:17,22,26,30; model/uniposeLSTM.py:12-14,30-38,85-89). */
@@ -152,6 +152,11 @@ int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const float* w_dg
  * [groups][up_conv_stats_tiles_grouped(d, groups)][K][3] — the layout up_bn_finalize_groups merges; no extra pass over y
  * (up_bn_batch_stats_t) is needed.  fp32 only, direct-to-LDS kernel with the LDS-transposed epilogue: up_conv_stats_tiles_grouped
  * returns 0 and up_conv2d_fwd_grouped UP_ERR_UNSUPPORTED (nothing launched) otherwise. */
+int up_bn_bwd_groups_prereduced_ok(int64_t rows_per_group, int C, int groups, int ld);
+int up_bn_bwd_groups_prereduced_t(const void* dz, int lddz, const uint32_t* relu_bits, const void* y, int ldy, const float* gamma,
+                                  const float* coef, int relu, void* dy, int lddy, void* dres, int lddres, float* dgamma, float* dbeta,
+                                  float* workspace, size_t workspace_bytes, const float* partial, int tiles, int64_t rows_per_group,
+                                  int C, int groups, int dtype, void* stream);
 int up_conv_stats_tiles_grouped(const up_conv_desc* d, int groups);
 int up_conv2d_fwd_grouped(const up_conv_desc* d, const float* x, const float* w_fwd, float* y, float* stats, int groups, void* stream);
 
@@ -162,13 +167,18 @@ typedef struct {
     const float* invstd;
     float* partial;            /* out: [up_conv2d_bwd_data_tiles_math(d, math)][C][2]                               */
     int32_t ld, C;             /* pixel stride of y; channels (== d->C of this convolution)                        */
+    int32_t group_stride;      /* row groups (ABI 8): floats between two groups' mean / invstd vectors, else 0     */
 } up_bn_reduce_slot;
 typedef struct {
     const void* add;               /* second gradient of the same input (element type of dx), or NULL              */
     const uint32_t* add_relu_bits; /* optional ReLU mask of the addend, see above                                   */
     const up_bn_reduce_slot* bn;   /* optional fused BatchNorm-backward reduction                                   */
     int32_t ld_add;
+    int32_t groups;                /* row groups (ABI 8; 0 / 1: none): the N images are `groups` equal batches, every one tiled
+                                      on its own; bn->partial is then [groups][up_conv2d_bwd_data_tiles_grouped][C][2] and
+                                      bn->mean / invstd are per group (group_stride).  fp32 only.                       */
 } up_dgrad_epilogue;
+int up_conv2d_bwd_data_tiles_grouped(const up_conv_desc* d, int groups);   /* tiles per group, 0: not supported */
 int up_conv2d_bwd_data_tiles(const up_conv_desc* d);                 /* = ..._tiles_math(d, UP_MATH_F32) */
 int up_conv2d_bwd_data_tiles_math(const up_conv_desc* d, int math);
 /* w_dgrad: the fp32 data-gradient image of up_pack_weights (math = UP_MATH_F32) or the bf16 `hi` plane of

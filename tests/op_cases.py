@@ -572,3 +572,47 @@ def bn_group_stats_case(dev, groups, rows, c, seed=0, momentum=0.1, eps=1e-5):
         erv = (1 - momentum) * erv + momentum * var[g] * rows / (rows - 1)
     assert float((rm.cpu().double() - erm).abs().max()) < 2e-6
     assert float((rv.cpu().double() / erv - 1).abs().max()) < 5e-6
+
+
+def bn_groups_chain_case(dev, groups, n, c, h, w, k1, k2, r2=1, tol=2e-5, seed=0):
+    """conv1 -> BN -> ReLU -> conv2 -> BN -> ReLU inside ops.bn_groups(G), the first BatchNorm's backward reduction riding in conv2's
+    data gradient (ops.BnSlot with row groups: that launch is tiled per group and reduces every group's sums against the group's own
+    mean / invstd) against the same chain with the separate grouped reduce pass (itself pinned to G torch calls by bn_groups_case)."""
+    from unipose_amd import _C
+    torch.manual_seed(seed)
+    conv1, bn1 = torch.nn.Conv2d(c, k1, 1, bias=False), torch.nn.BatchNorm2d(k1)
+    conv2, bn2 = torch.nn.Conv2d(k1, k2, r2, padding=r2 // 2, bias=False), torch.nn.BatchNorm2d(k2)
+    with torch.no_grad():
+        for b in (bn1, bn2):
+            b.weight.uniform_(0.5, 1.5)
+            b.bias.normal_(0, 0.3)
+    mods = [m.to(dev).train() for m in (conv1, bn1, conv2, bn2)]
+    x0 = torch.randn(groups * n, h, w, c) + torch.arange(groups).repeat_interleave(n).view(-1, 1, 1, 1) * 0.5   # groups differ
+    g0 = torch.randn(groups * n, h, w, k2)
+    out = {}
+    prev = ops.GROUPED_REDUCE
+    try:
+        for fused in (True, False):
+            ops.GROUPED_REDUCE = fused
+            for m in mods:
+                m.zero_grad(set_to_none=True)
+            x = x0.clone().to(dev).requires_grad_(True)
+            u0, b0 = ops.HOST_COUNTERS["bn_prereduced"], int(_C.lib().up_conv_counter(b"glds32_bnred"))
+            q0 = int(_C.lib().up_conv_counter(b"glds32_grouped"))
+            with ops.bn_groups(groups):
+                s1 = ops.BnSlot()
+                y1 = ops.conv_bn_act(x, mods[0], mods[1], relu=True, slot_out=s1)
+                y2 = ops.conv_bn_act(y1, mods[2], mods[3], relu=True, slot_in=s1)
+            (y2 * g0.to(dev)).sum().backward()
+            ops.wgrad_fence()
+            used = ops.HOST_COUNTERS["bn_prereduced"] - u0
+            assert used == (1 if fused else 0), used
+            assert (int(_C.lib().up_conv_counter(b"glds32_bnred")) - b0) == (1 if fused else 0)
+            assert (int(_C.lib().up_conv_counter(b"glds32_grouped")) - q0) == (1 if fused else 0)
+            out[fused] = {"y2": y2.detach().cpu(), "dx": x.grad.cpu(),
+                          **{f"p{i}": p.grad.cpu() for i, m in enumerate(mods) for p in m.parameters()}}
+    finally:
+        ops.GROUPED_REDUCE = prev
+    worst = max((rel(out[True][n_], out[False][n_]), n_) for n_ in out[True])
+    assert worst[0] < tol, worst
+    return worst

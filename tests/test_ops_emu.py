@@ -325,6 +325,16 @@ def test_grouped_statistics_and_finalize_many_tiles(emu_backend, groups, rows, c
     oc.bn_group_stats_case(emu_backend, groups, rows, c)
 
 
+@pytest.mark.parametrize("cfg", [
+    (3, 2, 32, 13, 11, 32, 32, 1),     # 286 rows per group: 4 tiles of 64 + 30 rows
+    (2, 3, 32, 10, 10, 64, 32, 3),     # the consumer is a 3x3 (tap-sorted rows inside every group)
+    (5, 1, 32, 17, 16, 32, 128, 1),    # five groups of one image
+    (2, 1, 32, 9, 9, 32, 32, 1),       # 81 rows per group: float64 statistics in the forward, fused reduction in the backward
+])
+def test_grouped_fused_reduction(emu_backend, cfg):
+    print(oc.bn_groups_chain_case(emu_backend, *cfg))
+
+
 def test_bn_large_mean_is_applied_centred(emu_backend):
     print(oc.bn_large_mean_case(emu_backend))
 

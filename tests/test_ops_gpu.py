@@ -195,6 +195,16 @@ def test_grouped_batchnorm_matches_separate_calls(cfg):
         assert e["grouped_tiles"] == (fwd and dt == "f32" and k % 4 == 0)
 
 
+@pytest.mark.parametrize("cfg", [
+    (5, 8, 1024, 23, 23, 256, 256, 3),    # configs[3]: five frames of eight images, layer3 bn1 reduced by conv2's data gradient
+    (5, 8, 256, 23, 23, 256, 1024, 1),    # ... bn2 by conv3's
+    (5, 8, 64, 92, 92, 64, 64, 3),        # layer1 (67 712 rows per group, a multiple of the tile height)
+    (3, 2, 64, 23, 23, 64, 128, 1),
+])
+def test_grouped_fused_reduction(cfg):
+    print(oc.bn_groups_chain_case(DEV, *cfg, tol=1e-4))
+
+
 @pytest.mark.parametrize("groups,rows,c", [(3, 40000, 8), (5, 4232, 256), (8, 67712, 64)])
 def test_grouped_statistics_and_finalize_many_tiles(groups, rows, c):
     oc.bn_group_stats_case(DEV, groups, rows, c)

@@ -33,12 +33,13 @@ _i, _i64, _f, _u64, _sz, _p = C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_siz
 class BnReduceSlot(C.Structure):
     """up_bn_reduce_slot"""
     _fields_ = [("y", C.c_void_p), ("relu_bits", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
-                ("partial", C.c_void_p), ("ld", C.c_int32), ("C", C.c_int32)]
+                ("partial", C.c_void_p), ("ld", C.c_int32), ("C", C.c_int32), ("group_stride", C.c_int32)]
 
 
 class DgradEpilogue(C.Structure):
     """up_dgrad_epilogue"""
-    _fields_ = [("add", C.c_void_p), ("add_relu_bits", C.c_void_p), ("bn", C.POINTER(BnReduceSlot)), ("ld_add", C.c_int32)]
+    _fields_ = [("add", C.c_void_p), ("add_relu_bits", C.c_void_p), ("bn", C.POINTER(BnReduceSlot)), ("ld_add", C.c_int32),
+                ("groups", C.c_int32)]
 
 
 _D, _E = C.POINTER(ConvDesc), C.POINTER(ConvEpilogue)
@@ -63,6 +64,9 @@ SIGNATURES = {
     "up_conv2d_bwd_data_tiles_math": (_i, [_D, _i]),
     "up_conv2d_bwd_data_ex": (_i, [_D, _p, _p, _p, C.POINTER(DgradEpilogue), _i, _p]),
     "up_conv_stats_tiles_grouped": (_i, [_D, _i]),
+    "up_conv2d_bwd_data_tiles_grouped": (_i, [_D, _i]),
+    "up_bn_bwd_groups_prereduced_ok": (_i, [_i64, _i, _i, _i]),
+    "up_bn_bwd_groups_prereduced_t": (_i, [_p, _i, _p, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _sz, _p, _i, _i64, _i, _i, _i, _p]),
     "up_conv2d_fwd_grouped": (_i, [_D, _p, _p, _p, _p, _i, _p]),
     "up_bn_bwd_prereduced_t": (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _i64, _i,
                                     _i, _p]),

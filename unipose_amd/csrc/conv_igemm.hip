@@ -2738,6 +2738,11 @@ extern "C" int up_conv2d_bwd_data_tiles_math(const up_conv_desc* d, int math) {
     return cdiv(M, choose_tile(M, d->C, d->R * d->S * d->Kp, math).bm);
 }
 extern "C" int up_conv2d_bwd_data_tiles(const up_conv_desc* d) { return up_conv2d_bwd_data_tiles_math(d, UP_MATH_F32); }
+extern "C" int up_conv2d_bwd_data_tiles_grouped(const up_conv_desc* d, int groups) {
+    if (up_conv2d_bwd_data_tiles_math(d, UP_MATH_F32) <= 0 || !grouped_ok(d, groups, true)) return 0;
+    const long long M = (long long)d->N * d->H * d->W;
+    return cdiv(M / groups, choose_tile(M, d->C, d->R * d->S * d->Kp).bm);
+}
 
 // up_conv2d_bwd_data / _bf16 (bf16 storage) with the extended epilogue: see up_dgrad_epilogue in the header.
 extern "C" int up_conv2d_bwd_data_ex(const up_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
@@ -2753,6 +2758,9 @@ extern "C" int up_conv2d_bwd_data_ex(const up_conv_desc* d, const void* dy, cons
                UP_ERR_INVALID, "conv2d_bwd_data_ex: bad BatchNorm slot (C=%d vs %d, ld=%d)", slot ? slot->C : 0, d->C, slot ? slot->ld : 0);
     UP_REQUIRE(!(slot || ep->add_relu_bits) || up_conv2d_bwd_data_tiles_math(d, math) > 0, UP_ERR_UNSUPPORTED,
                "conv2d_bwd_data_ex: this launch cannot carry a masked addend / a fused reduction (up_conv2d_bwd_data_tiles_math = 0)");
+    const int groups = ep->groups > 1 ? ep->groups : 1;
+    UP_REQUIRE(groups == 1 || (math == UP_MATH_F32 && up_conv2d_bwd_data_tiles_grouped(d, groups) > 0), UP_ERR_UNSUPPORTED,
+               "conv2d_bwd_data_ex: this launch cannot be tiled per row group (up_conv2d_bwd_data_tiles_grouped = 0)");
     IgemmArgs a;
     if (int e = fill_dgrad_args(a, d, static_cast<const float*>(dy), static_cast<const float*>(w_dgrad), static_cast<float*>(dx))) return e;
     a.residual = static_cast<const float*>(ep->add);
@@ -2766,7 +2774,10 @@ extern "C" int up_conv2d_bwd_data_ex(const up_conv_desc* d, const void* dy, cons
         a.bn_mean = slot->mean;
         a.bn_invstd = slot->invstd;
         a.bn_partial = slot->partial;
+        a.bn_grp_stride = groups > 1 ? slot->group_stride : 0;
     }
+    a.grp_rows = groups > 1 ? a.M / groups : 0;
+    g_group_refused = false;
     const uintptr_t ptrs = reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(w_dgrad) | reinterpret_cast<uintptr_t>(dx) |
                            reinterpret_cast<uintptr_t>(ep->add) | (slot ? reinterpret_cast<uintptr_t>(slot->y) : 0);
     UP_REQUIRE(!(slot || ep->add_relu_bits) || ((ptrs & 15) == 0 && (!ep->add || ep->ld_add % q == 0)), UP_ERR_UNSUPPORTED,
@@ -2782,6 +2793,8 @@ extern "C" int up_conv2d_bwd_data_ex(const up_conv_desc* d, const void* dy, cons
         UP_REQUIRE(!s2_decomposed(d->stride, d->dil), UP_ERR_UNSUPPORTED, "conv2d_bwd_data_ex: stride-2 convolutions use up_conv2d_bwd_data");
         run_igemm(a, choose_tile(a.M, a.Ng, a.Ktot), as_stream(stream));
     }
+    UP_REQUIRE(!g_group_refused, UP_ERR_UNSUPPORTED, "conv2d_bwd_data_ex: the launch did not qualify for the kernel with row groups; "
+               "nothing was launched");
     UP_REQUIRE(!g_extras_dropped, UP_ERR_UNSUPPORTED, "conv2d_bwd_data_ex: the launch ran on a kernel without the requested epilogue extras");
     return check_launch("conv2d_bwd_data_ex");
 }

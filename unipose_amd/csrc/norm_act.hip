@@ -863,7 +863,7 @@ constexpr int BNB_ROWS = 128;   // small chunks: enough workgroups (and bytes in
 using namespace up;
 
 extern "C" const char* up_last_error(void) { return g_err; }
-extern "C" int up_abi_version(void) { return 7; }   // 7: up_conv2d_bwd_data_ex / up_bn_bwd_prereduced_t / up_conv_counter; 6: centred BatchNorm; 5: up_conv2d_bwd_weight_acc; 4: element-typed (_t) twins + bf16 storage
+extern "C" int up_abi_version(void) { return 8; }   // 8: row groups (up_conv2d_fwd_grouped, groups in up_dgrad_epilogue, up_bn_bwd_groups_prereduced_t); 7: up_conv2d_bwd_data_ex / up_bn_bwd_prereduced_t / up_conv_counter; 6: centred BatchNorm; 5: up_conv2d_bwd_weight_acc; 4: element-typed (_t) twins + bf16 storage
 
 extern "C" int up_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                  int C, float* scale, float* shift, void* stream) {
@@ -1303,18 +1303,22 @@ namespace up {
 template <typename T>
 static bool launch_bn_bwd_groups(const T* dz, int lddz, const uint32_t* relu_bits, const T* y, int ldy, const float* gamma,
                                  const float* coef, int relu, T* dy, int lddy, T* dres, int lddres, float* dgamma, float* dbeta,
-                                 float* workspace, int64_t rows, int C, int groups, hipStream_t st) {
+                                 float* workspace, int64_t rows, int C, int groups, hipStream_t st,
+                                 const float* prereduced = nullptr, int prereduced_tiles = 0) {
     constexpr int E = 16 / (int)sizeof(T);
     dim3 grid;
     int lcs = 0;
     if (!(lddz % E == 0 && ldy % E == 0 && lddy % E == 0 && (!dres || lddres % E == 0) && rows_geometry<T>(rows, C, grid, lcs)))
         return false;
-    const int chunks = cdiv(rows, BNB_ROWS);
+    // prereduced: the data-gradient launch that produced dz (tiled per group, up_conv2d_bwd_data_ex with groups) already wrote
+    // [groups][prereduced_tiles][C][2] — pass 1 is skipped
+    const int chunks = prereduced ? prereduced_tiles : cdiv(rows, BNB_ROWS);
     float* gsum = workspace;                                   // [groups][dgamma | dbeta]
-    float* partial = workspace + (size_t)groups * 2 * C;       // [groups][chunks][C][2]
+    const float* partial = prereduced ? prereduced : workspace + (size_t)groups * 2 * C;       // [groups][chunks][C][2]
     const GroupArgs ga{4 * C, 2 * C};
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(chunks, cdiv(C, 64), groups), dim3(256), 0, st, dz, lddz, (const T*)nullptr, 0,
-                       relu_bits, y, ldy, coef, coef + C, relu, partial, rows, C, BNB_ROWS, ga);
+    if (!prereduced)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(chunks, cdiv(C, 64), groups), dim3(256), 0, st, dz, lddz, (const T*)nullptr, 0,
+                           relu_bits, y, ldy, coef, coef + C, relu, workspace + (size_t)groups * 2 * C, rows, C, BNB_ROWS, ga);
     if (groups <= BN_MAXG) {
         hipLaunchKernelGGL(bn_bwd_finalize_allgroups_kernel, dim3(C), dim3(256), 0, st, (const float*)partial, chunks, C, groups, gsum,
                            dgamma, dbeta);
@@ -1366,6 +1370,34 @@ extern "C" int up_bn_bwd_groups_t(const void* dz, int lddz, const uint32_t* relu
             return e;
     }
     return UP_OK;
+}
+
+// up_bn_bwd_groups_t without its first pass: `partial` = [groups][tiles][C][2] written by the data-gradient launch that produced dz
+// (up_conv2d_bwd_data_ex with ep->groups = groups, tiles = up_conv2d_bwd_data_tiles_grouped).  fp32, row-strided geometry only.
+extern "C" int up_bn_bwd_groups_prereduced_t(const void* dz, int lddz, const uint32_t* relu_bits, const void* y, int ldy,
+                                             const float* gamma, const float* coef, int relu, void* dy, int lddy, void* dres,
+                                             int lddres, float* dgamma, float* dbeta, float* workspace, size_t workspace_bytes,
+                                             const float* partial, int tiles, int64_t rows_per_group, int C, int groups, int dtype,
+                                             void* stream) {
+    UP_REQUIRE(dz && y && dy && gamma && coef && dgamma && dbeta && workspace && partial && tiles > 0 && groups > 0 && groups <= BN_MAXG &&
+               rows_per_group > 0, UP_ERR_INVALID, "bn_bwd_groups_prereduced: bad argument (1..%d groups)", BN_MAXG);
+    UP_REQUIRE(dtype == UP_DT_F32, UP_ERR_UNSUPPORTED, "bn_bwd_groups_prereduced: fp32 only");
+    UP_REQUIRE(!relu || relu_bits, UP_ERR_INVALID, "bn_bwd_groups_prereduced: relu needs the sign bits of the forward output");
+    UP_REQUIRE(C % 4 == 0 && rows_per_group * (C / 4) < (1ll << 31), UP_ERR_UNSUPPORTED, "bn_bwd_groups_prereduced: C %% 4 or tensor too large");
+    UP_REQUIRE(workspace_bytes >= (size_t)groups * 2 * C * sizeof(float), UP_ERR_WORKSPACE, "bn_bwd_groups_prereduced: workspace too small");
+    UP_REQUIRE(!relu_bits || (rows_per_group * C) % 32 == 0, UP_ERR_UNSUPPORTED,
+               "bn_bwd_groups_prereduced: rows_per_group * C must be a multiple of 32");
+    const bool done = launch_bn_bwd_groups<float>((const float*)dz, lddz, relu_bits, (const float*)y, ldy, gamma, coef, relu, (float*)dy,
+                                                  lddy, (float*)dres, lddres, dgamma, dbeta, workspace, rows_per_group, C, groups,
+                                                  as_stream(stream), partial, tiles);
+    UP_REQUIRE(done, UP_ERR_UNSUPPORTED, "bn_bwd_groups_prereduced: no row-strided geometry for C = %d (use up_bn_bwd_groups_t)", C);
+    return check_launch("bn_bwd_groups_prereduced");
+}
+// does launch_bn_bwd_groups have a row-strided geometry for this shape (else up_bn_bwd_groups_prereduced_t refuses)?
+extern "C" int up_bn_bwd_groups_prereduced_ok(int64_t rows_per_group, int C, int groups, int ld) {
+    dim3 grid;
+    int lcs = 0;
+    return groups >= 1 && groups <= BN_MAXG && ld % 4 == 0 && rows_geometry<float>(rows_per_group, C, grid, lcs) ? 1 : 0;
 }
 
 extern "C" int up_relu_bwd(const float* dz, const float* z, float* dx, int64_t n, void* stream) {

@@ -331,15 +331,19 @@ class BnSlot:
     moves — the kernels' raw writes never touch it), so the producer's backward uses the sums only if dz has the address AND the
     version the consumer's launch left, else it falls back to its own reduction.  The producer fills y / bits / mean / invstd in
     its forward; the consumer's backward fills partial, dz_ptr and dz_version."""
-    __slots__ = ("y", "bits", "mean", "invstd", "C", "partial", "dz_ptr", "dz_version")
+    __slots__ = ("y", "bits", "mean", "invstd", "C", "partial", "dz_ptr", "dz_version", "groups", "gstride")
 
     def __init__(self, y=None, bits=None, mean=None, invstd=None, C=0):
         self.y, self.bits, self.mean, self.invstd, self.C = y, bits, mean, invstd, C
         self.partial, self.dz_ptr, self.dz_version = None, 0, -1
+        # row groups (ops.bn_groups): mean / invstd are the first group's vectors inside coef[groups][4][C], gstride = 4 * C floats
+        # to the next group's; the consumer's data gradient is tiled per group and partial is [groups * tiles][C][2]
+        self.groups, self.gstride = 1, 0
 
     def clear(self):
         self.y = self.bits = self.mean = self.invstd = self.partial = None
         self.dz_ptr, self.dz_version = 0, -1
+        self.groups, self.gstride = 1, 0
 
     def matches(self, dz, y):
         return self.partial is not None and self.dz_ptr == dz.data_ptr() and self.dz_version == dz._version and self.y is y
@@ -349,6 +353,7 @@ class BnSlot:
 HOST_COUNTERS = {"bn_prereduced": 0, "dx_handed_over": 0}
 BN_FUSE_REDUCE = os.environ.get("UNIPOSE_BN_FUSE_REDUCE", "1") != "0"     # development switches (A/B runs)
 MASKED_ADDEND = os.environ.get("UNIPOSE_MASKED_ADDEND", "1") != "0"
+GROUPED_REDUCE = os.environ.get("UNIPOSE_GROUPED_REDUCE", "1") != "0"     # the fused reduction also inside ops.bn_groups (row groups)
 DX_HANDOVER = os.environ.get("UNIPOSE_DX_HANDOVER", "1") != "0"           # projection blocks: downsample's dx rides in conv1's launch
 
 
@@ -382,8 +387,17 @@ def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev, add=None, bn_slo
     tiles = 0
     want_slot = bn_slot is not None and bn_slot.y is not None and bn_slot.C == d.C == cp and bn_slot.y.dtype == dy.dtype and \
         bn_slot.y.shape[:3] == (n, h, w)
+    groups = bn_slot.groups if want_slot else 1
     if (want_slot or add_bits is not None) and ex_math >= 0:
         tiles = _C.lib().up_conv2d_bwd_data_tiles_math(C.byref(dd), ex_math)
+        if groups > 1 and tiles > 0:       # every group tiled on its own, or no fused reduction at all
+            gt = _C.lib().up_conv2d_bwd_data_tiles_grouped(C.byref(dd), groups) if ex_math == MATH_F32 else 0
+            if gt > 0:
+                tiles = groups * gt
+            else:
+                want_slot, groups = False, 1
+                if add_bits is None:
+                    tiles = 0
     if add_bits is not None and tiles <= 0:
         raise _C.UniPoseHipError("conv_bwd_data_raw: this launch cannot mask its addend (check dgrad_extras_tiles first)")
     if tiles > 0:
@@ -395,7 +409,9 @@ def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev, add=None, bn_slo
             sl.y, sl.relu_bits, sl.mean, sl.invstd = bn_slot.y.data_ptr(), _ptr(bn_slot.bits), bn_slot.mean.data_ptr(), \
                 bn_slot.invstd.data_ptr()
             sl.partial, sl.ld, sl.C = partial.data_ptr(), _nhwc_ok(bn_slot.y), d.C
+            sl.group_stride = bn_slot.gstride if groups > 1 else 0
             ep.bn = C.pointer(sl)
+            ep.groups = groups
         if ex_math == MATH_BF16S:
             if d.Kp % 32 or (add is not None and add.dtype != dy.dtype):
                 raise NotImplementedError("bf16-storage data gradient needs 32-aligned output channels and a bf16 addend")
@@ -788,6 +804,13 @@ class ConvBnAct(Function):
                     ((y.dtype == torch.float32 and CONV_MATH == MATH_F32) or y.dtype == torch.bfloat16):
                 slot_out.y, slot_out.bits, slot_out.mean, slot_out.invstd, slot_out.C = y, bits, coef[0], coef[1], k
                 ctx.slot_out = slot_out
+            elif BN_FUSE_REDUCE and GROUPED_REDUCE and 1 < groups <= 8 and d.ldy == k and (bits is not None or not relu) and \
+                    y.dtype == torch.float32 and CONV_MATH == MATH_F32 and \
+                    L.up_bn_bwd_groups_prereduced_ok((d.N * d.P * d.Q) // groups, k, groups, d.ldy):
+                # row groups: coef is [groups][4][k] (mean, invstd, scale, shift per group)
+                slot_out.y, slot_out.bits, slot_out.mean, slot_out.invstd, slot_out.C = y, bits, coef[0, 0], coef[0, 1], k
+                slot_out.groups, slot_out.gstride = groups, 4 * k
+                ctx.slot_out = slot_out
         # ... and as the consumer of the layer that produced x
         ctx.slot_in = slot_in if (slot_in is not None and slot_in.y is not None and ctx.needs_input_grad[0]) else None
         ctx.save_for_backward(x, weight, gamma, y, bits, coef)
@@ -805,8 +828,8 @@ class ConvBnAct(Function):
         dy = fresh(y)
         # the skip gradient dz * [z > 0]: not materialised when the block's first convolution masks its addend itself
         lo = ctx.link_out
-        masked = ctx.has_res and lo is not None and lo.armed and lo.masked_ok and ctx.relu and bits is not None and ctx.groups == 1 \
-            and d.ldy == k
+        masked = ctx.has_res and lo is not None and lo.armed and lo.masked_ok and ctx.relu and bits is not None and d.ldy == k \
+            and (ctx.groups == 1 or GROUPED_REDUCE)      # (row groups: the sign bits are indexed by the global row, like dz)
         dres = fresh(y) if ctx.has_res and not masked else None
         dgb = torch.empty((2, k), dtype=torch.float32, device=x.device)
         if dz.dtype != y.dtype:
@@ -814,11 +837,22 @@ class ConvBnAct(Function):
         if ctx.groups > 1:                    # per-group data gradient, parameter gradients summed over the groups
             rpg = rows // ctx.groups
             ws = workspace(x.device, L.up_bn_bwd_groups_workspace(rpg, k, ctx.groups))
+            so = ctx.slot_out
+            if so is not None and so.groups == ctx.groups and so.matches(dz, y):
+                # the data-gradient launch that wrote dz (tiled per group) already reduced every group's sums
+                partial, so.partial, so.dz_ptr, so.dz_version = so.partial, None, 0, -1
+                HOST_COUNTERS["bn_prereduced"] += 1
+                _C.check(L.up_bn_bwd_groups_prereduced_t(dz.data_ptr(), d.ldy, _ptr(bits), y.data_ptr(), d.ldy, gamma.data_ptr(),
+                                                         coef.data_ptr(), int(ctx.relu), dy.data_ptr(), d.ldy, _ptr(dres), d.ldy,
+                                                         dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(), ws.numel(),
+                                                         partial.data_ptr(), partial.shape[0] // ctx.groups, rpg, k, ctx.groups,
+                                                         _dt(y), _stream(x)), "bn_bwd_groups_prereduced")
+                return ConvBnAct._finish_backward(ctx, x, weight, d, dy, dres, dgb, True, (dz, bits) if masked else None)
             _C.check(L.up_bn_bwd_groups_t(dz.data_ptr(), d.ldy, _ptr(bits), y.data_ptr(), d.ldy, gamma.data_ptr(), coef.data_ptr(),
                                           int(ctx.relu), dy.data_ptr(), d.ldy, _ptr(dres), d.ldy, dgb[0].data_ptr(),
                                           dgb[1].data_ptr(), ws.data_ptr(), ws.numel(), rpg, k, ctx.groups, _dt(y), _stream(x)),
                      "bn_bwd_groups")
-            return ConvBnAct._finish_backward(ctx, x, weight, d, dy, dres, dgb, True)
+            return ConvBnAct._finish_backward(ctx, x, weight, d, dy, dres, dgb, True, (dz, bits) if masked else None)
         need = L.up_bn_bwd_workspace(rows, k)
         ws = workspace(x.device, need)
         beta = ctx.beta
