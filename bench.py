@@ -349,6 +349,24 @@ def other_config_leg(dev, name):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` with no launcher around it (WORLD_SIZE unset): start the N ranks ourselves — the same
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <the
+    same arguments>` the driver's launcher form uses — and hand its stdout (rank 0's ONE JSON line) and exit status on.
+    The parent process never touches the GPU or the process group."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    log(f"--gpus {n} without a launcher: starting {n} ranks: {' '.join(cmd)}")
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+        "HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -392,11 +410,13 @@ def main():
                     help="host threads for the CPU baseline (default: min(cores, 64); more oversubscribes oneDNN)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     emu = args.dry_run_emu
     use_dist = world > 1 or args.force_dp
     if emu:

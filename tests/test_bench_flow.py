@@ -20,13 +20,14 @@ def _free_port():
     return p
 
 
-def _run(nproc, extra=()):
+def _run(nproc, extra=(), plain=False):
     env = dict(os.environ, UP_EMU_THREADS="4", OMP_NUM_THREADS="2")
     # the emulator needs ~10-20 s per training step of the full ResNet-101: no warm-up, one timed step (plus the two of the
     # exclusive pass), no alt-math loop (that loop has no rank-dependent branch)
     args = ["--gpus", str(nproc), "--steps", "1", "--warmup", "0", "--batch", "2", "--size", "32", "--dry-run-emu",
             "--no-alt-math", *extra]     # (a later --steps in `extra` wins)
-    if nproc == 1:
+    if nproc == 1 or plain:           # plain: no launcher, bench.py starts its own ranks (bench.self_launch)
+        env.pop("WORLD_SIZE", None)
         cmd = [sys.executable, "bench.py", *args]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
@@ -49,6 +50,15 @@ def test_bench_flow_two_ranks():
     assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     assert "dry_run" in out and out["metric"].startswith("DRY RUN")
     assert "cpu_baseline" not in out                   # rank 0 at N = 1 only
+
+
+def test_plain_invocation_two_ranks():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (the shape of the driver's 1-GPU command with another N): the script
+    launches its own two ranks and still prints exactly one JSON line, from rank 0, spanning two ranks."""
+    out = _run(2, ["--no-profile"], plain=True)
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["data_parallel"]["comm_ranks"] == 2
+    assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    assert out["data_parallel"]["weights_identical_across_ranks"] is True
 
 
 def test_bench_flow_single_rank_contract():
