@@ -213,9 +213,11 @@ def wasp_dilated_leg(dev, batch=32, hw=23, iters=20, bf16=False, dilations=(6, 1
 HBM_PEAK_TBPS = 8.0
 
 
-def make_workload(dev, lstm, K, B, S, T, seed, emu=False):
+def make_workload(dev, lstm, K, B, S, T, seed, emu=False, init=None):
     """Model + resident synthetic batch + the train step of the reference's loops (unipose.py:100-131 /
-    uniposeLSTM.py:116-133).  Returns (model, optimizer, step(reducer=None))."""
+    uniposeLSTM.py:116-133).  Returns (model, optimizer, step(reducer=None)).
+    init (tests: the G16 trajectory fixture drives THIS step function): {"state_dict", "x", "t"} replace the random
+    initialisation and batch of the image model, "no_dropout" sets the three dropouts to p = 0."""
     from unipose_amd import ops
     g = torch.Generator(device="cpu").manual_seed(seed)
     if lstm:
@@ -232,6 +234,12 @@ def make_workload(dev, lstm, K, B, S, T, seed, emu=False):
         model = unipose("MPII", num_classes=K).to(dev).train()
         x = torch.randn(B, 3, S, S, generator=g).to(dev)
         t = torch.rand(B, K + 1, S // 8, S // 8, generator=g).to(dev)
+        if init is not None:
+            model.load_state_dict(init["state_dict"])
+            x, t = init["x"].to(dev), init["t"].to(dev)
+            if init.get("no_dropout"):
+                for d in (model.wasp.dropout, model.decoder.last_conv[3], model.decoder.last_conv[7]):
+                    d.p = 0.0
     # unipose.py:72 (no weight decay); `fused=True` is torch's own single-kernel implementation of the same update
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=not emu)  # 70.3 vs 71.7 ms/step with the foreach default
 

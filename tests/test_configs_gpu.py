@@ -153,6 +153,51 @@ def test_g11_train_b8_vs_reference_golden(golden_dir, fixture):
     assert np.allclose(norms, g["grad_norms"], rtol=0.02, atol=1e-9)
 
 
+def _g16_trajectory(golden_dir, reducer_factory=None, slack=2.0):
+    """G16 through bench.make_workload's step (fused Adam, batched weight re-pack, BatchNorm counters by one multi-tensor add,
+    optionally the data-parallel exchange with direct-write buckets): three optimiser steps against the genuine reference's
+    trajectory, each quantity held to `slack` x the reference's own fp32-vs-fp64 distance on this input (tools/make_goldens.py g16)."""
+    import bench
+    g = np.load(os.path.join(golden_dir, "g16_adam_3steps_b8_128.npz"))
+    K, wseed, xseed, tseed, B, size, steps = (int(v) for v in g["meta"])
+    sd = O.synth_state_dict(K, wseed)
+    init = {"state_dict": sd, "x": O.synth_input((B, 3, size, size), xseed),
+            "t": O.synth_input((B, K + 1, size // 8, size // 8), tseed, "rand"), "no_dropout": True}
+    model, opt, step = bench.make_workload(DEV, False, K, B, size, 1, seed=0, init=init)
+    reducer = reducer_factory(model) if reducer_factory else None
+    losses = [float(step(reducer).detach()) for _ in range(steps)]
+    torch.cuda.synchronize()
+    for i in range(steps):
+        noise = abs(float(g["loss"][i]) - float(g["loss64"][i]))
+        print(f"g16 step {i}: loss {losses[i]:.7f} vs reference {float(g['loss'][i]):.7f} (reference fp32 vs fp64 {noise:.1e})")
+        assert abs(losses[i] - float(g["loss"][i])) <= max(1e-5 * abs(float(g["loss"][i])), slack * noise), (i, losses)
+    p, msd = dict(model.named_parameters()), model.state_dict()
+    for k in g.files:
+        if k.startswith("move/"):
+            mv = (p[k[5:]].detach().cpu() - sd[k[5:]]).flatten()[::7].double()
+            ref, noise = torch.from_numpy(g[k]).double(), float(g["noise/" + k])
+            l2 = float((mv - ref).norm() / ref.norm())
+            print(f"g16 move of {k[5:]:36s} rel-L2 vs reference {l2:.3e} (reference fp32 vs fp64 {noise:.3e}, ratio {l2 / noise:.2f})")
+            assert l2 <= slack * noise + 1e-4, (k, l2, noise)
+        elif k.startswith("rm/") or k.startswith("rv/"):
+            name = k[3:] + (".running_mean" if k[1] == "m" else ".running_var")
+            e, noise = O.max_rel(msd[name].cpu(), g[k]), float(g["noise/" + k])
+            assert e <= max(2e-5, slack * noise), (k, e, noise)
+    names = ("backbone.bn1", "backbone.layer3.5.bn2", "backbone.layer4.2.bn3", "wasp.bn1", "wasp.global_avg_pool.2",
+             "decoder.last_conv.5", "decoder.bn2")
+    assert [int(msd[n + ".num_batches_tracked"]) for n in names] == [int(v) for v in g["num_batches_tracked"]]
+    moved = sum(1 for k, v in p.items() if not torch.equal(v.detach().cpu(), sd[k]))
+    assert moved == int(g["params_moved"]) == 342           # decoder.conv2 / bn2 never receive a gradient (SURVEY D9)
+    if reducer is not None:
+        reducer.close()
+
+
+def test_g16_adam_trajectory_vs_reference_golden(golden_dir):
+    """BASELINE's metric is a full optimiser step: G16 pins THREE of them (fwd + MSE + bwd + fused Adam through bench.py's own step
+    function) against the genuine reference — per-step loss, running statistics, counters, the move of six weights."""
+    _g16_trajectory(golden_dir)
+
+
 def _lstm_model(K, seed=4, trunk_gain=1.0):
     from model.uniposeLSTM import unipose_lstm
     m = unipose_lstm(num_classes=K)
@@ -273,6 +318,7 @@ def test_one_rank_rccl_gradient_exchange():
     print(r.stdout[-2000:])
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "1-rank RCCL exchange (bf16 storage" in r.stdout
+    assert "g16 trajectory through the 1-rank RCCL exchange ok" in r.stdout
 
 
 def _one_rank_rccl_gradient_exchange():
@@ -373,6 +419,12 @@ def _one_rank_rccl_gradient_exchange():
             reducer.close()
         finally:
             ops.set_conv_math("f32")
+        # G16: the reference's three-step Adam trajectory with the exchange in the loop (direct-write buckets, flat form)
+        del m, opt, x, t
+        torch.cuda.empty_cache()
+        _g16_trajectory(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"),
+                        lambda mod: GradAllReducer(mod, bucket_bytes=256 << 20, force=True))
+        print("g16 trajectory through the 1-rank RCCL exchange ok")
     finally:
         if created:
             dist.destroy_process_group()

@@ -572,6 +572,61 @@ def g15_lstm_train():
          loss=np.array(loss.item()), loss64=np.array(loss64.item()), **arrs, meta=np.array([K, 6, 71, 72, 73, T]))
 
 
+G16_WEIGHTS = ("backbone.conv1.weight", "backbone.layer2.0.conv2.weight", "backbone.layer3.11.conv1.weight",
+               "wasp.conv2.weight", "decoder.last_conv.0.weight", "decoder.last_conv.8.weight")
+G16_BN = ("backbone.bn1", "backbone.layer3.5.bn2", "backbone.layer4.2.bn3", "wasp.bn1", "wasp.global_avg_pool.2",
+          "decoder.last_conv.5")
+
+
+def g16_trajectory(name="g16_adam_3steps_b8_128.npz", K=16, B=8, size=128, steps=3, wseed=11, xseed=71, tseed=72):
+    """G16: a full OPTIMISER trajectory of the genuine reference — the loop of unipose.py:100-131 (zero_grad -> forward -> MSE ->
+    backward -> Adam(lr 1e-4).step) run `steps` times on one resident batch, dropouts at p = 0: per-step loss, the running
+    statistics and num_batches_tracked after the last step, and a strided sample of six weights as their MOVE (w_after - w_initial:
+    Adam's first steps are ~lr * sign(g), so the move — not the weight — is what carries information).  The same trajectory in
+    float64 gives the yardsticks: `loss_noise` per step, `noise/move/<weight>` = relative L2 distance of the fp32 move from the fp64
+    move (elements whose gradient sits at round-off take the other sign in ANY second evaluation), `noise/rm|rv/<bn>`."""
+    x = O.synth_input((B, 3, size, size), xseed)
+    t = O.synth_input((B, K + 1, size // 8, size // 8), tseed, "rand")
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        m = ref_image_model(K, wseed).to(dt).train()
+        m.wasp.dropout.p = 0.0
+        m.decoder.last_conv[3].p = 0.0
+        m.decoder.last_conv[7].p = 0.0
+        w0 = {k: v.detach().clone() for k, v in m.named_parameters()}
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4)                 # unipose.py:72
+        losses = []
+        for _ in range(steps):
+            opt.zero_grad()
+            loss = torch.nn.MSELoss()(m(x.to(dt)), t.to(dt))
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        res[dt] = (m, w0, losses)
+    m, w0, losses = res[torch.float32]
+    m64, w064, losses64 = res[torch.float64]
+    p, p64, sd, sd64 = dict(m.named_parameters()), dict(m64.named_parameters()), m.state_dict(), m64.state_dict()
+    arrs = {"loss": np.array(losses), "loss64": np.array(losses64)}
+    for k in G16_WEIGHTS:
+        mv = (p[k].detach() - w0[k]).flatten()[::7]
+        mv64 = (p64[k].detach() - w064[k]).flatten()[::7]
+        arrs["move/" + k] = mv.numpy()
+        arrs["noise/move/" + k] = np.array(float((mv.double() - mv64).norm() / mv64.norm()))
+    for k in G16_BN:
+        for tag, key in (("rm", ".running_mean"), ("rv", ".running_var")):
+            arrs[f"{tag}/{k}"] = sd[k + key].numpy()
+            arrs[f"noise/{tag}/{k}"] = np.array(O.max_rel(sd[k + key], sd64[k + key].float()))
+    arrs["num_batches_tracked"] = np.array([int(sd[k + ".num_batches_tracked"]) for k in G16_BN] +
+                                           [int(sd["decoder.bn2.num_batches_tracked"])])
+    moved = sorted(k for k in p if not torch.equal(p[k].detach(), w0[k]))
+    arrs["params_moved"] = np.array(len(moved))
+    print("g16 losses", losses, "fp64", losses64)
+    print("g16 move noise:", {k: round(float(arrs["noise/move/" + k]), 5) for k in G16_WEIGHTS})
+    print("g16 running-stat noise:", {k: float(v) for k, v in arrs.items() if k.startswith("noise/r")})
+    print("g16 parameters that moved:", len(moved), "of", len(p))
+    save(name, **arrs, meta=np.array([K, wseed, xseed, tseed, B, size, steps]))
+
+
 def g0_keys():
     """G0: the reference's state_dict contract (names, shapes, dtypes, order) for both models."""
     import json
@@ -585,9 +640,9 @@ def g0_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g0", "g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     fns = dict(g0=g0_keys, g1=g1_eval_full, g2=g2_taps, g4=g4_train, g5=g5_lstm, g6=g6_argmax, g7=g7_accuracy,
                g8=g8_targets, g9=g9_multi_person, g10=g10_eval_736, g11=g11_train_b8, g12=g12_eval_os8, g13=g13_bf16_yardstick,
-               g14=g14_train_368, g15=g15_lstm_train)
+               g14=g14_train_368, g15=g15_lstm_train, g16=g16_trajectory)
     for w in which:
         fns[w]()

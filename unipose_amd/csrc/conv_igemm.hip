@@ -1676,24 +1676,46 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* slab, fl
     const int co = (int)(t / taps);
     const size_t stride = (size_t)total4 * 4;
     // four splits in flight per step, four partial sums (fixed order: deterministic).  The pass is bound by the number of
-    // DEPENDENT load rounds per thread (14-30 splits on the layers that carry the step), not by bytes
+    // DEPENDENT load rounds per thread (14-30 splits on the layers that carry the step), not by bytes, so the sums are
+    // COMPENSATED (Kahan: the rounding error of every addition is carried along and subtracted; three more VALU operations per
+    // element and add, hidden behind the loads).  The weight gradient is a sum with heavy cancellation — BatchNorm's backward makes
+    // sum(dy) = sum(dy * xhat) = 0 per channel — and the stem reduces 1 083 392 pixels per weight: with plain additions the merge
+    // of its 488 slabs landed 2.3e-3 from the float64 gradient (ATen: 7e-5).
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
-    auto add4 = [](float4& d, const float4& a) { d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w; };
+    float4 c0 = s0, c1 = s0, c2 = s0, c3 = s0;
+    auto kadd1 = [](float& sum, float& comp, float a) {
+        const float y = a - comp;
+        const float t = sum + y;
+        comp = (t - sum) - y;
+        sum = t;
+    };
+    auto add4 = [&](float4& d, float4& c, const float4& a) {
+        kadd1(d.x, c.x, a.x);
+        kadd1(d.y, c.y, a.y);
+        kadd1(d.z, c.z, a.z);
+        kadd1(d.w, c.w, a.w);
+    };
     int sp = 0;
     for (; sp + 3 < splits; sp += 4) {
         const float4 a = *reinterpret_cast<const float4*>(slab + (size_t)sp * stride + e);
         const float4 b = *reinterpret_cast<const float4*>(slab + (size_t)(sp + 1) * stride + e);
         const float4 c = *reinterpret_cast<const float4*>(slab + (size_t)(sp + 2) * stride + e);
         const float4 d = *reinterpret_cast<const float4*>(slab + (size_t)(sp + 3) * stride + e);
-        add4(s0, a);
-        add4(s1, b);
-        add4(s2, c);
-        add4(s3, d);
+        add4(s0, c0, a);
+        add4(s1, c1, b);
+        add4(s2, c2, c);
+        add4(s3, c3, d);
     }
-    for (; sp < splits; ++sp) add4(s0, *reinterpret_cast<const float4*>(slab + (size_t)sp * stride + e));
-    add4(s0, s2);
-    add4(s1, s3);
-    const float v[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
+    for (; sp < splits; ++sp) add4(s0, c0, *reinterpret_cast<const float4*>(slab + (size_t)sp * stride + e));
+    // the four chains into the first one, their pending corrections included
+    auto neg = [](const float4& a) { return make_float4(-a.x, -a.y, -a.z, -a.w); };
+    add4(s0, c0, s1);
+    add4(s0, c0, neg(c1));
+    add4(s0, c0, s2);
+    add4(s0, c0, neg(c2));
+    add4(s0, c0, s3);
+    add4(s0, c0, neg(c3));
+    const float v[4] = {s0.x - c0.x, s0.y - c0.y, s0.z - c0.z, s0.w - c0.w};
     if (taps == 1 && ci + 3 < C && (C & 3) == 0) {
         float4* o = reinterpret_cast<float4*>(dw + (size_t)co * C + ci);
         float4 r = make_float4(v[0], v[1], v[2], v[3]);
@@ -1911,7 +1933,7 @@ static int g_glds = env_int("UP_GLDS", 1, 0);   // bf16 storage: direct-to-LDS k
 // igemm_kernel; glds32_epi: 1 = LDS-transposed 16-byte-store epilogue, 0 = igemm_epilogue
 static long long g_count_igemm = 0, g_count_glds32 = 0, g_count_glds32_epi1 = 0, g_count_glds32_bnred = 0;   // up_conv_counter
 static long long g_count_wgrad32 = 0, g_count_wgrad32_st1 = 0, g_count_glds32_wide = 0, g_count_glds32_grouped = 0;
-static bool g_extras_dropped = false;   // a launch was asked for a masked addend / fused reduction on a kernel without them
+static thread_local bool g_extras_dropped = false;   // (per host thread: autograd runs one thread per device) a launch was asked for a masked addend / fused reduction on a kernel without them
 static int g_glds32 = env_int("UP_GLDS32", 1, 0);
 static int g_glds32_epi = env_int("UP_GLDS32_EPI", 1, 0);
 
@@ -2218,7 +2240,7 @@ static auto glds32_wide_kernel(const IgemmArgs& a) -> void (*)(IgemmArgs) {
     return glds::igemm_glds32_kernel<BM, BN, false, 2, OCC2, 0, false, true>;
 }
 
-static bool g_group_refused = false;   // a launch asked for row groups on a kernel without them (nothing was launched)
+static thread_local bool g_group_refused = false;   // a launch asked for row groups on a kernel without them (nothing was launched)
 template <int BM, int BN>
 static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     int ntm = cdiv(a.M, BM);
@@ -2298,7 +2320,10 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
             grid = a.full_blocks + (a.nwg - a.full_blocks) * p;
         }
     }
-    if ((a.bn_partial || a.res_bits) && !(use32 && glds32_epi1_ok(a) && !(wide && a.bn_partial))) g_extras_dropped = true;
+    if ((a.bn_partial || a.res_bits) && !(use32 && glds32_epi1_ok(a) && !(wide && a.bn_partial))) {
+        g_extras_dropped = true;   // nothing is launched: dx without the masked addend must never be written
+        return;
+    }
     if (use32) {
         kernel = wide ? glds32_wide_kernel<BM, BN>(a) : glds32_kernel<BM, BN>(a);
         ++g_count_glds32;
@@ -2587,7 +2612,10 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
             hipLaunchKernelGGL(kernel, dim3(a.nwg), dim3(256), 0, st, a);
             return;
         }
-        if (a.bn_partial || a.res_bits) g_extras_dropped = true;   // (up_conv2d_bwd_data_ex checks eligibility first: cannot happen)
+        if (a.bn_partial || a.res_bits) {   // (up_conv2d_bwd_data_ex checks eligibility first: cannot happen)
+            g_extras_dropped = true;
+            return;
+        }
         a.fSpt = make_fastdiv(a.Cp / KT);
         if (of32 && fast)
             hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 2, false, KT, true, true>), dim3(a.nwg), dim3(256), 0, st, a);
@@ -2795,7 +2823,7 @@ extern "C" int up_conv2d_bwd_data_ex(const up_conv_desc* d, const void* dy, cons
     }
     UP_REQUIRE(!g_group_refused, UP_ERR_UNSUPPORTED, "conv2d_bwd_data_ex: the launch did not qualify for the kernel with row groups; "
                "nothing was launched");
-    UP_REQUIRE(!g_extras_dropped, UP_ERR_UNSUPPORTED, "conv2d_bwd_data_ex: the launch ran on a kernel without the requested epilogue extras");
+    UP_REQUIRE(!g_extras_dropped, UP_ERR_UNSUPPORTED, "conv2d_bwd_data_ex: the launch did not qualify for a kernel with the requested epilogue extras; nothing was launched");
     return check_launch("conv2d_bwd_data_ex");
 }
 

@@ -53,6 +53,7 @@ struct Epi32 {
     static constexpr int RSTEP = 256 / CQ;               // rows between two units of a thread
     static constexpr bool PF = UNITS_PF > 0;             // operands prefetched before the last K slice
     static_assert(!PF || UNITS_PF == UNITS, "prefetch holds every unit of the thread");
+    static_assert(!BNRED || BN <= 128, "BNRED: one thread per (column, sum) finishes the tile, 2 * BN <= 256 threads");
 
     float4 res[PF ? UNITS : 1], yb[PF ? UNITS : 1], pmu;
     uint32_t bw[PF ? UNITS : 1], rw[PF ? UNITS : 1];   // sign-bit nibbles: of the layer being reduced / of the layer the addend belongs to
@@ -297,13 +298,9 @@ struct Epi32 {
             __syncthreads();
             if (tid < 2 * BN) {
                 const int ch = tid >> 1, which = tid & 1;
-                float t = 0.f;
-                if (CQ < 64) {
+                float t = 0.f;   // every wave covers other rows of the tile, whatever the chunk count per row: always all four
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) t += red[(w * BN + ch) * 2 + which];
-                } else {
-                    t = red[ch * 2 + which];
-                }
+                for (int w = 0; w < 4; ++w) t += red[(w * BN + ch) * 2 + which];
                 const int cc = n0 + ch;
                 if (cc < a.Ng) {
                     if (which) t *= PF ? pis : a.bn_invstd[gmean + cc];

@@ -32,12 +32,16 @@ class _Bucket:
 
     def __init__(self, params):
         self.params = params
-        n = sum(p.numel() for p in params)
-        self.buf = torch.empty(n, dtype=params[0].dtype, device=params[0].device)
-        self.views, off = [], 0
+        # every parameter starts on a 16-byte boundary of the flat buffer: the weight-gradient reduce pass writes its destination
+        # with 16-byte stores (ops.set_grad_destinations), and an odd-sized parameter (the 17-element head bias) must not
+        # misalign everything behind it.  The pad elements are zero on every rank and ride through the all-reduce untouched.
+        q = max(16 // params[0].element_size(), 1)
+        offs, n = [], 0
         for p in params:
-            self.views.append(self.buf[off:off + p.numel()].view_as(p))
-            off += p.numel()
+            offs.append(n)
+            n += (p.numel() + q - 1) // q * q
+        self.buf = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
+        self.views = [self.buf[o:o + p.numel()].view_as(p) for o, p in zip(offs, params)]
         self.work = None
 
 
@@ -163,11 +167,18 @@ class GradAllReducer:
         # every rank must cut the same buckets: rank 0's order wins (the orders agree unless the graphs differ)
         if dist.is_initialized() and self.world > 1:
             index = {id(p): i for i, p in enumerate(self.params)}
-            idx = torch.tensor([index[id(p)] for p in order], dtype=torch.int64, device=order[0].device)
-            n = torch.tensor([idx.numel()], dtype=torch.int64, device=idx.device)
-            dist.broadcast(n, 0, group=self.group)
-            if int(n.item()) != idx.numel():
-                raise RuntimeError("data-parallel ranks disagree on the set of parameters that receive gradients")
+            known = [index.get(id(p), -1) for p in order]           # (-1: a hooked tensor that is not one of self.params)
+            dev = order[0].device
+            # the verdict is taken COLLECTIVELY before the order is broadcast: a rank that raised on its own would leave the
+            # others waiting in the second broadcast — min / max of the count over the ranks, then everyone agrees
+            cnt = len(known) if min(known, default=0) >= 0 else -1
+            lo, hi = (torch.tensor([cnt], dtype=torch.int64, device=dev) for _ in range(2))
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+            if int(lo.item()) != int(hi.item()) or int(lo.item()) < 0:
+                raise RuntimeError("data-parallel ranks disagree on the set of parameters that receive gradients "
+                                   f"(this rank: {cnt}, over the ranks: {int(lo.item())} .. {int(hi.item())})")
+            idx = torch.tensor(known, dtype=torch.int64, device=dev)
             dist.broadcast(idx, 0, group=self.group)
             order = [self.params[i] for i in idx.tolist()]
         self._make_buckets(order)
@@ -215,7 +226,8 @@ class GradAllReducer:
             self._finish_calibration()
 
     def payload_bytes(self) -> int:
-        return sum(b.buf.numel() * b.buf.element_size() for b in self.buckets) if self.buckets else 0
+        """bytes of gradients exchanged per step (the 16-byte alignment pads of the flat buffers not counted)"""
+        return sum(p.numel() * p.element_size() for b in self.buckets for p in b.params) if self.buckets else 0
 
     def close(self):
         for h in self._handles:

@@ -546,7 +546,9 @@ def set_grad_destinations(fn):
     """Data-parallel gradient exchange (unipose_amd.dist): `fn(weight)` returns a FRESH view of the exchange bucket's memory for
     that parameter (or None).  The weight-gradient reduce pass then writes the gradient there directly, autograd installs that
     view as ``weight.grad``, and the bucket needs no gather copy before its all-reduce (190 MB per step otherwise).  None switches
-    it off.  Only the first gradient of a weight in a backward pass is redirected; re-used weights keep the normal path."""
+    it off.  Only the first gradient of a weight in a backward pass is redirected; re-used weights keep the normal path.
+    Precondition: the redirect is meant for ``loss.backward()`` — with a reducer installed, two ``torch.autograd.grad``
+    calls on the same convolution weight (``weight.grad`` stays None there) return tensors that alias the same bucket memory."""
     _GRAD_DEST["fn"] = fn
 
 
@@ -813,8 +815,19 @@ class ConvBnAct(Function):
                 ctx.slot_out = slot_out
         # ... and as the consumer of the layer that produced x
         ctx.slot_in = slot_in if (slot_in is not None and slot_in.y is not None and ctx.needs_input_grad[0]) else None
+        # a tensor hook on z can edit dz IN PLACE through .data without moving its version counter (g.data.mul_(2), a clipping
+        # hook): BnSlot.matches cannot see that, so a hooked output always takes the separate reduction
+        ctx.z_ref = weakref.ref(z) if ctx.slot_out is not None else None
         ctx.save_for_backward(x, weight, gamma, y, bits, coef)
         return z
+
+    @staticmethod
+    def _slot_usable(ctx, dz, y):
+        so = ctx.slot_out
+        if so is None or not so.matches(dz, y):
+            return False
+        z = ctx.z_ref() if ctx.z_ref is not None else None
+        return z is None or not getattr(z, "_backward_hooks", None)
 
     @staticmethod
     @once_differentiable
@@ -838,7 +851,7 @@ class ConvBnAct(Function):
             rpg = rows // ctx.groups
             ws = workspace(x.device, L.up_bn_bwd_groups_workspace(rpg, k, ctx.groups))
             so = ctx.slot_out
-            if so is not None and so.groups == ctx.groups and so.matches(dz, y):
+            if so is not None and so.groups == ctx.groups and ConvBnAct._slot_usable(ctx, dz, y):
                 # the data-gradient launch that wrote dz (tiled per group) already reduced every group's sums
                 partial, so.partial, so.dz_ptr, so.dz_version = so.partial, None, 0, -1
                 HOST_COUNTERS["bn_prereduced"] += 1
@@ -867,7 +880,7 @@ class ConvBnAct(Function):
             else:
                 acc = entry[2]
         so = ctx.slot_out
-        if so is not None and so.matches(dz, y):
+        if ConvBnAct._slot_usable(ctx, dz, y):
             # the data-gradient launch that wrote dz already reduced this layer's sums (BnSlot): finalize + apply
             partial, so.partial, so.dz_ptr, so.dz_version = so.partial, None, 0, -1
             HOST_COUNTERS["bn_prereduced"] += 1
