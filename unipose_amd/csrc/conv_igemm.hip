@@ -141,6 +141,10 @@ struct IgemmArgs {
     // tail split (see launch_igemm): blocks [0, full_blocks) compute whole tiles, the rest compute 1/parts of the
     // K range of a tail tile; parts 0..parts-2 publish raw accumulators, the last part adds them and runs the epilogue
     int full_blocks, parts;
+    // f32_glds.h, round 5: persist > 0 = that many workgroups walk the whole tiles with stride persist (grid = persist + tail parts);
+    // stagger > 0 = start offset (sleep units of 1024 clocks) per CU slot for the workgroups of the first dispatch wave
+    int persist, stagger;
+    FastDiv fCus;
     int no_tap_skip;   // UP_TAP_SKIP=0 (A/B runs): visit every filter tap
     float* partials;
     int* flags;
@@ -1933,6 +1937,7 @@ static int g_glds = env_int("UP_GLDS", 1, 0);   // bf16 storage: direct-to-LDS k
 // igemm_kernel; glds32_epi: 1 = LDS-transposed 16-byte-store epilogue, 0 = igemm_epilogue
 static long long g_count_igemm = 0, g_count_glds32 = 0, g_count_glds32_epi1 = 0, g_count_glds32_bnred = 0;   // up_conv_counter
 static long long g_count_wgrad32 = 0, g_count_wgrad32_st1 = 0, g_count_glds32_wide = 0, g_count_glds32_grouped = 0;
+static long long g_count_glds32_persist = 0, g_count_tail_parts = 0;   // persistent launches; K parts of the last split launch
 static thread_local bool g_extras_dropped = false;   // (per host thread: autograd runs one thread per device) a launch was asked for a masked addend / fused reduction on a kernel without them
 static int g_glds32 = env_int("UP_GLDS32", 1, 0);
 static int g_glds32_epi = env_int("UP_GLDS32_EPI", 1, 0);
@@ -1942,6 +1947,12 @@ static int g_db_min_k = 1024;   // (settled in round 1/2; no longer a run-time k
 static int g_short_k = 512;            // reductions shorter than this are epilogue-heavy:
 static int g_short_k_mult = 4;         // they want g_short_k_mult / 2 times as many workgroups (r04_d sweep: 2 / 4 / 8 within noise)
 static int g_tail_split = env_int("UP_TAIL_SPLIT", 1, 0);
+// round 5 (f32_glds.h): tail workgroups per CU (1 = one K part per CU, the round-1 rule; 2 / 4 = finer parts so that
+// the tail round is a full house instead of lone, latency-bound workgroups), persistent whole-tile workgroups for launches of at
+// least `persist` dispatch waves (0 = off), start offset between the co-resident workgroups of multi-wave launches
+static int g_tail_per_cu = env_int("UP_TAIL_PER_CU", 1, 1);
+static int g_persist = env_int("UP_PERSIST", 0, 0);
+static int g_stagger = env_int("UP_STAGGER", 0, 0);
 static int g_tap_skip = 1;   // (tile-level tap skipping: on since round 1; the probe build switches it for its WASP report)
 static int g_wgrad_per_cu = 2;   // workgroups per CU a weight-gradient launch aims for (r04_d: 1 -> +0.7 ms, 3 -> +1.1 ms per step)
 static int g_wgrad_rect = env_int("UP_WGRAD_RECT", 1, 0);      // weight-gradient reduction over live rectangles (see WgradRectKey); on since r02_a (-0.65 ms per step)
@@ -2048,15 +2059,19 @@ namespace up {
 // parts each tail tile is split into (1 = no split) for a launch of `tiles` tiles reducing over Ktot
 // *all_tiles: every tile is split, not only the tail of the launch
 static int g_split_per_cu = env_int("UP_SPLIT_PER_CU", 2, 1);
-static int split_parts(int tiles, int Ktot, size_t slots, bool* all_tiles = nullptr) {
+static int split_parts(int tiles, int Ktot, size_t slots, bool* all_tiles = nullptr, int per_cu = 1) {
     if (all_tiles) *all_tiles = false;
     if (!tail_split_enabled()) return 1;
     const int cus = cu_count(), q = tiles / cus, r = tiles % cus, nk = Ktot / BK;
     // A/B over the whole step: r <= 25 % of the CUs 70.9 ms, 50 % 70.1, 75 % 70.1;  >= 2 / 4 / 8 slices per part 70.1 / 70.1 / 70.3
     int p = 1;
     if (!(r == 0 || r > cus / 2 || q > 12)) {
-        p = cus / r;                  // one part per CU (finer cuts of a TAIL measured slower: the merge chain grows)
+        // one part per CU (round 1: finer cuts measured slower with the serial flag -> loads merge chain); tail_per_cu > 1 cuts
+        // finer so that the tail round runs with several workgroups per CU (f32_glds.h merges with all flags awaited at once)
+        p = per_cu * cus / r;
         if (p > nk / 2) p = nk / 2;   // a part keeps >= 2 K slices
+        if (per_cu > 1 && p > 32) p = 32;
+        while (p >= 2 && (size_t)r * (p - 1) > slots) --p;   // one scratch slot + flag per published share
         if (p < 2) p = 1;
     }
     // Small batches (inference at B <= 4): with fewer tiles than CUs every workgroup is alone on its CU, where the K loop
@@ -2223,6 +2238,14 @@ static auto glds32_kernel(const IgemmArgs& a) -> void (*)(IgemmArgs) {
     const bool bnred = epi1 && a.bn_partial != nullptr;
     // (a one-stage form — 21 KB of LDS, six 64x64 workgroups per CU — for reductions shorter than 1024 measured 0.4 ms per step
     //  SLOWER than two stages at four per CU, profiles/r04_a_*, and is not instantiated)
+    if (a.persist > 0 && epi1) {   // persistent whole-tile workgroups (launch_igemm only asks for them with the Epi32 epilogue)
+        if (a.perm) {
+            if (bnred) return glds::igemm_glds32_kernel<BM, BN, true, 2, OCC2, 1, true, false, true>;
+            return glds::igemm_glds32_kernel<BM, BN, true, 2, OCC2, 1, false, false, true>;
+        }
+        if (bnred) return glds::igemm_glds32_kernel<BM, BN, false, 2, OCC2, 1, true, false, true>;
+        return glds::igemm_glds32_kernel<BM, BN, false, 2, OCC2, 1, false, false, true>;
+    }
     if (a.perm) {
         if (bnred) return glds::igemm_glds32_kernel<BM, BN, true, 2, OCC2, 1, true>;
         if (epi1) return glds::igemm_glds32_kernel<BM, BN, true, 2, OCC2, 1, false>;
@@ -2310,7 +2333,8 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     SplitScratch* sc0 = aligned && tail_split_enabled() ? split_scratch(st) : nullptr;
     bool all_tiles = false;
     const size_t slots = sc0 ? std::min(sc0->pfloats / (size_t)(BM * BN), sc0->nflags) : 0;
-    const int p = aligned ? split_parts(a.nwg, a.Ktot, slots, &all_tiles) : 1;
+    const int p = aligned ? split_parts(a.nwg, a.Ktot, slots, &all_tiles, g_tail_per_cu) : 1;
+    g_count_tail_parts = 1;
     if (p >= 2) {
         if (SplitScratch* sc = sc0) {
             a.full_blocks = all_tiles ? 0 : a.nwg / cu_count() * cu_count();
@@ -2318,13 +2342,24 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
             a.partials = sc->partials;
             a.flags = sc->flags;
             grid = a.full_blocks + (a.nwg - a.full_blocks) * p;
+            g_count_tail_parts = p;
         }
     }
     if ((a.bn_partial || a.res_bits) && !(use32 && glds32_epi1_ok(a) && !(wide && a.bn_partial))) {
         g_extras_dropped = true;   // nothing is launched: dx without the masked addend must never be written
         return;
     }
+    a.persist = a.stagger = 0;
+    a.fCus = make_fastdiv(cu_count());
     if (use32) {
+        // whole-tile workgroups resident at once (launch bounds of glds32_kernel: 4 / 3 / 2 per CU)
+        const int wave_wgs = ((BM == 128 && BN == 128) ? 2 : (BM == 64 && BN == 64) ? 4 : 3) * cu_count();
+        if (g_persist > 0 && !wide && glds32_epi1_ok(a) && a.full_blocks >= g_persist * wave_wgs) {
+            a.persist = wave_wgs;
+            grid = a.persist + (a.nwg - a.full_blocks) * a.parts;
+        }
+        if (g_stagger > 0 && a.full_blocks >= 2 * wave_wgs) a.stagger = g_stagger;
+        if (a.persist) ++g_count_glds32_persist;
         kernel = wide ? glds32_wide_kernel<BM, BN>(a) : glds32_kernel<BM, BN>(a);
         ++g_count_glds32;
         if (wide) ++g_count_glds32_wide;
@@ -2377,6 +2412,9 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "glds32_epi")) g_glds32_epi = value ? 1 : 0;
     else if (!strcmp(key, "glds32_wgrad")) g_glds32_wgrad = value ? 1 : 0;
     else if (!strcmp(key, "tail_split")) g_tail_split = value ? 1 : 0;
+    else if (!strcmp(key, "tail_per_cu") && value >= 1 && value <= 4) g_tail_per_cu = value;
+    else if (!strcmp(key, "persist") && value >= 0) g_persist = value;
+    else if (!strcmp(key, "stagger") && value >= 0) g_stagger = value;
     else if (!strcmp(key, "split_per_cu") && value > 0) g_split_per_cu = value;
     else if (!strcmp(key, "tap_sort")) g_tap_sort = value ? 1 : 0;
     else if (!strcmp(key, "wgrad_rect")) g_wgrad_rect = value ? 1 : 0;
@@ -2392,6 +2430,8 @@ extern "C" long long up_conv_counter(const char* name) {
     if (!strcmp(name, "glds32_grouped")) return g_count_glds32_grouped;
     if (!strcmp(name, "glds32_epi1")) return g_count_glds32_epi1;
     if (!strcmp(name, "glds32_bnred")) return g_count_glds32_bnred;
+    if (!strcmp(name, "glds32_persist")) return g_count_glds32_persist;
+    if (!strcmp(name, "tail_parts")) return g_count_tail_parts;
     if (!strcmp(name, "wgrad_glds32")) return g_count_wgrad32;
     if (!strcmp(name, "wgrad_glds32_st1")) return g_count_wgrad32_st1;
     return -1;
