@@ -40,7 +40,7 @@ typedef enum {
 } up_status;
 
 const char* up_last_error(void);
-int up_abi_version(void);   /* 8 */
+int up_abi_version(void);   /* 9 */
 
 /* Geometry of one 2-D convolution (nn.Conv2d as used at resnet.py:10-16,61,80-84,104-109;
  * wasp.py:9,52,59-60; decoder.py:17,22,26,30; model/uniposeLSTM.py:12-14,30-38,85-89). */
@@ -195,6 +195,18 @@ int up_conv2d_bwd_data_ex(const up_conv_desc* d, const void* dy, const void* w_d
 typedef enum { UP_MATH_F32 = 0, UP_MATH_BF16X3 = 1, UP_MATH_BF16 = 2, UP_MATH_BF16S = 3, UP_MATH_BF16S_F32OUT = 4 } up_math;
 int up_pack_weights_bf16(const up_conv_desc* d, const float* w_oihw, uint16_t* fwd_hi, uint16_t* fwd_lo,
                          uint16_t* dgrad_hi, uint16_t* dgrad_lo, void* stream);
+/* The same for many parameters in ONE launch (ABI 9; like up_pack_weights_batched: an optimizer step changes every weight, and
+ * 2 x 115 separate 5-us launches per step cost more than the packing itself).  `jobs` is a table in DEVICE memory; the
+ * fwd / dgrad plane pairs may be NULL per job. */
+typedef struct {
+    const float* w;        /* OIHW */
+    uint16_t* fwd_hi;
+    uint16_t* fwd_lo;
+    uint16_t* dgrad_hi;
+    uint16_t* dgrad_lo;
+    int32_t K, C, Cp, Kp, taps, reserved;
+} up_pack_job_bf16;
+int up_pack_weights_bf16_batched(const up_pack_job_bf16* jobs_device, int njobs, void* stream);
 int up_conv2d_fwd_bf16(const up_conv_desc* d, const float* x, const uint16_t* w_hi, const uint16_t* w_lo, float* y,
                        const up_conv_epilogue* ep, int math, void* stream);
 int up_conv2d_bwd_data_bf16(const up_conv_desc* d, const float* dy, const uint16_t* w_hi, const uint16_t* w_lo,

@@ -41,18 +41,14 @@ def _same(a, b, what):
                              f"first at {tuple(int(i) for i in (d > 0).nonzero()[0])}")
 
 
-DEFAULTS = dict(glds32=1, glds32_epi=1, glds32_wgrad=1, tile_want=1500, cu_count=0, tail_per_cu=1, persist=0, stagger=0)
+DEFAULTS = dict(glds32=1, glds32_epi=1, glds32_wgrad=1, tile_want=1500, cu_count=0)
 
 
 def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, affine=False, residual=False, relu=False,
-            add=False, seed=0, cus=0, forms=(1, 0), tail_per_cu=1, parts=None, persist=False):
+            add=False, seed=0, cus=0, forms=(1, 0)):
     """forward (+ optional BatchNorm partials / folded epilogue / residual) and data gradient (+ optional addend) of one fp32
     convolution: both epilogue forms (`forms` = glds32_epi values) against glds32 = 0 under the same tile rule.
-    `cus` shrinks the chip so that a small launch has whole rounds of tiles + K-split tail tiles.
-    `tail_per_cu` (round 5): tail workgroups per CU — the tail tiles are cut into tail_per_cu times as many K parts (`parts`: the
-    expected count of the forward launch); both kernel generations cut and merge alike, so the results stay equal.
-    `persist`: additionally, the direct-to-LDS kernel in its persistent form (whole-tile workgroups walk the tiles, with a
-    start offset per CU slot) must reproduce its one-workgroup-per-tile form bit for bit."""
+    `cus` shrinks the chip so that a small launch has whole rounds of tiles + K-split tail tiles."""
     cp, kp = ops.rup4(c), ops.rup4(k)
     x = _nhwc(torch.randn(n, c, h, w, generator=_g(seed)), dev, cp)
     wt = (torch.randn(k, c, r, r, generator=_g(seed + 1)) * (2.0 / (c * r * r)) ** 0.5).to(dev)
@@ -63,13 +59,10 @@ def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, 
         kw["shift"] = torch.randn(k, generator=_g(seed + 3)).to(dev)
         kw["bias"] = torch.randn(k, generator=_g(seed + 4)).to(dev)
 
-    seen = {}
-
     def run():
         d0 = ops.make_desc(x, wt, cfg)
         res = _nhwc(torch.randn(n, k, d0.P, d0.Q, generator=_g(seed + 5)), dev, kp) if residual else None
         y, d, st = ops.conv_fwd_raw(x, wt, cfg, residual=res, relu=relu, stats=stats, **kw)
-        seen["parts"] = int(_C.lib().up_conv_counter(b"tail_parts"))       # K parts of the forward launch's tail tiles
         dy = _nhwc(torch.randn(n, k, d.P, d.Q, generator=_g(seed + 6)), dev, kp)
         addt = _nhwc(torch.randn(n, c, h, w, generator=_g(seed + 7)), dev, cp) if add else None
         dx = ops.conv_bwd_data_raw(dy, wt, d, x.shape, x.device, add=addt)
@@ -78,11 +71,9 @@ def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, 
 
     cnt = lambda name: int(_C.lib().up_conv_counter(name.encode()))
     try:
-        _tune(tile_want=tile_want, cu_count=cus, glds32=0, glds32_wgrad=0, tail_per_cu=tail_per_cu)
+        _tune(tile_want=tile_want, cu_count=cus, glds32=0, glds32_wgrad=0)
         c0, w0 = cnt("glds32"), cnt("wgrad_glds32")
         y0, s0, dx0, dw0 = run()
-        if parts is not None:
-            assert seen["parts"] == parts, (seen["parts"], parts)
         assert cnt("glds32") == c0 and cnt("wgrad_glds32") == w0, "glds32 = 0 still launched a direct-to-LDS kernel"
         for epi in forms:
             _tune(glds32=1, glds32_epi=epi, glds32_wgrad=1)
@@ -98,16 +89,6 @@ def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, 
             if stats:
                 _same(s1, s0, "BatchNorm partials " + tag)
             _same(dx1, dx0, "dx " + tag)
-            if persist and epi == 1:
-                _tune(persist=1, stagger=2)
-                p0 = cnt("glds32_persist")
-                y2, s2, dx2, _ = run()
-                _tune(persist=0, stagger=0)
-                assert cnt("glds32_persist") > p0, "the case never reached the persistent form"
-                _same(y2, y0, "y persistent")
-                if stats:
-                    _same(s2, s0, "BatchNorm partials persistent")
-                _same(dx2, dx0, "dx persistent")
     finally:
         _tune(**DEFAULTS)
     return y0
@@ -209,17 +190,6 @@ SPLIT = [
     dict(n=1, c=256, h=5, w=5, k=64, r=1, stride=1, pad=0, dil=1, tile_want=1, affine=True, relu=True, residual=True, cus=0),   # 1x1 8 slices, folded epilogue
 ]
 
-# round 5: finer K parts for the tail tiles (several tail workgroups per CU, merged with all flags awaited at once) and the
-# persistent whole-tile form.  14 tiles of 64x64 on a 3-CU chip: 12 whole tiles (one dispatch wave of 4 per CU) + 2 tail tiles.
-FINE = [
-    dict(n=3, c=64, h=7, w=7, k=128, r=3, stride=1, pad=1, dil=1, tile_want=100000, stats=True, cus=4, tail_per_cu=4, parts=8),    # 2 tail tiles x 8 parts (9 = 18 slices / 2 is the cap)
-    dict(n=3, c=64, h=7, w=7, k=128, r=3, stride=1, pad=1, dil=1, tile_want=100000, stats=True, cus=4, tail_per_cu=2, parts=4),
-    dict(n=11, c=64, h=7, w=7, k=128, r=3, stride=1, pad=1, dil=1, tile_want=100000, stats=True, add=True, cus=4, tail_per_cu=2, parts=4, persist=True),   # 18 tiles = 16 persistent-walked + 2 tail tiles x 4 parts
-    dict(n=8, c=64, h=7, w=7, k=128, r=3, stride=1, pad=2, dil=2, tile_want=100000, stats=True, cus=1, persist=True),              # 14 tiles, 4 persistent workgroups, tap-sorted
-    dict(n=4, c=128, h=8, w=8, k=128, r=1, stride=1, pad=0, dil=1, tile_want=1, stats=True, add=True, cus=1, persist=True),      # 128x128 tiles: 2 per CU, 2 tiles -> one pass only
-    dict(n=8, c=128, h=8, w=8, k=192, r=1, stride=1, pad=0, dil=1, tile_want=12, stats=True, cus=1, persist=True),               # 64x128 / 128x64 by the rule
-]
-
 # more than 32 filter taps: the WIDE form of the forward / data-gradient kernel (separable row / column masks, every tap visited)
 # against the register-staged per-slice-tap path.  32-aligned input AND output channels (the data gradient's input is dy).
 WIDE = [
@@ -288,15 +258,6 @@ FULL = [
     dict(n=8, c=64, h=92, w=92, k=256, r=1, stride=1, pad=0, dil=1, tile_want=1500, stats=True),        # layer1 conv3 (B = 8)
     dict(n=8, c=128, h=46, w=46, k=128, r=3, stride=1, pad=1, dil=1, tile_want=1500, stats=True),       # layer2 conv2 (B = 8)
     dict(n=4, c=320, h=46, w=46, k=256, r=3, stride=1, pad=1, dil=1, tile_want=1500, affine=True, relu=True),   # decoder 3x3, folded epilogue
-]
-
-# round 5 forms at the headline geometries: 28 K parts per tail tile (four tail workgroups per CU), persistent walkers
-FINE_FULL = [
-    dict(n=32, c=256, h=23, w=23, k=256, r=3, stride=1, pad=1, dil=1, tile_want=1500, stats=True, tail_per_cu=4, parts=28, forms=(1,)),   # layer3 conv2: 1024 + 36 x 28
-    dict(n=32, c=1024, h=23, w=23, k=256, r=1, stride=1, pad=0, dil=1, tile_want=1500, stats=True, add=True, tail_per_cu=4, parts=16, forms=(1,)),   # layer3 conv1: 32 slices -> 16 parts
-    dict(n=32, c=256, h=23, w=23, k=1024, r=1, stride=1, pad=0, dil=1, tile_want=1500, stats=True, persist=True, forms=(1,)),   # layer3 conv3: 4240 tiles, 1024 walkers
-    dict(n=32, c=512, h=23, w=23, k=2048, r=1, stride=1, pad=0, dil=1, tile_want=1500, stats=True, persist=True, tail_per_cu=2, forms=(1,)),   # layer4 conv3: 128x128 tiles
-    dict(n=8, c=128, h=46, w=46, k=128, r=3, stride=1, pad=1, dil=1, tile_want=1500, stats=True, persist=True, forms=(1,)),     # layer2 conv2 (B = 8)
 ]
 
 BNRED_FULL = [

@@ -616,3 +616,35 @@ def bn_groups_chain_case(dev, groups, n, c, h, w, k1, k2, r2=1, tol=2e-5, seed=0
     worst = max((rel(out[True][n_], out[False][n_]), n_) for n_ in out[True])
     assert worst[0] < tol, worst
     return worst
+
+
+def optimizer_stale_case(dev, math, fused, nweights=3):
+    """torch's fused optimizers (one multi-tensor kernel) update the parameters WITHOUT moving their version counters — the
+    packed weight images the convolutions read must still follow (ops.invalidate_packed_weights, called from a global
+    optimizer post-step hook).  Found by the G16 trajectory golden in round 5: with Adam(fused=True) every convolution kept
+    running on the weights of step 0.  Both image caches (fp32, bf16 planes), both re-packed by their batched launch; with more
+    than 24 parameters on a GPU the launch is split between the current and the side stream (ops._launch_repack)."""
+    from unipose_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    ws = [torch.nn.Parameter((torch.randn(32, 32, 3, 3, generator=gen) * 0.05).to(dev)) for _ in range(nweights)]
+    x = torch.randn(2, 6, 6, 32, generator=gen).to(dev)
+    cfg = ops.ConvCfg(1, 1, 1)
+    opt = torch.optim.Adam(ws, lr=0.05, fused=fused)
+    tol = 1e-5 if math == "f32" else 3e-2
+    ops.set_conv_math(math)
+    try:
+        for step in range(3):
+            order = range(nweights) if step % 2 == 0 else reversed(range(nweights))     # (the side-stream half first, too)
+            for i in order:
+                y = ops.conv_fwd_raw(x, ws[i], cfg)[0].float().cpu()
+                r = torch.nn.functional.conv2d(x.cpu().permute(0, 3, 1, 2), ws[i].detach().cpu(), padding=1).permute(0, 2, 3, 1)
+                err = float((y - r).abs().max() / r.abs().max())
+                assert err < tol, (step, i, err)
+            v0 = [w._version for w in ws]
+            for w in ws:
+                w.grad = torch.randn(w.shape, generator=gen).to(dev)
+            opt.step()
+            if fused:
+                assert [w._version for w in ws] == v0, "torch's fused Adam now moves the version counter: the hook is belt and braces"
+    finally:
+        ops.set_conv_math("f32")

@@ -20,13 +20,6 @@ def test_glds32_kernel_tail_split(emu_backend, case):
     g32.conv_ab(emu_backend, **case)
 
 
-@pytest.mark.parametrize("case", g32.FINE, ids=lambda c: _id(c) + "_cus%d_pc%d%s" % (c["cus"], c.get("tail_per_cu", 1), "_persist" if c.get("persist") else ""))
-def test_glds32_fine_tail_parts_and_persistent_form(emu_backend, case):
-    """round 5: tail tiles cut into several K parts per CU (equal to the register-staged kernel under the same cut), persistent
-    whole-tile workgroups (equal to the one-workgroup-per-tile form)"""
-    g32.conv_ab(emu_backend, **case)
-
-
 @pytest.mark.parametrize("case", g32.WIDE, ids=_id)
 def test_glds32_kernel_filters_of_more_than_32_taps(emu_backend, case):
     """the WIDE form (11x11 video head, 7x7): equal to the register-staged per-slice-tap kernel, element for element"""

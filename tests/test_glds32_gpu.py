@@ -27,16 +27,6 @@ def test_glds32_kernel_at_the_layer_geometries_of_the_headline(dev, case):
     g32.conv_ab(dev, **case)
 
 
-_fid = lambda c: _id(c) + "_cus%d_pc%d%s" % (c.get("cus", 0), c.get("tail_per_cu", 1), "_persist" if c.get("persist") else "")
-
-
-@pytest.mark.parametrize("case", g32.FINE + g32.FINE_FULL, ids=_fid)
-def test_glds32_fine_tail_parts_and_persistent_form(dev, case):
-    """round 5: several tail workgroups per CU (finer K parts, flags awaited at once) equal the register-staged kernel under the
-    same cut; persistent whole-tile workgroups with a start offset per CU slot equal the one-workgroup-per-tile form"""
-    g32.conv_ab(dev, **case)
-
-
 @pytest.mark.parametrize("case", g32.BNRED + g32.BNRED_FULL, ids=_id)
 def test_bn_backward_reduction_fused_into_data_gradient(dev, case):
     g32.bnred_case(dev, **case)

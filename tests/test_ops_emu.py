@@ -343,3 +343,48 @@ def test_bn_small_batch_statistics_are_exact(emu_backend):
     oc.bn_small_batch_case(emu_backend)
     oc.bn_small_batch_case(emu_backend, n=7, c=64, k=40, seed=31)
     oc.conv_bn_case(emu_backend, 4, 64, 1, 1, 32, 1, 1, 0, 1, relu=True, train=True)      # gradients through the same path
+
+
+@pytest.mark.parametrize("math", ["f32", "bf16"])
+@pytest.mark.parametrize("fused", [True, False])
+def test_optimizer_step_makes_the_packed_weights_stale(emu_backend, math, fused):
+    oc.optimizer_stale_case(emu_backend, math, fused)
+
+
+def test_batched_repack_equals_single_pack(emu_backend):
+    """ONE up_pack_weights_batched / up_pack_weights_bf16_batched launch over many parameters against up_pack_weights /
+    up_pack_weights_bf16 per parameter, bit for bit: padded input and output channels, 7x7 / 3x3 / 1x1, the parity-class-major
+    data-gradient image of stride-2 convolutions, rows shorter and longer than a wavefront."""
+    import ctypes
+    from unipose_amd import _C, ops
+    gen = torch.Generator().manual_seed(5)
+    geo = [(64, 3, 7, 2, 3, 1), (32, 32, 3, 1, 1, 1), (96, 64, 3, 2, 1, 1), (17, 64, 1, 1, 0, 1), (128, 32, 1, 2, 0, 1),
+           (40, 96, 3, 1, 2, 2), (14, 15, 3, 1, 1, 1), (200, 72, 1, 1, 0, 1)]
+    ws, descs = [], []
+    for k, c, r, stride, pad, dil in geo:
+        w = torch.nn.Parameter(torch.randn(k, c, r, r, generator=gen))
+        x = torch.zeros(1, 12, 12, ops.rup32(c) if c % 32 == 0 else ops.rup4(c))
+        ws.append(w)
+        descs.append(ops.make_desc(x, w, ops.ConvCfg(stride, pad, dil)))
+    L = _C.lib()
+    for bf16 in (False, True):
+        use = [(w, d) for w, d in zip(ws, descs) if not bf16 or (d.Cp % 32 == 0)]
+        get = ops._packed_bf16 if bf16 else ops._packed
+        for w, d in use:
+            get(w, d)                                            # registers the parameter (single-pack launches)
+        with torch.no_grad():
+            for w, _ in use:
+                w.mul_(1.5).add_(0.25)                           # new values, new version
+        first = get(*use[0])                                     # the first stale hit re-packs EVERY registered parameter
+        for w, d in use:
+            wf, wd = get(w, d)
+            if bf16:
+                rf, rd = torch.empty_like(wf), torch.empty_like(wd)
+                _C.check(L.up_pack_weights_bf16(ctypes.byref(d), w.data_ptr(), rf[0].data_ptr(), rf[1].data_ptr(), rd[0].data_ptr(),
+                                                rd[1].data_ptr(), 0), "pack_weights_bf16")
+            else:
+                rf, rd = torch.empty_like(wf), torch.empty_like(wd)
+                _C.check(L.up_pack_weights(ctypes.byref(d), w.data_ptr(), rf.data_ptr(), rd.data_ptr(), 0), "pack_weights")
+            assert torch.equal(wf, rf), ("forward image", bf16, tuple(w.shape))
+            assert torch.equal(wd, rd), ("data-gradient image", bf16, tuple(w.shape), d.stride)
+        assert first[0].data_ptr() == get(*use[0])[0].data_ptr()     # persistent buffers

@@ -219,3 +219,10 @@ def test_bn_small_batch_statistics_are_exact():
     oc.bn_small_batch_case(DEV, n=7, c=64, k=40, seed=31)
     oc.bn_small_batch_case(DEV, n=32, c=2048, k=256, seed=33)                     # the GAP branch of the headline batch
     oc.conv_bn_case(DEV, 4, 64, 1, 1, 32, 1, 1, 0, 1, relu=True, train=True)
+
+
+@pytest.mark.parametrize("math", ["f32", "bf16"])
+@pytest.mark.parametrize("nweights", [3, 40])
+def test_optimizer_step_makes_the_packed_weights_stale(math, nweights):
+    """(40 parameters: the batched re-pack is split between the current and the side stream, both read orders)"""
+    oc.optimizer_stale_case(DEV, math, True, nweights)

@@ -13,6 +13,9 @@ import torch  # noqa: E402
 
 # (label, n, c, hw, k, r, pad, dil, launches per step as forward OR data gradient of the same GEMM shape)
 SHAPES = [
+    ("3x3 256->256 @92 (K2304, 16928 tiles)", 32, 256, 92, 256, 3, 1, 1, 0),     # many dispatch waves: the K loop without quantisation
+    ("1x1 1024->256 @92 (K1024, 16928 tiles)", 32, 1024, 92, 256, 1, 0, 1, 0),
+    ("1x1 256->1024 @46 (K256, 16928 tiles)", 32, 256, 46, 1024, 1, 0, 1, 0),
     ("3x3 256->256 @23 (K2304 N256)", 32, 256, 23, 256, 3, 1, 1, 51),
     ("1x1 1024->256 @23 (K1024 N256)", 32, 1024, 23, 256, 1, 0, 1, 46),
     ("1x1 256->1024 @23 (K256 N1024)", 32, 256, 23, 1024, 1, 0, 1, 45),
@@ -26,7 +29,7 @@ SHAPES = [
     ("3x3 512->512 d2 @23 (K4608 N512)", 32, 512, 23, 512, 3, 2, 2, 2),
     ("3x3 256->256 d18 @23 (WASP)", 32, 256, 23, 256, 3, 18, 18, 2),
 ]
-DEFAULTS = {"tail_per_cu": 1, "persist": 0, "stagger": 0, "tail_split": 1, "tile_want": 1500}
+DEFAULTS = {"tail_split": 1, "tile_want": 1500}
 
 
 def main():

@@ -71,6 +71,7 @@ SIGNATURES = {
     "up_bn_bwd_prereduced_t": (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _i64, _i,
                                     _i, _p]),
     "up_pack_weights_bf16": (_i, [_D, _p, _p, _p, _p, _p, _p]),
+    "up_pack_weights_bf16_batched": (_i, [_p, _i, _p]),
     "up_conv2d_fwd_bf16": (_i, [_D, _p, _p, _p, _p, _E, _i, _p]),
     "up_conv2d_bwd_data_bf16": (_i, [_D, _p, _p, _p, _p, _p, _i, _i, _p]),
     "up_conv2d_bwd_weight_workspace": (_sz, [_D]),

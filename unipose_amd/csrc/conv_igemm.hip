@@ -141,10 +141,6 @@ struct IgemmArgs {
     // tail split (see launch_igemm): blocks [0, full_blocks) compute whole tiles, the rest compute 1/parts of the
     // K range of a tail tile; parts 0..parts-2 publish raw accumulators, the last part adds them and runs the epilogue
     int full_blocks, parts;
-    // f32_glds.h, round 5: persist > 0 = that many workgroups walk the whole tiles with stride persist (grid = persist + tail parts);
-    // stagger > 0 = start offset (sleep units of 1024 clocks) per CU slot for the workgroups of the first dispatch wave
-    int persist, stagger;
-    FastDiv fCus;
     int no_tap_skip;   // UP_TAP_SKIP=0 (A/B runs): visit every filter tap
     float* partials;
     int* flags;
@@ -1810,33 +1806,49 @@ __global__ void __launch_bounds__(256) pack_dgrad_kernel(const float* w, float* 
 // both images of MANY parameters in one launch (blockIdx.y = job): the optimizer changes every weight once per
 // step, and 2 x 115 separate 5-us launches cost more than the packing itself
 __global__ void __launch_bounds__(256) pack_batched_kernel(const up_pack_job* jobs) {
+    // Round 5: one ROW of an image (fixed (k, tap) forward / (c, tap) data gradient: Cp resp. Kp consecutive outputs) per wave and
+    // iteration, 32 consecutive rows per block and round — one 32-bit division per row instead of three 64-bit div / mod pairs per
+    // ELEMENT (the re-pack of all 115 weights cost 1.1 ms per step that way: since the optimizer hook of ops.py it IS in every step),
+    // and the rows of a block share their source lines (data gradient: the 32 (c, tap) rows behind one 128-byte line of w[k][.][.]).
     const up_pack_job jb = jobs[blockIdx.y];
     const int taps = jb.taps;
-    const long long nf = jb.w_fwd ? (long long)jb.K * taps * jb.Cp : 0;
-    const long long nd = jb.w_dgrad ? (long long)jb.C * taps * jb.Kp : 0;
-    const long long step = (long long)gridDim.x * 256;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // geometry word: stride | R << 4 | S << 10 | pad << 16 | dil << 24 (0 = plain layout)
     const int gstride = jb.geometry & 15, gR = (jb.geometry >> 4) & 63, gS = (jb.geometry >> 10) & 63;
     const int gpad = (jb.geometry >> 16) & 255, gdil = (jb.geometry >> 24) & 255;
     const bool s2 = jb.geometry != 0 && s2_decomposed(gstride, gdil);
-    S2Classes cls;
-    if (s2) cls = s2_classes(gR, gS, gpad, jb.C, jb.Kp);
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < nf + nd; e += step) {
-        if (e < nf) {
-            int ci = (int)(e % jb.Cp);
-            long long t = e / jb.Cp;
-            int tap = (int)(t % taps);
-            int k = (int)(t / taps);
-            jb.w_fwd[e] = ci < jb.C ? jb.w[((size_t)k * jb.C + ci) * taps + tap] : 0.f;
-        } else if (s2) {
-            jb.w_dgrad[e - nf] = s2_dgrad_elem(jb.w, e - nf, cls, jb.K, jb.Kp, jb.C, gS, taps);
-        } else {
-            long long f = e - nf;
-            int k = (int)(f % jb.Kp);
-            long long t = f / jb.Kp;
-            int tap = (int)(t % taps);
-            int c = (int)(t / taps);
-            jb.w_dgrad[f] = k < jb.K ? jb.w[((size_t)k * jb.C + c) * taps + tap] : 0.f;
+    if (jb.w_fwd) {
+        const int rows = jb.K * taps;
+        for (int base = blockIdx.x * 32; base < rows; base += gridDim.x * 32) {
+            const int end = min(base + 32, rows);
+            for (int rt = base + wave; rt < end; rt += 4) {
+                const int k = rt / taps, tap = rt - k * taps;
+                const float* src = jb.w + (size_t)k * jb.C * taps + tap;
+                float* dst = jb.w_fwd + (size_t)rt * jb.Cp;
+                for (int ci = lane; ci < jb.Cp; ci += 64) dst[ci] = ci < jb.C ? src[(size_t)ci * taps] : 0.f;
+            }
+        }
+    }
+    if (!jb.w_dgrad) return;
+    if (s2) {   // parity-class-major image of a stride-2 convolution (three weights of the network): element by element
+        S2Classes cls = s2_classes(gR, gS, gpad, jb.C, jb.Kp);
+        const long long nd = (long long)jb.C * taps * jb.Kp;
+        const long long step = (long long)gridDim.x * 256;
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < nd; e += step)
+            jb.w_dgrad[e] = s2_dgrad_elem(jb.w, e, cls, jb.K, jb.Kp, jb.C, gS, taps);
+        return;
+    }
+    const int rows = jb.C * taps;
+    const size_t kstride = (size_t)jb.C * taps;
+    // the 64 output channels of a chunk sit kstride floats apart in w: 64 source lines, each holding the values of 32 consecutive
+    // rows — chunk OUTSIDE, rows inside, so that the block's 32 rows read them out of L1 (rows outside re-fetched every line from
+    // L2 once per row: 32x the bytes, 0.5 ms for the network's 115 weights)
+    for (int base = blockIdx.x * 32; base < rows; base += gridDim.x * 32) {
+        const int end = min(base + 32, rows);
+        for (int k = lane; k < jb.Kp; k += 64) {
+            const float* src = jb.w + (size_t)(k < jb.K ? k : 0) * kstride;
+            for (int rt = base + wave; rt < end; rt += 4)   // rt = c * taps + tap: the source offset inside w[k][.][.] as well
+                jb.w_dgrad[(size_t)rt * jb.Kp + k] = k < jb.K ? src[rt] : 0.f;
         }
     }
 }
@@ -1937,7 +1949,6 @@ static int g_glds = env_int("UP_GLDS", 1, 0);   // bf16 storage: direct-to-LDS k
 // igemm_kernel; glds32_epi: 1 = LDS-transposed 16-byte-store epilogue, 0 = igemm_epilogue
 static long long g_count_igemm = 0, g_count_glds32 = 0, g_count_glds32_epi1 = 0, g_count_glds32_bnred = 0;   // up_conv_counter
 static long long g_count_wgrad32 = 0, g_count_wgrad32_st1 = 0, g_count_glds32_wide = 0, g_count_glds32_grouped = 0;
-static long long g_count_glds32_persist = 0, g_count_tail_parts = 0;   // persistent launches; K parts of the last split launch
 static thread_local bool g_extras_dropped = false;   // (per host thread: autograd runs one thread per device) a launch was asked for a masked addend / fused reduction on a kernel without them
 static int g_glds32 = env_int("UP_GLDS32", 1, 0);
 static int g_glds32_epi = env_int("UP_GLDS32_EPI", 1, 0);
@@ -1947,12 +1958,6 @@ static int g_db_min_k = 1024;   // (settled in round 1/2; no longer a run-time k
 static int g_short_k = 512;            // reductions shorter than this are epilogue-heavy:
 static int g_short_k_mult = 4;         // they want g_short_k_mult / 2 times as many workgroups (r04_d sweep: 2 / 4 / 8 within noise)
 static int g_tail_split = env_int("UP_TAIL_SPLIT", 1, 0);
-// round 5 (f32_glds.h): tail workgroups per CU (1 = one K part per CU, the round-1 rule; 2 / 4 = finer parts so that
-// the tail round is a full house instead of lone, latency-bound workgroups), persistent whole-tile workgroups for launches of at
-// least `persist` dispatch waves (0 = off), start offset between the co-resident workgroups of multi-wave launches
-static int g_tail_per_cu = env_int("UP_TAIL_PER_CU", 1, 1);
-static int g_persist = env_int("UP_PERSIST", 0, 0);
-static int g_stagger = env_int("UP_STAGGER", 0, 0);
 static int g_tap_skip = 1;   // (tile-level tap skipping: on since round 1; the probe build switches it for its WASP report)
 static int g_wgrad_per_cu = 2;   // workgroups per CU a weight-gradient launch aims for (r04_d: 1 -> +0.7 ms, 3 -> +1.1 ms per step)
 static int g_wgrad_rect = env_int("UP_WGRAD_RECT", 1, 0);      // weight-gradient reduction over live rectangles (see WgradRectKey); on since r02_a (-0.65 ms per step)
@@ -2059,19 +2064,15 @@ namespace up {
 // parts each tail tile is split into (1 = no split) for a launch of `tiles` tiles reducing over Ktot
 // *all_tiles: every tile is split, not only the tail of the launch
 static int g_split_per_cu = env_int("UP_SPLIT_PER_CU", 2, 1);
-static int split_parts(int tiles, int Ktot, size_t slots, bool* all_tiles = nullptr, int per_cu = 1) {
+static int split_parts(int tiles, int Ktot, size_t slots, bool* all_tiles = nullptr) {
     if (all_tiles) *all_tiles = false;
     if (!tail_split_enabled()) return 1;
     const int cus = cu_count(), q = tiles / cus, r = tiles % cus, nk = Ktot / BK;
     // A/B over the whole step: r <= 25 % of the CUs 70.9 ms, 50 % 70.1, 75 % 70.1;  >= 2 / 4 / 8 slices per part 70.1 / 70.1 / 70.3
     int p = 1;
     if (!(r == 0 || r > cus / 2 || q > 12)) {
-        // one part per CU (round 1: finer cuts measured slower with the serial flag -> loads merge chain); tail_per_cu > 1 cuts
-        // finer so that the tail round runs with several workgroups per CU (f32_glds.h merges with all flags awaited at once)
-        p = per_cu * cus / r;
+        p = cus / r;                  // one part per CU (finer cuts of a TAIL measured slower: the merge chain grows)
         if (p > nk / 2) p = nk / 2;   // a part keeps >= 2 K slices
-        if (per_cu > 1 && p > 32) p = 32;
-        while (p >= 2 && (size_t)r * (p - 1) > slots) --p;   // one scratch slot + flag per published share
         if (p < 2) p = 1;
     }
     // Small batches (inference at B <= 4): with fewer tiles than CUs every workgroup is alone on its CU, where the K loop
@@ -2238,14 +2239,6 @@ static auto glds32_kernel(const IgemmArgs& a) -> void (*)(IgemmArgs) {
     const bool bnred = epi1 && a.bn_partial != nullptr;
     // (a one-stage form — 21 KB of LDS, six 64x64 workgroups per CU — for reductions shorter than 1024 measured 0.4 ms per step
     //  SLOWER than two stages at four per CU, profiles/r04_a_*, and is not instantiated)
-    if (a.persist > 0 && epi1) {   // persistent whole-tile workgroups (launch_igemm only asks for them with the Epi32 epilogue)
-        if (a.perm) {
-            if (bnred) return glds::igemm_glds32_kernel<BM, BN, true, 2, OCC2, 1, true, false, true>;
-            return glds::igemm_glds32_kernel<BM, BN, true, 2, OCC2, 1, false, false, true>;
-        }
-        if (bnred) return glds::igemm_glds32_kernel<BM, BN, false, 2, OCC2, 1, true, false, true>;
-        return glds::igemm_glds32_kernel<BM, BN, false, 2, OCC2, 1, false, false, true>;
-    }
     if (a.perm) {
         if (bnred) return glds::igemm_glds32_kernel<BM, BN, true, 2, OCC2, 1, true>;
         if (epi1) return glds::igemm_glds32_kernel<BM, BN, true, 2, OCC2, 1, false>;
@@ -2333,8 +2326,7 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     SplitScratch* sc0 = aligned && tail_split_enabled() ? split_scratch(st) : nullptr;
     bool all_tiles = false;
     const size_t slots = sc0 ? std::min(sc0->pfloats / (size_t)(BM * BN), sc0->nflags) : 0;
-    const int p = aligned ? split_parts(a.nwg, a.Ktot, slots, &all_tiles, g_tail_per_cu) : 1;
-    g_count_tail_parts = 1;
+    const int p = aligned ? split_parts(a.nwg, a.Ktot, slots, &all_tiles) : 1;
     if (p >= 2) {
         if (SplitScratch* sc = sc0) {
             a.full_blocks = all_tiles ? 0 : a.nwg / cu_count() * cu_count();
@@ -2342,24 +2334,13 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
             a.partials = sc->partials;
             a.flags = sc->flags;
             grid = a.full_blocks + (a.nwg - a.full_blocks) * p;
-            g_count_tail_parts = p;
         }
     }
     if ((a.bn_partial || a.res_bits) && !(use32 && glds32_epi1_ok(a) && !(wide && a.bn_partial))) {
         g_extras_dropped = true;   // nothing is launched: dx without the masked addend must never be written
         return;
     }
-    a.persist = a.stagger = 0;
-    a.fCus = make_fastdiv(cu_count());
     if (use32) {
-        // whole-tile workgroups resident at once (launch bounds of glds32_kernel: 4 / 3 / 2 per CU)
-        const int wave_wgs = ((BM == 128 && BN == 128) ? 2 : (BM == 64 && BN == 64) ? 4 : 3) * cu_count();
-        if (g_persist > 0 && !wide && glds32_epi1_ok(a) && a.full_blocks >= g_persist * wave_wgs) {
-            a.persist = wave_wgs;
-            grid = a.persist + (a.nwg - a.full_blocks) * a.parts;
-        }
-        if (g_stagger > 0 && a.full_blocks >= 2 * wave_wgs) a.stagger = g_stagger;
-        if (a.persist) ++g_count_glds32_persist;
         kernel = wide ? glds32_wide_kernel<BM, BN>(a) : glds32_kernel<BM, BN>(a);
         ++g_count_glds32;
         if (wide) ++g_count_glds32_wide;
@@ -2397,7 +2378,8 @@ extern "C" int up_conv_stats_tiles_math(const up_conv_desc* d, int math) {
 
 extern "C" int up_pack_weights_batched(const up_pack_job* jobs_device, int njobs, void* stream) {
     UP_REQUIRE(jobs_device && njobs > 0 && njobs <= 65535, UP_ERR_INVALID, "pack_weights_batched: bad job table");
-    hipLaunchKernelGGL(pack_batched_kernel, dim3(48, njobs), dim3(256), 0, as_stream(stream), jobs_device);
+    // 144 blocks per job: one round of 32-row groups for the largest weights (512x512x3x3: 4608 rows per image); blocks without rows leave at once
+    hipLaunchKernelGGL(pack_batched_kernel, dim3(144, njobs), dim3(256), 0, as_stream(stream), jobs_device);
     return check_launch("pack_weights_batched");
 }
 
@@ -2412,9 +2394,6 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "glds32_epi")) g_glds32_epi = value ? 1 : 0;
     else if (!strcmp(key, "glds32_wgrad")) g_glds32_wgrad = value ? 1 : 0;
     else if (!strcmp(key, "tail_split")) g_tail_split = value ? 1 : 0;
-    else if (!strcmp(key, "tail_per_cu") && value >= 1 && value <= 4) g_tail_per_cu = value;
-    else if (!strcmp(key, "persist") && value >= 0) g_persist = value;
-    else if (!strcmp(key, "stagger") && value >= 0) g_stagger = value;
     else if (!strcmp(key, "split_per_cu") && value > 0) g_split_per_cu = value;
     else if (!strcmp(key, "tap_sort")) g_tap_sort = value ? 1 : 0;
     else if (!strcmp(key, "wgrad_rect")) g_wgrad_rect = value ? 1 : 0;
@@ -2430,8 +2409,6 @@ extern "C" long long up_conv_counter(const char* name) {
     if (!strcmp(name, "glds32_grouped")) return g_count_glds32_grouped;
     if (!strcmp(name, "glds32_epi1")) return g_count_glds32_epi1;
     if (!strcmp(name, "glds32_bnred")) return g_count_glds32_bnred;
-    if (!strcmp(name, "glds32_persist")) return g_count_glds32_persist;
-    if (!strcmp(name, "tail_parts")) return g_count_tail_parts;
     if (!strcmp(name, "wgrad_glds32")) return g_count_wgrad32;
     if (!strcmp(name, "wgrad_glds32_st1")) return g_count_wgrad32_st1;
     return -1;
@@ -2885,6 +2862,51 @@ extern "C" int up_pack_weights_bf16(const up_conv_desc* d, const float* w, uint1
                            dgrad_lo, d->K, d->C, d->Kp, taps, total, 1);
     }
     return check_launch("pack_weights_bf16");
+}
+
+namespace up {
+// up_pack_weights_bf16 for many parameters in one launch (blockIdx.y = job), element order and rounding of pack_split_kernel
+__global__ void __launch_bounds__(256) pack_split_batched_kernel(const up_pack_job_bf16* jobs) {
+    const up_pack_job_bf16 jb = jobs[blockIdx.y];
+    const int taps = jb.taps;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    auto put = [](uint16_t* hi, uint16_t* lo, size_t e, float v) {
+        uint32_t h, l;
+        split_bf16x2(v, 0.f, h, l);
+        hi[e] = (uint16_t)(h & 0xffffu);
+        lo[e] = (uint16_t)(l & 0xffffu);
+    };
+    if (jb.fwd_hi) {   // rows (k, tap) of Cp channels — the row scheme of pack_batched_kernel
+        const int rows = jb.K * taps;
+        for (int base = blockIdx.x * 32; base < rows; base += gridDim.x * 32) {
+            const int end = min(base + 32, rows);
+            for (int rt = base + wave; rt < end; rt += 4) {
+                const int k = rt / taps, tap = rt - k * taps;
+                const float* src = jb.w + (size_t)k * jb.C * taps + tap;
+                for (int ci = lane; ci < jb.Cp; ci += 64)
+                    put(jb.fwd_hi, jb.fwd_lo, (size_t)rt * jb.Cp + ci, ci < jb.C ? src[(size_t)ci * taps] : 0.f);
+            }
+        }
+    }
+    if (jb.dgrad_hi) {   // rows (c, tap) of Kp output channels
+        const int rows = jb.C * taps;
+        const size_t kstride = (size_t)jb.C * taps;
+        for (int base = blockIdx.x * 32; base < rows; base += gridDim.x * 32) {
+            const int end = min(base + 32, rows);
+            for (int k = lane; k < jb.Kp; k += 64) {   // chunk outside, rows inside: see pack_batched_kernel
+                const float* src = jb.w + (size_t)(k < jb.K ? k : 0) * kstride;
+                for (int rt = base + wave; rt < end; rt += 4)
+                    put(jb.dgrad_hi, jb.dgrad_lo, (size_t)rt * jb.Kp + k, k < jb.K ? src[rt] : 0.f);
+            }
+        }
+    }
+}
+}  // namespace up
+
+extern "C" int up_pack_weights_bf16_batched(const up_pack_job_bf16* jobs_device, int njobs, void* stream) {
+    UP_REQUIRE(jobs_device && njobs > 0 && njobs <= 65535, UP_ERR_INVALID, "pack_weights_bf16_batched: bad job table");
+    hipLaunchKernelGGL(pack_split_batched_kernel, dim3(144, njobs), dim3(256), 0, as_stream(stream), jobs_device);
+    return check_launch("pack_weights_bf16_batched");
 }
 
 extern "C" int up_conv2d_fwd_bf16(const up_conv_desc* d, const float* x, const uint16_t* w_hi, const uint16_t* w_lo,

@@ -315,12 +315,11 @@ struct Epi32 {
 // flight during the MFMAs; 1: single stage, 16 KB per 64x64 workgroup — the co-resident workgroups hide the load).
 // EPI: 0 = igemm_epilogue (dword stores from the accumulator layout), 1 = Epi32 (LDS-transposed, 16-byte stores).
 // BNRED (EPI 1): BatchNorm-backward sums of the producing layer in the epilogue (a.bn_*).
-// PERS: persistent whole-tile workgroups (a.persist of them, see the kernel's first lines).
 // WIDE: filters of more than 32 taps (the video head's 11x11, uniposeLSTM.py:43-45).  The per-row validity is kept separably —
 //       bit r: filter row r reads a real pixel row, bit 16 + s: filter column s a real column (R, S <= 16) — instead of one bit per
 //       tap, every tap is visited (no tile-level skipping: with pad = 5 on 46x46 maps nearly every tap is live for some row of a
 //       tile), no tap-sorted rows.  Same slice order (tap-major, 32 channels per slice) as the register-staged per-slice-tap path.
-template <int BM, int BN, bool PERM, int ST = 2, int OCC = 4, int EPI = 1, bool BNRED = false, bool WIDE = false, bool PERS = false>
+template <int BM, int BN, bool PERM, int ST = 2, int OCC = 4, int EPI = 1, bool BNRED = false, bool WIDE = false>
 __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
     using G = GeomF<BM, BN, ST>;
     static_assert(ST == 1 || ST == 2, "one or two LDS stages");
@@ -340,29 +339,12 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
 
     // K-split tail tiles exactly as in igemm_kernel ("tail split"): blocks >= full_blocks reduce a 1 / parts share of the live
     // slices of tile full_blocks + tail; the last part of a tile adds the published shares in a fixed order and runs the epilogue
-    // PERSISTENT form (a.persist > 0, round 5): the first a.persist workgroups walk the whole tiles with stride a.persist (tile
-    // t, t + persist, ...: the same XCD every time, persist is a multiple of 8) instead of one workgroup per tile — no dispatch gap
-    // between two tiles of a CU slot (~1.2 us, tools/gpu/igemm_probe timeline) and a start offset between the co-resident
-    // workgroups (a.stagger) survives the whole launch; the tail parts follow behind them in the grid as before.
-    const int nwhole = PERS ? a.persist : a.full_blocks;   // workgroups that compute whole tiles
-    const bool split = (int)blockIdx.x >= nwhole;
-    if (a.stagger > 0 && (int)blockIdx.x < nwhole) {
-        // co-resident workgroups start in lockstep (one dispatch wave fills every slot of a CU at once) and, with equal tiles,
-        // stay there: all of them in the set-up / first-slice / epilogue phases together, the MFMA pipe idle.  Slot s of a CU
-        // (dispatch is round-robin over the CUs: block b sits in slot b / CUs of CU b % CUs) waits s * stagger sleep units first.
-#ifndef UP_EMU
-        const int slot = (int)fdiv(blockIdx.x, a.fCus);
-        if (slot < OCC)
-            for (int i = uniform(slot * a.stagger); i > 0; --i) __builtin_amdgcn_s_sleep(16);
-#endif
-    }
-    int tile_idx = (int)blockIdx.x;
-  for (;;) {   // (one pass unless persistent)
     int logical, part = 0, tail = 0;
+    const bool split = (int)blockIdx.x >= a.full_blocks;
     if (!split) {
-        logical = xcd_remap(tile_idx, a.full_blocks);
+        logical = xcd_remap(blockIdx.x, a.full_blocks);
     } else {
-        const int j = tile_idx - nwhole;
+        const int j = (int)blockIdx.x - a.full_blocks;
         tail = uniform(j / a.parts);
         part = j - tail * a.parts;
         logical = a.full_blocks + tail;
@@ -587,32 +569,9 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
             if (tid == 0) st_agent_flag(flag + part, 1);
             return;
         }
-        // all flags are awaited at once (one lane per part), then the shares are fetched MB at a time and added in part order: with
-        // the flag -> barrier -> 16 dependent loads chain once per part the merge of a finely cut tail tile (a.parts up to 28 with
-        // several tail workgroups per CU) was serial latency (~1.5 us per part)
-        if (tid < a.parts - 1) spin_until_set(flag + tid);
-        __syncthreads();
-        constexpr int NACC = TM * TN * 16;
-        constexpr int MB = NACC <= 16 ? 2 : 1;   // shares in flight (four cost the 64x64 forms 44 VGPRs and put them at the 128 cap)
-        int pp = 0;
-        for (; pp + MB <= a.parts - 1; pp += MB) {
-            float t[MB][NACC];
-#pragma unroll
-            for (int b = 0; b < MB; ++b) {
-                const float* o = pbase + (size_t)(pp + b) * (BM * BN) + tid;
-#pragma unroll
-                for (int e = 0; e < NACC; ++e) t[b][e] = ld_agent(o + e * 256);
-            }
-#pragma unroll
-            for (int b = 0; b < MB; ++b)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] += t[b][(i * TN + j) * 16 + r];
-        }
-        for (; pp < a.parts - 1; ++pp) {
+        for (int pp = 0; pp < a.parts - 1; ++pp) {
+            if (tid == 0) spin_until_set(flag + pp);
+            __syncthreads();
             const float* o = pbase + (size_t)pp * (BM * BN) + tid;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -630,12 +589,6 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
     } else {
         igemm_epilogue<BM, BN, PERM>(a, acc, reinterpret_cast<float*>(smem), mt, m0, n0, wm, wn, l31, lh);
     }
-    if constexpr (!PERS) break;   // (a template parameter: the loop's live ranges cost the one-pass form 27 VGPRs)
-    if (split) break;
-    tile_idx += a.persist;
-    if (tile_idx >= a.full_blocks) break;
-    __syncthreads();   // the epilogue image (and the tap masks) are read: the stages may be filled again
-  }
 }
 
 

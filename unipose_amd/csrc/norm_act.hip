@@ -863,7 +863,7 @@ constexpr int BNB_ROWS = 128;   // small chunks: enough workgroups (and bytes in
 using namespace up;
 
 extern "C" const char* up_last_error(void) { return g_err; }
-extern "C" int up_abi_version(void) { return 8; }   // 8: row groups (up_conv2d_fwd_grouped, groups in up_dgrad_epilogue, up_bn_bwd_groups_prereduced_t); 7: up_conv2d_bwd_data_ex / up_bn_bwd_prereduced_t / up_conv_counter; 6: centred BatchNorm; 5: up_conv2d_bwd_weight_acc; 4: element-typed (_t) twins + bf16 storage
+extern "C" int up_abi_version(void) { return 9; }   // 9: up_pack_weights_bf16_batched; 8: row groups (up_conv2d_fwd_grouped, groups in up_dgrad_epilogue, up_bn_bwd_groups_prereduced_t); 7: up_conv2d_bwd_data_ex / up_bn_bwd_prereduced_t / up_conv_counter; 6: centred BatchNorm; 5: up_conv2d_bwd_weight_acc; 4: element-typed (_t) twins + bf16 storage
 
 extern "C" int up_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                  int C, float* scale, float* shift, void* stream) {

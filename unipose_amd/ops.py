@@ -116,6 +116,39 @@ def make_desc(x: torch.Tensor, weight: torch.Tensor, cfg: ConvCfg, ldy: Optional
     return d
 
 
+# The batched re-pack of one step (0.44 ms for the 115 weights of the network, on the critical path of the forward since the
+# optimizer hook of round 5) is split: the images of the first _REPACK_HEAD parameters (stem + layer1: what the forward needs first)
+# are re-packed on the current stream, the rest on the weight-gradient side stream — idle during the forward — while the stem and
+# layer1 run; the first request for one of THOSE images makes the current stream wait for the side stream's event.
+ASYNC_REPACK = os.environ.get("UNIPOSE_ASYNC_REPACK", "1") != "0"
+_REPACK_HEAD = 12
+
+
+def _launch_repack(ps, weight, entry_point, what, job_bytes):
+    """`ps`: a _PackSet / _Pack16Set whose job table is current; launches the batched re-pack of all its jobs."""
+    n = len(ps.order)
+    L = _C.lib()
+    dev = weight.device
+    ps.pending = None
+    if ASYNC_REPACK and dev.type == "cuda" and n > 2 * _REPACK_HEAD and not torch.cuda.is_current_stream_capturing():
+        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+        _C.check(getattr(L, entry_point)(ps.table.data_ptr(), _REPACK_HEAD, main.cuda_stream), what)
+        side.wait_stream(main)                       # the optimizer's writes (and every reader of the old images) are behind us
+        _C.check(getattr(L, entry_point)(ps.table.data_ptr() + _REPACK_HEAD * job_bytes, n - _REPACK_HEAD, side.cuda_stream), what)
+        ev = torch.cuda.Event()
+        ev.record(side)
+        ps.pending = (ev, set(ps.order[_REPACK_HEAD:]))
+    else:
+        _C.check(getattr(L, entry_point)(ps.table.data_ptr(), n, _stream(weight)), what)
+
+
+def _await_repack(ps, key, dev):
+    """the current stream is about to read the images of parameter `key`"""
+    if ps.pending is not None and key in ps.pending[1]:
+        torch.cuda.current_stream(dev).wait_event(ps.pending[0])
+        ps.pending = None
+
+
 class _PackSet:
     """Packed weight images of every convolution parameter seen on one device.
 
@@ -129,6 +162,7 @@ class _PackSet:
         self.entries = {}          # id(weight) -> [weakref, version, wf, wd, (K, C, Cp, Kp, taps), data_ptr]
         self.table = None          # device job table, rebuilt when the membership changes
         self.order = []
+        self.pending = None        # (event, keys): images being re-packed on the side stream, see _launch_repack
 
     def get(self, weight, d):
         key = id(weight)
@@ -138,6 +172,7 @@ class _PackSet:
                 e[5] == weight.data_ptr():                 # `param.data = other` keeps the version but moves the storage
             if e[1] != weight._version:
                 self.repack(weight)
+            _await_repack(self, key, weight.device)
             return e[2], e[3]
         wf = torch.empty(nf, dtype=torch.float32, device=weight.device)
         wd = torch.empty(nd, dtype=torch.float32, device=weight.device)
@@ -169,8 +204,7 @@ class _PackSet:
         if any(e[0]() is None for e in live):                         # a parameter died: its pointer is stale
             self.table = None
             return self.repack(weight)
-        _C.check(_C.lib().up_pack_weights_batched(self.table.data_ptr(), len(live), _stream(weight)),
-                 "pack_weights_batched")
+        _launch_repack(self, weight, "up_pack_weights_batched", "pack_weights_batched", 48)
         for e in live:
             e[1] = e[0]()._version
 
@@ -217,27 +251,94 @@ def storage_dtype():
 if os.environ.get("UNIPOSE_CONV_MATH"):           # e.g. UNIPOSE_CONV_MATH=bf16x3 python -m pytest tests -m gpu
     set_conv_math(os.environ["UNIPOSE_CONV_MATH"])
 
-_PACK16_CACHE = {}
 WGRAD_BF16_ANY_WIDTH = False     # tests only: drive the bf16 weight-gradient kernel at channel counts the model keeps in fp32
 
 
+class _Pack16Set:
+    """bf16 (hi, lo) planes of the forward and data-gradient weight images of every convolution parameter seen on one device
+    (arithmetic modes bf16x3 / bf16 / bf16s): the _PackSet scheme — persistent buffers, staleness by version counter (and the
+    optimizer hook below), ALL registered parameters re-packed by ONE up_pack_weights_bf16_batched launch at the first stale hit
+    (2 x 115 pack launches per step otherwise, ~1 ms of the 37 ms bf16-storage step at 736x736)."""
+
+    def __init__(self):
+        self.entries = {}          # id(weight) -> [weakref, version, wf(2, nf) int16, wd(2, nd) int16, (K, C, Cp, Kp, taps), data_ptr]
+        self.table = None
+        self.order = []
+        self.pending = None
+
+    def get(self, weight, d):
+        key = id(weight)
+        nf, nd = d.K * d.R * d.S * d.Cp, d.C * d.R * d.S * d.Kp
+        e = self.entries.get(key)
+        if e is not None and e[0]() is weight and e[2].shape[1] == nf and e[3].shape[1] == nd and e[5] == weight.data_ptr():
+            if e[1] != weight._version:
+                self.repack(weight)
+            _await_repack(self, key, weight.device)
+            return e[2], e[3]
+        wf = torch.empty((2, nf), dtype=torch.int16, device=weight.device)
+        wd = torch.empty((2, nd), dtype=torch.int16, device=weight.device)
+        _C.check(_C.lib().up_pack_weights_bf16(C.byref(d), _dense(weight).data_ptr(), wf[0].data_ptr(), wf[1].data_ptr(),
+                                               wd[0].data_ptr(), wd[1].data_ptr(), _stream(weight)), "pack_weights_bf16")
+        if isinstance(weight, torch.nn.Parameter) and weight.is_contiguous():      # temporaries are packed per use
+            if len(self.entries) > 4096:
+                self.entries.clear()
+            self.entries[key] = [weakref.ref(weight), weight._version, wf, wd, (d.K, d.C, d.Cp, d.Kp, d.R * d.S), weight.data_ptr()]
+            self.table = None
+        return wf, wd
+
+    def repack(self, weight):
+        if self.table is None:
+            import numpy as np
+            for k in [k for k, e in self.entries.items() if e[0]() is None]:
+                del self.entries[k]
+            self.order = list(self.entries)
+            job = np.zeros((len(self.order), 8), dtype=np.int64)      # up_pack_job_bf16: 5 pointers + 6 int32
+            for i, k in enumerate(self.order):
+                w, _, wf, wd, (kk, cc, cp, kp, taps), _ = self.entries[k]
+                job[i, :5] = (w().data_ptr(), wf[0].data_ptr(), wf[1].data_ptr(), wd[0].data_ptr(), wd[1].data_ptr())
+                job[i, 5:].view(np.int32)[:] = (kk, cc, cp, kp, taps, 0)
+            self.table = torch.from_numpy(job).to(weight.device)
+        live = [self.entries[k] for k in self.order]
+        if any(e[0]() is None for e in live):                         # a parameter died: its pointer is stale
+            self.table = None
+            return self.repack(weight)
+        _launch_repack(self, weight, "up_pack_weights_bf16_batched", "pack_weights_bf16_batched", 64)
+        for e in live:
+            e[1] = e[0]()._version
+
+
+_PACK16_CACHE = {}                 # device index -> _Pack16Set
+
+
 def _packed_bf16(weight: torch.Tensor, d: _C.ConvDesc):
-    """bf16 (hi, lo) planes of the forward and data-gradient weight images; cached like _packed()."""
-    key = id(weight)
-    hit = _PACK16_CACHE.get(key)
-    nf, nd = d.K * d.R * d.S * d.Cp, d.C * d.R * d.S * d.Kp
-    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2].shape[1] == nf and \
-            hit[3].shape[1] == nd and hit[4] == weight.data_ptr() and hit[2].device == weight.device:
-        return hit[2], hit[3]                       # (`param.data = other` keeps the version but moves the storage)
-    wf = torch.empty((2, nf), dtype=torch.int16, device=weight.device)
-    wd = torch.empty((2, nd), dtype=torch.int16, device=weight.device)
-    _C.check(_C.lib().up_pack_weights_bf16(C.byref(d), _dense(weight).data_ptr(), wf[0].data_ptr(), wf[1].data_ptr(),
-                                           wd[0].data_ptr(), wd[1].data_ptr(), _stream(weight)), "pack_weights_bf16")
-    if len(_PACK16_CACHE) > 4096:
-        _PACK16_CACHE.clear()
-    if isinstance(weight, torch.nn.Parameter):
-        _PACK16_CACHE[key] = (weakref.ref(weight), weight._version, wf, wd, weight.data_ptr())
-    return wf, wd
+    """bf16 (hi, lo) planes of the forward and data-gradient weight images, see _Pack16Set."""
+    ps = _PACK16_CACHE.get(weight.device.index)
+    if ps is None:
+        ps = _PACK16_CACHE[weight.device.index] = _Pack16Set()
+    return ps.get(weight, d)
+
+
+def invalidate_packed_weights():
+    """Mark every cached weight image stale.  The cache follows a parameter's in-place version counter, but not every writer moves
+    it: torch's FUSED optimizers (``Adam(fused=True)``: one multi-tensor kernel through ``torch._fused_adam_``) and in-place edits
+    through ``.data`` leave ``_version`` untouched, and a training loop on such an optimizer then ran every convolution on the
+    weights of step 0 (found by the G16 trajectory golden, round 5: loss 1.5628 -> 1.5411 where the reference goes to 1.4078).
+    Called from a global optimizer post-step hook (below), so a plain ``optimizer.step()`` needs nothing; call it by hand after
+    editing weights through ``.data`` or a raw pointer."""
+    for ps in list(_PACK_CACHE.values()) + list(_PACK16_CACHE.values()):
+        for e in ps.entries.values():
+            e[1] = -1
+
+
+def _optimizer_stepped(_optimizer, _args, _kwargs):
+    invalidate_packed_weights()
+
+
+try:        # every torch.optim optimizer, fused or not, reports its step here
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_step_hook
+    _STEP_HOOK = _reg_step_hook(_optimizer_stepped)
+except ImportError:     # (older torch: the version counter alone, i.e. no fused optimizers)
+    _STEP_HOOK = None
 
 
 def packed_fwd(weight: torch.Tensor, d: _C.ConvDesc) -> torch.Tensor:
