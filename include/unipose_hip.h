@@ -425,6 +425,34 @@ int up_peak_mask(const float* maps, int nmaps, int H, int W, uint8_t* mask, void
 int up_box_argmax(const float* maps, int C, int H, int W, const int32_t* boxes, int P, int ch0, int nch,
                   int32_t* out_hw, void* stream);
 
+/* ---- whole-graph inference entry (ABI 9) ----------------------------------------------------------------------------
+ * The UniPose image network (model/unipose.py:8-38: ResNet-101 + WASP + decoder) with every BatchNorm folded into its
+ * convolution, as ONE call on one stream — what the reference's validation / test loops issue as `heat = model(input)`
+ * (unipose.py:150-160).  The plan owns the packed weight images and biases (device memory); activations live in a
+ * caller-provided workspace of up_unipose_plan_workspace() bytes (256-byte aligned), reused between calls.
+ *   up_unipose_plan_create(&cfg, &plan);
+ *   for i in [0, up_unipose_plan_num_convs): set_conv(plan, i, folded weight of <name>.weight, <name>.bias or NULL, stream)
+ *   up_unipose_forward(plan, input NCHW (batch, 3, H, W), heat-maps NCHW (batch, out_channels, H/8, W/8), workspace, bytes, stream)
+ * Convolution names are the reference's state_dict prefixes ("backbone.layer3.11.conv2", "wasp.aspp2.atrous_conv",
+ * "decoder.last_conv.8"); a parameter that is applied twice (wasp.conv2, wasp.py:72-80) appears twice, setting it once suffices.
+ * Launches and descriptors are those of the drop-in module's folded inference forward: equal bits.  Training has no
+ * whole-graph entry (it runs through autograd). */
+typedef struct up_unipose_plan up_unipose_plan;
+typedef struct {
+    int32_t batch, height, width;   /* input (batch, 3, height, width) */
+    int32_t output_stride;          /* 16 or 8 (resnet.py:49-58) */
+    int32_t out_channels;           /* channels of decoder.last_conv.8: num_classes + 1 (+ 5 for the multi-person box head) */
+} up_unipose_config;
+int up_unipose_plan_create(const up_unipose_config* cfg, up_unipose_plan** plan);
+void up_unipose_plan_destroy(up_unipose_plan* plan);
+int up_unipose_plan_num_convs(const up_unipose_plan* plan);
+const char* up_unipose_plan_conv_name(const up_unipose_plan* plan, int i);
+int up_unipose_plan_conv_shape(const up_unipose_plan* plan, int i, int32_t* oihw /* [4] */, int32_t* has_bias);
+int up_unipose_plan_set_conv(up_unipose_plan* plan, int i, const float* w_oihw, const float* bias, void* stream);
+size_t up_unipose_plan_workspace(const up_unipose_plan* plan);
+int up_unipose_forward(up_unipose_plan* plan, const float* x_nchw, float* heat_nchw, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
 /* ---- measurement hooks (bench.py roofline leg; no reference counterpart) ----
  * Between begin/end every MFMA convolution launch is bracketed by two hipEvents on its stream;
  * end() returns per kernel variant {launches, total ms, total algorithmic FLOP}. */

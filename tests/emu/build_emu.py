@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "unipose_amd", "csrc")
 OUT = os.path.join(HERE, "libunipose_emu.so")
-SOURCES = ["conv_igemm.hip", "norm_act.hip", "spatial.hip"]
+SOURCES = ["conv_igemm.hip", "norm_act.hip", "spatial.hip", "plan.hip"]
 
 
 def build(force: bool = False) -> str:

@@ -133,6 +133,14 @@ SIGNATURES = {
     "up_pck_accuracy": (_i, [_p, _p, _i, _i, _i, _i, _i, C.c_double, C.c_double, _p, _p, _p, _p, _p, _p]),
     "up_peak_mask": (_i, [_p, _i, _i, _i, _p, _p]),
     "up_box_argmax": (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _p, _p]),
+    "up_unipose_plan_create": (_i, [_p, C.POINTER(_p)]),
+    "up_unipose_plan_destroy": (None, [_p]),
+    "up_unipose_plan_num_convs": (_i, [_p]),
+    "up_unipose_plan_conv_name": (C.c_char_p, [_p, _i]),
+    "up_unipose_plan_conv_shape": (_i, [_p, _i, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "up_unipose_plan_set_conv": (_i, [_p, _i, _p, _p, _p]),
+    "up_unipose_plan_workspace": (_sz, [_p]),
+    "up_unipose_forward": (_i, [_p, _p, _p, _p, _sz, _p]),
     "up_profile_variants": (_i, []),
     "up_profile_variant_name": (C.c_char_p, [_i]),
     "up_profile_begin": (_i, []),

@@ -106,6 +106,12 @@ struct ProfScope {
 };
 #endif
 
+#ifndef UP_EMU
+static inline bool g_prof_on_host() { return g_prof_on; }
+#else
+static inline bool g_prof_on_host() { return false; }
+#endif
+
 constexpr int BK = 32;   // K slice of the weight-gradient kernel (the conv/dgrad kernel takes it as a template parameter)
 constexpr int KT_DEFAULT = 32;   // K slice every fp32 forward / data-gradient launch uses
 
@@ -2218,6 +2224,28 @@ static double visited_tap_fraction(const IgemmArgs& a, int bm, bool sorted, doub
     return (double)visited / ((double)tiles * a.taps);
 }
 
+// Share of (pixel, filter tap) pairs of a launch that read a real source pixel: what the per-launch FLOP of the profiler is charged
+// with (round 5) — the nominal 2 M N K counted the taps of a dilated convolution that fall into the padding for every pixel and
+// that the tile-level skipping / tap-sorted rows never multiply (WASP d = 18: 0.229), which inflated the per-kernel TFLOP/s by 1-2 %.
+// Per geometry, cached; only evaluated while the profiler is on.
+static double live_tap_share(const IgemmArgs& a) {
+    if (a.taps <= 1 || a.taps > 32 || a.no_tap_skip || a.divshift != 0) return 1.0;
+    static std::mutex mu;
+    static std::map<TapSortKey, double> cache;
+    TapSortKey key;
+    memset(&key, 0, sizeof(key));
+    key.M = 0; key.H = a.H; key.W = a.W; key.P = a.P; key.Q = a.Q; key.taps = a.taps; key.S = a.S;
+    key.mul = a.mul; key.off0 = a.off0; key.off0w = a.off0w; key.tapstep = a.tapstep;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    long long alive = 0;
+    for (unsigned mk : tap_masks(a)) alive += __builtin_popcount(mk);
+    const double share = (double)alive / ((double)a.P * a.Q * a.taps);
+    if (cache.size() < 4096) cache[key] = share;
+    return share;
+}
+
 // f32_glds.h: needs the aligned fast path (<= 32 taps, no strided gather), 31-bit BYTE offsets and 16-byte aligned operands
 static bool glds32_eligible(IgemmArgs& a, bool fast) {
     if (!g_glds32 || !fast || a.Cp % 32 != 0 || a.M % (a.P * a.Q) != 0) return false;
@@ -2281,7 +2309,9 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
         g_group_refused = true;   // only f32_glds.h's LDS-transposed epilogue knows row groups
         return;
     }
-    ProfScope prof(use32 ? 28 + vbase / 2 : vbase + (aligned ? 0 : 1), 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st,
+    a.no_tap_skip = g_tap_skip ? 0 : 1;
+    ProfScope prof(use32 ? 28 + vbase / 2 : vbase + (aligned ? 0 : 1),
+                   2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real * (g_prof_on_host() && fast ? live_tap_share(a) : 1.0), st,
                    a.M, a.Ng, a.Ktot, a.nwg);
     // double-buffered LDS (one barrier per slice) for long reductions.  In isolation it is 3-5 % faster than the
     // single-buffer loop down to K = 256 (probe), but in the network the rule K >= 1024 is 0.5 % faster per step (A/B in
@@ -2602,7 +2632,10 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
     const bool of32 = math == UP_MATH_BF16S_F32OUT;
     if (of32) math = UP_MATH_BF16S;
     const bool glds_form = math == UP_MATH_BF16S && !of32 && glds_eligible(a, fast);
-    ProfScope prof(glds_form ? v + 8 : v, 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st, a.M, a.Ng, a.Ktot, a.nwg);
+    a.no_tap_skip = g_tap_skip ? 0 : 1;
+    ProfScope prof(glds_form ? v + 8 : v,
+                   2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real * (g_prof_on_host() && fast ? live_tap_share(a) : 1.0), st, a.M, a.Ng,
+                   a.Ktot, a.nwg);
     const bool split = math == UP_MATH_BF16X3;
     // K slice: 64 on the 64x64 tile (6 -> 12 MFMAs per wave and barrier) measured no faster than 32 (141.7 vs 145.1 TF)
     constexpr int KT = 32;
