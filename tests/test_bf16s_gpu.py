@@ -146,3 +146,12 @@ def test_train_step_b8_within_twice_the_reference_bf16_yardstick(golden_dir):
     implementation lands from the fp32 gradients on this input; the HIP bf16-storage step must stay within twice that,
     parameter by parameter"""
     bc.model_train_yardstick_case(DEV, os.path.join(golden_dir, "g13_bf16_yardstick_b8_128.npz"))
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_lstm_bf16_storage(train):
+    """round 5: UniPose-LSTM under bf16 storage (bf16 trunk, fp32 heat-map hand-over, fp32 ConvLSTM state and head), B=2, T=3 at
+    128x128, batched frames: against the fp32 path with the head's measured amplification as the yardstick"""
+    import model_cases as mc
+    l16, l32 = mc.lstm_bf16s_case(torch.device("cuda:0"), B=2, size=128, T=3, train=train)
+    print(f"UniPose-LSTM bf16 storage: loss {l16:.6f} vs fp32 {l32:.6f}")

@@ -69,3 +69,12 @@ def test_output_stride_8_vs_reference_golden_emu(emu_backend, golden_dir):
     errs = mc.tap_case(emu_backend, os.path.join(golden_dir, "g12_eval_os8_160.npz"), 160, ("layer2", "layer3", "layer4", "wasp"),
                        sub=8, output_stride=8)
     assert max(errs.values()) < 1e-4, errs
+
+
+def test_lstm_bf16_storage_eval_emu(emu_backend):
+    """round 5: the video model no longer refuses ops.set_conv_math("bf16s") (bf16 trunk, fp32 ConvLSTM state and head)"""
+    mc.lstm_bf16s_case(emu_backend, train=False)
+
+
+def test_lstm_bf16_storage_train_emu(emu_backend):
+    mc.lstm_bf16s_case(emu_backend, train=True)

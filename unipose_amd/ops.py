@@ -771,11 +771,14 @@ class ConvBias(Function):
             dy = dy.to(x.dtype)
         if ctx.relu:
             if dy.dtype != torch.float32:
-                raise NotImplementedError("conv + bias + ReLU (the ConvLSTM head) has no bf16-storage backward")
-            g = torch.empty_like(dy)
-            _C.check(_C.lib().up_relu_bwd(dy.data_ptr(), y.data_ptr(), g.data_ptr(), dy.numel(), _stream(dy)),
-                     "relu_bwd")
-            dy = g
+                # bf16 storage: the only conv + bias + ReLU on bf16 tensors is the video WASP's global-average-pool branch
+                # (waspVideo.py:51-53, no BatchNorm there): N x 256 elements — a torch select, not a kernel of its own
+                dy = torch.where(y > 0, dy, torch.zeros_like(dy))
+            else:
+                g = torch.empty_like(dy)
+                _C.check(_C.lib().up_relu_bwd(dy.data_ptr(), y.data_ptr(), g.data_ptr(), dy.numel(), _stream(dy)),
+                         "relu_bwd")
+                dy = g
         dx = conv_bwd_data_raw(dy, weight, ctx.d, x.shape, x.device) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1]:

@@ -100,10 +100,13 @@ class unipose(nn.Module):
 
     def forward(self, input, centermap, iter, previous, previousHide, previousCell):
         b = input.shape[0]
-        if ops.storage_dtype() != torch.float32:
-            raise NotImplementedError("bf16 storage (BASELINE configs[4]) is an image-model configuration: the ConvLSTM "
-                                      "head (15-channel state, configs[3]) runs in fp32")
-        x = self._trunk_frame(input, iter)                         # (B,h,w,16), 14 real channels
+        # bf16 storage (ops.set_conv_math("bf16s")): the trunk runs on bf16 tensors like the image model's and hands over fp32
+        # heat-maps (the decoder's last convolution writes fp32); the ConvLSTM cell and the head — 15 / 16-channel state, outside
+        # the 32-channel granularity of the bf16 kernels — stay fp32 tensors, their 128-channel convolutions on bf16 MFMA operands
+        x = self._trunk_frame(input, iter)                         # (B,h,w,16) fp32, 14 real channels
+        cpad = ops.rup4(self.num_classes + 1)
+        if x.shape[3] != cpad:          # (a bf16-storage convolution pads its output to 32 channels: back to the fp32 layout, whose
+            x = x[..., :cpad]           #  one spare pad channel takes the centre map and whose width the stacked gate weights assume)
         z = _AddCenter.apply(x, centermap[:, iter], self.num_classes + 1)
         if iter == 0:
             cell, hide = self.lstm_0(z)
