@@ -9,7 +9,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <bool READS, bool DMA, bool WAIT, int RPER = 1, int DPER = 1>   // RPER / DPER: fragment reads / LDS-DMA only every RPER-th / DPER-th iteration
+template <bool READS, bool DMA, bool WAIT, int RPER = 1, int DPER = 1, bool AGPR = false>   // AGPR: accumulators in AccVGPRs (inline asm); RPER / DPER: fragment reads / LDS-DMA only every RPER-th / DPER-th iteration
 __global__ void __launch_bounds__(256, 4) mix_loop(float* out, const float* src, int iters) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[32768];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -38,7 +38,10 @@ __global__ void __launch_bounds__(256, 4) mix_loop(float* out, const float* src,
                 fb = *reinterpret_cast<const f32x4*>(smem + stage + 8192 + ((rd + g * 32) & 8191));
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc, 0, 0, 0);
+            for (int e = 0; e < 4; ++e) {
+                if constexpr (AGPR) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(fa[e]), "v"(fb[e]));
+                else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc, 0, 0, 0);
+            }
         }
     }
     float s = 0.f;
@@ -47,7 +50,7 @@ __global__ void __launch_bounds__(256, 4) mix_loop(float* out, const float* src,
     if (s == 12345.678f) out[blockIdx.x * 256 + tid] = s;
 }
 
-template <bool READS, bool DMA, bool WAIT, int RPER = 1, int DPER = 1>
+template <bool READS, bool DMA, bool WAIT, int RPER = 1, int DPER = 1, bool AGPR = false>
 static double run(float* buf, const float* src, int iters) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
@@ -55,7 +58,7 @@ static double run(float* buf, const float* src, int iters) {
     double best = 1e30;
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((mix_loop<READS, DMA, WAIT, RPER, DPER>), dim3(256 * 4), dim3(256), 0, 0, buf, src, iters);
+        hipLaunchKernelGGL((mix_loop<READS, DMA, WAIT, RPER, DPER, AGPR>), dim3(256 * 4), dim3(256), 0, 0, buf, src, iters);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms = 0.f;
@@ -80,6 +83,10 @@ int main() {
     printf("  reads at half rate, LDS-DMA at full rate        %.1f\n", run<true, true, false, 2, 1>(buf, src, iters));
     printf("  reads at full rate, LDS-DMA at half rate        %.1f\n", run<true, true, false, 1, 2>(buf, src, iters));
     printf("  both at half rate (a 128x128 tile on 8 waves)   %.1f\n", run<true, true, false, 2, 2>(buf, src, iters));
+    printf("  accumulators in AccVGPRs: MFMA only             %.1f\n", run<false, false, false, 1, 1, true>(buf, src, iters));
+    printf("  accumulators in AccVGPRs: + reads               %.1f\n", run<true, false, false, 1, 1, true>(buf, src, iters));
+    printf("  accumulators in AccVGPRs: + LDS-DMA             %.1f\n", run<false, true, false, 1, 1, true>(buf, src, iters));
+    printf("  accumulators in AccVGPRs: + both                %.1f\n", run<true, true, false, 1, 1, true>(buf, src, iters));
     printf("  both at quarter rate                            %.1f\n", run<true, true, false, 4, 4>(buf, src, iters));
     return 0;
 }
