@@ -116,7 +116,7 @@ def test_bn_backward_reduction_fused_into_data_gradients_gpu():
     print("fused BatchNorm-backward reductions per step:", launches, "worst gradient distance fused vs separate:", worst)
 
 
-def test_g4_train_128_vs_reference_golden(golden_dir):
+def test_g4_train_128_loss_statistics_and_gradient_norms_vs_reference_golden(golden_dir):
     """Reference train step at 128x128, B=2, dropouts off: loss / output / gradients / running stats."""
     from unipose_amd import ops
     g = np.load(os.path.join(golden_dir, "g4_train_128.npz"))

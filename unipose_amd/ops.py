@@ -330,7 +330,12 @@ def invalidate_packed_weights():
             e[1] = -1
 
 
+OPTIMIZER_STEPS = 0     # bumped by the hook: a cache key for anything derived from the parameters (unipose_lstm's clip cache)
+
+
 def _optimizer_stepped(_optimizer, _args, _kwargs):
+    global OPTIMIZER_STEPS
+    OPTIMIZER_STEPS += 1
     invalidate_packed_weights()
 
 

@@ -72,8 +72,9 @@ class unipose(nn.Module):
         # id / address.  A caller that passes a different tensor for a later frame simply gets the per-frame trunk.
         # ... and the key carries the in-place version of the trunk's first and last weight: an optimizer step or a
         # load_state_dict between two frames of a clip (both bump every parameter) makes the later frames miss
+        # (... and the count of optimizer steps: torch's fused optimizers do not move the version counters, round 5)
         key = (input._version, self.training, torch.is_grad_enabled(), self.backbone.conv1.weight._version,
-               self.decoder.last_conv[8].weight._version)
+               self.decoder.last_conv[8].weight._version, ops.OPTIMIZER_STEPS)
         hit = self._frames is not None and self._frames[0] is input and self._frames[1] == key
         if iter == 0:
             xa = input.transpose(0, 1).reshape(T * b, *input.shape[2:])      # frame-major: BatchNorm group g = frame g
