@@ -412,6 +412,9 @@ def main():
                     help="TEST INFRASTRUCTURE (tests/test_bench_flow.py): walk the whole control flow of this script — warm-up, "
                          "timed region, exclusive pass, alt-math loop, every barrier and collective — on the CPU kernel "
                          "emulator with the gloo backend.  Prints a line marked dry_run; never a measurement")
+    ap.add_argument("--settle", type=int, default=20,
+                    help="untimed steps BEFORE the --warmup steps (groups of 5, logged and reported as `settle`): lets a freshly "
+                         "touched GPU reach its steady state; 0 switches it off")
     ap.add_argument("--cpu-batch", type=int, default=4)
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=min(os.cpu_count() or 1, 64),
@@ -522,6 +525,21 @@ def main():
         torch.cuda.synchronize(dev)
 
     log(f"model on {dev}, {sum(p.numel() for p in model.parameters())} parameters; warm-up")
+    # Settling phase (untimed, before the W warm-up steps; fixed count so that every rank runs the same collectives): a process
+    # that starts its timed region within ~2 s of first touching the GPU has read 65-67 ms per step on boxes whose later
+    # processes read 61.5-62.4 (r04_y / r04_z / r05_z final sessions: timed region +5.7 %, the exclusive pass right behind it
+    # +1.6 %, the loop after that +1 % — a ramp, not a property of the step).  The groups are logged and reported (`settle`).
+    settle = {"steps": 0, "ms_per_step_by_group": []}
+    if not emu and args.settle > 0:
+        for _ in range(args.settle // 5):
+            torch.cuda.synchronize(dev)
+            ts = time.perf_counter()
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize(dev)
+            settle["ms_per_step_by_group"].append(round((time.perf_counter() - ts) * 200.0, 2))
+            settle["steps"] += 5
+        log(f"settling: {settle['steps']} untimed steps, ms per step by group of 5: {settle['ms_per_step_by_group']}")
     for i in range(args.warmup):
         step()
         torch.cuda.synchronize(dev)
@@ -680,6 +698,8 @@ def main():
                                          * (S / 368.0) ** 2 / 1e12, 2),
             "loss": loss_val,
         }
+        if settle["steps"]:
+            out["settle"] = settle
         if emu:
             out["dry_run"] = "CPU emulator + gloo: control-flow test only, the numbers mean nothing"
             out["metric"] = "DRY RUN (not a measurement): " + out["metric"]

@@ -2224,12 +2224,13 @@ static double visited_tap_fraction(const IgemmArgs& a, int bm, bool sorted, doub
     return (double)visited / ((double)tiles * a.taps);
 }
 
-// Share of (pixel, filter tap) pairs of a launch that read a real source pixel: what the per-launch FLOP of the profiler is charged
-// with (round 5) — the nominal 2 M N K counted the taps of a dilated convolution that fall into the padding for every pixel and
-// that the tile-level skipping / tap-sorted rows never multiply (WASP d = 18: 0.229), which inflated the per-kernel TFLOP/s by 1-2 %.
+// Share of (pixel, filter tap) pairs of a DILATED launch that read a real source pixel: what its per-launch FLOP is charged with in the
+// profiler (round 5) — the nominal 2 M N K counted the taps that fall into the padding and that the tile-level skipping / tap-sorted
+// rows never multiply (WASP d = 18: 0.229, layer4 d = 8: 0.59); it inflated the dominant variant's TFLOP/s by 3-4 %.
 // Per geometry, cached; only evaluated while the profiler is on.
 static double live_tap_share(const IgemmArgs& a) {
-    if (a.taps <= 1 || a.taps > 32 || a.no_tap_skip || a.divshift != 0) return 1.0;
+    // dilated launches only: a dense padded 3x3 keeps the nominal count, the convention behind SURVEY 8d's 31.279 GMAC per image
+    if (a.taps <= 1 || a.taps > 32 || a.no_tap_skip || a.divshift != 0 || (a.tapstep >= -1 && a.tapstep <= 1)) return 1.0;
     static std::mutex mu;
     static std::map<TapSortKey, double> cache;
     TapSortKey key;
