@@ -273,14 +273,18 @@ def profile_rows(lib, steps_profiled=1):
     arr = (ctypes.c_double * (nv * 3))()
     from unipose_amd import _C
     _C.check(lib.up_profile_end(arr, nv), "profile_end")
+    live = (ctypes.c_double * nv)()
+    _C.check(lib.up_profile_live_flops(live, nv), "profile_live_flops")
     rows = []
     for i in range(nv):
         n, ms, fl = arr[i * 3], arr[i * 3 + 1], arr[i * 3 + 2]
         if n:
             name = lib.up_profile_variant_name(i).decode()
             peak = BF16_MFMA_PEAK_TFLOPS if "bf16" in name else F32_MFMA_PEAK_TFLOPS
+            # tflops: nominal 2 M N K per launch (SURVEY 8d's convention, the sum over a step is its 6.0 TFLOP);
+            # tflops_live_taps: dilated launches charged for the (pixel, tap) pairs that touch the image only
             rows.append({"kernel": name, "launches": int(n), "avg_ms": ms / n, "total_ms": ms,
-                         "tflops": fl / ms / 1e9, "peak_tflops": peak})
+                         "tflops": fl / ms / 1e9, "tflops_live_taps": (live[i] or fl) / ms / 1e9, "peak_tflops": peak})
     # "dominant" = the variant that carries the most ALGORITHMIC FLOP.  Ranking by summed launch durations is not stable
     # here: the weight gradients run on a second stream, their event-bracketed durations include the time they are
     # starved by the main stream, and which of two kernels has the larger sum flips with the interleaving of the streams.
@@ -589,6 +593,10 @@ def main():
                         "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(top["tflops"] / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                         "avg_launch_ms": round(top["avg_ms"], 4), "launches": top["launches"],
+                        "achieved_live_taps": round(top["tflops_live_taps"], 2),
+                        "frac_live_taps": round(top["tflops_live_taps"] / F32_MFMA_PEAK_TFLOPS, 4),
+                        "flop_convention": "achieved / frac: nominal 2*M*N*K per launch (SURVEY 8d: 187.7 GFLOP per image); *_live_taps: "
+                                           "dilated launches (WASP, layer4) charged for their live (pixel, tap) pairs only",
                         "dominant_by": "algorithmic FLOP in the timed region (see profile_rows)",
                         "top_by_time": top_by_time(rows),
                         "all_mfma_kernels": {"achieved": round(tot_fl / tot_ms, 2),
@@ -636,6 +644,8 @@ def main():
                     "note": "same step with both streams serialised: the kernel's own duration",
                     "kernel": roofline["kernel"], "achieved": round(same[0]["tflops"], 2),
                     "frac": round(same[0]["tflops"] / F32_MFMA_PEAK_TFLOPS, 4),
+                    "achieved_live_taps": round(same[0]["tflops_live_taps"], 2),
+                    "frac_live_taps": round(same[0]["tflops_live_taps"] / F32_MFMA_PEAK_TFLOPS, 4),
                     "avg_launch_ms": round(same[0]["avg_ms"], 4), "launches": same[0]["launches"],
                     "all_mfma_kernels": {"achieved": round(x_fl / x_ms, 2),
                                          "frac": round(x_fl / x_ms / F32_MFMA_PEAK_TFLOPS, 4),

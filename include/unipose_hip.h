@@ -461,6 +461,8 @@ const char* up_profile_variant_name(int i);
 int up_profile_begin(void);
 int up_profile_enable(int on);   /* pause / resume recording between begin and end (sampled profiling) */
 int up_profile_end(double* out, int variants);
+/* per variant: FLOP of the collection up_profile_end just closed with dilated launches charged for their live (pixel, tap) pairs only */
+int up_profile_live_flops(double* out, int variants);
 
 #ifdef __cplusplus
 }

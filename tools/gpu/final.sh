@@ -21,7 +21,7 @@ for o in d.get("other_configs", []): print("other", o["value"], o["ms_per_step"]
 for w in r.get("wasp_dilated", []): print("wasp", w["dilation"], w["ms"], w["effective_mfma_frac"])
 PY
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-stock-baseline --no-profile --no-alt-math --no-other-configs"
+ARGS="--steps 3 --warmup 1 --settle 0 --no-cpu-baseline --no-stock-baseline --no-profile --no-alt-math --no-other-configs"
 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof.log 2>&1
 UNIPOSE_SYNC_WGRAD=1 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_sync -o bench -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_sync.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_736 -o bench -- python $GRAFT_REPO_ROOT/bench.py --size 736 --batch 16 --math bf16s $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_736.log 2>&1

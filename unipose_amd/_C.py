@@ -145,6 +145,7 @@ SIGNATURES = {
     "up_profile_variant_name": (C.c_char_p, [_i]),
     "up_profile_begin": (_i, []),
     "up_profile_enable": (_i, [_i]),
+    "up_profile_live_flops": (_i, [C.POINTER(C.c_double), _i]),
     "up_profile_end": (_i, [C.POINTER(C.c_double), _i]),
 }
 

@@ -59,10 +59,12 @@ static const char* const kVariantNames[PROF_VARIANTS] = {
 struct ProfRec {
     hipEvent_t a, b;
     int variant;
-    double flops;
+    double flops;        // nominal 2 M N K (real channels): SURVEY 8d's convention, what `roofline.achieved` is quoted on
+    double flops_live;   // the same with a DILATED launch charged for its live (pixel, tap) pairs only (live_tap_share)
     int M, N, K, grid;   // GEMM view of the launch + workgroups (for the per-launch CSV)
 };
 static bool g_prof_on = false;
+static double g_prof_live[64];   // per variant: live-tap FLOP of the last collection (up_profile_live_flops)
 static std::vector<ProfRec> g_prof;
 // events are recycled: creating two per launch cost a third of the profiled steps' overhead (bench line 62.9 vs 62.2 ms without
 // profiling, round 4)
@@ -81,11 +83,12 @@ struct ProfScope {
     ProfRec r;
     hipStream_t st;
     bool on;
-    ProfScope(int variant, double flops, hipStream_t s, int M = 0, int N = 0, int K = 0, int grid = 0)
+    ProfScope(int variant, double flops, hipStream_t s, int M = 0, int N = 0, int K = 0, int grid = 0, double live_share = 1.0)
         : st(s), on(g_prof_on) {
         if (!on) return;
         r.variant = variant;
         r.flops = flops;
+        r.flops_live = flops * live_share;
         r.M = M;
         r.N = N;
         r.K = K;
@@ -102,7 +105,7 @@ struct ProfScope {
 };
 #else
 struct ProfScope {
-    ProfScope(int, double, hipStream_t, int = 0, int = 0, int = 0, int = 0) {}
+    ProfScope(int, double, hipStream_t, int = 0, int = 0, int = 0, int = 0, double = 1.0) {}
 };
 #endif
 
@@ -2311,9 +2314,8 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
         return;
     }
     a.no_tap_skip = g_tap_skip ? 0 : 1;
-    ProfScope prof(use32 ? 28 + vbase / 2 : vbase + (aligned ? 0 : 1),
-                   2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real * (g_prof_on_host() && fast ? live_tap_share(a) : 1.0), st,
-                   a.M, a.Ng, a.Ktot, a.nwg);
+    ProfScope prof(use32 ? 28 + vbase / 2 : vbase + (aligned ? 0 : 1), 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st,
+                   a.M, a.Ng, a.Ktot, a.nwg, g_prof_on_host() && fast ? live_tap_share(a) : 1.0);
     // double-buffered LDS (one barrier per slice) for long reductions.  In isolation it is 3-5 % faster than the
     // single-buffer loop down to K = 256 (probe), but in the network the rule K >= 1024 is 0.5 % faster per step (A/B in
     // one session, 70.55 vs 70.95 ms): the 73 KB footprint leaves less room for the weight-gradient workgroups of
@@ -2634,9 +2636,8 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
     if (of32) math = UP_MATH_BF16S;
     const bool glds_form = math == UP_MATH_BF16S && !of32 && glds_eligible(a, fast);
     a.no_tap_skip = g_tap_skip ? 0 : 1;
-    ProfScope prof(glds_form ? v + 8 : v,
-                   2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real * (g_prof_on_host() && fast ? live_tap_share(a) : 1.0), st, a.M, a.Ng,
-                   a.Ktot, a.nwg);
+    ProfScope prof(glds_form ? v + 8 : v, 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st, a.M, a.Ng, a.Ktot, a.nwg,
+                   g_prof_on_host() && fast ? live_tap_share(a) : 1.0);
     const bool split = math == UP_MATH_BF16X3;
     // K slice: 64 on the 64x64 tile (6 -> 12 MFMAs per wave and barrier) measured no faster than 32 (141.7 vs 145.1 TF)
     constexpr int KT = 32;
@@ -3374,6 +3375,7 @@ extern "C" int up_profile_end(double* out /* [variants][3] = launches, ms, flops
     for (int i = 0; i < variants * 3; ++i) out[i] = 0.0;
 #ifndef UP_EMU
     g_prof_on = false;
+    for (double& v : g_prof_live) v = 0.0;
     FILE* csv = nullptr;
     if (const char* path = getenv("UP_PROFILE_CSV")) {   // optional per-launch dump for offline analysis: the first
         static int calls = 0;                            // collection goes to `path`, later ones to `path.1`, `path.2` ...
@@ -3391,6 +3393,7 @@ extern "C" int up_profile_end(double* out /* [variants][3] = launches, ms, flops
         out[r.variant * 3 + 0] += 1.0;
         out[r.variant * 3 + 1] += ms;
         out[r.variant * 3 + 2] += r.flops;
+        g_prof_live[r.variant] += r.flops_live;
         if (csv)
             fprintf(csv, "\"%s\",%d,%d,%d,%d,%.5f,%.2f\n", kVariantNames[r.variant], r.M, r.N, r.K, r.grid, ms,
                     r.flops / ms / 1e9);
@@ -3400,5 +3403,19 @@ extern "C" int up_profile_end(double* out /* [variants][3] = launches, ms, flops
     g_prof.clear();
     if (csv) fclose(csv);
 #endif
+    return UP_OK;
+}
+// FLOP of the collection up_profile_end just closed with every DILATED forward / data-gradient launch charged for its live
+// (pixel, filter tap) pairs only — the taps that fall into the padding for a pixel are never multiplied (tile-level skipping,
+// tap-sorted rows).  The nominal figures of up_profile_end stay the ones SURVEY 8d's per-image FLOP count is made of.
+extern "C" int up_profile_live_flops(double* out /* [variants] */, int variants) {
+    UP_REQUIRE(out && variants == PROF_VARIANTS, UP_ERR_INVALID, "profile_live_flops: expected %d variants", PROF_VARIANTS);
+    for (int i = 0; i < variants; ++i) {
+#ifndef UP_EMU
+        out[i] = g_prof_live[i];
+#else
+        out[i] = 0.0;
+#endif
+    }
     return UP_OK;
 }
