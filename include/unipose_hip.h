@@ -197,7 +197,7 @@ int up_pack_weights_bf16(const up_conv_desc* d, const float* w_oihw, uint16_t* f
                          uint16_t* dgrad_hi, uint16_t* dgrad_lo, void* stream);
 /* The same for many parameters in ONE launch (ABI 9; like up_pack_weights_batched: an optimizer step changes every weight, and
  * 2 x 115 separate 5-us launches per step cost more than the packing itself).  `jobs` is a table in DEVICE memory; the
- * fwd / dgrad plane pairs may be NULL per job. */
+ * fwd / dgrad plane pairs may be NULL per job, and so may the lo plane of a pair alone (only UP_MATH_BF16X3 reads lo planes). */
 typedef struct {
     const float* w;        /* OIHW */
     uint16_t* fwd_hi;

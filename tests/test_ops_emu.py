@@ -354,7 +354,8 @@ def test_optimizer_step_makes_the_packed_weights_stale(emu_backend, math, fused)
 def test_batched_repack_equals_single_pack(emu_backend):
     """ONE up_pack_weights_batched / up_pack_weights_bf16_batched launch over many parameters against up_pack_weights /
     up_pack_weights_bf16 per parameter, bit for bit: padded input and output channels, 7x7 / 3x3 / 1x1, the parity-class-major
-    data-gradient image of stride-2 convolutions, rows shorter and longer than a wavefront."""
+    data-gradient image of stride-2 convolutions, rows shorter and longer than a wavefront.  The bf16 lo planes are only kept
+    current for the split-bf16 arithmetic (the one that reads them); switching to it re-packs them."""
     import ctypes
     from unipose_amd import _C, ops
     gen = torch.Generator().manual_seed(5)
@@ -367,24 +368,30 @@ def test_batched_repack_equals_single_pack(emu_backend):
         ws.append(w)
         descs.append(ops.make_desc(x, w, ops.ConvCfg(stride, pad, dil)))
     L = _C.lib()
-    for bf16 in (False, True):
-        use = [(w, d) for w, d in zip(ws, descs) if not bf16 or (d.Cp % 32 == 0)]
-        get = ops._packed_bf16 if bf16 else ops._packed
-        for w, d in use:
-            get(w, d)                                            # registers the parameter (single-pack launches)
-        with torch.no_grad():
-            for w, _ in use:
-                w.mul_(1.5).add_(0.25)                           # new values, new version
-        first = get(*use[0])                                     # the first stale hit re-packs EVERY registered parameter
-        for w, d in use:
-            wf, wd = get(w, d)
-            if bf16:
+    try:
+        for math in ("f32", "bf16", "bf16x3", "bf16"):
+            bf16 = math != "f32"
+            ops.set_conv_math(math)
+            use = [(w, d) for w, d in zip(ws, descs) if not bf16 or (d.Cp % 32 == 0)]
+            get = ops._packed_bf16 if bf16 else ops._packed
+            for w, d in use:
+                get(w, d)                                            # registers the parameter (single-pack launches)
+            with torch.no_grad():
+                for w, _ in use:
+                    w.mul_(1.5).add_(0.25)                           # new values, new version
+            first = get(*use[0])                                     # the first stale hit re-packs EVERY registered parameter
+            for w, d in use:
+                wf, wd = get(w, d)
                 rf, rd = torch.empty_like(wf), torch.empty_like(wd)
-                _C.check(L.up_pack_weights_bf16(ctypes.byref(d), w.data_ptr(), rf[0].data_ptr(), rf[1].data_ptr(), rd[0].data_ptr(),
-                                                rd[1].data_ptr(), 0), "pack_weights_bf16")
-            else:
-                rf, rd = torch.empty_like(wf), torch.empty_like(wd)
-                _C.check(L.up_pack_weights(ctypes.byref(d), w.data_ptr(), rf.data_ptr(), rd.data_ptr(), 0), "pack_weights")
-            assert torch.equal(wf, rf), ("forward image", bf16, tuple(w.shape))
-            assert torch.equal(wd, rd), ("data-gradient image", bf16, tuple(w.shape), d.stride)
-        assert first[0].data_ptr() == get(*use[0])[0].data_ptr()     # persistent buffers
+                if bf16:
+                    _C.check(L.up_pack_weights_bf16(ctypes.byref(d), w.data_ptr(), rf[0].data_ptr(), rf[1].data_ptr(), rd[0].data_ptr(),
+                                                    rd[1].data_ptr(), 0), "pack_weights_bf16")
+                    if math != "bf16x3":                             # lo planes: not maintained, not read
+                        wf, wd, rf, rd = wf[0], wd[0], rf[0], rd[0]
+                else:
+                    _C.check(L.up_pack_weights(ctypes.byref(d), w.data_ptr(), rf.data_ptr(), rd.data_ptr(), 0), "pack_weights")
+                assert torch.equal(wf, rf), ("forward image", math, tuple(w.shape))
+                assert torch.equal(wd, rd), ("data-gradient image", math, tuple(w.shape), d.stride)
+            assert first[0].data_ptr() == get(*use[0])[0].data_ptr()     # persistent buffers
+    finally:
+        ops.set_conv_math("f32")

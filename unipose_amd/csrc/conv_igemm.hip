@@ -2905,11 +2905,13 @@ __global__ void __launch_bounds__(256) pack_split_batched_kernel(const up_pack_j
     const up_pack_job_bf16 jb = jobs[blockIdx.y];
     const int taps = jb.taps;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // (lo planes are only read by the split-bf16 arithmetic, UP_MATH_BF16X3: a job without them — fwd_lo / dgrad_lo NULL — skips
+    //  a third of the bytes)
     auto put = [](uint16_t* hi, uint16_t* lo, size_t e, float v) {
         uint32_t h, l;
         split_bf16x2(v, 0.f, h, l);
         hi[e] = (uint16_t)(h & 0xffffu);
-        lo[e] = (uint16_t)(l & 0xffffu);
+        if (lo) lo[e] = (uint16_t)(l & 0xffffu);
     };
     if (jb.fwd_hi) {   // rows (k, tap) of Cp channels — the row scheme of pack_batched_kernel
         const int rows = jb.K * taps;

@@ -265,11 +265,18 @@ class _Pack16Set:
         self.table = None
         self.order = []
         self.pending = None
+        self.with_lo = True        # the job table carries the lo planes (only the split-bf16 arithmetic reads them)
 
     def get(self, weight, d):
         key = id(weight)
         nf, nd = d.K * d.R * d.S * d.Cp, d.C * d.R * d.S * d.Kp
         e = self.entries.get(key)
+        need_lo = CONV_MATH == MATH_BF16X3
+        if need_lo != self.with_lo:        # the arithmetic changed: other planes in the job table, and lo planes may be stale
+            self.with_lo, self.table = need_lo, None
+            if need_lo:
+                for q in self.entries.values():
+                    q[1] = -1
         if e is not None and e[0]() is weight and e[2].shape[1] == nf and e[3].shape[1] == nd and e[5] == weight.data_ptr():
             if e[1] != weight._version:
                 self.repack(weight)
@@ -295,7 +302,8 @@ class _Pack16Set:
             job = np.zeros((len(self.order), 8), dtype=np.int64)      # up_pack_job_bf16: 5 pointers + 6 int32
             for i, k in enumerate(self.order):
                 w, _, wf, wd, (kk, cc, cp, kp, taps), _ = self.entries[k]
-                job[i, :5] = (w().data_ptr(), wf[0].data_ptr(), wf[1].data_ptr(), wd[0].data_ptr(), wd[1].data_ptr())
+                job[i, :5] = (w().data_ptr(), wf[0].data_ptr(), wf[1].data_ptr() if self.with_lo else 0, wd[0].data_ptr(),
+                              wd[1].data_ptr() if self.with_lo else 0)
                 job[i, 5:].view(np.int32)[:] = (kk, cc, cp, kp, taps, 0)
             self.table = torch.from_numpy(job).to(weight.device)
         live = [self.entries[k] for k in self.order]
