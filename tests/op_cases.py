@@ -631,8 +631,11 @@ def optimizer_stale_case(dev, math, fused, nweights=3):
     cfg = ops.ConvCfg(1, 1, 1)
     opt = torch.optim.Adam(ws, lr=0.05, fused=fused)
     tol = 1e-5 if math == "f32" else 3e-2
+    other = torch.nn.Parameter((torch.randn(32, 32, 3, 3, generator=gen) * 0.05).to(dev))     # a second "model": not this optimizer's
     ops.set_conv_math(math)
     try:
+        y_other = ops.conv_fwd_raw(x, other, cfg)[0].float().cpu()
+        cache = (ops._PACK_CACHE if math == "f32" else ops._PACK16_CACHE)[other.device.index]
         for step in range(3):
             order = range(nweights) if step % 2 == 0 else reversed(range(nweights))     # (the side-stream half first, too)
             for i in order:
@@ -646,5 +649,8 @@ def optimizer_stale_case(dev, math, fused, nweights=3):
             opt.step()
             if fused:
                 assert [w._version for w in ws] == v0, "torch's fused Adam now moves the version counter: the hook is belt and braces"
+            assert cache.entries[id(other)][1] == other._version, "a parameter of no stepping optimizer keeps its images"
+            assert all(cache.entries[id(w)][1] == -1 for w in ws)
+        assert torch.equal(ops.conv_fwd_raw(x, other, cfg)[0].float().cpu(), y_other)       # (a sub-table re-pack left it alone)
     finally:
         ops.set_conv_math("f32")

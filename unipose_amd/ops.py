@@ -125,21 +125,38 @@ _REPACK_HEAD = 12
 
 
 def _launch_repack(ps, weight, entry_point, what, job_bytes):
-    """`ps`: a _PackSet / _Pack16Set whose job table is current; launches the batched re-pack of all its jobs."""
-    n = len(ps.order)
+    """`ps`: a _PackSet / _Pack16Set whose job table is current; launches the batched re-pack of its STALE jobs — all of them
+    after a step of the one optimizer of a process, a sub-table (cached per stale set) when a second model keeps its images."""
+    stale = [k for k in ps.order if ps.entries[k][1] != ps.entries[k][0]()._version]
+    if len(stale) == len(ps.order):
+        table, keys = ps.table, ps.order
+    else:
+        sig = tuple(stale)
+        hit = ps.subtables.get(sig)
+        if hit is None:
+            if len(ps.subtables) >= 4:
+                ps.subtables.clear()
+            rows = torch.tensor([ps.order.index(k) for k in stale], dtype=torch.int64, device=ps.table.device)
+            hit = ps.subtables[sig] = ps.table.index_select(0, rows).contiguous()
+        table, keys = hit, stale
+    n = len(keys)
+    if n == 0:
+        return
     L = _C.lib()
     dev = weight.device
+    if ps.pending is not None and dev.type == "cuda":      # an earlier split launch nobody waited for yet: order behind it
+        torch.cuda.current_stream(dev).wait_event(ps.pending[0])
     ps.pending = None
     if ASYNC_REPACK and dev.type == "cuda" and n > 2 * _REPACK_HEAD and not torch.cuda.is_current_stream_capturing():
         main, side = torch.cuda.current_stream(dev), _side_stream(dev)
-        _C.check(getattr(L, entry_point)(ps.table.data_ptr(), _REPACK_HEAD, main.cuda_stream), what)
+        _C.check(getattr(L, entry_point)(table.data_ptr(), _REPACK_HEAD, main.cuda_stream), what)
         side.wait_stream(main)                       # the optimizer's writes (and every reader of the old images) are behind us
-        _C.check(getattr(L, entry_point)(ps.table.data_ptr() + _REPACK_HEAD * job_bytes, n - _REPACK_HEAD, side.cuda_stream), what)
+        _C.check(getattr(L, entry_point)(table.data_ptr() + _REPACK_HEAD * job_bytes, n - _REPACK_HEAD, side.cuda_stream), what)
         ev = torch.cuda.Event()
         ev.record(side)
-        ps.pending = (ev, set(ps.order[_REPACK_HEAD:]))
+        ps.pending = (ev, set(keys[_REPACK_HEAD:]))
     else:
-        _C.check(getattr(L, entry_point)(ps.table.data_ptr(), n, _stream(weight)), what)
+        _C.check(getattr(L, entry_point)(table.data_ptr(), n, _stream(weight)), what)
 
 
 def _await_repack(ps, key, dev):
@@ -163,6 +180,7 @@ class _PackSet:
         self.table = None          # device job table, rebuilt when the membership changes
         self.order = []
         self.pending = None        # (event, keys): images being re-packed on the side stream, see _launch_repack
+        self.subtables = {}        # stale-key tuple -> job table of just those parameters
 
     def get(self, weight, d):
         key = id(weight)
@@ -200,6 +218,7 @@ class _PackSet:
                 job[i, 0], job[i, 1], job[i, 2] = w().data_ptr(), wf.data_ptr(), wd.data_ptr()
                 job[i, 3:].view(np.int32)[:] = (kk, cc, cp, kp, taps, geom)
             self.table = torch.from_numpy(job).to(weight.device)
+            self.subtables = {}
         live = [self.entries[k] for k in self.order]
         if any(e[0]() is None for e in live):                         # a parameter died: its pointer is stale
             self.table = None
@@ -265,6 +284,7 @@ class _Pack16Set:
         self.table = None
         self.order = []
         self.pending = None
+        self.subtables = {}
         self.with_lo = True        # the job table carries the lo planes (only the split-bf16 arithmetic reads them)
 
     def get(self, weight, d):
@@ -306,6 +326,7 @@ class _Pack16Set:
                               wd[1].data_ptr() if self.with_lo else 0)
                 job[i, 5:].view(np.int32)[:] = (kk, cc, cp, kp, taps, 0)
             self.table = torch.from_numpy(job).to(weight.device)
+            self.subtables = {}
         live = [self.entries[k] for k in self.order]
         if any(e[0]() is None for e in live):                         # a parameter died: its pointer is stale
             self.table = None
@@ -341,10 +362,19 @@ def invalidate_packed_weights():
 OPTIMIZER_STEPS = 0     # bumped by the hook: a cache key for anything derived from the parameters (unipose_lstm's clip cache)
 
 
-def _optimizer_stepped(_optimizer, _args, _kwargs):
+def _optimizer_stepped(optimizer, _args, _kwargs):
+    """only the parameters of the optimizer that stepped go stale: a second model in the process (bench.py's legs, a frozen
+    teacher) keeps its images"""
     global OPTIMIZER_STEPS
     OPTIMIZER_STEPS += 1
-    invalidate_packed_weights()
+    try:
+        ids = {id(p) for g in optimizer.param_groups for p in g["params"]}
+    except Exception:       # noqa: BLE001  (an optimizer without the standard layout: everything goes stale)
+        return invalidate_packed_weights()
+    for ps in list(_PACK_CACHE.values()) + list(_PACK16_CACHE.values()):
+        for k, e in ps.entries.items():
+            if k in ids:
+                e[1] = -1
 
 
 try:        # every torch.optim optimizer, fused or not, reports its step here
