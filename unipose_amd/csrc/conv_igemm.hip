@@ -1834,7 +1834,19 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const up_pack_job* jo
                 const int k = rt / taps, tap = rt - k * taps;
                 const float* src = jb.w + (size_t)k * jb.C * taps + tap;
                 float* dst = jb.w_fwd + (size_t)rt * jb.Cp;
-                for (int ci = lane; ci < jb.Cp; ci += 64) dst[ci] = ci < jb.C ? src[(size_t)ci * taps] : 0.f;
+                // four loads in flight per lane, then their stores: one load -> store per iteration left a wave with ONE memory
+                // round trip at a time (the launch is a few dozen dependent round trips long, not bandwidth bound)
+                for (int c0 = lane; c0 < jb.Cp; c0 += 256) {
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ci = c0 + 64 * u;
+                        v[u] = ci < jb.C ? src[(size_t)ci * taps] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (c0 + 64 * u < jb.Cp) dst[c0 + 64 * u] = v[u];
+                }
             }
         }
     }
@@ -1849,15 +1861,29 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const up_pack_job* jo
     }
     const int rows = jb.C * taps;
     const size_t kstride = (size_t)jb.C * taps;
-    // the 64 output channels of a chunk sit kstride floats apart in w: 64 source lines, each holding the values of 32 consecutive
-    // rows — chunk OUTSIDE, rows inside, so that the block's 32 rows read them out of L1 (rows outside re-fetched every line from
-    // L2 once per row: 32x the bytes, 0.5 ms for the network's 115 weights)
+    // Transposed through LDS: for one output channel k the 32 rows of a block are 32 CONSECUTIVE floats of w[k][.][.] (one 128-byte
+    // line), so a wave reads two channels' lines per instruction (lanes = rows), parks them in a [32 rows][64 channels] tile and
+    // the tile leaves as 256-byte rows (lanes = channels).  Lanes = channels on the read side touched 64 different lines per load.
+    __shared__ float tile[32][65];
+    const int r31 = lane & 31, khalf = lane >> 5;
     for (int base = blockIdx.x * 32; base < rows; base += gridDim.x * 32) {
         const int end = min(base + 32, rows);
-        for (int k = lane; k < jb.Kp; k += 64) {
-            const float* src = jb.w + (size_t)(k < jb.K ? k : 0) * kstride;
-            for (int rt = base + wave; rt < end; rt += 4)   // rt = c * taps + tap: the source offset inside w[k][.][.] as well
-                jb.w_dgrad[(size_t)rt * jb.Kp + k] = k < jb.K ? src[rt] : 0.f;
+        for (int k0 = 0; k0 < jb.Kp; k0 += 64) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {   // wave w reads channels k0 + 16 w + 2 j + khalf
+                const int k = k0 + wave * 16 + 2 * j + khalf;
+                v[j] = (k < jb.K && base + r31 < end) ? jb.w[(size_t)k * kstride + base + r31] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tile[r31][wave * 16 + 2 * j + khalf] = v[j];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int rt = base + wave + 4 * j;
+                if (rt < end && k0 + lane < jb.Kp) jb.w_dgrad[(size_t)rt * jb.Kp + k0 + lane] = tile[wave + 4 * j][lane];
+            }
+            __syncthreads();
         }
     }
 }
@@ -2920,20 +2946,43 @@ __global__ void __launch_bounds__(256) pack_split_batched_kernel(const up_pack_j
             for (int rt = base + wave; rt < end; rt += 4) {
                 const int k = rt / taps, tap = rt - k * taps;
                 const float* src = jb.w + (size_t)k * jb.C * taps + tap;
-                for (int ci = lane; ci < jb.Cp; ci += 64)
-                    put(jb.fwd_hi, jb.fwd_lo, (size_t)rt * jb.Cp + ci, ci < jb.C ? src[(size_t)ci * taps] : 0.f);
+                for (int c0 = lane; c0 < jb.Cp; c0 += 256) {   // four loads in flight, then the stores (see pack_batched_kernel)
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int ci = c0 + 64 * u;
+                        v[u] = ci < jb.C ? src[(size_t)ci * taps] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (c0 + 64 * u < jb.Cp) put(jb.fwd_hi, jb.fwd_lo, (size_t)rt * jb.Cp + c0 + 64 * u, v[u]);
+                }
             }
         }
     }
-    if (jb.dgrad_hi) {   // rows (c, tap) of Kp output channels
+    if (jb.dgrad_hi) {   // rows (c, tap) of Kp output channels, transposed through LDS like pack_batched_kernel's
+        __shared__ float tile[32][65];
         const int rows = jb.C * taps;
         const size_t kstride = (size_t)jb.C * taps;
+        const int r31 = lane & 31, khalf = lane >> 5;
         for (int base = blockIdx.x * 32; base < rows; base += gridDim.x * 32) {
             const int end = min(base + 32, rows);
-            for (int k = lane; k < jb.Kp; k += 64) {   // chunk outside, rows inside: see pack_batched_kernel
-                const float* src = jb.w + (size_t)(k < jb.K ? k : 0) * kstride;
-                for (int rt = base + wave; rt < end; rt += 4)
-                    put(jb.dgrad_hi, jb.dgrad_lo, (size_t)rt * jb.Kp + k, k < jb.K ? src[rt] : 0.f);
+            for (int k0 = 0; k0 < jb.Kp; k0 += 64) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = k0 + wave * 16 + 2 * j + khalf;
+                    v[j] = (k < jb.K && base + r31 < end) ? jb.w[(size_t)k * kstride + base + r31] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tile[r31][wave * 16 + 2 * j + khalf] = v[j];
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int rt = base + wave + 4 * j;
+                    if (rt < end && k0 + lane < jb.Kp) put(jb.dgrad_hi, jb.dgrad_lo, (size_t)rt * jb.Kp + k0 + lane, tile[wave + 4 * j][lane]);
+                }
+                __syncthreads();
             }
         }
     }
