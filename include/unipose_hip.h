@@ -104,6 +104,7 @@ int up_stream_release(void* stream);
 /* Development knobs (A/B runs inside one process; each also has an environment variable read at load time).  Twelve keys
  * (round 4 removed the ones whose question is settled: short_k, short_k_mult, db_min_k, wgrad_per_cu, tap_skip, lds_swz and
  * the bf16 forms that lost in round 3):
+ * "tiny_k" (UP_TINY_K, round 5: fp32 reductions of at most this length always take 64x64 tiles; default 128),
  * "tile_want" (UP_TILE_WANT; "tile_want_bf16" for the plain-bf16 kernels) workgroups a launch should at least have when the tile
  * size is chosen, "tail_split" (UP_TAIL_SPLIT), "split_per_cu" (UP_SPLIT_PER_CU: launches with fewer tiles than CUs split every tile
  * along K up to this many workgroups per CU), "tap_sort" (UP_TAP_SORT: GEMM rows ordered by their set of live filter taps so that

@@ -29,7 +29,7 @@ SHAPES = [
     ("3x3 512->512 d2 @23 (K4608 N512)", 32, 512, 23, 512, 3, 2, 2, 2),
     ("3x3 256->256 d18 @23 (WASP)", 32, 256, 23, 256, 3, 18, 18, 2),
 ]
-DEFAULTS = {"tail_split": 1, "tile_want": 1500}
+DEFAULTS = {"tiny_k": 128, "tail_split": 1, "tile_want": 1500}
 
 
 def main():

@@ -13,7 +13,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import torch  # noqa: E402
 
 DEFAULTS = {"tile_want": 1500, "tile_want_bf16": 500, "tail_split": 1, "split_per_cu": 2, "tap_sort": 1, "wgrad_rect": 1,
-            "glds": 1, "glds32": 1, "glds32_epi": 1, "glds32_wgrad": 1, "bn_rows": 1}
+            "glds": 1, "glds32": 1, "glds32_epi": 1, "glds32_wgrad": 1, "bn_rows": 1, "tiny_k": 128}
 # (round 2, profiles/r02_a_knob_ab.txt: occ64, wgrad_single and the high-priority main stream measured no gain and were removed)
 
 

@@ -2002,8 +2002,16 @@ static int cu_count();
 // 128x128 85 TF).
 // (math >= UP_MATH_BF16: the plain-bf16 kernels do 16x the MFMA work per cycle and live on operand reuse, they want
 //  larger tiles: 736^2 B=16 step in bf16 storage 52.0 ms at 1500, 49.0-49.5 ms anywhere in 300..1000, profiles/r02_t)
+// Round 5: reductions of at most tiny_k (K <= 128: the 1x1 64->256 / 128->512 layers of the 92x92 / 46x46 stages and their data
+// gradients, two to four K slices per tile) always take 64x64 tiles, whatever the workgroup count: such a tile's life is set-up and
+// epilogue, and four small workgroups per CU overlap those better than two large ones.  Whole fp32 step, three alternations
+// (profiles/r05_experiments.txt): 0 (the workgroup-count rule alone) 61.95-62.07 ms, 64: 61.72-61.95, 128: 61.58-61.69,
+// 256: 61.60-61.68, 512: 61.75-61.81, 576: 61.91-61.96, 1152: 61.76-61.92.  fp32 only: the bf16-storage kernels lose with it
+// (736^2 step 37.56 / 37.81 ms without, 37.71-38.27 at 64, 37.90-37.95 at 128, 38.47-38.51 at 256).
+static int g_tiny_k = env_int("UP_TINY_K", 128, 0);
 static TileChoice choose_tile(int64_t M, int Ng, int Ktot, int math = 0) {
     const int cands[4][2] = {{128, 128}, {64, 128}, {128, 64}, {64, 64}};
+    if (math == UP_MATH_F32 && Ktot <= g_tiny_k) return {64, 64};
     const int base_want = math >= UP_MATH_BF16 ? g_tile_want_bf16 : g_tile_want;   // workgroups a launch should at least have
     const int64_t want = Ktot < g_short_k ? (int64_t)g_short_k_mult * base_want / 2 : base_want;
     for (auto& c : cands) {
@@ -2453,6 +2461,7 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "glds32_epi")) g_glds32_epi = value ? 1 : 0;
     else if (!strcmp(key, "glds32_wgrad")) g_glds32_wgrad = value ? 1 : 0;
     else if (!strcmp(key, "tail_split")) g_tail_split = value ? 1 : 0;
+    else if (!strcmp(key, "tiny_k") && value >= 0) g_tiny_k = value;
     else if (!strcmp(key, "split_per_cu") && value > 0) g_split_per_cu = value;
     else if (!strcmp(key, "tap_sort")) g_tap_sort = value ? 1 : 0;
     else if (!strcmp(key, "wgrad_rect")) g_wgrad_rect = value ? 1 : 0;
