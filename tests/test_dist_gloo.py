@@ -125,3 +125,26 @@ def test_trainer_world2_gloo():
     assert np.array_equal(w0_a, w0_b)              # weights replicated from rank 0 before the first step
     assert not np.array_equal(w0_a, w1_a)          # the steps moved them
     assert np.array_equal(w1_a, w1_b)              # identical averaged gradients -> identical weights after Adam
+
+
+def test_bucket_views_are_16_byte_aligned():
+    """the weight-gradient reduce pass writes its destination with 16-byte stores, so every parameter's slice of the flat
+    exchange buffer starts on a 16-byte boundary whatever odd-sized parameter (the 17-element head bias) sits in front of it; the pad
+    elements are zeros and the payload figure counts parameters only."""
+    import torch
+    from unipose_amd.dist import _Bucket
+    ps = [torch.nn.Parameter(torch.randn(*s)) for s in ((17,), (8, 3, 3, 3), (5,), (64, 16, 1, 1), (1,))]
+    b = _Bucket(ps)
+    base = b.buf.data_ptr()
+    assert base % 16 == 0
+    for p, v in zip(ps, b.views):
+        assert v.shape == p.shape and (v.data_ptr() - base) % 16 == 0
+    for p, v in zip(ps, b.views):
+        v.copy_(p.detach())
+    flat = b.buf.clone()
+    covered = torch.zeros_like(flat, dtype=torch.bool)
+    for v in b.views:
+        off = (v.data_ptr() - base) // 4
+        covered[off:off + v.numel()] = True
+    assert float(flat[~covered].abs().sum()) == 0.0                      # pads stay zero
+    assert int(covered.sum()) == sum(p.numel() for p in ps)
