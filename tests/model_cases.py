@@ -488,6 +488,43 @@ def tapped_block_output_case(dev, planes=32, B=2, size=12, tol=2e-5):
     return worst
 
 
+def hooked_block_output_case(dev, planes=32, B=2, size=12, tol=2e-5):
+    """a tensor hook on the tensor between two identity Bottlenecks that edits the gradient IN PLACE through .data
+    (`g.data.mul_(2)`, a clipping hook) changes dz without moving its version counter or its address — BnSlot.matches cannot see
+    it, so a hooked output must take the separate reduction.  Gradients with the fused reduction on equal those with it off
+    (the reproduction read a relative error of 10.9 on b1.bn2.weight before the fix)."""
+    from unipose_amd import ops
+    from unipose_amd.modules import Bottleneck
+    torch.manual_seed(6)
+    b1, b2 = Bottleneck(4 * planes, planes).to(dev).train(), Bottleneck(4 * planes, planes).to(dev).train()
+    x0 = torch.randn(B, size, size, 4 * planes)
+
+    def run(fuse):
+        prev, ops.BN_FUSE_REDUCE = ops.BN_FUSE_REDUCE, fuse
+        try:
+            for b in (b1, b2):
+                b.zero_grad(set_to_none=True)
+            x = x0.clone().to(dev).requires_grad_(True)
+            t = b1(x)
+            def double_in_place(g):          # in place, through .data: no version bump; returns None (the gradient is kept)
+                g.data.mul_(2.0)
+            t.register_hook(double_in_place)
+            b2(t).sum().backward()
+            ops.wgrad_fence()
+            return {f"b{i}.{n}": p.grad.detach().cpu().clone() for i, b in ((1, b1), (2, b2)) for n, p in b.named_parameters()}
+        finally:
+            ops.BN_FUSE_REDUCE = prev
+
+    g_ref = run(False)
+    u0 = ops.HOST_COUNTERS["bn_prereduced"]
+    g_fused = run(True)
+    used = ops.HOST_COUNTERS["bn_prereduced"] - u0
+    assert used == 4, used            # b1.bn3 (the hooked tensor's producer) reduced on its own, the other four from the consumers' sums
+    worst = max((O.max_rel(g_fused[k], g_ref[k]), k) for k in g_ref)
+    assert worst[0] < tol, worst
+    return worst
+
+
 def projection_block_case(dev, inplanes=64, planes=32, stride=2, dilation=1, B=2, size=10, tol=5e-5):
     """A projection Bottleneck (resnet.py:22-42 with `downsample`): the block input feeds conv1 and the down-sampling convolution;
     the latter's data gradient is handed to conv1's launch (ops.GradLink via link_dx) instead of autograd adding the two.  Against

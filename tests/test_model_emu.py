@@ -78,3 +78,7 @@ def test_lstm_bf16_storage_eval_emu(emu_backend):
 
 def test_lstm_bf16_storage_train_emu(emu_backend):
     mc.lstm_bf16s_case(emu_backend, train=True)
+
+
+def test_hooked_block_output_takes_the_separate_reduction_emu(emu_backend):
+    mc.hooked_block_output_case(emu_backend)

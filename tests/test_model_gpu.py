@@ -111,6 +111,10 @@ def test_tap_between_blocks_falls_back_to_the_separate_reduction_gpu():
     print(mc.tapped_block_output_case(DEV, planes=64, B=4, size=23))
 
 
+def test_hooked_block_output_takes_the_separate_reduction_gpu():
+    mc.hooked_block_output_case(DEV)
+
+
 def test_bn_backward_reduction_fused_into_data_gradients_gpu():
     launches, worst = mc.fused_reduce_case(DEV, B=8, size=128)
     print("fused BatchNorm-backward reductions per step:", launches, "worst gradient distance fused vs separate:", worst)
