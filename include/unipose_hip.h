@@ -40,7 +40,7 @@ typedef enum {
 } up_status;
 
 const char* up_last_error(void);
-int up_abi_version(void);   /* 9 */
+int up_abi_version(void);   /* 10 */
 
 /* Geometry of one 2-D convolution (nn.Conv2d as used at resnet.py:10-16,61,80-84,104-109;
  * wasp.py:9,52,59-60; decoder.py:17,22,26,30; model/uniposeLSTM.py:12-14,30-38,85-89). */
@@ -61,6 +61,23 @@ typedef struct {
  *   if(bias) v += bias[k];  if(residual) v += residual[pixel*ldr + k];  if(relu) v = max(v,0)
  * `stats` != NULL asks for per-(row-tile, channel) Welford partials {count, mean, M2} of the RAW
  * accumulator (train-mode BatchNorm statistics, K7); it excludes scale/bias/residual/relu. */
+/* ABI 10: BatchNorm finalize FOLDED into the launch that writes `stats`.  Every workgroup takes a ticket after publishing its
+ * partial row; the last arriver merges the partials in a fixed order (deterministic; the same bits as up_bn_finalize on the same
+ * stats) and writes mean / invstd / scale / shift (+ the running-statistics update) — no up_bn_finalize launch on the critical
+ * path.  `folded` is set by the call: 1 = done by the launch, 0 = the caller runs up_bn_finalize (row groups, fold switched off
+ * with up_conv_tune("bn_fold", 0), scratch exhausted).  Scratch (tickets + level-1 rows, ~8 MB) is per stream, like the K-split's. */
+typedef struct {
+    float eps, momentum;
+    float* running_mean;   /* optional pair, updated in place */
+    float* running_var;
+    const float* gamma;
+    const float* beta;
+    float* mean;           /* out [K] */
+    float* invstd;
+    float* scale;
+    float* shift;
+    int32_t folded;        /* out */
+} up_bn_fold;
 typedef struct {
     const float* scale;
     const float* shift;
@@ -69,6 +86,7 @@ typedef struct {
     int32_t ldr;
     int32_t relu;
     float* stats;         /* [up_conv_stats_tiles(desc)][K][3] or NULL */
+    up_bn_fold* fold;     /* optional (ABI 10, needs stats): see above */
 } up_conv_epilogue;
 
 /* Re-lay an OIHW fp32 weight (PyTorch layout) for the implicit-GEMM kernels:
@@ -169,11 +187,14 @@ typedef struct {
     float* partial;            /* out: [up_conv2d_bwd_data_tiles_math(d, math)][C][2]                               */
     int32_t ld, C;             /* pixel stride of y; channels (== d->C of this convolution)                        */
     int32_t group_stride;      /* row groups (ABI 8): floats between two groups' mean / invstd vectors, else 0     */
+    float* dgamma;             /* ABI 10, optional pair: the launch also FINISHES the reduction (last-arriver ticket, see      */
+    float* dbeta;              /* up_bn_fold): [C] sums over all rows; then up_bn_bwd_finalized_t runs the apply pass alone   */
+    int32_t folded;            /* out: 1 = dgamma / dbeta are final; 0 = call up_bn_bwd_prereduced_t on `partial`             */
 } up_bn_reduce_slot;
 typedef struct {
     const void* add;               /* second gradient of the same input (element type of dx), or NULL              */
     const uint32_t* add_relu_bits; /* optional ReLU mask of the addend, see above                                   */
-    const up_bn_reduce_slot* bn;   /* optional fused BatchNorm-backward reduction                                   */
+    up_bn_reduce_slot* bn;         /* optional fused BatchNorm-backward reduction                                   */
     int32_t ld_add;
     int32_t groups;                /* row groups (ABI 8; 0 / 1: none): the N images are `groups` equal batches, every one tiled
                                       on its own; bn->partial is then [groups][up_conv2d_bwd_data_tiles_grouped][C][2] and
@@ -299,6 +320,11 @@ int up_bn_bwd_prereduced_t(const void* dz, int lddz, const uint32_t* relu_bits, 
                            const float* mean, const float* invstd, int relu, int use_batch_stats, void* dy, int lddy, void* dres,
                            int lddres, float* dgamma, float* dbeta, float* acc_dgamma, float* acc_dbeta, float* partial, int chunks,
                            int64_t rows, int C, int dtype, void* stream);
+/* ABI 10: ... and when that launch also carried the merge (up_bn_reduce_slot.dgamma / dbeta, folded = 1): dgamma / dbeta are
+ * final, the apply pass alone (bn_bwd_apply of native_batch_norm_backward). */
+int up_bn_bwd_finalized_t(const void* dz, int lddz, const uint32_t* relu_bits, const void* y, int ldy, const float* gamma,
+                          const float* mean, const float* invstd, int relu, int use_batch_stats, void* dy, int lddy, void* dres,
+                          int lddres, const float* dgamma, const float* dbeta, int64_t rows, int C, int dtype, void* stream);
 
 /* ---- grouped BatchNorm: one tensor holds `groups` row groups of equal size (the T frames of a clip batch, frame-major), each
  * normalised with ITS OWN batch statistics — what `groups` separate module calls do in the reference's video loop

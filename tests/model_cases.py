@@ -379,6 +379,49 @@ def fused_reduce_case(dev, K=16, B=2, size=32, wseed=3, tol=2e-5):
     return launches[True], worst
 
 
+def bn_fold_step_case(dev, K=16, B=2, size=32, wseed=3, math="f32"):
+    """One training step of the whole image model with the BatchNorm finalize folded into the producing launches (bn_fold.h:
+    forward statistics merged by the convolution's last workgroup per channel column, backward sums by the data gradient / reduce
+    pass that produced them) against the same step with up_conv_tune("bn_fold", 0) (stand-alone arrive kernels, same merge tree):
+    loss, every gradient and every running statistic must agree BIT FOR BIT; the host counters give the folded launches per step."""
+    from unipose_amd import _C, ops
+    ops.set_conv_math(math)
+    try:
+        m, _ = build_image_model(K, wseed, dev)
+        m.train()
+        for d in (m.wasp.dropout, m.decoder.last_conv[3], m.decoder.last_conv[7]):
+            d.p = 0.0
+        x = O.synth_input((B, 3, size, size), 13).to(dev)
+        t = O.synth_input((B, K + 1, size // 8, size // 8), 14, "rand").to(dev)
+        L = _C.lib()
+        sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+        res, counts = {}, {}
+        try:
+            for fold in (1, 0):
+                _C.check(L.up_conv_tune(b"bn_fold", fold), "tune")
+                m.load_state_dict(sd0)
+                m.zero_grad(set_to_none=True)
+                f0, b0 = ops.HOST_COUNTERS["bn_fwd_folded"], ops.HOST_COUNTERS["bn_bwd_folded"]
+                loss = ops.mse_loss(m(x), t)
+                loss.backward()
+                ops.wgrad_fence()
+                counts[fold] = (ops.HOST_COUNTERS["bn_fwd_folded"] - f0, ops.HOST_COUNTERS["bn_bwd_folded"] - b0)
+                res[fold] = {"loss": loss.detach().cpu().reshape(1),
+                             **{"g." + n: p.grad.detach().cpu().clone() for n, p in m.named_parameters() if p.grad is not None},
+                             **{"s." + n: b.detach().cpu().clone() for n, b in m.named_buffers()}}
+        finally:
+            _C.check(L.up_conv_tune(b"bn_fold", 1), "tune")
+    finally:
+        ops.set_conv_math("f32")
+    assert counts[0] == (0, 0), counts
+    assert res[1].keys() == res[0].keys()
+    # (bias gradients of the plain convolutions are float-atomic column sums: equal to round-off, not to the bit)
+    bad = [k for k in res[1] if not (torch.equal(res[1][k], res[0][k]) or
+                                     (k.endswith(".bias") and O.max_rel(res[1][k], res[0][k]) < 1e-5 and "last_conv.8" in k))]
+    assert not bad, (len(bad), bad[:5])
+    return counts[1]
+
+
 def g15_case(dev, path, batch_frames, slack=2.0, floor=5e-3):
     """UniPose-LSTM TRAINING against the genuine reference (G15: K=13, B=1, T=5 at 368x368, train mode, dropouts off, summed MSE,
     one backward): per-frame heat-maps, loss, sampled gradients at `slack` x the reference's own fp32-vs-fp64 distance (+ floor:

@@ -654,3 +654,66 @@ def optimizer_stale_case(dev, math, fused, nweights=3):
         assert torch.equal(ops.conv_fwd_raw(x, other, cfg)[0].float().cpu(), y_other)       # (a sub-table re-pack left it alone)
     finally:
         ops.set_conv_math("f32")
+
+
+def bn_fold_case(dev, n, c, h, w, k1, k2, r2=1, dtype=torch.float32, cus=0, seed=0):
+    """conv1 -> BN -> ReLU -> conv2 -> BN -> ReLU, one training step, with the BatchNorm finalize FOLDED into the producing launches
+    (forward: the convolution's last workgroup per channel column merges the statistics partials, up_bn_fold; backward: the data
+    gradient that carries the reduction also merges it, up_bn_reduce_slot.dgamma / folded; bn2's reduce pass takes the tickets in
+    bn_bwd_reduce_kernel) against the same step with up_conv_tune("bn_fold", 0), where the stand-alone arrive kernel runs the
+    same merge tree: EQUAL bits everywhere, and the host counters prove which form ran.
+    cus: shrink the "chip" so that the launches have K-split tail tiles (only their finishing workgroup arrives)."""
+    from unipose_amd import _C
+    torch.manual_seed(seed)
+    conv1, bn1 = torch.nn.Conv2d(c, k1, 1, bias=False), torch.nn.BatchNorm2d(k1)
+    conv2, bn2 = torch.nn.Conv2d(k1, k2, r2, padding=r2 // 2, bias=False), torch.nn.BatchNorm2d(k2)
+    with torch.no_grad():
+        for b in (bn1, bn2):
+            b.weight.uniform_(0.5, 1.5)
+            b.bias.normal_(0, 0.3)
+            b.running_mean.normal_(0, 0.1)
+    mods = [m.to(dev).train() for m in (conv1, bn1, conv2, bn2)]
+    state0 = [{k_: v.clone() for k_, v in m.state_dict().items()} for m in mods]
+    x0 = (torch.randn(n, h, w, c) + 0.3).to(dtype)
+    g0 = torch.randn(n, h, w, k2).to(dtype)
+    L = _C.lib()
+    out, counts = {}, {}
+    if cus:
+        _C.check(L.up_conv_tune(b"cu_count", cus), "tune")
+    try:
+        for fold in (1, 0):
+            _C.check(L.up_conv_tune(b"bn_fold", fold), "tune")
+            for m, s0 in zip(mods, state0):
+                m.load_state_dict(s0)
+                m.zero_grad(set_to_none=True)
+            x = x0.clone().to(dev).requires_grad_(True)
+            f0, b0 = ops.HOST_COUNTERS["bn_fwd_folded"], ops.HOST_COUNTERS["bn_bwd_folded"]
+            s1 = ops.BnSlot()
+            y1 = ops.conv_bn_act(x, mods[0], mods[1], relu=True, slot_out=s1)
+            y2 = ops.conv_bn_act(y1, mods[2], mods[3], relu=True, slot_in=s1)
+            (y2.float() * g0.to(dev).float()).sum().backward()
+            ops.wgrad_fence()
+            counts[fold] = (ops.HOST_COUNTERS["bn_fwd_folded"] - f0, ops.HOST_COUNTERS["bn_bwd_folded"] - b0)
+            out[fold] = {"y2": y2.detach().float().cpu(), "dx": x.grad.float().cpu(),
+                         **{f"p{i}.{nm}": p.grad.cpu() for i, m in enumerate(mods) for nm, p in m.named_parameters()},
+                         **{f"b{i}.{nm}": b.detach().clone().cpu() for i, m in enumerate(mods) for nm, b in m.named_buffers()}}
+    finally:
+        _C.check(L.up_conv_tune(b"bn_fold", 1), "tune")
+        if cus:
+            _C.check(L.up_conv_tune(b"cu_count", 0), "tune")
+    assert counts[0] == (0, 0), counts
+    assert counts[1][0] == 2, counts                  # both convolutions finalized their own statistics
+    if dtype == torch.float32 and c % 32 == 0 and k1 % 32 == 0:
+        assert counts[1][1] == 1, counts              # conv2's data gradient reduced AND merged bn1's sums
+    for k_ in out[1]:
+        assert torch.equal(out[1][k_], out[0][k_]), (k_, float((out[1][k_].double() - out[0][k_].double()).abs().max()))
+    # ... and the statistics themselves are right: batch mean / biased variance of conv1's output against float64
+    with torch.no_grad():
+        y = torch.nn.functional.conv2d(x0.double().permute(0, 3, 1, 2), state0[0]["weight"].double().cpu())
+        mean, var = y.mean((0, 2, 3)), y.var((0, 2, 3), unbiased=True)
+        rm = 0.9 * state0[1]["running_mean"].double().cpu() + 0.1 * mean
+        rv = 0.9 * state0[1]["running_var"].double().cpu() + 0.1 * var
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert rel(out[1]["b1.running_mean"].double(), rm) < tol, rel(out[1]["b1.running_mean"].double(), rm)
+    assert rel(out[1]["b1.running_var"].double(), rv) < tol, rel(out[1]["b1.running_var"].double(), rv)
+    return counts[1]

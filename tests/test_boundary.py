@@ -91,7 +91,7 @@ def test_hip_library_exports_every_declared_symbol():
     for name in _declared_symbols():
         assert hasattr(lib, name), name
     lib.up_abi_version.restype = ctypes.c_int
-    assert lib.up_abi_version() == 9
+    assert lib.up_abi_version() == 10
     # argument validation happens before any launch, so it is testable without a device
     lib.up_last_error.restype = ctypes.c_char_p
     assert lib.up_conv2d_fwd(None, None, None, None, None, None) == -1

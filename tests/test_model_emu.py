@@ -82,3 +82,10 @@ def test_lstm_bf16_storage_train_emu(emu_backend):
 
 def test_hooked_block_output_takes_the_separate_reduction_emu(emu_backend):
     mc.hooked_block_output_case(emu_backend)
+
+
+def test_bn_finalize_folded_whole_step(emu_backend):
+    fwd, bwd = mc.bn_fold_step_case(emu_backend, B=3, size=64)
+    print("folded finalize launches per step: forward", fwd, "backward", bwd)
+    # 64x64 inputs, B = 3: the stem, layer1 and layer2.0 see more than 256 rows per channel (the rest: float64 statistics, no fold)
+    assert fwd >= 12 and bwd >= 60, (fwd, bwd)

@@ -120,6 +120,13 @@ def test_bn_backward_reduction_fused_into_data_gradients_gpu():
     print("fused BatchNorm-backward reductions per step:", launches, "worst gradient distance fused vs separate:", worst)
 
 
+@pytest.mark.parametrize("math,B,size", [("f32", 8, 128), ("bf16s", 4, 160)])
+def test_bn_finalize_folded_whole_step_gpu(math, B, size):
+    fwd, bwd = mc.bn_fold_step_case(DEV, B=B, size=size, math=math)
+    print("folded finalize launches per step: forward", fwd, "backward", bwd)
+    assert fwd >= 105 and bwd >= 80, (fwd, bwd)
+
+
 def test_g4_train_128_loss_statistics_and_gradient_norms_vs_reference_golden(golden_dir):
     """Reference train step at 128x128, B=2, dropouts off: loss / output / gradients / running stats."""
     from unipose_amd import ops

@@ -395,3 +395,23 @@ def test_batched_repack_equals_single_pack(emu_backend):
             assert first[0].data_ptr() == get(*use[0])[0].data_ptr()     # persistent buffers
     finally:
         ops.set_conv_math("f32")
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n=2, c=32, h=13, w=11, k1=64, k2=32),                    # 286 rows: 5 tiles, one group, ragged last tile
+    dict(n=2, c=32, h=48, w=47, k1=96, k2=160, r2=1),             # 4512 rows: 71 tiles = 3 groups; 96 / 160 channels: ragged columns
+    dict(n=3, c=32, h=60, w=50, k1=32, k2=32, r2=3),              # 9000 rows: 141 tiles = 5 groups (level 2 uses every row lane); 3x3 consumer
+    dict(n=2, c=32, h=20, w=20, k1=64, k2=64, cus=6),             # shrunk chip: K-split tail tiles, only the finisher arrives
+    dict(n=1, c=20, h=20, w=19, k1=32, k2=32),                    # 20 input channels: the register-staged generic kernel carries the ticket
+])
+def test_bn_finalize_folded_into_the_producing_launch(emu_backend, cfg):
+    print(oc.bn_fold_case(emu_backend, **cfg))
+
+
+def test_bn_finalize_folded_bf16_storage(emu_backend):
+    from unipose_amd import ops
+    ops.set_conv_math("bf16s")
+    try:
+        print(oc.bn_fold_case(emu_backend, n=2, c=32, h=30, w=33, k1=64, k2=96, dtype=torch.bfloat16))
+    finally:
+        ops.set_conv_math("f32")

@@ -226,3 +226,49 @@ def test_bn_small_batch_statistics_are_exact():
 def test_optimizer_step_makes_the_packed_weights_stale(math, nweights):
     """(40 parameters: the batched re-pack is split between the current and the side stream, both read orders)"""
     oc.optimizer_stale_case(DEV, math, True, nweights)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(n=32, c=1024, h=23, w=23, k1=256, k2=256, r2=3),         # layer3 bn1 (265 tiles = 9 groups), merged by conv2's data gradient
+    dict(n=32, c=256, h=23, w=23, k1=256, k2=1024),               # bn2 by conv3's; 1024 channels = 16 ticket columns
+    dict(n=8, c=64, h=92, w=92, k1=64, k2=256),                   # layer1: 1058 partial rows per column
+    dict(n=4, c=32, h=46, w=47, k1=96, k2=160),                   # ragged tiles and columns
+    dict(n=2, c=20, h=30, w=30, k1=32, k2=32),                    # register-staged generic kernel
+])
+def test_bn_finalize_folded_into_the_producing_launch(cfg):
+    print(oc.bn_fold_case(DEV, **cfg))
+
+
+def test_bn_finalize_folded_bf16_storage():
+    from unipose_amd import ops
+    ops.set_conv_math("bf16s")
+    try:
+        print(oc.bn_fold_case(DEV, n=16, c=256, h=46, w=46, k1=256, k2=1024, dtype=torch.bfloat16))
+    finally:
+        ops.set_conv_math("f32")
+
+
+def test_bn_fold_is_deterministic_under_load():
+    """The last arriver differs from launch to launch; the merged statistics must not: 20 repetitions of a 1060-tile launch with
+    co-running work on a second stream, every result bit-equal to the first."""
+    from unipose_amd import ops
+    torch.manual_seed(5)
+    conv, bn = torch.nn.Conv2d(256, 256, 3, padding=1, bias=False).to(DEV), torch.nn.BatchNorm2d(256).to(DEV).train()
+    x = torch.randn(32, 23, 23, 256, device=DEV)
+    noise = torch.randn(64 << 20, device=DEV)
+    side = torch.cuda.Stream()
+    ref = None
+    for rep in range(20):
+        bn.running_mean.zero_()
+        bn.running_var.fill_(1.0)
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                noise.mul_(1.0001)
+        with torch.no_grad():
+            y = ops.conv_bn_act(x, conv, bn, relu=True)
+        got = (y.clone(), bn.running_mean.clone(), bn.running_var.clone())
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = got
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(ref, got)), rep

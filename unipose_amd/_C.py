@@ -21,10 +21,17 @@ class ConvDesc(C.Structure):
                 ("N", "H", "W", "C", "Cp", "ldx", "K", "R", "S", "stride", "pad", "dil", "P", "Q", "ldy", "Kp")]
 
 
+class BnFold(C.Structure):
+    """up_bn_fold: BatchNorm finalize folded into the launch that writes the statistics partials (ABI 10)"""
+    _fields_ = [("eps", C.c_float), ("momentum", C.c_float), ("running_mean", C.c_void_p), ("running_var", C.c_void_p),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("scale", C.c_void_p),
+                ("shift", C.c_void_p), ("folded", C.c_int32)]
+
+
 class ConvEpilogue(C.Structure):
     """up_conv_epilogue"""
     _fields_ = [("scale", C.c_void_p), ("shift", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p),
-                ("ldr", C.c_int32), ("relu", C.c_int32), ("stats", C.c_void_p)]
+                ("ldr", C.c_int32), ("relu", C.c_int32), ("stats", C.c_void_p), ("fold", C.POINTER(BnFold))]
 
 
 _i, _i64, _f, _u64, _sz, _p = C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_size_t, C.c_void_p
@@ -33,7 +40,8 @@ _i, _i64, _f, _u64, _sz, _p = C.c_int, C.c_int64, C.c_float, C.c_uint64, C.c_siz
 class BnReduceSlot(C.Structure):
     """up_bn_reduce_slot"""
     _fields_ = [("y", C.c_void_p), ("relu_bits", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
-                ("partial", C.c_void_p), ("ld", C.c_int32), ("C", C.c_int32), ("group_stride", C.c_int32)]
+                ("partial", C.c_void_p), ("ld", C.c_int32), ("C", C.c_int32), ("group_stride", C.c_int32),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("folded", C.c_int32)]
 
 
 class DgradEpilogue(C.Structure):
@@ -70,6 +78,7 @@ SIGNATURES = {
     "up_conv2d_fwd_grouped": (_i, [_D, _p, _p, _p, _p, _i, _p]),
     "up_bn_bwd_prereduced_t": (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _i64, _i,
                                     _i, _p]),
+    "up_bn_bwd_finalized_t": (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _i64, _i, _i, _p]),
     "up_pack_weights_bf16": (_i, [_D, _p, _p, _p, _p, _p, _p]),
     "up_pack_weights_bf16_batched": (_i, [_p, _i, _p]),
     "up_conv2d_fwd_bf16": (_i, [_D, _p, _p, _p, _p, _E, _i, _p]),

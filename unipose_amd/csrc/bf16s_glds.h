@@ -173,10 +173,10 @@ __device__ __forceinline__ void tile_stats(const IgemmArgs& a, f32x16 (&acc)[BM 
             wf_merge(sc[j], sm[j], s2[j], FULL ? (float)(TM * 32) : s[0], s[1], s[2]);
             const int n = ncol0 + j * 32;
             if (n < a.Ng) {
-                float* o = a.stats + ((size_t)mt * a.Ng + n) * 3;
-                o[0] = sc[j];
-                o[1] = sm[j];
-                o[2] = s2[j];
+                float* o = a.stats + ((size_t)mt * a.Ng + n) * 3;   // (sc1: the last arriver of the fold reads them)
+                st_agent(o, sc[j]);
+                st_agent(o + 1, sm[j]);
+                st_agent(o + 2, s2[j]);
             }
         }
     }
@@ -422,7 +422,7 @@ __device__ __forceinline__ void store_tile(const IgemmArgs& a, f32x16 (&acc)[BM 
             const int cc = n0 + ch;
             if (cc < a.Ng) {
                 if (which) t *= a.bn_invstd[cc];
-                a.bn_partial[((size_t)mt * a.Ng + cc) * 2 + which] = t;
+                st_agent(a.bn_partial + ((size_t)mt * a.Ng + cc) * 2 + which, t);
             }
         }
     }
@@ -613,6 +613,7 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds_kernel(IgemmArgs a) {
     } else {
         store_tile<BM, BN, PERM, BNRED>(a, acc, smem, xch, mt, m0, n0, tid, wm, wn, l31, lh);
     }
+    igemm_fold_arrive<BN>(a, mt, n0, smem);
     if (DBG && tid == 0) {
         stamp[4] = wall_clock64();
         wait_dma();   // stores of this wave acknowledged

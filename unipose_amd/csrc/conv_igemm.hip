@@ -20,6 +20,7 @@
 // Within each group of 8 k the two half-waves take k = {0..3} / {4..7}: any k permutation is
 // legal as long as A and B use the same one, and it turns 4 ds_read_b32 into one ds_read_b128.
 #include "up_common.h"
+#include "bn_fold.h"
 
 #include <algorithm>
 #include <map>
@@ -175,7 +176,20 @@ struct IgemmArgs {
     // bn_grp_stride: floats between two groups' bn_mean / bn_invstd vectors.
     int grp_rows, grp_tiles, bn_grp_stride;
     FastDiv fGrpTiles;
+    // BatchNorm finalize folded into this launch (bn_fold.h): fold.tickets != nullptr -> every finishing workgroup arrives after its
+    // partial row (a.stats in the forward, a.bn_partial in a BNRED data gradient); fold_nv = 3 / 2 says which
+    BnFold fold;
+    int fold_nv;
 };
+
+// end of an implicit-GEMM workgroup that ran the epilogue of tile (mt, n0..n0+BN): the fold's ticket (see bn_fold.h)
+template <int BN>
+__device__ __forceinline__ void igemm_fold_arrive(const IgemmArgs& a, int mt, int n0, unsigned char* lds) {
+    if (a.fold.tickets == nullptr) return;   // uniform
+    const int ncols = a.Ng - n0 < BN ? a.Ng - n0 : BN;
+    if (a.fold_nv == 3) bn_fold_arrive<3>(a.fold, a.stats, mt, n0, ncols, lds);
+    else bn_fold_arrive<2>(a.fold, a.bn_partial, mt, n0, ncols, lds);
+}
 
 __device__ __forceinline__ void wf_merge(float& n1, float& m1, float& s1, float n2, float m2, float s2) {
     if (n2 == 0.f) return;
@@ -198,34 +212,14 @@ __device__ __forceinline__ float4 keep_or_zero(bool k, float4 v) {
     return make_float4(k ? v.x : 0.f, k ? v.y : 0.f, k ? v.z : 0.f, k ? v.w : 0.f);
 }
 
-// agent-scope (device-coherent) accesses for the K-split partials and their ready flags
+// agent-scope (device-coherent) accesses for the K-split partials and their ready flags: st_agent / ld_agent / st_agent_flag live
+// in bn_fold.h (shared with the BatchNorm fold)
 #ifdef UP_EMU
-__device__ __forceinline__ void st_agent(float* p, float v) {
-    uint32_t u;
-    memcpy(&u, &v, 4);
-    __atomic_store_n(reinterpret_cast<uint32_t*>(p), u, __ATOMIC_RELEASE);
-}
-__device__ __forceinline__ float ld_agent(const float* p) {
-    uint32_t u = __atomic_load_n(reinterpret_cast<const uint32_t*>(p), __ATOMIC_ACQUIRE);
-    float v;
-    memcpy(&v, &u, 4);
-    return v;
-}
-__device__ __forceinline__ void st_agent_flag(int* p, int v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 __device__ __forceinline__ void spin_until_set(const int* p) {
     while (__atomic_load_n(p, __ATOMIC_ACQUIRE) == 0) sched_yield();
 }
 __device__ __forceinline__ void wait_stores() {}
 #else
-__device__ __forceinline__ void st_agent(float* p, float v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float ld_agent(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_agent_flag(int* p, int v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ void spin_until_set(const int* p) {
     while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(8);
 }
@@ -357,10 +351,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                 wf_merge(sc[j], sm[j], s2[j], s[0], s[1], s[2]);
                 int n = ncol0 + j * 32;
                 if (n < a.Ng) {
-                    float* o = a.stats + ((size_t)mt * a.Ng + n) * 3;
-                    o[0] = sc[j];
-                    o[1] = sm[j];
-                    o[2] = s2[j];
+                    float* o = a.stats + ((size_t)mt * a.Ng + n) * 3;   // (sc1: the last arriver of the fold reads them)
+                    st_agent(o, sc[j]);
+                    st_agent(o + 1, sm[j]);
+                    st_agent(o + 2, s2[j]);
                 }
             }
         }
@@ -875,6 +869,7 @@ __global__ void __launch_bounds__(256, (BM == 128 && BN == 128) ? 2 : 3) igemm_k
     }
 
     igemm_epilogue<BM, BN, PERM>(a, acc, smem, mt, m0, n0, wm, wn, l31, lh);
+    igemm_fold_arrive<BN>(a, mt, n0, reinterpret_cast<unsigned char*>(smem));
     if (DBG & 32) dbg_record();
 }
 
@@ -1135,6 +1130,7 @@ __global__ void __launch_bounds__(256, 2) igemm_bf16_kernel(IgemmArgs a) {
     }
     igemm_epilogue<BM, BN, false, std::conditional_t<HS && !OF32, bf16_t, float>>(a, acc, reinterpret_cast<float*>(smem), mt, m0, n0,
                                                                                   wm, wn, l31, lh);
+    igemm_fold_arrive<BN>(a, mt, n0, reinterpret_cast<unsigned char*>(smem));
 }
 
 // OIHW fp32 -> bf16 hi / lo planes in the [rows][tap][channel] order of pack_fwd / pack_dgrad
@@ -2036,7 +2032,12 @@ struct SplitScratch {
     float* partials = nullptr;
     int* flags = nullptr;
     size_t pfloats = 0, nflags = 0;   // capacity
+    // BatchNorm fold (bn_fold.h): tickets (zero between launches) + level-1 rows, allocated by the first folding launch on the stream
+    int* tickets = nullptr;
+    double* part2 = nullptr;
 };
+constexpr size_t FOLD_TICKETS = 1 << 16;          // ints: columns * (groups + 1) of the largest merge
+constexpr size_t FOLD_PART2_BYTES = 8u << 20;     // level-1 rows: groups * C * nv doubles
 static int g_cu_override = 0;   // up_conv_tune("cu_count", n): tests shrink the "chip" so that small launches have whole rounds + a tail
 static int cu_count() {
     if (g_cu_override > 0) return g_cu_override;
@@ -2083,6 +2084,75 @@ static SplitScratch* split_scratch(hipStream_t st) {
     return &s;
 }
 static bool tail_split_enabled() { return g_tail_split != 0; }
+
+// ---- BatchNorm fold (bn_fold.h) -----------------------------------------------------------------------
+static int g_bn_fold = env_int("UP_BN_FOLD", 1, 0);   // up_conv_tune("bn_fold", 0): producers leave the finalize to the stand-alone kernel (same bits)
+bool bn_fold_enabled() { return g_bn_fold != 0; }
+bool bn_fold_scratch(hipStream_t st, int tiles, int C, int nv, BnFold* f) {
+    if (tiles < 1 || C < 1) return false;
+    const int groups = (tiles + FOLD_G - 1) / FOLD_G;
+    const size_t cols = (size_t)(C + FOLD_COLS - 1) / FOLD_COLS;
+    if (cols * (size_t)(groups + 1) > FOLD_TICKETS || (size_t)groups * C * nv * sizeof(double) > FOLD_PART2_BYTES) return false;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    SplitScratch& s = g_scratch[st];
+    if (!s.tickets) {
+#ifdef UP_EMU
+        s.tickets = static_cast<int*>(calloc(FOLD_TICKETS, sizeof(int)));
+        s.part2 = static_cast<double*>(malloc(FOLD_PART2_BYTES));
+#else
+        if (hipMalloc(reinterpret_cast<void**>(&s.tickets), FOLD_TICKETS * sizeof(int)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&s.part2), FOLD_PART2_BYTES) != hipSuccess ||
+            hipMemset(s.tickets, 0, FOLD_TICKETS * sizeof(int)) != hipSuccess) {
+            (void)hipGetLastError();
+            if (s.tickets) (void)hipFree(s.tickets);
+            s.tickets = nullptr;
+            return false;
+        }
+#endif
+    }
+    f->tickets = s.tickets;
+    f->part2 = s.part2;
+    f->tiles = tiles;
+    f->groups = groups;
+    f->C = C;
+    return true;
+}
+// what the entry point asked the next launch to fold (per host thread, consumed by launch_igemm / launch_igemm_bf16)
+struct FoldRequest {
+    up_bn_fold* fwd = nullptr;
+    up_bn_reduce_slot* bwd = nullptr;
+};
+static thread_local FoldRequest g_fold_req;
+// `tiles`: row tiles of the launch about to be issued (its partial rows).  Fills a.fold when the launch carries the finalize.
+static void apply_fold(IgemmArgs& a, int tiles, hipStream_t st) {
+    a.fold.tickets = nullptr;
+    a.fold_nv = 0;
+    const FoldRequest rq = g_fold_req;
+    g_fold_req = FoldRequest();
+    if (!g_bn_fold || a.grp_rows) return;
+    if (rq.fwd && a.stats) {
+        up_bn_fold* q = rq.fwd;
+        if (!bn_fold_scratch(st, tiles, a.Ng, 3, &a.fold)) return;
+        a.fold.eps = q->eps;
+        a.fold.mom = q->momentum;
+        a.fold.rm = q->running_mean;
+        a.fold.rv = q->running_var;
+        a.fold.gamma = q->gamma;
+        a.fold.beta = q->beta;
+        a.fold.mean = q->mean;
+        a.fold.invstd = q->invstd;
+        a.fold.scale = q->scale;
+        a.fold.shift = q->shift;
+        a.fold_nv = 3;
+        q->folded = 1;
+    } else if (rq.bwd && a.bn_partial && rq.bwd->dgamma && rq.bwd->dbeta) {
+        if (!bn_fold_scratch(st, tiles, a.Ng, 2, &a.fold)) return;
+        a.fold.dgamma = rq.bwd->dgamma;
+        a.fold.dbeta = rq.bwd->dbeta;
+        a.fold_nv = 2;
+        rq.bwd->folded = 1;
+    }
+}
 }  // namespace up
 // The library's only per-stream device memory is the K-split scratch above (16 MB + flags, allocated by the first split launch on
 // a stream).  A caller that retires a stream — unipose_amd.graph.GraphedForward owns a private capture stream — hands it back
@@ -2095,9 +2165,13 @@ extern "C" int up_stream_release(void* stream) {
 #ifdef UP_EMU
     free(it->second.partials);
     free(it->second.flags);
+    free(it->second.tickets);
+    free(it->second.part2);
 #else
     if (it->second.partials) (void)hipFree(it->second.partials);
     if (it->second.flags) (void)hipFree(it->second.flags);
+    if (it->second.tickets) (void)hipFree(it->second.tickets);
+    if (it->second.part2) (void)hipFree(it->second.part2);
 #endif
     g_scratch.erase(it);
     return UP_OK;
@@ -2417,6 +2491,7 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     } else {
         ++g_count_igemm;
     }
+    apply_fold(a, ntm, st);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, st, a);
 }
 
@@ -2465,6 +2540,7 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "split_per_cu") && value > 0) g_split_per_cu = value;
     else if (!strcmp(key, "tap_sort")) g_tap_sort = value ? 1 : 0;
     else if (!strcmp(key, "wgrad_rect")) g_wgrad_rect = value ? 1 : 0;
+    else if (!strcmp(key, "bn_fold")) g_bn_fold = value ? 1 : 0;
     else UP_REQUIRE(false, UP_ERR_INVALID, "conv_tune: unknown key '%s'", key);
     return UP_OK;
 }
@@ -2557,6 +2633,14 @@ static int fill_fwd_args(IgemmArgs& a, const up_conv_desc* d, const float* x, co
         a.ldr = ep->ldr;
         a.relu = ep->relu;
         a.stats = ep->stats;
+        if (ep->fold) {   // BatchNorm finalize folded into this launch (bn_fold.h); the launch code decides and reports `folded`
+            up_bn_fold* q = ep->fold;
+            q->folded = 0;
+            UP_REQUIRE(ep->stats && q->gamma && q->beta && q->mean && q->invstd && q->scale && q->shift &&
+                           (q->running_mean == nullptr) == (q->running_var == nullptr),
+                       UP_ERR_INVALID, "conv2d_fwd: fold needs stats, gamma / beta, the four outputs and running statistics in pairs");
+            g_fold_req.fwd = q;
+        }
     }
     return UP_OK;
 }
@@ -2567,8 +2651,10 @@ extern "C" int up_conv2d_fwd(const up_conv_desc* d, const float* x, const float*
     if (int e = check_desc(d)) return e;
     UP_REQUIRE(x && w_fwd && y, UP_ERR_INVALID, "conv2d_fwd: null pointer");
     IgemmArgs a;
+    g_fold_req = FoldRequest();
     if (int e = fill_fwd_args(a, d, x, w_fwd, y, ep)) return e;
     run_igemm(a, choose_tile(a.M, a.Ng, a.Ktot), as_stream(stream));
+    g_fold_req = FoldRequest();
     return check_launch("conv2d_fwd");
 }
 
@@ -2673,6 +2759,7 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
     a.no_tap_skip = g_tap_skip ? 0 : 1;
     ProfScope prof(glds_form ? v + 8 : v, 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st, a.M, a.Ng, a.Ktot, a.nwg,
                    g_prof_on_host() && fast ? live_tap_share(a) : 1.0);
+    apply_fold(a, ntm, st);
     const bool split = math == UP_MATH_BF16X3;
     // K slice: 64 on the 64x64 tile (6 -> 12 MFMAs per wave and barrier) measured no faster than 32 (141.7 vs 145.1 TF)
     constexpr int KT = 32;
@@ -2867,8 +2954,11 @@ extern "C" int up_conv2d_bwd_data_ex(const up_conv_desc* d, const void* dy, cons
     UP_REQUIRE(math == UP_MATH_F32 || math == UP_MATH_BF16S, UP_ERR_INVALID, "conv2d_bwd_data_ex: math %d (fp32 or bf16 storage)", math);
     UP_REQUIRE(!ep->add || ep->ld_add >= d->C, UP_ERR_INVALID, "conv2d_bwd_data_ex: ld_add=%d < C=%d", ep->ld_add, d->C);
     UP_REQUIRE(!ep->add_relu_bits || ep->add, UP_ERR_INVALID, "conv2d_bwd_data_ex: add_relu_bits without an addend");
-    const up_bn_reduce_slot* slot = ep->bn;
+    up_bn_reduce_slot* slot = ep->bn;
     const int q = math == UP_MATH_BF16S ? 8 : 4;
+    if (slot) slot->folded = 0;
+    UP_REQUIRE(!slot || (slot->dgamma == nullptr) == (slot->dbeta == nullptr), UP_ERR_INVALID,
+               "conv2d_bwd_data_ex: dgamma and dbeta of a BatchNorm slot come together");
     UP_REQUIRE(!slot || (slot->y && slot->mean && slot->invstd && slot->partial && slot->C == d->C && slot->ld >= d->C && slot->ld % q == 0),
                UP_ERR_INVALID, "conv2d_bwd_data_ex: bad BatchNorm slot (C=%d vs %d, ld=%d)", slot ? slot->C : 0, d->C, slot ? slot->ld : 0);
     UP_REQUIRE(!(slot || ep->add_relu_bits) || up_conv2d_bwd_data_tiles_math(d, math) > 0, UP_ERR_UNSUPPORTED,
@@ -2898,15 +2988,20 @@ extern "C" int up_conv2d_bwd_data_ex(const up_conv_desc* d, const void* dy, cons
     UP_REQUIRE(!(slot || ep->add_relu_bits) || ((ptrs & 15) == 0 && (!ep->add || ep->ld_add % q == 0)), UP_ERR_UNSUPPORTED,
                "conv2d_bwd_data_ex: 16-byte alignment");
     g_extras_dropped = false;
+    g_fold_req = FoldRequest();
+    if (slot && slot->dgamma && groups == 1) g_fold_req.bwd = slot;   // the launch also finishes dgamma / dbeta (bn_fold.h)
     if (math == UP_MATH_BF16S) {
         UP_REQUIRE(!s2_decomposed(d->stride, d->dil) || !(slot || ep->add_relu_bits), UP_ERR_UNSUPPORTED, "conv2d_bwd_data_ex: stride 2");
         a.w = nullptr;
         a.w_hi = static_cast<const uint16_t*>(w_dgrad);
         a.w_lo = nullptr;
-        if (int e = run_igemm_bf16(a, math, as_stream(stream))) return e;
+        const int e = run_igemm_bf16(a, math, as_stream(stream));
+        g_fold_req = FoldRequest();
+        if (e) return e;
     } else {
         UP_REQUIRE(!s2_decomposed(d->stride, d->dil), UP_ERR_UNSUPPORTED, "conv2d_bwd_data_ex: stride-2 convolutions use up_conv2d_bwd_data");
         run_igemm(a, choose_tile(a.M, a.Ng, a.Ktot), as_stream(stream));
+        g_fold_req = FoldRequest();
     }
     UP_REQUIRE(!g_group_refused, UP_ERR_UNSUPPORTED, "conv2d_bwd_data_ex: the launch did not qualify for the kernel with row groups; "
                "nothing was launched");
@@ -3009,10 +3104,13 @@ extern "C" int up_conv2d_fwd_bf16(const up_conv_desc* d, const float* x, const u
     if (int e = check_desc(d)) return e;
     UP_REQUIRE(x && w_hi && y && (w_lo || math != UP_MATH_BF16X3), UP_ERR_INVALID, "conv2d_fwd_bf16: null pointer");
     IgemmArgs a;
+    g_fold_req = FoldRequest();
     if (int e = fill_fwd_args(a, d, x, nullptr, y, ep)) return e;
     a.w_hi = w_hi;
     a.w_lo = w_lo;
-    if (int e = run_igemm_bf16(a, math, as_stream(stream))) return e;
+    const int e = run_igemm_bf16(a, math, as_stream(stream));
+    g_fold_req = FoldRequest();
+    if (e) return e;
     return check_launch("conv2d_fwd_bf16");
 }
 

@@ -199,10 +199,10 @@ struct Epi32 {
                 wf_merge(sc[j], sm[j], s2[j], s[0], s[1], s[2]);
                 const int n = ncol0 + j * 32;
                 if (n < a.Ng) {
-                    float* o = a.stats + ((size_t)mt * a.Ng + n) * 3;
-                    o[0] = sc[j];
-                    o[1] = sm[j];
-                    o[2] = s2[j];
+                    float* o = a.stats + ((size_t)mt * a.Ng + n) * 3;   // (sc1: the last arriver of the fold reads them)
+                    st_agent(o, sc[j]);
+                    st_agent(o + 1, sm[j]);
+                    st_agent(o + 2, s2[j]);
                 }
             }
         }
@@ -304,7 +304,7 @@ struct Epi32 {
                 const int cc = n0 + ch;
                 if (cc < a.Ng) {
                     if (which) t *= PF ? pis : a.bn_invstd[gmean + cc];
-                    a.bn_partial[((size_t)mt * a.Ng + cc) * 2 + which] = t;
+                    st_agent(a.bn_partial + ((size_t)mt * a.Ng + cc) * 2 + which, t);
                 }
             }
         }
@@ -589,6 +589,7 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
     } else {
         igemm_epilogue<BM, BN, PERM>(a, acc, reinterpret_cast<float*>(smem), mt, m0, n0, wm, wn, l31, lh);
     }
+    igemm_fold_arrive<BN>(a, mt, n0, smem);
 }
 
 

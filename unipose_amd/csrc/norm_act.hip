@@ -3,6 +3,7 @@
 // NHWC tensors, grid-stride loops capped at a few blocks per CU, wave-level shuffles + LDS for
 // the per-channel reductions.
 #include "up_common.h"
+#include "bn_fold.h"
 
 #include <stdarg.h>
 #include <stdlib.h>
@@ -65,6 +66,16 @@ __global__ void __launch_bounds__(256) bn_eval_coeffs_kernel(const float* g, con
 struct GroupArgs {
     int pstride, gstride;
 };
+
+// The stand-alone form of the BatchNorm fold (bn_fold.h): one workgroup per (partial row, 64-channel column) that does nothing but
+// ARRIVE — the merge tree, and therefore every result bit, is the one a producing launch that carries the ticket itself computes.
+// Used when the producer could not fold (row groups excluded: they keep bn_finalize_kernel's per-group forms), and by the tests.
+template <int NV>
+__global__ void __launch_bounds__(256) bn_fold_arrive_kernel(const float* partial, BnFold f) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[FOLD_LDS_BYTES];
+    const int c0 = blockIdx.y * FOLD_COLS;
+    bn_fold_arrive<NV>(f, partial, blockIdx.x, c0, f.C - c0 < FOLD_COLS ? f.C - c0 : FOLD_COLS, lds);
+}
 
 // One workgroup per channel: thread t merges the partials of row tiles t, t+256, ... (one or two independent loads for
 // the layer shapes of this network: 265 tiles at 23x23 / B = 32), then an 8-level merge tree over LDS.  These few-hundred-
@@ -572,8 +583,10 @@ template <typename T>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* dz, int lddz, const T* z, int ldz,
                                                             const uint32_t* bits, const T* y, int ldy,
                                                             const float* mean, const float* invstd, int relu,
-                                                            float* partial, int64_t rows, int C, int rows_per_chunk, GroupArgs grp) {
-    __shared__ float red[16][64][2];
+                                                            float* partial, int64_t rows, int C, int rows_per_chunk, GroupArgs grp,
+                                                            BnFold fold) {
+    __shared__ __attribute__((aligned(16))) float red[16][64][2];
+    static_assert(sizeof(float) * 16 * 64 * 2 >= FOLD_LDS_BYTES, "the fold's ticket re-uses the reduction buffer");
     const int64_t grow0 = (int64_t)blockIdx.z * rows;      // first row of this group (rows = rows of one group)
     dz += grow0 * lddz;
     y += grow0 * ldy;
@@ -646,7 +659,11 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* dz, int ldd
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += red[k][ch][which];
         const int cc = blockIdx.y * 64 + ch;
-        if (cc < C) partial[((size_t)blockIdx.x * C + cc) * 2 + which] = t;
+        if (cc < C) st_agent(partial + ((size_t)blockIdx.x * C + cc) * 2 + which, t);   // (sc1: the fold's last arriver reads them)
+    }
+    if (fold.tickets) {   // uniform: this launch also finishes dgamma / dbeta (bn_fold.h)
+        const int c0 = blockIdx.y * 64;
+        bn_fold_arrive<2>(fold, partial, blockIdx.x, c0, C - c0 < 64 ? C - c0 : 64, reinterpret_cast<unsigned char*>(&red[0][0][0]));
     }
 }
 // pass 2: one workgroup per channel, thread t sums chunks t, t+256, ... (four independent loads per round), LDS tree;
@@ -863,7 +880,7 @@ constexpr int BNB_ROWS = 128;   // small chunks: enough workgroups (and bytes in
 using namespace up;
 
 extern "C" const char* up_last_error(void) { return g_err; }
-extern "C" int up_abi_version(void) { return 9; }   // 9: up_pack_weights_bf16_batched; 8: row groups (up_conv2d_fwd_grouped, groups in up_dgrad_epilogue, up_bn_bwd_groups_prereduced_t); 7: up_conv2d_bwd_data_ex / up_bn_bwd_prereduced_t / up_conv_counter; 6: centred BatchNorm; 5: up_conv2d_bwd_weight_acc; 4: element-typed (_t) twins + bf16 storage
+extern "C" int up_abi_version(void) { return 10; }   // 10: BatchNorm finalize folded into the producing launch (up_bn_fold, up_bn_reduce_slot.dgamma, up_bn_bwd_finalized_t); 9: up_pack_weights_bf16_batched; 8: row groups (up_conv2d_fwd_grouped, groups in up_dgrad_epilogue, up_bn_bwd_groups_prereduced_t); 7: up_conv2d_bwd_data_ex / up_bn_bwd_prereduced_t / up_conv_counter; 6: centred BatchNorm; 5: up_conv2d_bwd_weight_acc; 4: element-typed (_t) twins + bf16 storage
 
 extern "C" int up_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                  int C, float* scale, float* shift, void* stream) {
@@ -879,8 +896,21 @@ extern "C" int up_bn_finalize(const float* stats, int tiles, int C, float eps, f
     UP_REQUIRE(stats && gamma && beta && mean && invstd && scale && shift && tiles > 0 && C > 0, UP_ERR_INVALID,
                "bn_finalize: bad argument");
     UP_REQUIRE((rm == nullptr) == (rv == nullptr), UP_ERR_INVALID, "bn_finalize: running stats must come in pairs");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, as_stream(stream), stats, tiles, C, eps,
-                       momentum, rm, rv, gamma, beta, mean, invstd, scale, shift, GroupArgs{0, 0});
+    BnFold f;
+    memset(&f, 0, sizeof(f));
+    UP_REQUIRE(bn_fold_scratch(as_stream(stream), tiles, C, 3, &f), UP_ERR_WORKSPACE,
+               "bn_finalize: %d partial rows x %d channels exceed the per-stream merge scratch", tiles, C);
+    f.eps = eps;
+    f.mom = momentum;
+    f.rm = rm;
+    f.rv = rv;
+    f.gamma = gamma;
+    f.beta = beta;
+    f.mean = mean;
+    f.invstd = invstd;
+    f.scale = scale;
+    f.shift = shift;
+    hipLaunchKernelGGL(bn_fold_arrive_kernel<3>, dim3(tiles, cdiv(C, FOLD_COLS)), dim3(256), 0, as_stream(stream), stats, f);
     return check_launch("bn_finalize");
 }
 
@@ -951,13 +981,29 @@ static void launch_bn_bwd(const T* dz, int lddz, const T* z, int ldz, const uint
                           int lddy, T* dres, int lddres, float* dgamma, float* dbeta, float* acc_dgamma, float* acc_dbeta,
                           float* workspace, int64_t rows, int C, hipStream_t st, int prereduced_chunks = 0) {
     // prereduced_chunks > 0: `workspace` already holds that many rows of partial sums [chunk][C][2] — the data-gradient launch
-    // that produced dz reduced them in its epilogue (f32_glds.h BNRED) — so pass 1 is skipped
-    int chunks = prereduced_chunks > 0 ? prereduced_chunks : cdiv(rows, BNB_ROWS);
-    if (prereduced_chunks <= 0)
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(chunks, cdiv(C, 64)), dim3(256), 0, st, dz, lddz, z, ldz, relu_bits,
-                           y, ldy, mean, invstd, relu, workspace, rows, C, BNB_ROWS, GroupArgs{0, 0});
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (const float*)workspace, chunks, C,
-                       dgamma, dbeta, acc_dgamma, acc_dbeta, GroupArgs{0, 0});
+    // that produced dz reduced them in its epilogue (f32_glds.h BNRED) — so pass 1 is skipped;  < 0: dgamma / dbeta are FINAL
+    // (that launch, or the reduce pass below, also carried the merge ticket of bn_fold.h): the apply pass alone.
+    // Pass 2 is the fold's merge tree in every form (one set of bits whoever runs it); only the accumulating variant of the video
+    // unroll (acc_dgamma) keeps bn_bwd_finalize_kernel.
+    if (prereduced_chunks >= 0) {
+        int chunks = prereduced_chunks > 0 ? prereduced_chunks : cdiv(rows, BNB_ROWS);
+        BnFold f;
+        memset(&f, 0, sizeof(f));
+        const bool tree = !acc_dgamma && bn_fold_scratch(st, chunks, C, 2, &f);
+        f.dgamma = dgamma;
+        f.dbeta = dbeta;
+        const bool carried = tree && prereduced_chunks == 0 && bn_fold_enabled();   // the reduce pass takes the tickets itself
+        BnFold none;
+        memset(&none, 0, sizeof(none));
+        if (prereduced_chunks == 0)
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(chunks, cdiv(C, 64)), dim3(256), 0, st, dz, lddz, z, ldz, relu_bits,
+                               y, ldy, mean, invstd, relu, workspace, rows, C, BNB_ROWS, GroupArgs{0, 0}, carried ? f : none);
+        if (tree && !carried)
+            hipLaunchKernelGGL(bn_fold_arrive_kernel<2>, dim3(chunks, cdiv(C, FOLD_COLS)), dim3(256), 0, st, (const float*)workspace, f);
+        else if (!tree)
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, st, (const float*)workspace, chunks, C,
+                               dgamma, dbeta, acc_dgamma, acc_dbeta, GroupArgs{0, 0});
+    }
     int64_t total = rows * (C / 4);
     {
         dim3 grid;
@@ -1042,6 +1088,28 @@ extern "C" int up_bn_bwd_prereduced_t(const void* dz, int lddz, const uint32_t* 
                              use_batch_stats, (float*)dy, lddy, (float*)dres, lddres, dgamma, dbeta, acc_dgamma, acc_dbeta, partial,
                              rows, C, as_stream(stream), chunks);
     return check_launch("bn_bwd_prereduced");
+}
+// BatchNorm backward whose dgamma / dbeta are already FINAL: the data-gradient launch that produced dz carried the reduction AND
+// its merge ticket (up_bn_reduce_slot.dgamma / dbeta / folded, ABI 10); the apply pass alone.
+extern "C" int up_bn_bwd_finalized_t(const void* dz, int lddz, const uint32_t* relu_bits, const void* y, int ldy, const float* gamma,
+                                     const float* mean, const float* invstd, int relu, int use_batch_stats, void* dy, int lddy,
+                                     void* dres, int lddres, const float* dgamma, const float* dbeta, int64_t rows, int C, int dtype,
+                                     void* stream) {
+    UP_REQUIRE(dz && y && gamma && mean && invstd && dy && dgamma && dbeta, UP_ERR_INVALID, "bn_bwd_finalized: null pointer");
+    UP_REQUIRE(!relu || relu_bits, UP_ERR_INVALID, "bn_bwd_finalized: relu needs the sign bits of the forward output");
+    UP_REQUIRE(C % 4 == 0 && lddz % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && (!dres || lddres % 4 == 0), UP_ERR_INVALID,
+               "bn_bwd_finalized: C and strides must be multiples of 4");
+    UP_REQUIRE(rows * (C / 4) < (1ll << 31), UP_ERR_UNSUPPORTED, "bn_bwd_finalized: tensor too large");
+    UP_REQUIRE(dtype == UP_DT_F32 || dtype == UP_DT_BF16, UP_ERR_INVALID, "bn_bwd_finalized: dtype %d", dtype);
+    if (dtype == UP_DT_BF16)
+        launch_bn_bwd<bf16_t>((const bf16_t*)dz, lddz, (const bf16_t*)nullptr, 0, relu_bits, (const bf16_t*)y, ldy, gamma, mean, invstd,
+                              relu, use_batch_stats, (bf16_t*)dy, lddy, (bf16_t*)dres, lddres, const_cast<float*>(dgamma),
+                              const_cast<float*>(dbeta), nullptr, nullptr, nullptr, rows, C, as_stream(stream), -1);
+    else
+        launch_bn_bwd<float>((const float*)dz, lddz, (const float*)nullptr, 0, relu_bits, (const float*)y, ldy, gamma, mean, invstd, relu,
+                             use_batch_stats, (float*)dy, lddy, (float*)dres, lddres, const_cast<float*>(dgamma),
+                             const_cast<float*>(dbeta), nullptr, nullptr, nullptr, rows, C, as_stream(stream), -1);
+    return check_launch("bn_bwd_finalized");
 }
 extern "C" int up_bn_bwd(const float* dz, int lddz, const float* z, int ldz, const uint32_t* relu_bits,
                          const float* y, int ldy,
@@ -1316,9 +1384,12 @@ static bool launch_bn_bwd_groups(const T* dz, int lddz, const uint32_t* relu_bit
     float* gsum = workspace;                                   // [groups][dgamma | dbeta]
     const float* partial = prereduced ? prereduced : workspace + (size_t)groups * 2 * C;       // [groups][chunks][C][2]
     const GroupArgs ga{4 * C, 2 * C};
-    if (!prereduced)
+    if (!prereduced) {
+        BnFold none;
+        memset(&none, 0, sizeof(none));
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(chunks, cdiv(C, 64), groups), dim3(256), 0, st, dz, lddz, (const T*)nullptr, 0,
-                           relu_bits, y, ldy, coef, coef + C, relu, workspace + (size_t)groups * 2 * C, rows, C, BNB_ROWS, ga);
+                           relu_bits, y, ldy, coef, coef + C, relu, workspace + (size_t)groups * 2 * C, rows, C, BNB_ROWS, ga, none);
+    }
     if (groups <= BN_MAXG) {
         hipLaunchKernelGGL(bn_bwd_finalize_allgroups_kernel, dim3(C), dim3(256), 0, st, (const float*)partial, chunks, C, groups, gsum,
                            dgamma, dbeta);

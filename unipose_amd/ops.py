@@ -393,9 +393,11 @@ def packed_dgrad(weight: torch.Tensor, d: _C.ConvDesc) -> torch.Tensor:
 
 
 def conv_fwd_raw(x, weight, cfg, *, scale=None, shift=None, bias=None, residual=None, relu=False, stats=False,
-                 out=None, out_f32=False):
+                 out=None, out_f32=False, fold=None):
     """One launch of the implicit-GEMM kernel.  Returns (y, desc, stats_tensor|None).
-    out_f32: in bf16 storage, write an fp32 output (no effect on fp32 tensors)."""
+    out_f32: in bf16 storage, write an fp32 output (no effect on fp32 tensors).
+    fold (with stats): a _C.BnFold the launch may carry out itself (BatchNorm finalize by its last workgroup, include/unipose_hip.h
+    up_bn_fold); fold.folded tells afterwards whether it did."""
     _dev_ok(x, weight, scale, shift, bias, residual)
     d = make_desc(x, weight, cfg, None if out is None else _nhwc_ok(out))
     out_f32 = out_f32 and x.dtype == torch.bfloat16
@@ -418,6 +420,8 @@ def conv_fwd_raw(x, weight, cfg, *, scale=None, shift=None, bias=None, residual=
         tiles = _C.lib().up_conv_stats_tiles_math(C.byref(d), math)   # the tile rule depends on the arithmetic
         st = torch.empty((tiles, d.K, 3), dtype=torch.float32, device=x.device)
         ep.stats = st.data_ptr()
+        if fold is not None:
+            ep.fold = C.pointer(fold)
     if x.dtype == torch.bfloat16:                                  # bf16 storage: the kernels follow the tensor
         if d.Cp % 32 or (residual is not None and residual.dtype != x.dtype) or \
                 out.dtype != (torch.float32 if out_f32 else x.dtype) or (out_f32 and (residual is not None or stats)):
@@ -475,17 +479,19 @@ class BnSlot:
     moves — the kernels' raw writes never touch it), so the producer's backward uses the sums only if dz has the address AND the
     version the consumer's launch left, else it falls back to its own reduction.  The producer fills y / bits / mean / invstd in
     its forward; the consumer's backward fills partial, dz_ptr and dz_version."""
-    __slots__ = ("y", "bits", "mean", "invstd", "C", "partial", "dz_ptr", "dz_version", "groups", "gstride")
+    __slots__ = ("y", "bits", "mean", "invstd", "C", "partial", "dz_ptr", "dz_version", "groups", "gstride", "dgb")
 
     def __init__(self, y=None, bits=None, mean=None, invstd=None, C=0):
         self.y, self.bits, self.mean, self.invstd, self.C = y, bits, mean, invstd, C
         self.partial, self.dz_ptr, self.dz_version = None, 0, -1
+        # (2, C) dgamma / dbeta when the consumer's launch also carried the merge of its partial rows (up_bn_reduce_slot.folded)
+        self.dgb = None
         # row groups (ops.bn_groups): mean / invstd are the first group's vectors inside coef[groups][4][C], gstride = 4 * C floats
         # to the next group's; the consumer's data gradient is tiled per group and partial is [groups * tiles][C][2]
         self.groups, self.gstride = 1, 0
 
     def clear(self):
-        self.y = self.bits = self.mean = self.invstd = self.partial = None
+        self.y = self.bits = self.mean = self.invstd = self.partial = self.dgb = None
         self.dz_ptr, self.dz_version = 0, -1
         self.groups, self.gstride = 1, 0
 
@@ -494,7 +500,7 @@ class BnSlot:
 
 
 # tests: how often a BatchNorm backward really started from a consumer's sums / a projection's data gradient rode in conv1's launch
-HOST_COUNTERS = {"bn_prereduced": 0, "dx_handed_over": 0}
+HOST_COUNTERS = {"bn_prereduced": 0, "dx_handed_over": 0, "bn_fwd_folded": 0, "bn_bwd_folded": 0}
 BN_FUSE_REDUCE = os.environ.get("UNIPOSE_BN_FUSE_REDUCE", "1") != "0"     # development switches (A/B runs)
 MASKED_ADDEND = os.environ.get("UNIPOSE_MASKED_ADDEND", "1") != "0"
 GROUPED_REDUCE = os.environ.get("UNIPOSE_GROUPED_REDUCE", "1") != "0"     # the fused reduction also inside ops.bn_groups (row groups)
@@ -554,6 +560,10 @@ def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev, add=None, bn_slo
                 bn_slot.invstd.data_ptr()
             sl.partial, sl.ld, sl.C = partial.data_ptr(), _nhwc_ok(bn_slot.y), d.C
             sl.group_stride = bn_slot.gstride if groups > 1 else 0
+            dgb = None
+            if groups == 1 and not _DEFER["on"]:      # the launch also finishes dgamma / dbeta (last-arriver merge, up_bn_reduce_slot)
+                dgb = torch.empty((2, d.C), dtype=torch.float32, device=dev)
+                sl.dgamma, sl.dbeta = dgb[0].data_ptr(), dgb[1].data_ptr()
             ep.bn = C.pointer(sl)
             ep.groups = groups
         if ex_math == MATH_BF16S:
@@ -566,6 +576,7 @@ def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev, add=None, bn_slo
                                                 _stream(dy)), "conv2d_bwd_data_ex")
         if want_slot:
             bn_slot.partial, bn_slot.dz_ptr, bn_slot.dz_version = partial, dx.data_ptr(), dx._version
+            bn_slot.dgb = dgb if (dgb is not None and sl.folded) else None
         return dx
     if dy.dtype == torch.bfloat16:
         if d.Kp % 32 or (add is not None and add.dtype != dy.dtype):
@@ -898,7 +909,17 @@ class ConvBnAct(Function):
         elif train:
             small = x.shape[0] * ((x.shape[1] + 2 * cfg.pad - cfg.dil * (weight.shape[2] - 1) - 1) // cfg.stride + 1) * \
                 ((x.shape[2] + 2 * cfg.pad - cfg.dil * (weight.shape[3] - 1) - 1) // cfg.stride + 1) <= EXACT_STATS_ROWS
-            y, d, st = conv_fwd_raw(x, weight, cfg, stats=not small)
+            coef = torch.empty((4, k), dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
+            # the convolution's last workgroup per channel column merges the partials and writes coef + the running statistics
+            # itself (up_bn_fold); `folded` = 0 (fold switched off, scratch exhausted): the stand-alone merge below, same bits
+            fold = None
+            if not small:
+                fold = _C.BnFold()
+                fold.eps, fold.momentum, fold.running_mean, fold.running_var = eps, momentum, _ptr(rm), _ptr(rv)
+                fold.gamma, fold.beta = gamma.data_ptr(), beta.data_ptr()
+                base, step = coef.data_ptr(), 4 * k
+                fold.mean, fold.invstd, fold.scale, fold.shift = base, base + step, base + 2 * step, base + 3 * step
+            y, d, st = conv_fwd_raw(x, weight, cfg, stats=not small, fold=fold)
             rows = d.N * d.P * d.Q
             if rows <= 1:
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size "
@@ -907,10 +928,12 @@ class ConvBnAct(Function):
                 assert rows <= EXACT_STATS_ROWS
                 st = torch.empty((1, k, 3), dtype=torch.float32, device=dev)
                 _C.check(L.up_bn_exact_stats_t(y.data_ptr(), d.ldy, rows, k, 1, _dt(y), st.data_ptr(), _stream(x)), "bn_exact_stats")
-            coef = torch.empty((4, k), dtype=torch.float32, device=dev)   # mean, invstd, scale, shift
-            _C.check(L.up_bn_finalize(st.data_ptr(), st.shape[0], k, eps, momentum, _ptr(rm), _ptr(rv),
-                                      gamma.data_ptr(), beta.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
-                                      coef[2].data_ptr(), coef[3].data_ptr(), _stream(x)), "bn_finalize")
+            if fold is not None and fold.folded:
+                HOST_COUNTERS["bn_fwd_folded"] += 1
+            else:
+                _C.check(L.up_bn_finalize(st.data_ptr(), st.shape[0], k, eps, momentum, _ptr(rm), _ptr(rv),
+                                          gamma.data_ptr(), beta.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                                          coef[2].data_ptr(), coef[3].data_ptr(), _stream(x)), "bn_finalize")
         else:
             y, d, _ = conv_fwd_raw(x, weight, cfg)
             rows = d.N * d.P * d.Q
@@ -1031,6 +1054,15 @@ class ConvBnAct(Function):
             # the data-gradient launch that wrote dz already reduced this layer's sums (BnSlot): finalize + apply
             partial, so.partial, so.dz_ptr, so.dz_version = so.partial, None, 0, -1
             HOST_COUNTERS["bn_prereduced"] += 1
+            done, so.dgb = so.dgb, None
+            if done is not None and acc is None:      # ... and merged them: dgamma / dbeta are final, the apply pass alone
+                HOST_COUNTERS["bn_bwd_folded"] += 1
+                dgb = done
+                _C.check(L.up_bn_bwd_finalized_t(dz.data_ptr(), d.ldy, _ptr(bits), y.data_ptr(), d.ldy, gamma.data_ptr(),
+                                                 coef[0].data_ptr(), coef[1].data_ptr(), int(ctx.relu), int(ctx.train), dy.data_ptr(),
+                                                 d.ldy, _ptr(dres), d.ldy, dgb[0].data_ptr(), dgb[1].data_ptr(), rows, k, _dt(y),
+                                                 _stream(x)), "bn_bwd_finalized")
+                return ConvBnAct._finish_backward(ctx, x, weight, d, dy, dres, dgb, hand_over, (dz, bits) if masked else None)
             _C.check(L.up_bn_bwd_prereduced_t(dz.data_ptr(), d.ldy, _ptr(bits), y.data_ptr(), d.ldy, gamma.data_ptr(),
                                               coef[0].data_ptr(), coef[1].data_ptr(), int(ctx.relu), int(ctx.train), dy.data_ptr(),
                                               d.ldy, _ptr(dres), d.ldy, dgb[0].data_ptr(), dgb[1].data_ptr(),
