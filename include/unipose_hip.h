@@ -459,7 +459,7 @@ int up_box_argmax(const float* maps, int C, int H, int W, const int32_t* boxes, 
  * caller-provided workspace of up_unipose_plan_workspace() bytes (256-byte aligned), reused between calls.
  *   up_unipose_plan_create(&cfg, &plan);
  *   for i in [0, up_unipose_plan_num_convs): set_conv(plan, i, folded weight of <name>.weight, <name>.bias or NULL, stream)
- *   up_unipose_forward(plan, input NCHW (batch, 3, H, W), heat-maps NCHW (batch, out_channels, H/8, W/8), workspace, bytes, stream)
+ *   up_unipose_forward(plan, input NCHW (batch, 3, H, W), heat-maps NCHW (batch, out_channels, ceil(H/8), ceil(W/8)), workspace, bytes, stream)
  * Convolution names are the reference's state_dict prefixes ("backbone.layer3.11.conv2", "wasp.aspp2.atrous_conv",
  * "decoder.last_conv.8"); a parameter that is applied twice (wasp.conv2, wasp.py:72-80) appears twice, setting it once suffices.
  * Launches and descriptors are those of the drop-in module's folded inference forward: equal bits.  Training has no

@@ -46,5 +46,15 @@ def plan_case(dev, K=14, B=1, size=64, wseed=1, xseed=5, output_stride=16, bbox=
         raise AssertionError("a mis-shaped input must be refused")
     except ValueError:
         pass
+    oh = (size - 1) // 8 + 1
+    for bad in (torch.empty((B, first.shape[1], oh - 1, oh), device=dev), torch.empty((B, first.shape[1], oh, oh), device=dev).double(),
+                torch.empty((B, first.shape[1], oh, 2 * oh), device=dev)[..., ::2]):
+        try:                            # a caller-supplied `out` of the wrong shape / dtype / layout was written past its end
+            plan(x, out=bad)
+            raise AssertionError("a mis-shaped / mis-typed / strided `out` must be refused")
+        except ValueError:
+            pass
+    own = torch.empty((B, first.shape[1], oh, oh), device=dev)
+    assert plan(x, out=own) is own or bbox
     plan.close()
     return first

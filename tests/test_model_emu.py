@@ -89,3 +89,11 @@ def test_bn_finalize_folded_whole_step(emu_backend):
     print("folded finalize launches per step: forward", fwd, "backward", bwd)
     # 64x64 inputs, B = 3: the stem, layer1 and layer2.0 see more than 256 rows per channel (the rest: float64 statistics, no fold)
     assert fwd >= 12 and bwd >= 60, (fwd, bwd)
+
+
+def test_lstm_any_num_classes(emu_backend):
+    """the reference's video model accepts any num_classes (model/uniposeLSTM.py:68-91); K + 1 a multiple of 4 (15, 19,
+    23 ...) leaves no spare pad channel for the centre map, so the hand-over tensor grows to the next multiple of 4."""
+    mc.lstm_case(emu_backend, K=15, size=32, T=2, B=1)
+    mc.lstm_case(emu_backend, K=15, size=32, T=3, B=2, train=True, deferred=True, batch_frames=True)
+    mc.lstm_case(emu_backend, K=19, size=32, T=2, B=1, batch_frames=True)

@@ -287,3 +287,8 @@ def test_eval_golden_bf16_operand_modes(golden_dir, math, tol):
     assert e < tol, e
     if math == "bf16x3":
         assert agree == 1.0
+
+
+def test_lstm_any_num_classes_gpu():
+    mc.lstm_case(DEV, K=15, size=64, T=2, B=2)
+    mc.lstm_case(DEV, K=15, size=64, T=3, B=2, train=True, deferred=True, batch_frames=True)

@@ -6,6 +6,12 @@ def test_plan_forward_equals_folded_module_emu(emu_backend):
     pc.plan_case(emu_backend, K=14, B=1, size=64)
 
 
+def test_plan_forward_size_not_a_multiple_of_8_emu(emu_backend):
+    """52 x 52 gives ceil(52 / 8) = 7 x 7 heat-maps; the plan used to allocate 6 x 6 and write past the end"""
+    out = pc.plan_case(emu_backend, K=14, B=1, size=52)
+    assert out.shape[-2:] == (7, 7)
+
+
 def test_plan_forward_output_stride_8_and_box_head_emu(emu_backend):
     pc.plan_case(emu_backend, K=16, B=2, size=48, output_stride=8, bbox=True)
 

@@ -282,7 +282,10 @@ class LSTM(nn.Module):
             setattr(self, f"conv_{n}h_lstm", nn.Conv2d(planes, planes, kernel_size, padding=padding))
         self.inplanes, self.planes, self.pad = inplanes, planes, padding
 
-    def forward(self, z, prev_hide, prev_cell):
+    def stacked(self):
+        """(weight, bias) of the ONE gate convolution over cat(x, h): the eight weights stacked along both channel axes (the x
+        part padded to the physical width of z), the x- and h-path biases summed.  Built with torch ops, so gradients flow back to
+        the sixteen parameters through autograd."""
         order = "giof"
         padx = ops.rup4(self.inplanes) - self.inplanes
         padh = ops.rup4(self.planes) - self.planes
@@ -291,6 +294,13 @@ class LSTM(nn.Module):
         w = torch.cat([nn.functional.pad(wx, (0, 0, 0, 0, 0, padx)), nn.functional.pad(wh, (0, 0, 0, 0, 0, padh))], 1)
         b = torch.cat([getattr(self, f"conv_{n}x_lstm").bias + getattr(self, f"conv_{n}h_lstm").bias
                        for n in order], 0)
+        return w, b
+
+    def forward(self, z, prev_hide, prev_cell, stacked=None):
+        """stacked: the result of an earlier ``self.stacked()`` in the SAME autograd graph (the frames of one clip unroll share it:
+        one cat / pad chain and ONE gradient split per clip instead of one per frame — 4 cat + 2 pad + 16 gradient adds per
+        frame in the five-frame step of uniposeLSTM.py:116-133)."""
+        w, b = stacked if stacked is not None else self.stacked()
         zh = ops.ConcatC.apply(0, z, prev_hide)
         gates = ops.ConvBias.apply(zh, w, b, ops.ConvCfg(1, self.pad, 1), False)
         return ops.LSTMGates.apply(gates, prev_cell, self.planes)

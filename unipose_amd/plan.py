@@ -35,6 +35,8 @@ class UniPosePlan:
             raise ValueError("UniPosePlan captures the inference forward: call model.eval() first")
         if getattr(model, "stride", 8) != 8:
             raise NotImplementedError("UniPosePlan: stride != 8 (the extra 8x up-sampling of model/unipose.py:31-32) is not planned")
+        if batch < 1 or height < 8 or width < 8:
+            raise ValueError(f"UniPosePlan: batch {batch}, {height} x {width} input")
         w0 = model.backbone.conv1.weight
         if not w0.is_cuda and not _C._ALLOW_HOST_POINTERS:
             raise _C.UniPoseHipError("UniPosePlan needs a CUDA(HIP) model; there is no CPU fallback")
@@ -48,6 +50,9 @@ class UniPosePlan:
         L = _C.lib()
         _C.check(L.up_unipose_plan_create(C.byref(self.cfg), C.byref(self._plan)), "unipose_plan_create")
         self.batch, self.height, self.width, self.out_channels = batch, height, width, out_channels
+        # heat-map size: three ceil-halvings (7x7 stride-2 stem, 3x3 stride-2 max-pool, layer2's stride 2), the arithmetic of
+        # plan.hip's build(): ceil(H / 8), NOT H // 8 — the two differ whenever H % 8 != 0 (a 52 x 52 input gives 7 x 7 maps)
+        self.out_height, self.out_width = (height - 1) // 8 + 1, (width - 1) // 8 + 1
         self.workspace = torch.empty(max(L.up_unipose_plan_workspace(self._plan), 256) + 256, dtype=torch.uint8, device=self.device)
         self.refresh(model)
 
@@ -84,9 +89,12 @@ class UniPosePlan:
             raise ValueError(f"UniPosePlan: input {tuple(x.shape)} {x.dtype} on {x.device}, planned for "
                              f"{(self.batch, 3, self.height, self.width)} float32 on {self.device}")
         x = x.contiguous()
+        shape = (self.batch, self.out_channels, self.out_height, self.out_width)
         if out is None:
-            out = torch.empty((self.batch, self.out_channels, self.height // 8, self.width // 8), dtype=torch.float32,
-                              device=self.device)
+            out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        elif tuple(out.shape) != shape or out.dtype != torch.float32 or out.device != self.device or not out.is_contiguous():
+            raise ValueError(f"UniPosePlan: `out` is {tuple(out.shape)} {out.dtype} on {out.device} (contiguous: {out.is_contiguous()}), "
+                             f"the plan writes a contiguous float32 {shape} on {self.device}")
         ws = self.workspace
         off = (-ws.data_ptr()) % 256
         _C.check(_C.lib().up_unipose_forward(self._plan, x.data_ptr(), out.data_ptr(), ws.data_ptr() + off, ws.numel() - off,

@@ -17,12 +17,20 @@ class _AddCenter(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, heat_nhwc, center_nchw, k):
-        z = heat_nhwc.clone()
+        n, h, w, cp = heat_nhwc.shape
+        if k < cp:
+            z = heat_nhwc.clone()
+        else:       # (k + 1) % 4 == 0 — K = 15, 19, 23 ...: no spare pad channel, the hand-over tensor grows to the next multiple of 4
+            z = torch.zeros((n, h, w, ops.rup4(k + 1)), dtype=heat_nhwc.dtype, device=heat_nhwc.device)
+            ops._copy2d(heat_nhwc, ops._nhwc_ok(heat_nhwc), 0, z, z.shape[3], 0, n * h * w, cp)
+        ctx.cp = cp
         ops.avgpool9s8_into(center_nchw, z, k)
         return z
 
     @staticmethod
     def backward(ctx, dz):
+        if dz.shape[3] != ctx.cp:          # the widened hand-over: the trunk's own channels
+            dz = dz[..., :ctx.cp].contiguous()
         return dz, None, None     # channels >= k are ignored upstream (the producer masks them)
 
 
@@ -36,8 +44,6 @@ class unipose(nn.Module):
         self.wasp = build_wasp(backbone, output_stride, self.BatchNorm, video=True)
         self.decoder = build_decoder("Penn_Action", num_classes, backbone, self.BatchNorm)
         c = num_classes + 2                     # joints + background + centre map (15 for Penn Action)
-        if (num_classes + 1) % 4 == 0:
-            raise NotImplementedError("num_classes+1 must leave a pad channel for the centre map")
         self.lstm_0 = LSTM_0(c, c, 3, 1)
         self.lstm = LSTM(c, c, 3, 1)
         self.conv1 = nn.Conv2d(c, 128, kernel_size=11, padding=5)
@@ -54,6 +60,7 @@ class unipose(nn.Module):
         # for T frames and see T running-statistics updates.  unipose_amd.trainer.VideoTrainer and bench.py switch it on.
         self.batch_frames = False
         self._frames = None
+        self._stacked = None        # the ConvLSTM cell's stacked gate weights of the running clip unroll, see modules.LSTM.forward
         if freeze_bn:
             self.freeze_bn()
 
@@ -91,6 +98,7 @@ class unipose(nn.Module):
 
     def train(self, mode: bool = True):
         self._frames = None          # a clip that was not served to its last frame must not outlive a mode switch
+        self._stacked = None
         return super().train(mode)
 
     def _state(self, t, like, b):
@@ -110,9 +118,18 @@ class unipose(nn.Module):
             x = x[..., :cpad]           #  one spare pad channel takes the centre map and whose width the stacked gate weights assume)
         z = _AddCenter.apply(x, centermap[:, iter], self.num_classes + 1)
         if iter == 0:
+            self._stacked = None
             cell, hide = self.lstm_0(z)
         else:
-            cell, hide = self.lstm(z, self._state(previousHide, x, b), self._state(previousCell, x, b))
+            # frames 1 .. T-1 of one unroll share ONE stacked gate weight (same autograd graph: rebuilt at iter == 1 and whenever
+            # the grad mode or a weight version changed in between)
+            key = (torch.is_grad_enabled(), self.training, ops.OPTIMIZER_STEPS, self.lstm.conv_gx_lstm.weight._version,
+                   self.lstm.conv_fh_lstm.weight._version)
+            if iter == 1 or self._stacked is None or self._stacked[0] != key:
+                self._stacked = (key, self.lstm.stacked())
+            cell, hide = self.lstm(z, self._state(previousHide, x, b), self._state(previousCell, x, b), stacked=self._stacked[1])
+            if iter == input.shape[1] - 1:
+                self._stacked = None                                # the clip is served
         h = hide
         for conv in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5):
             h = ops.conv_bias_act(h, conv, relu=True)
