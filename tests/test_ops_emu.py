@@ -415,3 +415,24 @@ def test_bn_finalize_folded_bf16_storage(emu_backend):
         print(oc.bn_fold_case(emu_backend, n=2, c=32, h=30, w=33, k1=64, k2=96, dtype=torch.bfloat16))
     finally:
         ops.set_conv_math("f32")
+
+
+def test_debug_pack_mode_catches_a_weight_edited_behind_the_cache(emu_backend):
+    """UNIPOSE_DEBUG_PACK: a weight changed through .data (no version bump, no optimizer hook) makes the next convolution raise
+    instead of running on the stale packed image; ops.invalidate_packed_weights() is the cure."""
+    from unipose_amd import _C, ops
+    w = torch.nn.Parameter(torch.randn(32, 32, 3, 3) * 0.05)
+    x = torch.randn(1, 6, 6, 32)
+    cfg = ops.ConvCfg(1, 1, 1)
+    prev = ops.DEBUG_PACK
+    ops.DEBUG_PACK = True
+    try:
+        y0 = ops.conv_fwd_raw(x, w, cfg)[0].clone()
+        assert torch.equal(ops.conv_fwd_raw(x, w, cfg)[0], y0)                 # an untouched weight passes the check
+        w.data.mul_(2.0)                                                     # behind the cache's back
+        with pytest.raises(_C.UniPoseHipError, match="stale packed weight image"):
+            ops.conv_fwd_raw(x, w, cfg)
+        ops.invalidate_packed_weights()
+        assert torch.allclose(ops.conv_fwd_raw(x, w, cfg)[0], 2.0 * y0, rtol=1e-6, atol=1e-6)
+    finally:
+        ops.DEBUG_PACK = prev

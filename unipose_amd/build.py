@@ -28,12 +28,23 @@ def source_hash() -> str:
     return h.hexdigest()
 
 
+def binary_hash() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    with open(OUT, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    return h.hexdigest()
+
+
 def library_is_current() -> bool:
-    """True when libunipose_hip.so exists and its stamp names exactly the sources of this tree (not a time-stamp comparison:
-    a shipped binary must be provably the tree's)."""
+    """True when libunipose_hip.so exists, its stamp names exactly the sources of this tree AND the sha256 of the binary the
+    build wrote (a stamp that only names sources is a statement about a text file — a library swapped in afterwards,
+    e.g. by tools/gpu/ab.sh, kept passing).  Not a time-stamp comparison: a shipped binary must be provably the tree's."""
     try:
         with open(STAMP) as f:
-            return os.path.exists(OUT) and f.read().strip() == source_hash()
+            words = f.read().split()
+        return os.path.exists(OUT) and len(words) == 2 and words[0] == source_hash() and words[1] == binary_hash()
     except OSError:
         return False
 
@@ -56,7 +67,7 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         os.remove(STAMP)
     subprocess.check_call(cmd)
     with open(STAMP, "w") as f:
-        f.write(source_hash() + "\n")
+        f.write(source_hash() + " " + binary_hash() + "\n")
     return OUT
 
 

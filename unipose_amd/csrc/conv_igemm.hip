@@ -2421,6 +2421,12 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
         g_group_refused = true;   // only f32_glds.h's LDS-transposed epilogue knows row groups
         return;
     }
+    if ((a.bn_partial || a.res_bits) && !(use32 && glds32_epi1_ok(a) && !(wide && a.bn_partial))) {
+        // nothing is launched — and nothing is recorded by the profiler (the refusal used to sit behind the ProfScope):
+        // dx without the masked addend must never be written
+        g_extras_dropped = true;
+        return;
+    }
     a.no_tap_skip = g_tap_skip ? 0 : 1;
     ProfScope prof(use32 ? 28 + vbase / 2 : vbase + (aligned ? 0 : 1), 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st,
                    a.M, a.Ng, a.Ktot, a.nwg, g_prof_on_host() && fast ? live_tap_share(a) : 1.0);
@@ -2476,10 +2482,6 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
             a.flags = sc->flags;
             grid = a.full_blocks + (a.nwg - a.full_blocks) * p;
         }
-    }
-    if ((a.bn_partial || a.res_bits) && !(use32 && glds32_epi1_ok(a) && !(wide && a.bn_partial))) {
-        g_extras_dropped = true;   // nothing is launched: dx without the masked addend must never be written
-        return;
     }
     if (use32) {
         kernel = wide ? glds32_wide_kernel<BM, BN>(a) : glds32_kernel<BM, BN>(a);

@@ -168,10 +168,10 @@ class GradAllReducer:
         if dist.is_initialized() and self.world > 1:
             index = {id(p): i for i, p in enumerate(self.params)}
             known = [index.get(id(p), -1) for p in order]           # (-1: a hooked tensor that is not one of self.params)
-            dev = order[0].device
+            dev = self.params[0].device              # (not order[0]: a rank whose hooks never fired has an empty order)
             # the verdict is taken COLLECTIVELY before the order is broadcast: a rank that raised on its own would leave the
             # others waiting in the second broadcast — min / max of the count over the ranks, then everyone agrees
-            cnt = len(known) if min(known, default=0) >= 0 else -1
+            cnt = len(known) if known and min(known) >= 0 else -1      # (an empty order counts as a disagreement, collectively)
             lo, hi = (torch.tensor([cnt], dtype=torch.int64, device=dev) for _ in range(2))
             dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)

@@ -124,9 +124,22 @@ ASYNC_REPACK = os.environ.get("UNIPOSE_ASYNC_REPACK", "1") != "0"
 _REPACK_HEAD = 12
 
 
+def _settle_repack(ps, dev=None):
+    """An earlier split re-pack may still be writing images / reading a job table on the side stream: make the current stream
+    wait for it BEFORE any of those buffers is dropped, replaced or re-written (the caching allocator could otherwise hand a
+    freed block to a main-stream allocation while the side stream still uses it)."""
+    if ps.pending is not None:
+        ev = ps.pending[0]
+        ps.pending = None
+        if dev is None or dev.type == "cuda":
+            torch.cuda.current_stream(dev).wait_event(ev)
+
+
 def _launch_repack(ps, weight, entry_point, what, job_bytes):
     """`ps`: a _PackSet / _Pack16Set whose job table is current; launches the batched re-pack of its STALE jobs — all of them
     after a step of the one optimizer of a process, a sub-table (cached per stale set) when a second model keeps its images."""
+    dev = weight.device
+    _settle_repack(ps, dev)          # first: the sub-table below may replace one an in-flight launch still reads
     stale = [k for k in ps.order if ps.entries[k][1] != ps.entries[k][0]()._version]
     if len(stale) == len(ps.order):
         table, keys = ps.table, ps.order
@@ -143,10 +156,6 @@ def _launch_repack(ps, weight, entry_point, what, job_bytes):
     if n == 0:
         return
     L = _C.lib()
-    dev = weight.device
-    if ps.pending is not None and dev.type == "cuda":      # an earlier split launch nobody waited for yet: order behind it
-        torch.cuda.current_stream(dev).wait_event(ps.pending[0])
-    ps.pending = None
     if ASYNC_REPACK and dev.type == "cuda" and n > 2 * _REPACK_HEAD and not torch.cuda.is_current_stream_capturing():
         main, side = torch.cuda.current_stream(dev), _side_stream(dev)
         _C.check(getattr(L, entry_point)(table.data_ptr(), _REPACK_HEAD, main.cuda_stream), what)
@@ -154,16 +163,20 @@ def _launch_repack(ps, weight, entry_point, what, job_bytes):
         _C.check(getattr(L, entry_point)(table.data_ptr() + _REPACK_HEAD * job_bytes, n - _REPACK_HEAD, side.cuda_stream), what)
         ev = torch.cuda.Event()
         ev.record(side)
-        ps.pending = (ev, set(keys[_REPACK_HEAD:]))
+        ps.pending = (ev, set(keys[_REPACK_HEAD:]), set())
     else:
         _C.check(getattr(L, entry_point)(table.data_ptr(), n, _stream(weight)), what)
 
 
 def _await_repack(ps, key, dev):
     """the current stream is about to read the images of parameter `key`"""
+    # (the event stays pending after a reader waited — a reader on ANOTHER stream must wait too, ADVICE r5 — but every stream
+    #  waits only once; _settle_repack retires it)
     if ps.pending is not None and key in ps.pending[1]:
-        torch.cuda.current_stream(dev).wait_event(ps.pending[0])
-        ps.pending = None
+        st = torch.cuda.current_stream(dev)
+        if st.cuda_stream not in ps.pending[2]:
+            st.wait_event(ps.pending[0])
+            ps.pending[2].add(st.cuda_stream)
 
 
 class _PackSet:
@@ -192,6 +205,7 @@ class _PackSet:
                 self.repack(weight)
             _await_repack(self, key, weight.device)
             return e[2], e[3]
+        _settle_repack(self, weight.device)     # an entry / the table is about to be replaced
         wf = torch.empty(nf, dtype=torch.float32, device=weight.device)
         wd = torch.empty(nd, dtype=torch.float32, device=weight.device)
         _C.check(_C.lib().up_pack_weights(C.byref(d), _dense(weight).data_ptr(), wf.data_ptr(), wd.data_ptr(),
@@ -302,6 +316,7 @@ class _Pack16Set:
                 self.repack(weight)
             _await_repack(self, key, weight.device)
             return e[2], e[3]
+        _settle_repack(self, weight.device)     # an entry / the table is about to be replaced
         wf = torch.empty((2, nf), dtype=torch.int16, device=weight.device)
         wd = torch.empty((2, nd), dtype=torch.int16, device=weight.device)
         _C.check(_C.lib().up_pack_weights_bf16(C.byref(d), _dense(weight).data_ptr(), wf[0].data_ptr(), wf[1].data_ptr(),
@@ -384,8 +399,27 @@ except ImportError:     # (older torch: the version counter alone, i.e. no fused
     _STEP_HOOK = None
 
 
+# UNIPOSE_DEBUG_PACK=1: every use of a cached packed image first re-packs the weight into a scratch image and compares — a weight
+# edited behind the cache's back (`.data`, a raw pointer, an optimizer that neither moves version counters nor reports its step)
+# raises at the first convolution that reads the stale image instead of silently training on old weights (the round-2..4 bug the
+# G16 trajectory golden found).  One extra pack launch and a device-to-host comparison per convolution: a debugging mode.
+DEBUG_PACK = os.environ.get("UNIPOSE_DEBUG_PACK", "0") != "0"
+
+
+def _check_packed(weight, d, wf):
+    ref = torch.empty_like(wf)
+    _C.check(_C.lib().up_pack_weights(C.byref(d), _dense(weight).data_ptr(), ref.data_ptr(), None, _stream(weight)), "pack_weights")
+    if not torch.equal(ref, wf):
+        raise _C.UniPoseHipError(
+            f"stale packed weight image for a {tuple(weight.shape)} convolution weight: the parameter changed without the cache "
+            "noticing (edited through .data / a raw pointer?) — call ops.invalidate_packed_weights() after such edits")
+
+
 def packed_fwd(weight: torch.Tensor, d: _C.ConvDesc) -> torch.Tensor:
-    return _packed(weight, d)[0]
+    wf = _packed(weight, d)[0]
+    if DEBUG_PACK:
+        _check_packed(weight, d, wf)
+    return wf
 
 
 def packed_dgrad(weight: torch.Tensor, d: _C.ConvDesc) -> torch.Tensor:
@@ -996,8 +1030,10 @@ class ConvBnAct(Function):
         so = ctx.slot_out
         if so is None or not so.matches(dz, y):
             return False
+        # a dead weak reference says nothing about hooks: one registered on z stays on its grad_fn after the Python tensor is gone
+        # (`z.register_hook(h); loss = z.sum(); del z`), so an unknown z takes the separate reduction
         z = ctx.z_ref() if ctx.z_ref is not None else None
-        return z is None or not getattr(z, "_backward_hooks", None)
+        return z is not None and not getattr(z, "_backward_hooks", None)
 
     @staticmethod
     @once_differentiable
