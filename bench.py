@@ -213,7 +213,7 @@ def wasp_dilated_leg(dev, batch=32, hw=23, iters=20, bf16=False, dilations=(6, 1
 HBM_PEAK_TBPS = 8.0
 
 
-def make_workload(dev, lstm, K, B, S, T, seed, emu=False, init=None):
+def make_workload(dev, lstm, K, B, S, T, seed, emu=False, init=None, graph=False):
     """Model + resident synthetic batch + the train step of the reference's loops (unipose.py:100-131 /
     uniposeLSTM.py:116-133).  Returns (model, optimizer, step(reducer=None)).
     init (tests: the G16 trajectory fixture drives THIS step function): {"state_dict", "x", "t"} replace the random
@@ -241,7 +241,19 @@ def make_workload(dev, lstm, K, B, S, T, seed, emu=False, init=None):
                 for d in (model.wasp.dropout, model.decoder.last_conv[3], model.decoder.last_conv[7]):
                     d.p = 0.0
     # unipose.py:72 (no weight decay); `fused=True` is torch's own single-kernel implementation of the same update
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=not emu)  # 70.3 vs 71.7 ms/step with the foreach default
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=not emu,  # 70.3 vs 71.7 ms/step with the foreach default
+                           **({"capturable": True} if graph else {}))
+    if graph:       # the whole step as ONE hipGraph (unipose_amd.graph.GraphedTrainStep): same launches, no per-layer host work
+        if lstm or emu:
+            raise ValueError("--graph: the image model on a GPU")
+        from unipose_amd.graph import GraphedTrainStep
+        gstep = GraphedTrainStep(model, opt, x, t)
+
+        def graphed(reducer=None):
+            if reducer is not None:
+                raise ValueError("--graph does not capture the data-parallel exchange")
+            return gstep()
+        return model, opt, graphed
 
     def step(reducer=None):
         opt.zero_grad(set_to_none=True)
@@ -415,6 +427,8 @@ def main():
                          "all-reduce after it; the default for --math bf16s, whose step (< 40 ms) is short enough for the flat "
                          "190 MB exchange to show (--no-overlap switches it off)")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole training step as ONE hipGraph (unipose_amd.graph.GraphedTrainStep; image model, one GPU)")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the extra split-bf16 timing loop")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the BASELINE configs[3] (LSTM) and configs[4] (736x736 bf16) legs appended at N=1")
@@ -496,7 +510,10 @@ def main():
             K = 13                                             # Penn Action joints (configs[3])
         if args.batch == 32:
             B = 8
-    model, opt, step1 = make_workload(dev, lstm, K, B, S, T, seed=shard_seed(0, rank), emu=emu)
+    if args.graph:          # the capture fixes the arithmetic: set it first; per-launch events cannot ride in a replay
+        ops.set_conv_math(args.math)
+        args.no_profile = True
+    model, opt, step1 = make_workload(dev, lstm, K, B, S, T, seed=shard_seed(0, rank), emu=emu, graph=args.graph)
     ops.manual_seed(shard_seed(0, rank))
     ops.set_conv_math(args.math)
     # default: ONE flat all-reduce after backward (190 MB: ~1-2 ms on xGMI against a 66 ms fp32 step); --overlap: 32 MB
@@ -715,6 +732,8 @@ def main():
                                          * (S / 368.0) ** 2 / 1e12, 2),
             "loss": loss_val,
         }
+        if args.graph:
+            out["config"]["step_launch"] = "one hipGraph replay per step (unipose_amd.graph.GraphedTrainStep, capturable fused Adam)"
         if settle["steps"]:
             out["settle"] = settle
         if emu:

@@ -119,6 +119,13 @@ int up_conv_split_parts(const up_conv_desc* d);
 /* Frees the per-stream scratch of a stream the caller retires (no launch or captured graph of that stream may run afterwards);
  * a stream that never ran a split launch has none: no-op. */
 int up_stream_release(void* stream);
+/* ABI 10, experiment support: a HIP stream whose kernels run only on the compute units named by `mask` (bit i of `words` 32-bit
+ * words = logical CU i; hipExtStreamCreateWithCUMask) — the weight-gradient side stream on a fixed share of the chip
+ * (UNIPOSE_SIDE_CUS, profiles/r06_experiments.txt) — and a probe that reports where the workgroups of a stream run:
+ * out[blocks][2] = (XCC id, CU | SH << 4 | SE << 5 of HW_ID), device memory. */
+int up_stream_create_cu_mask(const uint32_t* mask, int words, void** stream);
+int up_stream_destroy(void* stream);
+int up_probe_placement(int blocks, int* out_device, void* stream);
 /* Development knobs (A/B runs inside one process; each also has an environment variable read at load time).  Twelve keys
  * (round 4 removed the ones whose question is settled: short_k, short_k_mult, db_min_k, wgrad_per_cu, tap_skip, lds_swz and
  * the bf16 forms that lost in round 3):
@@ -391,6 +398,11 @@ int up_gap_fwd_t(const void* x, int ldx, void* y, int N, int HW, int C, int dtyp
 int up_gap_bwd_t(const void* dy, void* dx, int lddx, int N, int HW, int C, int dtype, void* stream);
 int up_dropout_fwd_t(const void* x, void* y, uint8_t* mask, const float* ext_mask, int64_t n, float p, uint64_t seed,
                      int dtype, void* stream);
+/* ABI 10: ... with a step counter in DEVICE memory mixed into the seed (seed + *step_device * 0x9E3779B97F4A7C15): a captured
+ * training step (hipGraph, unipose_amd.graph.GraphedTrainStep) replays the launch with unchanged arguments, its masks still
+ * differ from step to step.  step_device = NULL: up_dropout_fwd_t. */
+int up_dropout_fwd_step_t(const void* x, void* y, uint8_t* mask, const float* ext_mask, int64_t n, float p, uint64_t seed,
+                          const uint64_t* step_device, int dtype, void* stream);
 int up_dropout_bwd_t(const void* dy, const uint8_t* mask, void* dx, int64_t n, float p, int dtype, void* stream);
 /* nn.MSELoss() mean reduction (unipose.py:70,117): loss[0] = mean((y-t)^2); bwd: dy = 2(y-t)/n * dloss[0] */
 int up_mse_fwd(const float* y, const float* t, float* loss, float* workspace, int64_t n, void* stream);

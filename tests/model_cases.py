@@ -531,7 +531,7 @@ def tapped_block_output_case(dev, planes=32, B=2, size=12, tol=2e-5):
     return worst
 
 
-def hooked_block_output_case(dev, planes=32, B=2, size=12, tol=2e-5):
+def hooked_block_output_case(dev, planes=32, B=2, size=12, tol=2e-5, drop_tensor=False):
     """a tensor hook on the tensor between two identity Bottlenecks that edits the gradient IN PLACE through .data
     (`g.data.mul_(2)`, a clipping hook) changes dz without moving its version counter or its address — BnSlot.matches cannot see
     it, so a hooked output must take the separate reduction.  Gradients with the fused reduction on equal those with it off

@@ -133,3 +133,80 @@ def test_two_live_graphs_on_one_stream_handle_share_the_scratch():
     for _ in range(3):
         assert torch.equal(first(x), ref)
     first.close()
+
+
+@pytest.mark.parametrize("math", ["f32", "bf16s"])
+def test_graphed_train_step_equals_eager_steps(math):
+    """unipose_amd.graph.GraphedTrainStep (the whole-graph TRAINING entry): the step captured as one hipGraph — both
+    streams, the weight re-pack, the BatchNorm fold tickets, capturable fused Adam — against the same steps issued eagerly:
+    loss, gradients, weights, running statistics and Adam state after 3 + 2 steps agree bit for bit (B = 4, 128x128, dropouts 0;
+    the one float-atomic quantity, the last convolution's bias gradient, to round-off)."""
+    import copy
+    from model.unipose import unipose
+    from unipose_amd import ops
+    from unipose_amd.graph import GraphedTrainStep
+    dev = torch.device("cuda:0")
+    ops.set_conv_math(math)
+    try:
+        torch.manual_seed(0)
+        base = unipose("MPII", num_classes=16).to(dev).train()
+        for d in (base.wasp.dropout, base.decoder.last_conv[3], base.decoder.last_conv[7]):
+            d.p = 0.0
+        x = torch.randn(4, 3, 128, 128, device=dev)
+        t = torch.rand(4, 17, 16, 16, device=dev)
+        results = []
+        for graphed in (False, True):
+            m = copy.deepcopy(base)
+            opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=True, capturable=True)
+            if graphed:
+                step = GraphedTrainStep(m, opt, x, t, warmup=3)
+                for _ in range(2):
+                    loss = step(x, t)
+                loss = loss.clone()
+            else:
+                for _ in range(5):
+                    opt.zero_grad(set_to_none=True)
+                    loss = ops.mse_loss(m(x), t)
+                    loss.backward()
+                    opt.step()
+            torch.cuda.synchronize()
+            st = opt.state_dict()["state"]
+            results.append({"loss": loss.detach().reshape(1).cpu(),
+                            **{"w." + n: p.detach().cpu().clone() for n, p in m.named_parameters()},
+                            **{"g." + n: p.grad.detach().cpu().clone() for n, p in m.named_parameters() if p.grad is not None},
+                            **{"b." + n: b.detach().cpu().clone() for n, b in m.named_buffers()},
+                            **{f"adam.{i}.exp_avg": v["exp_avg"].cpu().clone() for i, v in st.items()}})
+            if graphed:
+                step.close()
+        eager, graph = results
+        assert eager.keys() == graph.keys()
+        loose = ("decoder.last_conv.8.bias",)          # float-atomic column sum (and the Adam state / weight it feeds)
+        bad = []
+        for k in eager:
+            if torch.equal(eager[k], graph[k]):
+                continue
+            if any(k.endswith(s) for s in loose) or k == f"adam.{len(list(base.parameters())) - 1}.exp_avg":
+                assert torch.allclose(eager[k], graph[k], rtol=1e-4, atol=1e-7), k
+                continue
+            bad.append(k)
+        assert not bad, (len(bad), bad[:6])
+        print(f"graphed train step ({math}): loss {float(graph['loss']):.7f} == eager, {len(eager)} tensors equal")
+    finally:
+        ops.set_conv_math("f32")
+
+
+def test_graphed_train_step_dropout_masks_differ_between_replays():
+    """A replay re-issues the dropout launches with unchanged arguments; the device-side step counter still gives every step its
+    own masks (two replays on the same batch produce different losses; with p = 0 they would be the trajectory of test 1)."""
+    from model.unipose import unipose
+    from unipose_amd.graph import GraphedTrainStep
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = unipose("MPII", num_classes=16).to(dev).train()
+    opt = torch.optim.Adam(m.parameters(), lr=0.0, fused=True, capturable=True)        # lr 0: only the masks change
+    x = torch.randn(2, 3, 128, 128, device=dev)
+    t = torch.rand(2, 17, 16, 16, device=dev)
+    step = GraphedTrainStep(m, opt, x, t, warmup=1)
+    losses = [float(step().clone()) for _ in range(4)]
+    step.close()
+    assert len(set(losses)) == 4, losses

@@ -82,6 +82,7 @@ def test_lstm_bf16_storage_train_emu(emu_backend):
 
 def test_hooked_block_output_takes_the_separate_reduction_emu(emu_backend):
     mc.hooked_block_output_case(emu_backend)
+    mc.hooked_block_output_case(emu_backend, drop_tensor=True)
 
 
 def test_bn_finalize_folded_whole_step(emu_backend):

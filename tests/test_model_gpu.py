@@ -113,6 +113,7 @@ def test_tap_between_blocks_falls_back_to_the_separate_reduction_gpu():
 
 def test_hooked_block_output_takes_the_separate_reduction_gpu():
     mc.hooked_block_output_case(DEV)
+    mc.hooked_block_output_case(DEV, drop_tensor=True)
 
 
 def test_bn_backward_reduction_fused_into_data_gradients_gpu():

@@ -63,6 +63,9 @@ SIGNATURES = {
     "up_conv_stats_tiles_math": (_i, [_D, _i]),
     "up_conv_split_parts": (_i, [_D]),
     "up_stream_release": (_i, [_p]),
+    "up_stream_create_cu_mask": (_i, [C.POINTER(C.c_uint32), _i, C.POINTER(_p)]),
+    "up_stream_destroy": (_i, [_p]),
+    "up_probe_placement": (_i, [_i, _p, _p]),
     "up_conv_tune": (_i, [C.c_char_p, _i]),
     "up_conv_counter": (C.c_longlong, [C.c_char_p]),
     "up_conv_wgrad_visits": (_i, [_D, C.POINTER(C.c_double)]),
@@ -127,6 +130,7 @@ SIGNATURES = {
     "up_gap_fwd_t": (_i, [_p, _i, _p, _i, _i, _i, _i, _p]),
     "up_gap_bwd_t": (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     "up_dropout_fwd_t": (_i, [_p, _p, _p, _p, _i64, _f, _u64, _i, _p]),
+    "up_dropout_fwd_step_t": (_i, [_p, _p, _p, _p, _i64, _f, _u64, _p, _i, _p]),
     "up_dropout_bwd_t": (_i, [_p, _p, _p, _i64, _f, _i, _p]),
     "up_mse_fwd": (_i, [_p, _p, _p, _p, _i64, _p]),
     "up_mse_bwd": (_i, [_p, _p, _p, _p, _i64, _p]),

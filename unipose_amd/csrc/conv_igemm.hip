@@ -1884,9 +1884,11 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const up_pack_job* jo
     }
 }
 
-// column sums of a [rows][ld] matrix (bias gradient): partial per block, atomically combined
+// column sums of a [rows][ld] matrix (bias gradient): one partial row per block, part[block][C]; colsum_finish_kernel adds the
+// rows in a fixed order (round 6: the float atomics of rounds 1-5 made the bias gradient — and through the bias every later step —
+// differ from run to run in the last bit)
 template <typename T>
-__global__ void __launch_bounds__(256) colsum_kernel(const T* x, int ld, long long rows, int C, float* out,
+__global__ void __launch_bounds__(256) colsum_kernel(const T* x, int ld, long long rows, int C, float* part,
                                                      int rows_per_block) {
     // blockDim = 256 = 4 row-lanes x 64 columns
     __shared__ float red[256];
@@ -1901,14 +1903,24 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* x, int ld, long lo
     __syncthreads();
     if (rl == 0 && c < C) {
         s = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
-        atomicAdd(out + c, s);
+        part[(size_t)blockIdx.x * C + c] = s;
     }
+}
+// one wavefront per channel: lane l adds partial rows l, l + 64, ... in order, then a butterfly over the lanes (fixed order)
+__global__ void __launch_bounds__(256) colsum_finish_kernel(const float* part, int blocks, int C, float* out, int accumulate) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    float s = 0.f;
+    if (c < C)
+        for (int b = lane; b < blocks; b += 64) s += part[(size_t)b * C + c];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (c < C && lane == 0) out[c] = accumulate ? out[c] + s : s;
 }
 
 // the same with four channels per thread (16-byte loads, 16 row lanes x 16 channel quads) and 256-row blocks: the 1024-row form above
 // ran the bias gradient of the video head (16 928 x 128) on 34 workgroups in 66 us, 31 times per step (profiles/r03_m_kernel_stats_lstm)
 template <typename T>
-__global__ void __launch_bounds__(256) colsum4_kernel(const T* x, int ld, long long rows, int C, float* out, int rows_per_block) {
+__global__ void __launch_bounds__(256) colsum4_kernel(const T* x, int ld, long long rows, int C, float* part, int rows_per_block) {
     __shared__ float red[16][64];
     const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.y * 64 + cq * 4;
@@ -1941,7 +1953,7 @@ __global__ void __launch_bounds__(256) colsum4_kernel(const T* x, int ld, long l
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
         const int cc = blockIdx.y * 64 + threadIdx.x;
-        if (cc < C) atomicAdd(out + cc, t);
+        if (cc < C) part[(size_t)blockIdx.x * C + cc] = t;
     }
 }
 
@@ -3277,8 +3289,10 @@ extern "C" int up_conv_wgrad_visits(const up_conv_desc* d, double* rect_fraction
 
 extern "C" size_t up_conv2d_bwd_weight_workspace(const up_conv_desc* d) {
     if (!d || check_desc(d)) return 0;
-    WgradPlan p = plan_wgrad(d);
-    return (size_t)p.splits * d->K * d->R * d->S * d->Cp * sizeof(float);
+    const size_t slab = (size_t)d->K * d->R * d->S * d->Cp * sizeof(float);
+    const size_t a = (size_t)plan_wgrad(d).splits * slab, b = (size_t)plan_wgrad(d, 64).splits * slab;
+    // + the bias gradient's partial rows (one per 256 pixel rows), behind the split-K slabs
+    return (a > b ? a : b) + 64 + (size_t)cdiv((int64_t)d->N * d->P * d->Q, 256) * d->K * sizeof(float);
 }
 
 namespace up {
@@ -3489,20 +3503,25 @@ static int up::conv2d_bwd_weight_impl(const up_conv_desc* d, const float* x, con
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total4, 256)), dim3(256), 0, st, (const float*)workspace, dw,
                        p.splits, d->K, d->C, d->Cp, d->R * d->S, total4, accumulate);
     if (dbias) {
-        if (!accumulate && hipMemsetAsync(dbias, 0, sizeof(float) * d->K, st) != hipSuccess) return check_launch("dbias memset");
         const bool quads = d->ldy % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
         const int rpb = quads ? 256 : 1024;
         dim3 g(cdiv(a.M, rpb), cdiv(d->K, 64));
+        const size_t off = (need + 63) / 64 * 64;
+        UP_REQUIRE(workspace_bytes >= off + (size_t)g.x * d->K * sizeof(float), UP_ERR_WORKSPACE,
+                   "conv2d_bwd_weight: workspace %zu too small for the bias gradient's partial rows", workspace_bytes);
+        float* part = reinterpret_cast<float*>(static_cast<char*>(workspace) + off);
         if (quads && bf16 == 2)
             hipLaunchKernelGGL(colsum4_kernel<bf16_t>, g, dim3(256), 0, st, reinterpret_cast<const bf16_t*>(dy), d->ldy,
-                               (long long)a.M, d->K, dbias, rpb);
+                               (long long)a.M, d->K, part, rpb);
         else if (quads)
-            hipLaunchKernelGGL(colsum4_kernel<float>, g, dim3(256), 0, st, dy, d->ldy, (long long)a.M, d->K, dbias, rpb);
+            hipLaunchKernelGGL(colsum4_kernel<float>, g, dim3(256), 0, st, dy, d->ldy, (long long)a.M, d->K, part, rpb);
         else if (bf16 == 2)
             hipLaunchKernelGGL(colsum_kernel<bf16_t>, g, dim3(256), 0, st, reinterpret_cast<const bf16_t*>(dy), d->ldy,
-                               (long long)a.M, d->K, dbias, rpb);
+                               (long long)a.M, d->K, part, rpb);
         else
-            hipLaunchKernelGGL(colsum_kernel<float>, g, dim3(256), 0, st, dy, d->ldy, (long long)a.M, d->K, dbias, rpb);
+            hipLaunchKernelGGL(colsum_kernel<float>, g, dim3(256), 0, st, dy, d->ldy, (long long)a.M, d->K, part, rpb);
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3(cdiv(d->K, 4)), dim3(256), 0, st, (const float*)part, (int)g.x, d->K, dbias,
+                           accumulate);
     }
     return check_launch("conv2d_bwd_weight");
 }

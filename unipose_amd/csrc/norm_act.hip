@@ -821,7 +821,10 @@ __device__ __forceinline__ uint32_t mix_hash(uint64_t seed, uint64_t idx) {
 template <typename T>
 __global__ void __launch_bounds__(256) dropout_fwd_kernel(const T* x, T* y, uint8_t* mask,
                                                           const float* ext, int64_t n, float p, float inv_keep,
-                                                          uint64_t seed) {
+                                                          uint64_t seed, const uint64_t* step_dev) {
+    // step_dev (optional): a counter in DEVICE memory mixed into the seed — a captured training step (hipGraph) replays this launch
+    // with the same kernel arguments, its masks must still differ from step to step (the graph bumps the counter once per replay)
+    if (step_dev) seed += *step_dev * 0x9E3779B97F4A7C15ull;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         bool keep;
         if (ext)
@@ -880,6 +883,56 @@ constexpr int BNB_ROWS = 128;   // small chunks: enough workgroups (and bytes in
 using namespace up;
 
 extern "C" const char* up_last_error(void) { return g_err; }
+// ---- CU-masked streams (round 6 experiment: the weight-gradient side stream on a fixed share of the chip) -----------------------
+// A stream created with a compute-unit mask runs its kernels only on the CUs whose bit is set.  `words` 32-bit words, bit i of the
+// mask = logical CU i in the runtime's enumeration (up_probe_placement shows where the workgroups of such a stream really run).
+extern "C" int up_stream_create_cu_mask(const uint32_t* mask, int words, void** stream) {
+    UP_REQUIRE(mask && words > 0 && stream, UP_ERR_INVALID, "stream_create_cu_mask: bad argument");
+#ifdef UP_EMU
+    *stream = nullptr;
+    return UP_OK;
+#else
+    hipStream_t st = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask);
+    if (e != hipSuccess) {
+        set_error("stream_create_cu_mask: %s", hipGetErrorString(e));
+        return UP_ERR_LAUNCH;
+    }
+    *stream = st;
+    return UP_OK;
+#endif
+}
+extern "C" int up_stream_destroy(void* stream) {
+#ifndef UP_EMU
+    if (stream && hipStreamDestroy(as_stream(stream)) != hipSuccess) {
+        (void)hipGetLastError();
+        return UP_ERR_LAUNCH;
+    }
+#endif
+    return UP_OK;
+}
+namespace up {
+__global__ void __launch_bounds__(64) placement_kernel(int* out) {
+#ifndef UP_EMU
+    if (threadIdx.x == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));      // HW_REG_XCC_ID, bits 0..3
+        const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));        // HW_REG_HW_ID: cu_id 8..11, sh 12, se 13..15
+        out[2 * blockIdx.x] = (int)(xcc & 15u);
+        out[2 * blockIdx.x + 1] = (int)((hw >> 8) & 0xffu);                                      // cu | sh << 4 | se << 5
+        for (int i = 0; i < 2000; ++i) __builtin_amdgcn_s_sleep(32);                              // stay resident: later blocks must spread
+    }
+#else
+    if (threadIdx.x == 0) out[2 * blockIdx.x] = out[2 * blockIdx.x + 1] = 0;
+#endif
+}
+}  // namespace up
+// where do the workgroups of `stream` run?  out[blocks][2] = (XCC id, CU / SH / SE bits of HW_ID) per workgroup (device memory)
+extern "C" int up_probe_placement(int blocks, int* out_device, void* stream) {
+    UP_REQUIRE(blocks > 0 && out_device, UP_ERR_INVALID, "probe_placement: bad argument");
+    hipLaunchKernelGGL(placement_kernel, dim3(blocks), dim3(64), 0, as_stream(stream), out_device);
+    return check_launch("probe_placement");
+}
+
 extern "C" int up_abi_version(void) { return 10; }   // 10: BatchNorm finalize folded into the producing launch (up_bn_fold, up_bn_reduce_slot.dgamma, up_bn_bwd_finalized_t); 9: up_pack_weights_bf16_batched; 8: row groups (up_conv2d_fwd_grouped, groups in up_dgrad_epilogue, up_bn_bwd_groups_prereduced_t); 7: up_conv2d_bwd_data_ex / up_bn_bwd_prereduced_t / up_conv_counter; 6: centred BatchNorm; 5: up_conv2d_bwd_weight_acc; 4: element-typed (_t) twins + bf16 storage
 
 extern "C" int up_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
@@ -1477,17 +1530,21 @@ extern "C" int up_relu_bwd(const float* dz, const float* z, float* dx, int64_t n
     return check_launch("relu_bwd");
 }
 
-extern "C" int up_dropout_fwd_t(const void* x, void* y, uint8_t* mask, const float* ext_mask, int64_t n, float p,
-                                uint64_t seed, int dtype, void* stream) {
+extern "C" int up_dropout_fwd_step_t(const void* x, void* y, uint8_t* mask, const float* ext_mask, int64_t n, float p,
+                                     uint64_t seed, const uint64_t* step_device, int dtype, void* stream) {
     UP_REQUIRE(x && y && mask && n > 0 && p >= 0.f && p < 1.f, UP_ERR_INVALID, "dropout_fwd: bad argument");
     UP_REQUIRE(dtype == UP_DT_F32 || dtype == UP_DT_BF16, UP_ERR_INVALID, "dropout_fwd: dtype %d", dtype);
     if (dtype == UP_DT_BF16)
         hipLaunchKernelGGL(dropout_fwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), (const bf16_t*)x,
-                           (bf16_t*)y, mask, ext_mask, n, p, 1.0f / (1.0f - p), seed);
+                           (bf16_t*)y, mask, ext_mask, n, p, 1.0f / (1.0f - p), seed, step_device);
     else
         hipLaunchKernelGGL(dropout_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), (const float*)x,
-                           (float*)y, mask, ext_mask, n, p, 1.0f / (1.0f - p), seed);
+                           (float*)y, mask, ext_mask, n, p, 1.0f / (1.0f - p), seed, step_device);
     return check_launch("dropout_fwd");
+}
+extern "C" int up_dropout_fwd_t(const void* x, void* y, uint8_t* mask, const float* ext_mask, int64_t n, float p,
+                                uint64_t seed, int dtype, void* stream) {
+    return up_dropout_fwd_step_t(x, y, mask, ext_mask, n, p, seed, nullptr, dtype, stream);
 }
 extern "C" int up_dropout_fwd(const float* x, float* y, uint8_t* mask, const float* ext_mask, int64_t n, float p,
                               uint64_t seed, void* stream) {

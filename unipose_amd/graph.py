@@ -1,4 +1,4 @@
-"""Inference forward as ONE hipGraph.
+"""Inference forward — and, since round 6, the whole TRAINING step — as ONE hipGraph.
 
 At small batches the forward of the image model is ~130 launches of a few microseconds each and the step is bound by the
 host issuing them (B = 1 at 368^2: 3.1 ms wall for 1.3 ms of kernel time).  `GraphedForward` captures one forward —
@@ -103,4 +103,104 @@ class GraphedForward:
         try:
             self.close()
         except Exception:      # interpreter shutdown: the process takes the memory with it
+            pass
+
+
+class GraphedTrainStep:
+    """The reference's training step (unipose.py:100-131: zero_grad -> forward -> MSE -> backward -> Adam.step) captured as ONE
+    hipGraph and replayed per call: the whole-graph training entry of SURVEY 8(b).  ~800 launches on two streams (the weight
+    gradients fork to the side stream and join at the end of the backward pass), the batched weight re-pack, the BatchNorm
+    counters' multi-tensor add and the optimizer's fused kernels become one graph launch; the host issues nothing per layer.
+
+        model = unipose("MPII", num_classes=16).cuda().train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True, capturable=True)      # capturable: the step count lives on the device
+        step = GraphedTrainStep(model, opt, images, targets)            # warms up (3 eager steps on the capture stream), captures
+        loss = step(images, targets)                                    # copies the batch into the static inputs, replays
+
+    Equal bits to the eager step: the same launches with the same arguments in the same per-stream order (tests/test_graph_gpu.py).
+    What is fixed at capture: shapes, the arithmetic mode (ops.set_conv_math), every kernel-selection decision, the addresses of
+    parameters, gradients (`param.grad` are the graph's static buffers: read them after a replay, do not replace them) and
+    optimizer state.  Dropout masks change from replay to replay through a device-side step counter (up_dropout_fwd_step_t).
+    Not captured: a data-parallel gradient exchange (capture per rank with the all-reduce is left to torch's own tooling),
+    ops.deferred_wgrad / the video model's unroll.  The warm-up steps are REAL optimizer steps on the example batch.
+    """
+
+    def __init__(self, model, optimizer, x, target, loss_fn=None, warmup=3):
+        from . import ops
+        if not model.training:
+            raise ValueError("GraphedTrainStep captures a training step: call model.train() first")
+        if not (torch.is_tensor(x) and x.is_cuda and torch.is_tensor(target) and target.is_cuda):
+            raise TypeError("GraphedTrainStep needs CUDA example tensors (there is no CPU path)")
+        for g in optimizer.param_groups:
+            if not g.get("capturable", False):
+                raise ValueError("GraphedTrainStep: construct the optimizer with capturable=True (its step counter must live on the "
+                                 "device; torch refuses to capture a non-capturable step)")
+        self.model, self.optimizer = model, optimizer
+        self.loss_fn = loss_fn or ops.mse_loss
+        self.device = x.device
+        self.stream = torch.cuda.Stream(device=self.device)
+        _acquire_stream((self.device.index, self.stream.cuda_stream))
+        self.static_x, self.static_t = x.clone(), target.clone()
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)       # dropout's step counter, bumped inside the graph
+        self.graph, self.static_loss = None, None
+        self._capture(warmup)
+
+    def _one_step(self):
+        from . import ops
+        prev = ops._DROPOUT_STATE["step_dev"]
+        ops._DROPOUT_STATE["step_dev"] = self.step_dev
+        try:
+            self.step_dev.add_(1)
+            loss = self.loss_fn(self.model(self.static_x), self.static_t)
+            loss.backward()
+            self.optimizer.step()
+        finally:
+            ops._DROPOUT_STATE["step_dev"] = prev
+        return loss
+
+    def _capture(self, warmup):
+        from . import ops
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        ops._side_stream(self.device)          # the side stream exists before the capture (stream creation is not capturable)
+        with torch.cuda.stream(self.stream):
+            for _ in range(max(warmup, 1)):    # eager steps on the capture stream: library scratch, tables, workspaces, Adam state
+                self.optimizer.zero_grad(set_to_none=True)
+                self._one_step()
+        self.stream.synchronize()
+        torch.cuda.synchronize(self.device)
+        ops.retire_pending_repacks()           # (their events were recorded outside the capture)
+        # the gradients of the captured step live in the graph's private pool: drop the eager ones first, so that backward
+        # allocates (and the graph owns) fresh static .grad tensors
+        self.optimizer.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=self.stream):
+            loss = self._one_step()
+        cur.wait_stream(self.stream)
+        self.graph, self.static_loss = graph, loss.detach()
+
+    def __call__(self, x=None, target=None):
+        for dst, src in ((self.static_x, x), (self.static_t, target)):
+            if src is None:
+                continue
+            if src.shape != dst.shape or src.dtype != dst.dtype:
+                raise ValueError(f"batch of shape {tuple(src.shape)} / {src.dtype}: the step was captured for {tuple(dst.shape)} / {dst.dtype}")
+            dst.copy_(src, non_blocking=True)
+        self.graph.replay()
+        return self.static_loss
+
+    def close(self):
+        if getattr(self, "stream", None) is None:
+            return
+        from . import _C
+        self.graph, self.static_loss = None, None
+        torch.cuda.synchronize(self.device)
+        if _release_stream((self.device.index, self.stream.cuda_stream)):
+            _C.lib().up_stream_release(self.stream.cuda_stream)
+        self.stream = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown
             pass

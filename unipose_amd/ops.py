@@ -7,6 +7,7 @@ raw pointers and run on the current stream.
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import os
 import weakref
@@ -166,6 +167,13 @@ def _launch_repack(ps, weight, entry_point, what, job_bytes):
         ps.pending = (ev, set(keys[_REPACK_HEAD:]), set())
     else:
         _C.check(getattr(L, entry_point)(table.data_ptr(), n, _stream(weight)), what)
+
+
+def retire_pending_repacks():
+    """Forget the events of finished split re-packs (call after a device synchronisation: graph.GraphedTrainStep does before it
+    captures — a capturing stream must not wait for an event recorded outside the capture)."""
+    for ps in list(_PACK_CACHE.values()) + list(_PACK16_CACHE.values()):
+        ps.pending = None
 
 
 def _await_repack(ps, key, dev):
@@ -539,6 +547,9 @@ BN_FUSE_REDUCE = os.environ.get("UNIPOSE_BN_FUSE_REDUCE", "1") != "0"     # deve
 MASKED_ADDEND = os.environ.get("UNIPOSE_MASKED_ADDEND", "1") != "0"
 GROUPED_REDUCE = os.environ.get("UNIPOSE_GROUPED_REDUCE", "1") != "0"     # the fused reduction also inside ops.bn_groups (row groups)
 DX_HANDOVER = os.environ.get("UNIPOSE_DX_HANDOVER", "1") != "0"           # projection blocks: downsample's dx rides in conv1's launch
+# the fused reduction only on data-gradient launches whose reduction (taps x output channels) is at least this long (A/B knobs)
+BNRED_MIN_K = int(os.environ.get("UNIPOSE_BNRED_MIN_K", "0"))
+BNRED_MIN_K_BF16 = int(os.environ.get("UNIPOSE_BNRED_MIN_K_BF16", "0"))
 
 
 def dgrad_extras_tiles(d: _C.ConvDesc, x_shape, dtype) -> int:
@@ -570,7 +581,7 @@ def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev, add=None, bn_slo
     ex_math = MATH_BF16S if dy.dtype == torch.bfloat16 else (MATH_F32 if CONV_MATH == MATH_F32 else -1)
     tiles = 0
     want_slot = bn_slot is not None and bn_slot.y is not None and bn_slot.C == d.C == cp and bn_slot.y.dtype == dy.dtype and \
-        bn_slot.y.shape[:3] == (n, h, w)
+        bn_slot.y.shape[:3] == (n, h, w) and d.R * d.S * d.Kp >= (BNRED_MIN_K_BF16 if dy.dtype == torch.bfloat16 else BNRED_MIN_K)
     groups = bn_slot.groups if want_slot else 1
     if (want_slot or add_bits is not None) and ex_math >= 0:
         tiles = _C.lib().up_conv2d_bwd_data_tiles_math(C.byref(dd), ex_math)
@@ -741,10 +752,35 @@ def set_grad_destinations(fn):
     _GRAD_DEST["fn"] = fn
 
 
+def cu_mask_stream(dev, mask_bits):
+    """A torch stream handle around a HIP stream restricted to the compute units in `mask_bits` (iterable of logical CU indices):
+    up_stream_create_cu_mask.  Experiment support (UNIPOSE_SIDE_CUS): the stream is never destroyed."""
+    words = (C.c_uint32 * 8)()
+    for b in mask_bits:
+        words[b // 32] |= 1 << (b % 32)
+    h = C.c_void_p()
+    _C.check(_C.lib().up_stream_create_cu_mask(words, 8, C.byref(h)), "stream_create_cu_mask")
+    return torch.cuda.ExternalStream(h.value, device=dev)
+
+
 def _side_stream(dev):
     st = _SIDE.get(dev.index)
     if st is None:
-        st = torch.cuda.Stream(device=dev, priority=int(os.environ.get("UNIPOSE_SIDE_PRIO", "0")))
+        ncu = int(os.environ.get("UNIPOSE_SIDE_CUS", "0"))
+        if ncu > 0 and dev.type == "cuda":
+            # experiment (profiles/r06_experiments.txt): the weight-gradient stream on `ncu` of the 256 CUs; UNIPOSE_SIDE_CU_STRIDE
+            # picks how the bits are spread (1: the lowest ncu bits, k: every k-th bit, wrapping)
+            stride = max(1, int(os.environ.get("UNIPOSE_SIDE_CU_STRIDE", "1")))
+            bits, b = [], 0
+            while len(bits) < ncu:
+                if b not in bits:
+                    bits.append(b)
+                b = (b + stride) % 256
+                if b in bits:
+                    b = (b + 1) % 256
+            st = cu_mask_stream(dev, bits)
+        else:
+            st = torch.cuda.Stream(device=dev, priority=int(os.environ.get("UNIPOSE_SIDE_PRIO", "0")))
         _SIDE[dev.index] = st
     return st
 
@@ -1020,8 +1056,8 @@ class ConvBnAct(Function):
         # ... and as the consumer of the layer that produced x
         ctx.slot_in = slot_in if (slot_in is not None and slot_in.y is not None and ctx.needs_input_grad[0]) else None
         # a tensor hook on z can edit dz IN PLACE through .data without moving its version counter (g.data.mul_(2), a clipping
-        # hook): BnSlot.matches cannot see that, so a hooked output always takes the separate reduction
-        ctx.z_ref = weakref.ref(z) if ctx.slot_out is not None else None
+        # hook): BnSlot.matches cannot see that, so a hooked output always takes the separate reduction: conv_bn_act
+        # attaches z's hook dictionary to this node (ctx.z_hooks) once z has its grad_fn
         ctx.save_for_backward(x, weight, gamma, y, bits, coef)
         return z
 
@@ -1030,10 +1066,11 @@ class ConvBnAct(Function):
         so = ctx.slot_out
         if so is None or not so.matches(dz, y):
             return False
-        # a dead weak reference says nothing about hooks: one registered on z stays on its grad_fn after the Python tensor is gone
-        # (`z.register_hook(h); loss = z.sum(); del z`), so an unknown z takes the separate reduction
-        z = ctx.z_ref() if ctx.z_ref is not None else None
-        return z is not None and not getattr(z, "_backward_hooks", None)
+        # tensor hooks of z: conv_bn_act registered z's hook dictionary with the node right after the forward and keeps it on the
+        # node, so hooks added later are seen here even when the Python tensor is long gone (`t = block(x); t.register_hook(h);
+        # return next_block(t)`: a dead weak reference said nothing about them)
+        hooks = getattr(ctx, "z_hooks", None)
+        return hooks is not None and len(hooks) == 0
 
     @staticmethod
     @once_differentiable
@@ -1220,8 +1257,18 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, link_in=None, link_out=No
     else:
         mom = 0.0
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    return ConvBnAct.apply(x, weight, bn.weight, bn.bias, residual, rm, rv, cfg, relu, train, bn.eps, mom,
-                           link_in, link_out, slot_in, slot_out, link_dx)
+    z = ConvBnAct.apply(x, weight, bn.weight, bn.bias, residual, rm, rv, cfg, relu, train, bn.eps, mom,
+                        link_in, link_out, slot_in, slot_out, link_dx)
+    node = z.grad_fn
+    if node is not None and getattr(node, "slot_out", None) is not None:
+        # the node watches z's tensor hooks through the dictionary torch itself files them in (Tensor.register_hook): created
+        # and registered here, while z is certainly alive, and kept on the node — see ConvBnAct._slot_usable
+        hooks = z._backward_hooks
+        if hooks is None:
+            hooks = z._backward_hooks = collections.OrderedDict()
+            node._register_hook_dict(z)
+        node.z_hooks = hooks
+    return z
 
 
 def conv_bias_act(x, conv, relu=False, out_f32=False):
@@ -1418,8 +1465,9 @@ class Dropout(Function):
         x = _dense(x)
         y = torch.empty_like(x)
         mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
-        _C.check(_C.lib().up_dropout_fwd_t(x.data_ptr(), y.data_ptr(), mask.data_ptr(), _ptr(ext_mask), x.numel(),
-                                           float(p), int(seed) & (2 ** 64 - 1), _dt(x), _stream(x)), "dropout_fwd")
+        step = _DROPOUT_STATE["step_dev"]        # (a device counter while a training step is captured / replayed, see graph.py)
+        _C.check(_C.lib().up_dropout_fwd_step_t(x.data_ptr(), y.data_ptr(), mask.data_ptr(), _ptr(ext_mask), x.numel(),
+                                                float(p), int(seed) & (2 ** 64 - 1), _ptr(step), _dt(x), _stream(x)), "dropout_fwd")
         ctx.p = float(p)
         ctx.save_for_backward(mask)
         return y
@@ -1435,7 +1483,7 @@ class Dropout(Function):
         return dx, None, None, None
 
 
-_DROPOUT_STATE = {"seed": 0x5EED, "calls": 0, "ext": None}
+_DROPOUT_STATE = {"seed": 0x5EED, "calls": 0, "ext": None, "step_dev": None}
 
 
 def set_dropout_masks(masks):
