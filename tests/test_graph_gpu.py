@@ -135,8 +135,8 @@ def test_two_live_graphs_on_one_stream_handle_share_the_scratch():
     first.close()
 
 
-@pytest.mark.parametrize("math", ["f32", "bf16s"])
-def test_graphed_train_step_equals_eager_steps(math):
+@pytest.mark.parametrize("math,two_streams", [("f32", False), ("f32", True), ("bf16s", False)])
+def test_graphed_train_step_equals_eager_steps(math, two_streams):
     """unipose_amd.graph.GraphedTrainStep (the whole-graph TRAINING entry): the step captured as one hipGraph — both
     streams, the weight re-pack, the BatchNorm fold tickets, capturable fused Adam — against the same steps issued eagerly:
     loss, gradients, weights, running statistics and Adam state after 3 + 2 steps agree bit for bit (B = 4, 128x128, dropouts 0;
@@ -159,7 +159,7 @@ def test_graphed_train_step_equals_eager_steps(math):
             m = copy.deepcopy(base)
             opt = torch.optim.Adam(m.parameters(), lr=1e-4, fused=True, capturable=True)
             if graphed:
-                step = GraphedTrainStep(m, opt, x, t, warmup=3)
+                step = GraphedTrainStep(m, opt, x, t, warmup=3, two_streams=two_streams)
                 for _ in range(2):
                     loss = step(x, t)
                 loss = loss.clone()

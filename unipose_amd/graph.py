@@ -125,8 +125,13 @@ class GraphedTrainStep:
     ops.deferred_wgrad / the video model's unroll.  The warm-up steps are REAL optimizer steps on the example batch.
     """
 
-    def __init__(self, model, optimizer, x, target, loss_fn=None, warmup=3):
+    def __init__(self, model, optimizer, x, target, loss_fn=None, warmup=3, two_streams=False):
+        """two_streams: capture the weight gradients on the side stream like the eager step issues them.  Off by default: on
+        ROCm 7.2 every cross-stream edge of a replayed graph is expensive (fp32 B = 32: 77.2 ms two-stream replay against 63.4 ms
+        single-stream replay and 61.2 ms for the eager two-stream step, profiles/r06_experiments.txt), so the captured step keeps
+        everything on one stream; the results are the same bits either way."""
         from . import ops
+        self.two_streams = bool(two_streams)
         if not model.training:
             raise ValueError("GraphedTrainStep captures a training step: call model.train() first")
         if not (torch.is_tensor(x) and x.is_cuda and torch.is_tensor(target) and target.is_cuda):
@@ -147,8 +152,9 @@ class GraphedTrainStep:
 
     def _one_step(self):
         from . import ops
-        prev = ops._DROPOUT_STATE["step_dev"]
+        prev, prev_async = ops._DROPOUT_STATE["step_dev"], ops.ASYNC_WGRAD
         ops._DROPOUT_STATE["step_dev"] = self.step_dev
+        ops.ASYNC_WGRAD = prev_async and self.two_streams
         try:
             self.step_dev.add_(1)
             loss = self.loss_fn(self.model(self.static_x), self.static_t)
@@ -156,6 +162,7 @@ class GraphedTrainStep:
             self.optimizer.step()
         finally:
             ops._DROPOUT_STATE["step_dev"] = prev
+            ops.ASYNC_WGRAD = prev_async
         return loss
 
     def _capture(self, warmup):
@@ -164,7 +171,9 @@ class GraphedTrainStep:
         self.stream.wait_stream(cur)
         ops._side_stream(self.device)          # the side stream exists before the capture (stream creation is not capturable)
         with torch.cuda.stream(self.stream):
-            for _ in range(max(warmup, 1)):    # eager steps on the capture stream: library scratch, tables, workspaces, Adam state
+            # eager steps on the capture stream: library scratch, tap / rectangle tables, workspaces, Adam state — and at least
+            # TWO: the batched re-pack builds its job table (a host-to-device copy) at the first stale hit, i.e. in the second step
+            for _ in range(max(warmup, 2)):
                 self.optimizer.zero_grad(set_to_none=True)
                 self._one_step()
         self.stream.synchronize()
