@@ -427,6 +427,9 @@ def main():
                          "all-reduce after it; the default for --math bf16s, whose step (< 40 ms) is short enough for the flat "
                          "190 MB exchange to show (--no-overlap switches it off)")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--allow-shared-queues", action="store_true",
+                    help="run a data-parallel measurement although GPU_MAX_HW_QUEUES < 8 (the weight-gradient stream may share a "
+                         "hardware queue with RCCL's streams: +10 ... +14 %% per step measured)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the whole training step as ONE hipGraph (unipose_amd.graph.GraphedTrainStep; image model, one GPU)")
     ap.add_argument("--no-alt-math", action="store_true", help="skip the extra split-bf16 timing loop")
@@ -470,6 +473,15 @@ def main():
         dev = torch.device("cuda", local)
         from unipose_amd import ops as _ops
         _ops._side_stream(dev)          # create it BEFORE RCCL creates its own streams (hardware-queue assignment)
+    if use_dist and not emu:
+        # the weight-gradient side stream must keep a hardware queue of its own once RCCL has created its streams:
+        # this script exports GPU_MAX_HW_QUEUES=8 before `import torch` unless the caller set something else; a smaller value is
+        # a measurement of the queue collision, not of the step — refuse it loudly unless asked for
+        hwq = int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0)
+        if hwq < 8 and not args.allow_shared_queues:
+            raise SystemExit(f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')!r}: a data-parallel run needs >= 8 hardware "
+                             "queues (side stream vs RCCL's streams, +10 ... +14 % per step otherwise); unset it or pass "
+                             "--allow-shared-queues")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -598,6 +610,7 @@ def main():
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         dp = {"comm_ranks": comm_ranks, "backend": dist.get_backend(), "exchange": "overlap" if args.overlap else "flat",
+              "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
               "payload_mb": round(reducer.payload_bytes() / 1e6, 1),
               "ms_per_step_by_rank": [round(1e3 * float(r[0]) / args.steps, 3) for r in allr],
               "exchange_ms_by_rank": [round(float(r[1]), 3) for r in allr],

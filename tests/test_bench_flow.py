@@ -20,8 +20,8 @@ def _free_port():
     return p
 
 
-def _run(nproc, extra=(), plain=False):
-    env = dict(os.environ, UP_EMU_THREADS="4", OMP_NUM_THREADS="2")
+def _run(nproc, extra=(), plain=False, emu_threads=4, timeout=900):
+    env = dict(os.environ, UP_EMU_THREADS=str(emu_threads), OMP_NUM_THREADS="2" if nproc <= 2 else "1")
     # the emulator needs ~10-20 s per training step of the full ResNet-101: no warm-up, one timed step (plus the two of the
     # exclusive pass), no alt-math loop (that loop has no rank-dependent branch)
     args = ["--gpus", str(nproc), "--steps", "1", "--warmup", "0", "--batch", "2", "--size", "32", "--dry-run-emu",
@@ -32,7 +32,7 @@ def _run(nproc, extra=(), plain=False):
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
                "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", *args]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]          # ONE JSON line, from rank 0 only
@@ -69,3 +69,25 @@ def test_bench_flow_single_rank_contract():
     assert out["warmup"] == 0 and out["n_gpus"] == 1 and out["scaling"] == "weak" and out["higher_is_better"] is True
     assert out["vs_baseline"] is None and out["dtype"] == "f32" and out["data"] == "synthetic"
     assert set(out["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and out["cpu_baseline"]["kind"] == "port"
+
+
+def test_bench_flow_four_ranks_overlapped_buckets():
+    """VERDICT r5 pre-flight: four ranks, the hook-driven bucketed exchange (--overlap): step 1 is the calibration step (plain
+    exchange, hand-out order recorded), then rank 0's bucket order is broadcast and the collective verdict on the parameter set is
+    taken, steps 2-3 run the overlapped buckets.  A rank whose order or verdict differed would hang or mismatch here."""
+    out = _run(4, ["--steps", "3", "--overlap", "--no-profile"], emu_threads=2, timeout=1500)
+    dp = out["data_parallel"]
+    assert out["n_gpus"] == 4 and out["rccl_ranks"] == 4 and dp["comm_ranks"] == 4
+    assert dp["exchange"] == "overlap" and len(dp["ms_per_step_by_rank"]) == 4
+    assert dp["weights_identical_across_ranks"] is True
+    assert out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp4"
+
+
+def test_bench_flow_eight_ranks():
+    """... and the driver's largest launch, eight ranks (one step, flat exchange): one JSON line from rank 0, an all-reduce of ones
+    spans eight ranks, the replicas agree after the averaged-gradient step."""
+    out = _run(8, ["--no-profile"], emu_threads=1, timeout=1800)
+    dp = out["data_parallel"]
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and dp["comm_ranks"] == 8
+    assert len(dp["ms_per_step_by_rank"]) == 8 and dp["weights_identical_across_ranks"] is True
+    assert out["config"]["global_batch"] == 16 and out["config"]["parallelism"] == "dp8"

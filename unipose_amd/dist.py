@@ -68,6 +68,16 @@ class GradAllReducer:
         self._handles = []
         backend = dist.get_backend(group) if dist.is_initialized() else ""
         self._avg = backend == "nccl"              # gloo has no AVG: sum, then scale
+        if self.active and backend == "nccl":
+            # the weight-gradient side stream needs a hardware queue of its own next to RCCL's streams (ROCm maps HIP streams onto
+            # GPU_MAX_HW_QUEUES queues round-robin, default 4): unipose_amd/__init__.py exports 8 at import time, which only takes
+            # effect if that import precedes the first HIP call — say so loudly when the value in force is smaller
+            import warnings
+            hwq = int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0)
+            if hwq < 8:
+                warnings.warn(f"GradAllReducer: GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')!r} (< 8): the weight-gradient "
+                              "side stream may share a hardware queue with RCCL's streams (+10 ... +14 % per step measured); export "
+                              "GPU_MAX_HW_QUEUES=8 before the process touches the GPU", RuntimeWarning, stacklevel=2)
         # replicate the initial weights / buffers from rank 0 once (documented choice: BN running
         # statistics are NOT re-broadcast per step; each rank keeps its own like the reference would)
         if self.active:
