@@ -178,6 +178,14 @@ int up_conv2d_bwd_data(const up_conv_desc* d, const float* dy, const float* w_dg
  * [groups][up_conv_stats_tiles_grouped(d, groups)][K][3] — the layout up_bn_finalize_groups merges; no extra pass over y
  * (up_bn_batch_stats_t) is needed.  fp32 only, direct-to-LDS kernel with the LDS-transposed epilogue: up_conv_stats_tiles_grouped
  * returns 0 and up_conv2d_fwd_grouped UP_ERR_UNSUPPORTED (nothing launched) otherwise. */
+/* ABI 10 (row groups): the statistics pass and the finalize as one launch where the fold applies (else the two launches);
+ * and the grouped backward whose sums the data gradient already merged (up_bn_reduce_slot.gsum, folded = 1): the apply pass alone. */
+int up_bn_stats_groups_t(const void* y, int ldy, int64_t rows_per_group, int C, int groups, int dtype, float* stats, float eps,
+                         float momentum, float* running_mean, float* running_var, const float* gamma, const float* beta, float* coef,
+                         void* stream);
+int up_bn_bwd_groups_finalized_t(const void* dz, int lddz, const uint32_t* relu_bits, const void* y, int ldy, const float* gamma,
+                                 const float* coef, int relu, void* dy, int lddy, void* dres, int lddres, const float* gsum,
+                                 int64_t rows_per_group, int C, int groups, int dtype, void* stream);
 int up_bn_bwd_groups_prereduced_ok(int64_t rows_per_group, int C, int groups, int ld);
 int up_bn_bwd_groups_prereduced_t(const void* dz, int lddz, const uint32_t* relu_bits, const void* y, int ldy, const float* gamma,
                                   const float* coef, int relu, void* dy, int lddy, void* dres, int lddres, float* dgamma, float* dbeta,
@@ -196,7 +204,9 @@ typedef struct {
     int32_t group_stride;      /* row groups (ABI 8): floats between two groups' mean / invstd vectors, else 0     */
     float* dgamma;             /* ABI 10, optional pair: the launch also FINISHES the reduction (last-arriver ticket, see      */
     float* dbeta;              /* up_bn_fold): [C] sums over all rows; then up_bn_bwd_finalized_t runs the apply pass alone   */
-    int32_t folded;            /* out: 1 = dgamma / dbeta are final; 0 = call up_bn_bwd_prereduced_t on `partial`             */
+    float* gsum;               /* row groups (ep->groups > 1): [groups][dgamma | dbeta][C], every group's own sums (its data     */
+                               /* gradient needs them: up_bn_bwd_groups_finalized_t); NULL: a grouped launch does not fold        */
+    int32_t folded;            /* out: 1 = dgamma / dbeta (/ gsum) are final; 0 = call up_bn_bwd_(groups_)prereduced_t on `partial` */
 } up_bn_reduce_slot;
 typedef struct {
     const void* add;               /* second gradient of the same input (element type of dx), or NULL              */

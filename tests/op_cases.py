@@ -598,6 +598,7 @@ def bn_groups_chain_case(dev, groups, n, c, h, w, k1, k2, r2=1, tol=2e-5, seed=0
                 m.zero_grad(set_to_none=True)
             x = x0.clone().to(dev).requires_grad_(True)
             u0, b0 = ops.HOST_COUNTERS["bn_prereduced"], int(_C.lib().up_conv_counter(b"glds32_bnred"))
+            f0 = ops.HOST_COUNTERS["bn_bwd_folded"]
             q0 = int(_C.lib().up_conv_counter(b"glds32_grouped"))
             with ops.bn_groups(groups):
                 s1 = ops.BnSlot()
@@ -607,6 +608,8 @@ def bn_groups_chain_case(dev, groups, n, c, h, w, k1, k2, r2=1, tol=2e-5, seed=0
             ops.wgrad_fence()
             used = ops.HOST_COUNTERS["bn_prereduced"] - u0
             assert used == (1 if fused else 0), used
+            merged = ops.HOST_COUNTERS["bn_bwd_folded"] - f0
+            assert merged == (1 if fused else 0), merged     # round 6: that launch also merged every group's sums (bn_fold.h)
             assert (int(_C.lib().up_conv_counter(b"glds32_bnred")) - b0) == (1 if fused else 0)
             assert (int(_C.lib().up_conv_counter(b"glds32_grouped")) - q0) == (1 if fused else 0)
             out[fused] = {"y2": y2.detach().cpu(), "dx": x.grad.cpu(),
@@ -717,3 +720,48 @@ def bn_fold_case(dev, n, c, h, w, k1, k2, r2=1, dtype=torch.float32, cus=0, seed
     assert rel(out[1]["b1.running_mean"].double(), rm) < tol, rel(out[1]["b1.running_mean"].double(), rm)
     assert rel(out[1]["b1.running_var"].double(), rv) < tol, rel(out[1]["b1.running_var"].double(), rv)
     return counts[1]
+
+
+def bn_groups_fold_case(dev, groups, n, c, h, w, k1, k2, r2=1, seed=0):
+    """Row groups (ops.bn_groups) with the finalize folded into the producers — the statistics pass merges every group's partial
+    rows (up_bn_stats_groups_t), the grouped data gradient / reduce pass merges the backward sums per group and over the groups
+    (up_bn_reduce_slot.gsum) — against up_conv_tune("bn_fold", 0), where the stand-alone arrive kernels run the same merge tree:
+    EQUAL bits for outputs, gradients and running statistics."""
+    from unipose_amd import _C
+    torch.manual_seed(seed)
+    conv1, bn1 = torch.nn.Conv2d(c, k1, 1, bias=False), torch.nn.BatchNorm2d(k1)
+    conv2, bn2 = torch.nn.Conv2d(k1, k2, r2, padding=r2 // 2, bias=False), torch.nn.BatchNorm2d(k2)
+    with torch.no_grad():
+        for b in (bn1, bn2):
+            b.weight.uniform_(0.5, 1.5)
+            b.bias.normal_(0, 0.3)
+    mods = [m.to(dev).train() for m in (conv1, bn1, conv2, bn2)]
+    state0 = [{k_: v.clone() for k_, v in m.state_dict().items()} for m in mods]
+    x0 = torch.randn(groups * n, h, w, c) + torch.arange(groups).repeat_interleave(n).view(-1, 1, 1, 1) * 0.5
+    g0 = torch.randn(groups * n, h, w, k2)
+    L = _C.lib()
+    out, merged = {}, {}
+    try:
+        for fold in (1, 0):
+            _C.check(L.up_conv_tune(b"bn_fold", fold), "tune")
+            for m, s0 in zip(mods, state0):
+                m.load_state_dict(s0)
+                m.zero_grad(set_to_none=True)
+            x = x0.clone().to(dev).requires_grad_(True)
+            f0 = ops.HOST_COUNTERS["bn_bwd_folded"]
+            with ops.bn_groups(groups):
+                s1 = ops.BnSlot()
+                y1 = ops.conv_bn_act(x, mods[0], mods[1], relu=True, slot_out=s1)
+                y2 = ops.conv_bn_act(y1, mods[2], mods[3], relu=True, slot_in=s1)
+            (y2 * g0.to(dev)).sum().backward()
+            ops.wgrad_fence()
+            merged[fold] = ops.HOST_COUNTERS["bn_bwd_folded"] - f0
+            out[fold] = {"y2": y2.detach().cpu(), "dx": x.grad.cpu(),
+                         **{f"p{i}.{nm}": p.grad.cpu() for i, m in enumerate(mods) for nm, p in m.named_parameters()},
+                         **{f"b{i}.{nm}": b.detach().clone().cpu() for i, m in enumerate(mods) for nm, b in m.named_buffers()}}
+    finally:
+        _C.check(L.up_conv_tune(b"bn_fold", 1), "tune")
+    assert merged == {1: 1, 0: 0}, merged
+    for k_ in out[1]:
+        assert torch.equal(out[1][k_], out[0][k_]), (k_, float((out[1][k_].double() - out[0][k_].double()).abs().max()))
+    return merged

@@ -436,3 +436,12 @@ def test_debug_pack_mode_catches_a_weight_edited_behind_the_cache(emu_backend):
         assert torch.allclose(ops.conv_fwd_raw(x, w, cfg)[0], 2.0 * y0, rtol=1e-6, atol=1e-6)
     finally:
         ops.DEBUG_PACK = prev
+
+
+@pytest.mark.parametrize("cfg", [
+    (3, 2, 32, 13, 11, 32, 32, 1),     # 286 rows per group: 2 statistics chunks / 5 data-gradient tiles per group
+    (5, 1, 32, 40, 41, 64, 96, 1),     # five groups, 1640 rows each: 7 chunks, 26 tiles per group
+    (2, 3, 32, 24, 30, 32, 32, 3),     # 2160 rows per group = 34 tiles: two level-1 rows per group; 3x3 consumer
+])
+def test_grouped_bn_finalize_folded(emu_backend, cfg):
+    print(oc.bn_groups_fold_case(emu_backend, *cfg))

@@ -272,3 +272,12 @@ def test_bn_fold_is_deterministic_under_load():
             ref = got
         else:
             assert all(torch.equal(a, b) for a, b in zip(ref, got)), rep
+
+
+@pytest.mark.parametrize("cfg", [
+    (5, 8, 1024, 23, 23, 256, 256, 3),    # configs[3]: five frames of eight images, layer3
+    (5, 8, 64, 92, 92, 64, 64, 3),        # layer1: 67 712 rows per group
+    (3, 2, 64, 23, 23, 64, 128, 1),
+])
+def test_grouped_bn_finalize_folded(cfg):
+    print(oc.bn_groups_fold_case(DEV, *cfg))

@@ -41,7 +41,7 @@ class BnReduceSlot(C.Structure):
     """up_bn_reduce_slot"""
     _fields_ = [("y", C.c_void_p), ("relu_bits", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
                 ("partial", C.c_void_p), ("ld", C.c_int32), ("C", C.c_int32), ("group_stride", C.c_int32),
-                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("folded", C.c_int32)]
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("gsum", C.c_void_p), ("folded", C.c_int32)]
 
 
 class DgradEpilogue(C.Structure):
@@ -77,6 +77,8 @@ SIGNATURES = {
     "up_conv_stats_tiles_grouped": (_i, [_D, _i]),
     "up_conv2d_bwd_data_tiles_grouped": (_i, [_D, _i]),
     "up_bn_bwd_groups_prereduced_ok": (_i, [_i64, _i, _i, _i]),
+    "up_bn_stats_groups_t": (_i, [_p, _i, _i64, _i, _i, _i, _p, _f, _f, _p, _p, _p, _p, _p, _p]),
+    "up_bn_bwd_groups_finalized_t": (_i, [_p, _i, _p, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _i64, _i, _i, _i, _p]),
     "up_bn_bwd_groups_prereduced_t": (_i, [_p, _i, _p, _p, _i, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _sz, _p, _i, _i64, _i, _i, _i, _p]),
     "up_conv2d_fwd_grouped": (_i, [_D, _p, _p, _p, _p, _i, _p]),
     "up_bn_bwd_prereduced_t": (_i, [_p, _i, _p, _p, _i, _p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p, _p, _i, _i64, _i,

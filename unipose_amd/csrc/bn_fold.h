@@ -44,6 +44,13 @@ struct BnFold {
     // backward (nv = 2: partial rows are (sum g, invstd * sum g (y - mean)) per channel)
     float* dgamma;
     float* dbeta;
+    // row groups (the frames of the video model's batched trunk, ops.bn_groups): partial rows are [fgroups][tiles][C][nv], every
+    // group is merged on its own, ONE last arriver per channel column finishes all of them in group order — forward: the outputs
+    // of group g at + g * ostride floats (coef[g][4][C]: ostride = 4 C), the running statistics take the groups' momentum updates
+    // in order; backward: gsum[g][dgamma | dbeta][C] (ostride = 2 C: what group g's data gradient needs) and dgamma / dbeta = the
+    // sums over the groups.  fgroups <= 1: one group (gsum unused).
+    int fgroups, ostride;
+    float* gsum;
 };
 
 #ifdef UP_EMU
@@ -92,8 +99,11 @@ __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0
 // [c0, c0 + ncols) (c0 a multiple of FOLD_COLS; ncols <= 128).  `lds`: >= FOLD_LDS_BYTES of workgroup memory nobody else uses any more.
 constexpr int FOLD_LDS_BYTES = 4 * FOLD_COLS * 3 * 8 + 16;
 template <int NV>
-__device__ __forceinline__ void bn_fold_arrive(const BnFold& f, const float* partial, int tile, int c0, int ncols, unsigned char* lds) {
+__device__ __forceinline__ void bn_fold_arrive(const BnFold& f, const float* partial, int tile, int c0, int ncols, unsigned char* lds,
+                                               int fg = 0) {
     static_assert(NV == 2 || NV == 3, "backward sums or forward statistics");
+    const int FG = f.fgroups > 1 ? f.fgroups : 1;
+    partial += (size_t)fg * f.tiles * f.C * NV;      // this row group's partial rows
     double* const red = reinterpret_cast<double*>(lds);
     int* const flag = reinterpret_cast<int*>(lds + 4 * FOLD_COLS * 3 * 8);
     const int tid = threadIdx.x;
@@ -101,11 +111,12 @@ __device__ __forceinline__ void bn_fold_arrive(const BnFold& f, const float* par
     drain_stores();
     __syncthreads();      // the whole workgroup's partial row is out (and `lds` is free)
     const int g = tile / FOLD_G;
-    int* const tk = f.tickets + (size_t)(c0 / FOLD_COLS) * (f.groups + 1);
+    int* const tk = f.tickets + (size_t)(c0 / FOLD_COLS) * (FG * f.groups + 1);
+    const int row2 = fg * f.groups + g;              // this group's level-1 row (and ticket)
     if (tid == 0) {
         const int expect = f.tiles - g * FOLD_G < FOLD_G ? f.tiles - g * FOLD_G : FOLD_G;
-        const int last = ticket_take(tk + g) == expect - 1;
-        if (last) st_agent_flag(tk + g, 0);
+        const int last = ticket_take(tk + row2) == expect - 1;
+        if (last) st_agent_flag(tk + row2, 0);
         flag[0] = last;
     }
     __syncthreads();
@@ -150,7 +161,7 @@ __device__ __forceinline__ void bn_fold_arrive(const BnFold& f, const float* par
             for (int k = 0; k < NV; ++k) {
                 double t = red[cl * NV + k];
                 for (int rr = 1; rr < 4; ++rr) t += red[(rr * FOLD_COLS + cl) * NV + k];
-                st_agent_f64(f.part2 + ((size_t)g * f.C + c) * NV + k, t);
+                st_agent_f64(f.part2 + ((size_t)row2 * f.C + c) * NV + k, t);
             }
         }
         __syncthreads();
@@ -158,19 +169,17 @@ __device__ __forceinline__ void bn_fold_arrive(const BnFold& f, const float* par
     drain_stores();
     __syncthreads();
     if (tid == 0) {
-        const int last = ticket_take(tk + f.groups) == f.groups - 1;
-        if (last) st_agent_flag(tk + f.groups, 0);
+        const int last = ticket_take(tk + FG * f.groups) == FG * f.groups - 1;
+        if (last) st_agent_flag(tk + FG * f.groups, 0);
         flag[0] = last;
     }
     __syncthreads();
     if (!flag[0]) return;
-    // ---- level 2: row lane r takes groups r, r + 4, ... in order; lanes summed 0..3; one thread per channel finishes ----
+    // ---- level 2: per row group, row lane r takes level-1 rows r, r + 4, ... in order; lanes summed 0..3; one thread per channel
+    //      finishes the groups in order ----
     for (int cb = 0; cb < ncols; cb += FOLD_COLS) {
         const int c = c0 + cb + cl;
         const bool cok = cb + cl < ncols && c < f.C;
-        double s[NV];
-#pragma unroll
-        for (int k = 0; k < NV; ++k) s[k] = 0.0;
         // the finishing thread's per-channel operands ride with the level-1 rows (one round trip less on the launch's tail)
         float pg = 0.f, pb = 0.f, prm = 0.f, prv = 0.f;
         if constexpr (NV == 3) {
@@ -183,65 +192,86 @@ __device__ __forceinline__ void bn_fold_arrive(const BnFold& f, const float* par
                 }
             }
         }
-        if (cok) {
-            for (int gg = r; gg < f.groups; gg += 16) {   // four rows in flight
-                double v[4][NV];
+        double tot0 = 0.0, tot1 = 0.0;      // backward: sums over the row groups
+        for (int fgi = 0; fgi < FG; ++fgi) {
+            const double* const rows = f.part2 + (size_t)fgi * f.groups * f.C * NV;
+            double s[NV];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int g2 = gg + 4 * u;
-                    const double* p = f.part2 + ((size_t)(g2 < f.groups ? g2 : gg) * f.C + c) * NV;
+            for (int k = 0; k < NV; ++k) s[k] = 0.0;
+            if (cok) {
+                for (int gg = r; gg < f.groups; gg += 16) {   // four rows in flight
+                    double v[4][NV];
 #pragma unroll
-                    for (int k = 0; k < NV; ++k) v[u][k] = ld_agent_f64(p + k);
-                }
+                    for (int u = 0; u < 4; ++u) {
+                        const int g2 = gg + 4 * u;
+                        const double* p = rows + ((size_t)(g2 < f.groups ? g2 : gg) * f.C + c) * NV;
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (gg + 4 * u < f.groups) {
-#pragma unroll
-                        for (int k = 0; k < NV; ++k) s[k] += v[u][k];
+                        for (int k = 0; k < NV; ++k) v[u][k] = ld_agent_f64(p + k);
                     }
-            }
-        }
 #pragma unroll
-        for (int k = 0; k < NV; ++k) red[(r * FOLD_COLS + cl) * NV + k] = s[k];
-        __syncthreads();
-        if (r == 0 && cok) {
-            double t[NV];
+                    for (int u = 0; u < 4; ++u)
+                        if (gg + 4 * u < f.groups) {
 #pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                t[k] = red[cl * NV + k];
-                for (int rr = 1; rr < 4; ++rr) t[k] += red[(rr * FOLD_COLS + cl) * NV + k];
+                            for (int k = 0; k < NV; ++k) s[k] += v[u][k];
+                        }
+                }
             }
-            if constexpr (NV == 3) {
-                const double N = t[0];
-                const double md = N > 0.0 ? t[1] / N : 0.0;
-                double m2 = t[2] - t[1] * md;
-                if (m2 < 0.0) m2 = 0.0;
-                const float m = (float)md;
-                const float var = N > 0.0 ? (float)(m2 / N) : 0.f;
-                const float is = 1.0f / sqrtf(var + f.eps);
-                f.mean[c] = m;
-                f.invstd[c] = is;
-                const float sc = pg * is;
-                f.scale[c] = sc;
-                f.shift[c] = pb - m * sc;
-                if (f.rm) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) red[(r * FOLD_COLS + cl) * NV + k] = s[k];
+            __syncthreads();
+            if (r == 0 && cok) {
+                double t[NV];
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    t[k] = red[cl * NV + k];
+                    for (int rr = 1; rr < 4; ++rr) t[k] += red[(rr * FOLD_COLS + cl) * NV + k];
+                }
+                const size_t o = (size_t)fgi * f.ostride + c;
+                if constexpr (NV == 3) {
+                    const double N = t[0];
+                    const double md = N > 0.0 ? t[1] / N : 0.0;
+                    double m2 = t[2] - t[1] * md;
+                    if (m2 < 0.0) m2 = 0.0;
+                    const float m = (float)md;
+                    const float var = N > 0.0 ? (float)(m2 / N) : 0.f;
+                    const float is = 1.0f / sqrtf(var + f.eps);
+                    f.mean[o] = m;
+                    f.invstd[o] = is;
+                    const float sc = pg * is;
+                    f.scale[o] = sc;
+                    f.shift[o] = pb - m * sc;
                     const float unb = N > 1.0 ? (float)(m2 / (N - 1.0)) : var;
-                    f.rm[c] = (1.f - f.mom) * prm + f.mom * m;
-                    f.rv[c] = (1.f - f.mom) * prv + f.mom * unb;
+                    prm = (1.f - f.mom) * prm + f.mom * m;      // the groups' momentum updates, in order
+                    prv = (1.f - f.mom) * prv + f.mom * unb;
+                } else {
+                    if (FG > 1) {
+                        f.gsum[o] = (float)t[1];                  // dgamma of the group (sum g * xhat)
+                        f.gsum[o + f.C] = (float)t[0];            // dbeta of the group (sum g)
+                    }
+                    tot0 += t[0];
+                    tot1 += t[1];
+                }
+            }
+            __syncthreads();
+        }
+        if (r == 0 && cok) {
+            if constexpr (NV == 3) {
+                if (f.rm) {
+                    f.rm[c] = prm;
+                    f.rv[c] = prv;
                 }
             } else {
-                f.dbeta[c] = (float)t[0];
-                f.dgamma[c] = (float)t[1];
+                f.dbeta[c] = (float)tot0;
+                f.dgamma[c] = (float)tot1;
             }
         }
-        __syncthreads();
     }
 }
 
 // scratch of the fold on one stream (conv_igemm.hip owns the per-stream device memory): tickets + level-1 rows for a merge of
-// `tiles` partial rows over C channels with nv values each; false when it does not fit (the caller runs the stand-alone form,
-// which fails loudly) or the fold is switched off
-bool bn_fold_scratch(hipStream_t st, int tiles, int C, int nv, BnFold* f);
+// `tiles` partial rows (per row group) over C channels with nv values each; false when it does not fit (the caller runs the
+// stand-alone form, which fails loudly) or the fold is switched off
+bool bn_fold_scratch(hipStream_t st, int tiles, int C, int nv, BnFold* f, int fgroups = 1);
 bool bn_fold_enabled();
 
 }  // namespace up

@@ -187,8 +187,13 @@ template <int BN>
 __device__ __forceinline__ void igemm_fold_arrive(const IgemmArgs& a, int mt, int n0, unsigned char* lds) {
     if (a.fold.tickets == nullptr) return;   // uniform
     const int ncols = a.Ng - n0 < BN ? a.Ng - n0 : BN;
-    if (a.fold_nv == 3) bn_fold_arrive<3>(a.fold, a.stats, mt, n0, ncols, lds);
-    else bn_fold_arrive<2>(a.fold, a.bn_partial, mt, n0, ncols, lds);
+    int fg = 0, t = mt;
+    if (a.grp_rows) {   // row groups: tile mt % grp_tiles of group mt / grp_tiles
+        fg = fdiv(mt, a.fGrpTiles);
+        t = mt - fg * a.grp_tiles;
+    }
+    if (a.fold_nv == 3) bn_fold_arrive<3>(a.fold, a.stats, t, n0, ncols, lds, fg);
+    else bn_fold_arrive<2>(a.fold, a.bn_partial, t, n0, ncols, lds, fg);
 }
 
 __device__ __forceinline__ void wf_merge(float& n1, float& m1, float& s1, float n2, float m2, float s2) {
@@ -2100,11 +2105,11 @@ static bool tail_split_enabled() { return g_tail_split != 0; }
 // ---- BatchNorm fold (bn_fold.h) -----------------------------------------------------------------------
 static int g_bn_fold = env_int("UP_BN_FOLD", 1, 0);   // up_conv_tune("bn_fold", 0): producers leave the finalize to the stand-alone kernel (same bits)
 bool bn_fold_enabled() { return g_bn_fold != 0; }
-bool bn_fold_scratch(hipStream_t st, int tiles, int C, int nv, BnFold* f) {
-    if (tiles < 1 || C < 1) return false;
+bool bn_fold_scratch(hipStream_t st, int tiles, int C, int nv, BnFold* f, int fgroups) {
+    if (tiles < 1 || C < 1 || fgroups < 1) return false;
     const int groups = (tiles + FOLD_G - 1) / FOLD_G;
-    const size_t cols = (size_t)(C + FOLD_COLS - 1) / FOLD_COLS;
-    if (cols * (size_t)(groups + 1) > FOLD_TICKETS || (size_t)groups * C * nv * sizeof(double) > FOLD_PART2_BYTES) return false;
+    const size_t cols = (size_t)(C + FOLD_COLS - 1) / FOLD_COLS, rows2 = (size_t)fgroups * groups;
+    if (cols * (rows2 + 1) > FOLD_TICKETS || rows2 * C * nv * sizeof(double) > FOLD_PART2_BYTES) return false;
     std::lock_guard<std::mutex> lock(g_scratch_mu);
     SplitScratch& s = g_scratch[st];
     if (!s.tickets) {
@@ -2127,6 +2132,7 @@ bool bn_fold_scratch(hipStream_t st, int tiles, int C, int nv, BnFold* f) {
     f->tiles = tiles;
     f->groups = groups;
     f->C = C;
+    f->fgroups = fgroups;
     return true;
 }
 // what the entry point asked the next launch to fold (per host thread, consumed by launch_igemm / launch_igemm_bf16)
@@ -2141,8 +2147,9 @@ static void apply_fold(IgemmArgs& a, int tiles, hipStream_t st) {
     a.fold_nv = 0;
     const FoldRequest rq = g_fold_req;
     g_fold_req = FoldRequest();
-    if (!g_bn_fold || a.grp_rows) return;
-    if (rq.fwd && a.stats) {
+    if (!g_bn_fold) return;
+    const int fgroups = a.grp_rows ? a.M / a.grp_rows : 1;
+    if (rq.fwd && a.stats && !a.grp_rows) {
         up_bn_fold* q = rq.fwd;
         if (!bn_fold_scratch(st, tiles, a.Ng, 3, &a.fold)) return;
         a.fold.eps = q->eps;
@@ -2157,10 +2164,13 @@ static void apply_fold(IgemmArgs& a, int tiles, hipStream_t st) {
         a.fold.shift = q->shift;
         a.fold_nv = 3;
         q->folded = 1;
-    } else if (rq.bwd && a.bn_partial && rq.bwd->dgamma && rq.bwd->dbeta) {
-        if (!bn_fold_scratch(st, tiles, a.Ng, 2, &a.fold)) return;
+    } else if (rq.bwd && a.bn_partial && rq.bwd->dgamma && rq.bwd->dbeta && (fgroups == 1 || rq.bwd->gsum)) {
+        // row groups: `tiles` counts all groups' tiles; every group merges its own grp_tiles rows
+        if (!bn_fold_scratch(st, a.grp_rows ? a.grp_tiles : tiles, a.Ng, 2, &a.fold, fgroups)) return;
         a.fold.dgamma = rq.bwd->dgamma;
         a.fold.dbeta = rq.bwd->dbeta;
+        a.fold.gsum = rq.bwd->gsum;
+        a.fold.ostride = 2 * a.Ng;
         a.fold_nv = 2;
         rq.bwd->folded = 1;
     }
@@ -3003,7 +3013,7 @@ extern "C" int up_conv2d_bwd_data_ex(const up_conv_desc* d, const void* dy, cons
                "conv2d_bwd_data_ex: 16-byte alignment");
     g_extras_dropped = false;
     g_fold_req = FoldRequest();
-    if (slot && slot->dgamma && groups == 1) g_fold_req.bwd = slot;   // the launch also finishes dgamma / dbeta (bn_fold.h)
+    if (slot && slot->dgamma && (groups == 1 || slot->gsum)) g_fold_req.bwd = slot;   // the launch also finishes dgamma / dbeta (bn_fold.h)
     if (math == UP_MATH_BF16S) {
         UP_REQUIRE(!s2_decomposed(d->stride, d->dil) || !(slot || ep->add_relu_bits), UP_ERR_UNSUPPORTED, "conv2d_bwd_data_ex: stride 2");
         a.w = nullptr;

@@ -74,7 +74,7 @@ template <int NV>
 __global__ void __launch_bounds__(256) bn_fold_arrive_kernel(const float* partial, BnFold f) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[FOLD_LDS_BYTES];
     const int c0 = blockIdx.y * FOLD_COLS;
-    bn_fold_arrive<NV>(f, partial, blockIdx.x, c0, f.C - c0 < FOLD_COLS ? f.C - c0 : FOLD_COLS, lds);
+    bn_fold_arrive<NV>(f, partial, blockIdx.x, c0, f.C - c0 < FOLD_COLS ? f.C - c0 : FOLD_COLS, lds, blockIdx.z);
 }
 
 // One workgroup per channel: thread t merges the partials of row tiles t, t+256, ... (one or two independent loads for
@@ -485,8 +485,10 @@ static bool bn_rows_enabled() {
 // merged in a fixed order.
 constexpr int BNS_ROWS = 256;
 template <typename T>
-__global__ void __launch_bounds__(256) bn_batch_stats_kernel(const T* y, int ldy, int rows_per_group, int C, float* stats, int tiles) {
-    __shared__ float red[16][64][3];
+__global__ void __launch_bounds__(256) bn_batch_stats_kernel(const T* y, int ldy, int rows_per_group, int C, float* stats, int tiles,
+                                                             BnFold fold) {
+    __shared__ __attribute__((aligned(16))) float red[16][64][3];
+    static_assert(sizeof(float) * 16 * 64 * 3 >= FOLD_LDS_BYTES, "the fold's ticket re-uses the reduction buffer");
     const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.y * 64 + cq * 4;
     const int g = blockIdx.z;
@@ -533,11 +535,15 @@ __global__ void __launch_bounds__(256) bn_batch_stats_kernel(const T* y, int ldy
         for (int k = 0; k < 16; ++k) wf_merge3(cn, cm, cs, red[k][ch][0], red[k][ch][1], red[k][ch][2]);
         const int cc = blockIdx.y * 64 + ch;
         if (cc < C) {
-            float* o = stats + (((size_t)g * tiles + blockIdx.x) * C + cc) * 3;
-            o[0] = cn;
-            o[1] = cm;
-            o[2] = cs;
+            float* o = stats + (((size_t)g * tiles + blockIdx.x) * C + cc) * 3;   // (sc1: the fold's last arriver reads them)
+            st_agent(o, cn);
+            st_agent(o + 1, cm);
+            st_agent(o + 2, cs);
         }
+    }
+    if (fold.tickets) {   // uniform: this launch also finalizes every group (bn_fold.h, row groups)
+        const int c0 = blockIdx.y * 64;
+        bn_fold_arrive<3>(fold, stats, blockIdx.x, c0, C - c0 < 64 ? C - c0 : 64, reinterpret_cast<unsigned char*>(&red[0][0][0]), g);
     }
 }
 
@@ -593,6 +599,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* dz, int ldd
     if (z) z += grow0 * ldz;
     mean += (size_t)blockIdx.z * grp.pstride;
     invstd += (size_t)blockIdx.z * grp.pstride;
+    float* const partial0 = partial;                       // [groups][chunks][C][2]
     partial += (size_t)blockIdx.z * gridDim.x * C * 2;
     const int64_t bq0 = grow0 * (C >> 2);                  // quad index of the group's first element in the bit array
     const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
@@ -663,7 +670,8 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* dz, int ldd
     }
     if (fold.tickets) {   // uniform: this launch also finishes dgamma / dbeta (bn_fold.h)
         const int c0 = blockIdx.y * 64;
-        bn_fold_arrive<2>(fold, partial, blockIdx.x, c0, C - c0 < 64 ? C - c0 : 64, reinterpret_cast<unsigned char*>(&red[0][0][0]));
+        bn_fold_arrive<2>(fold, partial0, blockIdx.x, c0, C - c0 < 64 ? C - c0 : 64, reinterpret_cast<unsigned char*>(&red[0][0][0]),
+                          blockIdx.z);
     }
 }
 // pass 2: one workgroup per channel, thread t sums chunks t, t+256, ... (four independent loads per round), LDS tree;
@@ -1173,130 +1181,10 @@ extern "C" int up_bn_bwd(const float* dz, int lddz, const float* z, int ldz, con
                        lddres, dgamma, dbeta, workspace, workspace_bytes, rows, C, UP_DT_F32, stream);
 }
 
-// Grouped BatchNorm with up to BN_MAXG groups, ONE launch (round 4): a workgroup per channel merges the partials of every group
-// (one wave per group, see the kernel), writes coef[g] = mean, invstd, scale, shift per group and applies the groups' momentum
-// updates to the running statistics in order, from the merged (count, M2) themselves (the two-launch form recovered the variance
-// from invstd: 1 / invstd^2 - eps cancels for constant channels).
+// Grouped BatchNorm with up to BN_MAXG row groups: coefficients of every group + the running statistics (the groups' momentum
+// updates in order) / the per-group and total backward sums come from ONE merge (bn_fold.h with row groups) — folded into the
+// producing launch or stand-alone (bn_fold_arrive_kernel with grid.z = groups); more groups take the per-group kernels below.
 constexpr int BN_MAXG = 8;
-__global__ void __launch_bounds__(256) bn_finalize_allgroups_kernel(const float* stats, int tiles, int C, int groups, float eps, float mom,
-                                                                    float* rm, float* rv, const float* gamma, const float* beta,
-                                                                    float* coef) {
-    // one workgroup per channel; wave w merges groups w and w + 4: its 64 lanes stride over the group's tiles (two in flight per
-    // lane), then a six-level shuffle merge — no LDS tree and no barrier inside the reduction (the 8-level tree over 8 groups took
-    // 17 us per launch, 112 launches per UniPose-LSTM step on the forward's critical path)
-    __shared__ float fin[BN_MAXG][3];
-    const int c = blockIdx.x, t0 = threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int g = wave; g < groups; g += 4) {
-        float gn = 0.f, gm = 0.f, gq = 0.f;
-        const float* s = stats + ((size_t)g * tiles * C + c) * 3;
-        for (int t = lane; t < tiles; t += 128) {
-            const int t2 = t + 64;
-            const float* s1 = s + (size_t)t * C * 3;
-            const float* s2 = s + (size_t)(t2 < tiles ? t2 : t) * C * 3;
-            const float a0 = s1[0], a1 = s1[1], a2 = s1[2];
-            const float b0 = t2 < tiles ? s2[0] : 0.f, b1 = s2[1], b2 = s2[2];
-            wf_merge3(gn, gm, gq, a0, a1, a2);
-            wf_merge3(gn, gm, gq, b0, b1, b2);
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const float n2 = __shfl_down(gn, off), m2 = __shfl_down(gm, off), q2 = __shfl_down(gq, off);
-            if (lane + off < 64) wf_merge3(gn, gm, gq, n2, m2, q2);
-        }
-        if (lane == 0) {
-            fin[g][0] = gn;
-            fin[g][1] = gm;
-            fin[g][2] = gq;
-        }
-    }
-    __syncthreads();
-    float n[BN_MAXG], m[BN_MAXG], q[BN_MAXG];
-#pragma unroll
-    for (int g = 0; g < BN_MAXG; ++g) {
-        n[g] = g < groups ? fin[g][0] : 0.f;
-        m[g] = g < groups ? fin[g][1] : 0.f;
-        q[g] = g < groups ? fin[g][2] : 0.f;
-    }
-    if (t0 == 0) {
-        float rmean = rm ? rm[c] : 0.f, rvar = rv ? rv[c] : 0.f;
-#pragma unroll
-        for (int g = 0; g < BN_MAXG; ++g) {
-            if (g >= groups) break;
-            const float var = q[g] / n[g];
-            const float is = 1.0f / sqrtf(var + eps);
-            float* cg = coef + (size_t)g * 4 * C;
-            cg[c] = m[g];
-            cg[C + c] = is;
-            const float sc = gamma[c] * is;
-            cg[2 * C + c] = sc;
-            cg[3 * C + c] = beta[c] - m[g] * sc;
-            const float unb = n[g] > 1.f ? q[g] / (n[g] - 1.f) : var;
-            rmean = (1.f - mom) * rmean + mom * m[g];
-            rvar = (1.f - mom) * rvar + mom * unb;
-        }
-        if (rm) {
-            rm[c] = rmean;
-            rv[c] = rvar;
-        }
-    }
-}
-// backward twin: per-group sums of the chunk partials (gsum[g] = dgamma | dbeta of group g, what the data gradient of that
-// group needs) and their totals over the groups (the parameter gradients), one launch
-__global__ void __launch_bounds__(256) bn_bwd_finalize_allgroups_kernel(const float* partial, int chunks, int C, int groups, float* gsum,
-                                                                        float* dgamma, float* dbeta) {
-    __shared__ float red[256][BN_MAXG][2];
-    const int c = blockIdx.x, t0 = threadIdx.x;
-    float a[BN_MAXG], b[BN_MAXG];
-#pragma unroll
-    for (int g = 0; g < BN_MAXG; ++g) a[g] = b[g] = 0.f;
-    for (int t = t0; t < chunks; t += 256) {
-        float va[BN_MAXG], vb[BN_MAXG];
-#pragma unroll
-        for (int g = 0; g < BN_MAXG; ++g) {
-            const float* v = partial + (((size_t)(g < groups ? g : 0) * chunks + t) * C + c) * 2;
-            va[g] = g < groups ? v[0] : 0.f;
-            vb[g] = g < groups ? v[1] : 0.f;
-        }
-#pragma unroll
-        for (int g = 0; g < BN_MAXG; ++g) {
-            a[g] += va[g];
-            b[g] += vb[g];
-        }
-    }
-#pragma unroll
-    for (int g = 0; g < BN_MAXG; ++g) {
-        red[t0][g][0] = a[g];
-        red[t0][g][1] = b[g];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int off = 128; off >= 1; off >>= 1) {
-        if (t0 < off) {
-#pragma unroll
-            for (int g = 0; g < BN_MAXG; ++g) {
-                a[g] += red[t0 + off][g][0];
-                b[g] += red[t0 + off][g][1];
-                red[t0][g][0] = a[g];
-                red[t0][g][1] = b[g];
-            }
-        }
-        __syncthreads();
-    }
-    if (t0 == 0) {
-        float ta = 0.f, tb = 0.f;
-#pragma unroll
-        for (int g = 0; g < BN_MAXG; ++g) {
-            if (g >= groups) break;
-            gsum[(size_t)g * 2 * C + C + c] = a[g];      // dbeta of the group (sum g): layout of bn_bwd_finalize_kernel's outputs
-            gsum[(size_t)g * 2 * C + c] = b[g];          // dgamma of the group (sum g * xhat)
-            ta += b[g];
-            tb += a[g];
-        }
-        dgamma[c] = ta;
-        dbeta[c] = tb;
-    }
-}
-
 // running statistics after `groups` batches, in order (one thread per channel): the momentum updates of `groups` module calls
 __global__ void __launch_bounds__(256) bn_running_groups_kernel(const float* coef, int groups, int C, float n, float eps, float mom,
                                                                 float* rm, float* rv) {
@@ -1328,21 +1216,61 @@ __global__ void __launch_bounds__(256) bn_sum_groups_kernel(const float* gsum, i
 
 // ---- grouped BatchNorm: G row groups of equal size in one tensor, each normalised with its own batch statistics ------------
 extern "C" int up_bn_batch_stats_tiles(int64_t rows_per_group) { return cdiv(rows_per_group, BNS_ROWS); }
+namespace up {
+static void launch_bn_batch_stats(const void* y, int ldy, int64_t rows_per_group, int C, int groups, int dtype, float* stats,
+                                  const BnFold& fold, hipStream_t st) {
+    const int tiles = cdiv(rows_per_group, BNS_ROWS);
+    dim3 grid(tiles, cdiv(C, 64), groups);
+    if (dtype == UP_DT_BF16)
+        hipLaunchKernelGGL(bn_batch_stats_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)y, ldy, (int)rows_per_group, C, stats,
+                           tiles, fold);
+    else
+        hipLaunchKernelGGL(bn_batch_stats_kernel<float>, grid, dim3(256), 0, st, (const float*)y, ldy, (int)rows_per_group, C, stats,
+                           tiles, fold);
+}
+}  // namespace up
 extern "C" int up_bn_batch_stats_t(const void* y, int ldy, int64_t rows_per_group, int C, int groups, int dtype, float* stats,
                                    void* stream) {
     UP_REQUIRE(y && stats && rows_per_group > 0 && rows_per_group < (1ll << 31) && C > 0 && groups > 0 && groups <= 65535,
                UP_ERR_INVALID, "bn_batch_stats: bad argument");
     UP_REQUIRE(C % 4 == 0 && ldy % 4 == 0, UP_ERR_INVALID, "bn_batch_stats: C and ldy must be multiples of 4");
     UP_REQUIRE(dtype == UP_DT_F32 || dtype == UP_DT_BF16, UP_ERR_INVALID, "bn_batch_stats: dtype %d", dtype);
-    const int tiles = cdiv(rows_per_group, BNS_ROWS);
-    dim3 grid(tiles, cdiv(C, 64), groups);
-    if (dtype == UP_DT_BF16)
-        hipLaunchKernelGGL(bn_batch_stats_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), (const bf16_t*)y, ldy,
-                           (int)rows_per_group, C, stats, tiles);
-    else
-        hipLaunchKernelGGL(bn_batch_stats_kernel<float>, grid, dim3(256), 0, as_stream(stream), (const float*)y, ldy,
-                           (int)rows_per_group, C, stats, tiles);
+    BnFold none;
+    memset(&none, 0, sizeof(none));
+    launch_bn_batch_stats(y, ldy, rows_per_group, C, groups, dtype, stats, none, as_stream(stream));
     return check_launch("bn_batch_stats");
+}
+// ABI 10: up_bn_batch_stats_t + up_bn_finalize_groups as ONE launch where the fold applies (bn_fold.h with row groups: the statistics
+// pass's last workgroup per channel column merges every group's partial rows and writes coef[groups][4][C] + the running
+// statistics, the groups' momentum updates in order); else the two launches.
+extern "C" int up_bn_stats_groups_t(const void* y, int ldy, int64_t rows_per_group, int C, int groups, int dtype, float* stats,
+                                    float eps, float momentum, float* rm, float* rv, const float* gamma, const float* beta, float* coef,
+                                    void* stream) {
+    UP_REQUIRE(y && stats && gamma && beta && coef && rows_per_group > 0 && rows_per_group < (1ll << 31) && C > 0 && groups > 0 &&
+                   groups <= 65535, UP_ERR_INVALID, "bn_stats_groups: bad argument");
+    UP_REQUIRE(C % 4 == 0 && ldy % 4 == 0, UP_ERR_INVALID, "bn_stats_groups: C and ldy must be multiples of 4");
+    UP_REQUIRE(dtype == UP_DT_F32 || dtype == UP_DT_BF16, UP_ERR_INVALID, "bn_stats_groups: dtype %d", dtype);
+    UP_REQUIRE((rm == nullptr) == (rv == nullptr), UP_ERR_INVALID, "bn_stats_groups: running stats must come in pairs");
+    const int tiles = cdiv(rows_per_group, BNS_ROWS);
+    BnFold f;
+    memset(&f, 0, sizeof(f));
+    if (bn_fold_enabled() && groups <= BN_MAXG && bn_fold_scratch(as_stream(stream), tiles, C, 3, &f, groups)) {
+        f.eps = eps;
+        f.mom = momentum;
+        f.rm = rm;
+        f.rv = rv;
+        f.gamma = gamma;
+        f.beta = beta;
+        f.mean = coef;
+        f.invstd = coef + C;
+        f.scale = coef + 2 * C;
+        f.shift = coef + 3 * C;
+        f.ostride = 4 * C;
+        launch_bn_batch_stats(y, ldy, rows_per_group, C, groups, dtype, stats, f, as_stream(stream));
+        return check_launch("bn_stats_groups");
+    }
+    if (int e = up_bn_batch_stats_t(y, ldy, rows_per_group, C, groups, dtype, stats, stream)) return e;
+    return up_bn_finalize_groups(stats, tiles, C, groups, rows_per_group, eps, momentum, rm, rv, gamma, beta, coef, stream);
 }
 extern "C" int up_bn_exact_stats_t(const void* y, int ldy, int64_t rows_per_group, int C, int groups, int dtype, float* stats,
                                    void* stream) {
@@ -1368,9 +1296,23 @@ extern "C" int up_bn_finalize_groups(const float* stats, int tiles, int C, int g
     UP_REQUIRE((rm == nullptr) == (rv == nullptr), UP_ERR_INVALID, "bn_finalize_groups: running stats must come in pairs");
     // every group's partials are merged by its own workgroups (grid C x groups); the running statistics then take the groups'
     // momentum updates in order (the unbiased variance is recovered from invstd: var = 1 / invstd^2 - eps)
-    if (groups <= BN_MAXG) {   // one launch: coefficients of every group + the running statistics
-        hipLaunchKernelGGL(bn_finalize_allgroups_kernel, dim3(C), dim3(256), 0, as_stream(stream), stats, tiles, C, groups, eps,
-                           momentum, rm, rv, gamma, beta, coef);
+    BnFold f;
+    memset(&f, 0, sizeof(f));
+    if (groups <= BN_MAXG && bn_fold_scratch(as_stream(stream), tiles, C, 3, &f, groups)) {
+        // one launch, the fold's merge tree stand-alone (bn_fold.h with row groups: one workgroup per partial row that only
+        // arrives): coefficients of every group + the running statistics — the bits up_bn_stats_groups_t's folded form writes
+        f.eps = eps;
+        f.mom = momentum;
+        f.rm = rm;
+        f.rv = rv;
+        f.gamma = gamma;
+        f.beta = beta;
+        f.mean = coef;
+        f.invstd = coef + C;
+        f.scale = coef + 2 * C;
+        f.shift = coef + 3 * C;
+        f.ostride = 4 * C;
+        hipLaunchKernelGGL(bn_fold_arrive_kernel<3>, dim3(tiles, cdiv(C, FOLD_COLS), groups), dim3(256), 0, as_stream(stream), stats, f);
         return check_launch("bn_finalize_groups");
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C, groups), dim3(256), 0, as_stream(stream), stats, tiles, C, eps, momentum,
@@ -1425,31 +1367,43 @@ template <typename T>
 static bool launch_bn_bwd_groups(const T* dz, int lddz, const uint32_t* relu_bits, const T* y, int ldy, const float* gamma,
                                  const float* coef, int relu, T* dy, int lddy, T* dres, int lddres, float* dgamma, float* dbeta,
                                  float* workspace, int64_t rows, int C, int groups, hipStream_t st,
-                                 const float* prereduced = nullptr, int prereduced_tiles = 0) {
+                                 const float* prereduced = nullptr, int prereduced_tiles = 0, const float* finalized_gsum = nullptr) {
     constexpr int E = 16 / (int)sizeof(T);
     dim3 grid;
     int lcs = 0;
     if (!(lddz % E == 0 && ldy % E == 0 && lddy % E == 0 && (!dres || lddres % E == 0) && rows_geometry<T>(rows, C, grid, lcs)))
         return false;
     // prereduced: the data-gradient launch that produced dz (tiled per group, up_conv2d_bwd_data_ex with groups) already wrote
-    // [groups][prereduced_tiles][C][2] — pass 1 is skipped
+    // [groups][prereduced_tiles][C][2] — pass 1 is skipped;  finalized_gsum: that launch also merged them (bn_fold.h, row groups):
+    // gsum / dgamma / dbeta are final, the apply pass alone
     const int chunks = prereduced ? prereduced_tiles : cdiv(rows, BNB_ROWS);
-    float* gsum = workspace;                                   // [groups][dgamma | dbeta]
+    float* gsum = finalized_gsum ? const_cast<float*>(finalized_gsum) : workspace;      // [groups][dgamma | dbeta]
     const float* partial = prereduced ? prereduced : workspace + (size_t)groups * 2 * C;       // [groups][chunks][C][2]
     const GroupArgs ga{4 * C, 2 * C};
-    if (!prereduced) {
+    if (!finalized_gsum) {
+        BnFold f;
+        memset(&f, 0, sizeof(f));
+        const bool tree = groups <= BN_MAXG && bn_fold_scratch(st, chunks, C, 2, &f, groups);
+        f.dgamma = dgamma;
+        f.dbeta = dbeta;
+        f.gsum = gsum;
+        f.ostride = 2 * C;
+        const bool carried = tree && !prereduced && bn_fold_enabled();     // the reduce pass takes the tickets itself
         BnFold none;
         memset(&none, 0, sizeof(none));
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(chunks, cdiv(C, 64), groups), dim3(256), 0, st, dz, lddz, (const T*)nullptr, 0,
-                           relu_bits, y, ldy, coef, coef + C, relu, workspace + (size_t)groups * 2 * C, rows, C, BNB_ROWS, ga, none);
-    }
-    if (groups <= BN_MAXG) {
-        hipLaunchKernelGGL(bn_bwd_finalize_allgroups_kernel, dim3(C), dim3(256), 0, st, (const float*)partial, chunks, C, groups, gsum,
-                           dgamma, dbeta);
-    } else {
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C, groups), dim3(256), 0, st, (const float*)partial, chunks, C, gsum, gsum + C,
-                           (float*)nullptr, (float*)nullptr, ga);
-        hipLaunchKernelGGL(bn_sum_groups_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)gsum, groups, C, dgamma, dbeta);
+        if (!prereduced)
+            hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(chunks, cdiv(C, 64), groups), dim3(256), 0, st, dz, lddz, (const T*)nullptr, 0,
+                               relu_bits, y, ldy, coef, coef + C, relu, workspace + (size_t)groups * 2 * C, rows, C, BNB_ROWS, ga,
+                               carried ? f : none);
+        if (carried) {
+            // merged inside the reduce pass
+        } else if (tree) {      // the same merge tree stand-alone
+            hipLaunchKernelGGL(bn_fold_arrive_kernel<2>, dim3(chunks, cdiv(C, FOLD_COLS), groups), dim3(256), 0, st, (const float*)partial, f);
+        } else {
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C, groups), dim3(256), 0, st, (const float*)partial, chunks, C, gsum, gsum + C,
+                               (float*)nullptr, (float*)nullptr, ga);
+            hipLaunchKernelGGL(bn_sum_groups_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, (const float*)gsum, groups, C, dgamma, dbeta);
+        }
     }
     grid.z = groups;
     launch_bn_bwd_apply_rows<T>(grid, st, dz, lddz, (const T*)nullptr, 0, relu_bits, y, ldy, gamma, coef, coef + C, (const float*)gsum,
@@ -1516,6 +1470,23 @@ extern "C" int up_bn_bwd_groups_prereduced_t(const void* dz, int lddz, const uin
                                                   as_stream(stream), partial, tiles);
     UP_REQUIRE(done, UP_ERR_UNSUPPORTED, "bn_bwd_groups_prereduced: no row-strided geometry for C = %d (use up_bn_bwd_groups_t)", C);
     return check_launch("bn_bwd_groups_prereduced");
+}
+// ... and when that launch also MERGED the sums (up_bn_reduce_slot.gsum / dgamma / dbeta, folded = 1): the apply pass alone.
+extern "C" int up_bn_bwd_groups_finalized_t(const void* dz, int lddz, const uint32_t* relu_bits, const void* y, int ldy,
+                                            const float* gamma, const float* coef, int relu, void* dy, int lddy, void* dres, int lddres,
+                                            const float* gsum, int64_t rows_per_group, int C, int groups, int dtype, void* stream) {
+    UP_REQUIRE(dz && y && dy && gamma && coef && gsum && groups > 0 && groups <= BN_MAXG && rows_per_group > 0, UP_ERR_INVALID,
+               "bn_bwd_groups_finalized: bad argument (1..%d groups)", BN_MAXG);
+    UP_REQUIRE(dtype == UP_DT_F32, UP_ERR_UNSUPPORTED, "bn_bwd_groups_finalized: fp32 only");
+    UP_REQUIRE(!relu || relu_bits, UP_ERR_INVALID, "bn_bwd_groups_finalized: relu needs the sign bits of the forward output");
+    UP_REQUIRE(C % 4 == 0 && rows_per_group * (C / 4) < (1ll << 31), UP_ERR_UNSUPPORTED, "bn_bwd_groups_finalized: C %% 4 or tensor too large");
+    UP_REQUIRE(!relu_bits || (rows_per_group * C) % 32 == 0, UP_ERR_UNSUPPORTED,
+               "bn_bwd_groups_finalized: rows_per_group * C must be a multiple of 32");
+    const bool done = launch_bn_bwd_groups<float>((const float*)dz, lddz, relu_bits, (const float*)y, ldy, gamma, coef, relu, (float*)dy,
+                                                  lddy, (float*)dres, lddres, nullptr, nullptr, nullptr, rows_per_group, C, groups,
+                                                  as_stream(stream), nullptr, 0, gsum);
+    UP_REQUIRE(done, UP_ERR_UNSUPPORTED, "bn_bwd_groups_finalized: no row-strided geometry for C = %d", C);
+    return check_launch("bn_bwd_groups_finalized");
 }
 // does launch_bn_bwd_groups have a row-strided geometry for this shape (else up_bn_bwd_groups_prereduced_t refuses)?
 extern "C" int up_bn_bwd_groups_prereduced_ok(int64_t rows_per_group, int C, int groups, int ld) {

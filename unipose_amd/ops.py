@@ -521,19 +521,20 @@ class BnSlot:
     moves — the kernels' raw writes never touch it), so the producer's backward uses the sums only if dz has the address AND the
     version the consumer's launch left, else it falls back to its own reduction.  The producer fills y / bits / mean / invstd in
     its forward; the consumer's backward fills partial, dz_ptr and dz_version."""
-    __slots__ = ("y", "bits", "mean", "invstd", "C", "partial", "dz_ptr", "dz_version", "groups", "gstride", "dgb")
+    __slots__ = ("y", "bits", "mean", "invstd", "C", "partial", "dz_ptr", "dz_version", "groups", "gstride", "dgb", "gsum")
 
     def __init__(self, y=None, bits=None, mean=None, invstd=None, C=0):
         self.y, self.bits, self.mean, self.invstd, self.C = y, bits, mean, invstd, C
         self.partial, self.dz_ptr, self.dz_version = None, 0, -1
         # (2, C) dgamma / dbeta when the consumer's launch also carried the merge of its partial rows (up_bn_reduce_slot.folded)
         self.dgb = None
+        self.gsum = None       # (groups, 2, C) per-group sums of a grouped launch that merged them (up_bn_reduce_slot.gsum)
         # row groups (ops.bn_groups): mean / invstd are the first group's vectors inside coef[groups][4][C], gstride = 4 * C floats
         # to the next group's; the consumer's data gradient is tiled per group and partial is [groups * tiles][C][2]
         self.groups, self.gstride = 1, 0
 
     def clear(self):
-        self.y = self.bits = self.mean = self.invstd = self.partial = self.dgb = None
+        self.y = self.bits = self.mean = self.invstd = self.partial = self.dgb = self.gsum = None
         self.dz_ptr, self.dz_version = 0, -1
         self.groups, self.gstride = 1, 0
 
@@ -605,10 +606,15 @@ def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev, add=None, bn_slo
                 bn_slot.invstd.data_ptr()
             sl.partial, sl.ld, sl.C = partial.data_ptr(), _nhwc_ok(bn_slot.y), d.C
             sl.group_stride = bn_slot.gstride if groups > 1 else 0
-            dgb = None
-            if groups == 1 and not _DEFER["on"]:      # the launch also finishes dgamma / dbeta (last-arriver merge, up_bn_reduce_slot)
+            dgb = gsum = None
+            # the launch also finishes dgamma / dbeta (last-arriver merge, up_bn_reduce_slot); under ops.deferred_wgrad only for
+            # row groups (their backward sums every use into one buffer itself, the ungrouped one uses the accumulating finalize)
+            if groups > 1 or not _DEFER["on"]:
                 dgb = torch.empty((2, d.C), dtype=torch.float32, device=dev)
                 sl.dgamma, sl.dbeta = dgb[0].data_ptr(), dgb[1].data_ptr()
+                if groups > 1:
+                    gsum = torch.empty((groups, 2, d.C), dtype=torch.float32, device=dev)
+                    sl.gsum = gsum.data_ptr()
             ep.bn = C.pointer(sl)
             ep.groups = groups
         if ex_math == MATH_BF16S:
@@ -622,6 +628,7 @@ def conv_bwd_data_raw(dy, weight, d: _C.ConvDesc, x_shape, dev, add=None, bn_slo
         if want_slot:
             bn_slot.partial, bn_slot.dz_ptr, bn_slot.dz_version = partial, dx.data_ptr(), dx._version
             bn_slot.dgb = dgb if (dgb is not None and sl.folded) else None
+            bn_slot.gsum = gsum if bn_slot.dgb is not None else None
         return dx
     if dy.dtype == torch.bfloat16:
         if d.Kp % 32 or (add is not None and add.dtype != dy.dtype):
@@ -967,15 +974,20 @@ class ConvBnAct(Function):
                 raise ValueError(f"Expected more than 1 value per channel when training, got input size "
                                  f"{(d.N // groups, k, d.P, d.Q)}")
             coef = torch.empty((groups, 4, k), dtype=torch.float32, device=dev)   # per group: mean, invstd, scale, shift
+            done = False
             if fused is None:
                 tiles = 1 if rpg <= EXACT_STATS_ROWS else L.up_bn_batch_stats_tiles(rpg)
                 st = torch.empty((groups, tiles, k, 3), dtype=torch.float32, device=dev)
                 if rpg <= EXACT_STATS_ROWS:
                     _C.check(L.up_bn_exact_stats_t(y.data_ptr(), d.ldy, rpg, k, groups, _dt(y), st.data_ptr(), _stream(x)), "bn_exact_stats")
-                else:
-                    _C.check(L.up_bn_batch_stats_t(y.data_ptr(), d.ldy, rpg, k, groups, _dt(y), st.data_ptr(), _stream(x)), "bn_batch_stats")
-            _C.check(L.up_bn_finalize_groups(st.data_ptr(), tiles, k, groups, rpg, eps, momentum, _ptr(rm), _ptr(rv),
-                                             gamma.data_ptr(), beta.data_ptr(), coef.data_ptr(), _stream(x)), "bn_finalize_groups")
+                else:       # statistics pass + finalize of every group in ONE launch (the pass's last workgroups merge, bn_fold.h)
+                    _C.check(L.up_bn_stats_groups_t(y.data_ptr(), d.ldy, rpg, k, groups, _dt(y), st.data_ptr(), eps, momentum,
+                                                    _ptr(rm), _ptr(rv), gamma.data_ptr(), beta.data_ptr(), coef.data_ptr(),
+                                                    _stream(x)), "bn_stats_groups")
+                    done = True
+            if not done:
+                _C.check(L.up_bn_finalize_groups(st.data_ptr(), tiles, k, groups, rpg, eps, momentum, _ptr(rm), _ptr(rv),
+                                                 gamma.data_ptr(), beta.data_ptr(), coef.data_ptr(), _stream(x)), "bn_finalize_groups")
         elif train:
             small = x.shape[0] * ((x.shape[1] + 2 * cfg.pad - cfg.dil * (weight.shape[2] - 1) - 1) // cfg.stride + 1) * \
                 ((x.shape[2] + 2 * cfg.pad - cfg.dil * (weight.shape[3] - 1) - 1) // cfg.stride + 1) <= EXACT_STATS_ROWS
@@ -1098,6 +1110,15 @@ class ConvBnAct(Function):
                 # the data-gradient launch that wrote dz (tiled per group) already reduced every group's sums
                 partial, so.partial, so.dz_ptr, so.dz_version = so.partial, None, 0, -1
                 HOST_COUNTERS["bn_prereduced"] += 1
+                done, gsum, so.dgb, so.gsum = so.dgb, so.gsum, None, None
+                if done is not None and gsum is not None:      # ... and merged them: the apply pass alone
+                    HOST_COUNTERS["bn_bwd_folded"] += 1
+                    dgb = done
+                    _C.check(L.up_bn_bwd_groups_finalized_t(dz.data_ptr(), d.ldy, _ptr(bits), y.data_ptr(), d.ldy, gamma.data_ptr(),
+                                                            coef.data_ptr(), int(ctx.relu), dy.data_ptr(), d.ldy, _ptr(dres), d.ldy,
+                                                            gsum.data_ptr(), rpg, k, ctx.groups, _dt(y), _stream(x)),
+                             "bn_bwd_groups_finalized")
+                    return ConvBnAct._finish_backward(ctx, x, weight, d, dy, dres, dgb, True, (dz, bits) if masked else None)
                 _C.check(L.up_bn_bwd_groups_prereduced_t(dz.data_ptr(), d.ldy, _ptr(bits), y.data_ptr(), d.ldy, gamma.data_ptr(),
                                                          coef.data_ptr(), int(ctx.relu), dy.data_ptr(), d.ldy, _ptr(dres), d.ldy,
                                                          dgb[0].data_ptr(), dgb[1].data_ptr(), ws.data_ptr(), ws.numel(),
