@@ -41,7 +41,7 @@ def _same(a, b, what):
                              f"first at {tuple(int(i) for i in (d > 0).nonzero()[0])}")
 
 
-DEFAULTS = dict(glds32=1, glds32_epi=1, glds32_wgrad=1, tile_want=1500, cu_count=0)
+DEFAULTS = dict(glds32=1, glds32_epi=1, glds32_wgrad=1, tile_want=1500, cu_count=0, breg=0)
 
 
 def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, affine=False, residual=False, relu=False,
@@ -89,6 +89,19 @@ def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, 
             if stats:
                 _same(s1, s0, "BatchNorm partials " + tag)
             _same(dx1, dx0, "dx " + tag)
+        if r == 1 and stride == 1:
+            # round 6: the hybrid operand path (f32_glds.h BREG: weight fragments global -> registers, activations through LDS-DMA)
+            # of the pointwise launches — same values, same k order: equal bits in every epilogue form
+            for epi in forms:
+                _tune(glds32=1, glds32_epi=epi, glds32_wgrad=1, breg=1)
+                b0 = cnt("glds32_breg")
+                y2, s2, dx2, _ = run()
+                assert cnt("glds32_breg") > b0, "the pointwise case never reached the hybrid kernel"
+                tag = f"breg, epi={epi}"
+                _same(y2, y0, "y " + tag)
+                if stats:
+                    _same(s2, s0, "BatchNorm partials " + tag)
+                _same(dx2, dx0, "dx " + tag)
     finally:
         _tune(**DEFAULTS)
     return y0
@@ -180,6 +193,8 @@ SMALL = [
     dict(n=2, c=64, h=9, w=9, k=128, r=1, stride=2, pad=0, dil=1, tile_want=1, stats=True),          # 1x1 stride 2 (down-sampling branch)
     dict(n=1, c=160, h=5, w=5, k=34, r=1, stride=1, pad=0, dil=1, tile_want=1),                      # five slices, N = 34 (not a multiple of 4: dword epilogue)
     dict(n=1, c=32, h=6, w=6, k=32, r=5, stride=1, pad=2, dil=1, tile_want=1, stats=True),           # 25 taps (> 16: no tap sort, live-tap skipping only)
+    dict(n=3, c=96, h=7, w=9, k=200, r=1, stride=1, pad=0, dil=1, tile_want=1, stats=True, add=True),  # 1x1, three slices (odd count: the unrolled loop's tail), N = 200 (ragged 128-wide tile), 189 rows
+    dict(n=2, c=32, h=9, w=9, k=72, r=1, stride=1, pad=0, dil=1, tile_want=100000, stats=True),      # 1x1, ONE slice, 64x64 tiles, N = 72
 ]
 
 # K-split tail tiles (chip shrunk to `cus` CUs): whole rounds + tail parts in one launch
@@ -188,6 +203,7 @@ SPLIT = [
     dict(n=2, c=128, h=6, w=6, k=72, r=3, stride=1, pad=1, dil=1, tile_want=1, add=True, cus=0),          # one 128x128 tile: every tile split
     dict(n=4, c=64, h=7, w=7, k=64, r=3, stride=1, pad=3, dil=3, tile_want=100000, stats=True, cus=3),    # tap-sorted, tiles with different live taps
     dict(n=1, c=256, h=5, w=5, k=64, r=1, stride=1, pad=0, dil=1, tile_want=1, affine=True, relu=True, residual=True, cus=0),   # 1x1 8 slices, folded epilogue
+    dict(n=4, c=160, h=7, w=7, k=128, r=1, stride=1, pad=0, dil=1, tile_want=100000, stats=True, cus=3),   # 1x1, 4 x 2 tiles of 64x64 on a 3-CU chip: K-split tails with an odd slice count per part
 ]
 
 # more than 32 filter taps: the WIDE form of the forward / data-gradient kernel (separable row / column masks, every tap visited)

@@ -28,7 +28,7 @@ def main():
     model, opt, _ = bench.make_workload(dev, False, 16, args.batch, args.size, 1, seed=0)
     x = torch.randn(args.batch, 3, args.size, args.size, device=dev)
     t = torch.rand(args.batch, 17, args.size // 8, args.size // 8, device=dev)
-    names = ["zero_grad", "forward", "backward", "optimizer"]
+    names = ["(nothing)", "zero_grad", "forward", "backward", "optimizer"]
 
     def one(rec):
         def mark():
@@ -36,6 +36,7 @@ def main():
             e.record()
             rec.append((time.perf_counter(), e))
         mark()
+        mark()              # two consecutive records: what an empty interval reads
         opt.zero_grad(set_to_none=True)
         mark()
         loss = ops.mse_loss(model(x), t)
@@ -61,20 +62,20 @@ def main():
     wall = (time.perf_counter() - base_h) * 1e3 / args.steps
     print(f"wall per step {wall:.2f} ms (unsynchronised loop of {args.steps} steps)")
     print(f"{'step':>4} " + " ".join(f"{n + ' host/gpu':>22}" for n in names) + f" {'lead at: fwd end':>18} {'bwd end':>9} {'opt end':>9}")
-    tot_h = [0.0] * 4
-    tot_g = [0.0] * 4
+    tot_h = [0.0] * 5
+    tot_g = [0.0] * 5
     for i, r in enumerate(recs):
         h = [(a - base_h) * 1e3 for a, _ in r]
         g = [base_e.elapsed_time(e) for _, e in r]
         cells = []
-        for k in range(4):
+        for k in range(5):
             tot_h[k] += h[k + 1] - h[k]
             tot_g[k] += g[k + 1] - g[k]
             cells.append(f"{h[k + 1] - h[k]:9.2f} /{g[k + 1] - g[k]:9.2f}  ")
-        lead = [g[k] - h[k] for k in (2, 3, 4)]
+        lead = [g[k] - h[k] for k in (3, 4, 5)]
         print(f"{i:4d} " + " ".join(cells) + f" {lead[0]:18.2f} {lead[1]:9.2f} {lead[2]:9.2f}")
     n = len(recs)
-    print("mean " + " ".join(f"{tot_h[k] / n:9.2f} /{tot_g[k] / n:9.2f}  " for k in range(4)))
+    print("mean " + " ".join(f"{tot_h[k] / n:9.2f} /{tot_g[k] / n:9.2f}  " for k in range(5)))
     print(f"host issue time per step {sum(tot_h) / n:.2f} ms; GPU time per step {sum(tot_g) / n:.2f} ms")
 
 

@@ -2394,11 +2394,22 @@ static bool glds32_epi1_ok(const IgemmArgs& a) {
     const uintptr_t ptrs = reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.residual);
     return g_glds32_epi && !a.o_mode && a.Ng % 4 == 0 && a.ldy % 4 == 0 && (!a.residual || a.ldr % 4 == 0) && (ptrs & 15) == 0;
 }
+// "hybrid" operand path of the direct-to-LDS fp32 kernel (f32_glds.h BREG): weight fragments global -> registers.  0: off,
+// 1: pointwise (1x1) launches.  up_conv_tune("breg", v) / UP_BREG.
+static int g_breg = env_int("UP_BREG", 0, 0);
+static long long g_count_glds32_breg = 0;
 template <int BM, int BN>
 static auto glds32_kernel(const IgemmArgs& a) -> void (*)(IgemmArgs) {
     constexpr int OCC2 = (BM == 128 && BN == 128) ? 2 : (BM == 64 && BN == 64) ? 4 : 3;
     const bool epi1 = glds32_epi1_ok(a);
     const bool bnred = epi1 && a.bn_partial != nullptr;
+    // (the 64x64 form with the fused reduction would spill: 128 VGPRs at four workgroups per CU; it keeps the LDS operand path)
+    if (g_breg && a.taps == 1 && !a.perm && !(bnred && BM == 64 && BN == 64)) {
+        ++g_count_glds32_breg;
+        if (bnred) return glds::igemm_glds32_kernel<BM, BN, false, 2, OCC2, 1, true, false, true>;
+        if (epi1) return glds::igemm_glds32_kernel<BM, BN, false, 2, OCC2, 1, false, false, true>;
+        return glds::igemm_glds32_kernel<BM, BN, false, 2, OCC2, 0, false, false, true>;
+    }
     // (a one-stage form — 21 KB of LDS, six 64x64 workgroups per CU — for reductions shorter than 1024 measured 0.4 ms per step
     //  SLOWER than two stages at four per CU, profiles/r04_a_*, and is not instantiated)
     if (a.perm) {
@@ -2565,6 +2576,7 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "tap_sort")) g_tap_sort = value ? 1 : 0;
     else if (!strcmp(key, "wgrad_rect")) g_wgrad_rect = value ? 1 : 0;
     else if (!strcmp(key, "bn_fold")) g_bn_fold = value ? 1 : 0;
+    else if (!strcmp(key, "breg") && value >= 0) g_breg = value;
     else UP_REQUIRE(false, UP_ERR_INVALID, "conv_tune: unknown key '%s'", key);
     return UP_OK;
 }
@@ -2577,6 +2589,7 @@ extern "C" long long up_conv_counter(const char* name) {
     if (!strcmp(name, "glds32_grouped")) return g_count_glds32_grouped;
     if (!strcmp(name, "glds32_epi1")) return g_count_glds32_epi1;
     if (!strcmp(name, "glds32_bnred")) return g_count_glds32_bnred;
+    if (!strcmp(name, "glds32_breg")) return g_count_glds32_breg;
     if (!strcmp(name, "wgrad_glds32")) return g_count_wgrad32;
     if (!strcmp(name, "wgrad_glds32_st1")) return g_count_wgrad32_st1;
     return -1;

@@ -28,10 +28,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 #endif
 
-template <int BM, int BN, int ST>
+template <int BM, int BN, int ST, bool BREG = false>
 struct GeomF {
     static constexpr int ROWB = 128, CH = 8, RPI = 8;                   // bytes per row slice, 16-byte chunks per row, rows per LDS-DMA instruction
-    static constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    // BREG: the weight operand never enters LDS (its fragments go global -> registers), a stage holds the activation slice only
+    static constexpr int A_BYTES = BM * ROWB, B_BYTES = BREG ? 0 : BN * ROWB, STAGE = A_BYTES + B_BYTES;
     static constexpr int IMG_LD = BN + 8;                               // floats: rows 4 apart land 32 banks apart
     static constexpr int IMG_BYTES = BM * IMG_LD * 4;
     static constexpr int XCH_BYTES = BN * 12;                           // BatchNorm statistics exchange between the two M-waves
@@ -44,9 +45,9 @@ struct GeomF {
 };
 
 // LDS-transposed epilogue: see the header comment.  `smem` must be free (every wave past its last fragment read).
-template <int BM, int BN, bool PERM, int ST, bool BNRED, int UNITS_PF>
+template <int BM, int BN, bool PERM, int ST, bool BNRED, int UNITS_PF, bool BREG = false>
 struct Epi32 {
-    using G = GeomF<BM, BN, ST>;
+    using G = GeomF<BM, BN, ST, BREG>;
     static constexpr int TM = BM / 64, TN = BN / 64;
     static constexpr int CQ = BN / 4;                    // float4 chunks per tile row
     static constexpr int UNITS = BM * CQ / 256;          // (row, chunk) units per thread
@@ -319,16 +320,21 @@ struct Epi32 {
 //       bit r: filter row r reads a real pixel row, bit 16 + s: filter column s a real column (R, S <= 16) — instead of one bit per
 //       tap, every tap is visited (no tile-level skipping: with pad = 5 on 46x46 maps nearly every tap is live for some row of a
 //       tile), no tap-sorted rows.  Same slice order (tap-major, 32 channels per slice) as the register-staged per-slice-tap path.
-template <int BM, int BN, bool PERM, int ST = 2, int OCC = 4, int EPI = 1, bool BNRED = false, bool WIDE = false>
+// BREG (round 6, "hybrid" operand path): the B (weight) fragments go global -> registers, one slice ahead of their MFMAs, and
+//       only the A (activation) slice goes through LDS-DMA: half the LDS-DMA writes and half the fragment reads per MFMA — the two
+//       that collide in the LDS (profiles/r05_z_mix_probe.txt: MFMA + both 126 TF, hybrid 130).  Same values, same k order: bit-
+//       identical results.  Weight rows >= N are clamped to the last row (their columns are never stored).  Two LDS stages only.
+template <int BM, int BN, bool PERM, int ST = 2, int OCC = 4, int EPI = 1, bool BNRED = false, bool WIDE = false, bool BREG = false>
 __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
-    using G = GeomF<BM, BN, ST>;
+    using G = GeomF<BM, BN, ST, BREG>;
+    static_assert(!BREG || ST == 2, "the register operand is double-buffered with the two LDS stages");
     static_assert(ST == 1 || ST == 2, "one or two LDS stages");
     static_assert(!BNRED || EPI == 1, "the fused reduction lives in the LDS-transposed epilogue");
     static_assert(!WIDE || (!PERM && !BNRED), "the > 32-tap form has no tap-sorted rows and no fused reduction");
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int NA = BM / (4 * G::RPI), NB = BN / (4 * G::RPI);   // LDS-DMA instructions per wave, slice and operand
     constexpr int UNITS = BM * BN / 1024;
-    using E = Epi32<BM, BN, PERM, ST, BNRED, (UNITS <= 4 ? UNITS : 0)>;
+    using E = Epi32<BM, BN, PERM, ST, BNRED, (UNITS <= 4 ? UNITS : 0), BREG>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::TOTAL];
     unsigned* const wmask = reinterpret_cast<unsigned*>(smem + G::MASK_OFF);
 
@@ -372,7 +378,27 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
         const int n = n0 + row;
         woffB[j] = n < a.Ng ? (uint32_t)n * (uint32_t)a.Ktot * 4u + (uint32_t)((slot ^ G::swz(row)) << 4) : OOB;
     }
+    // BREG: this lane's B rows (column n = n0 + wn * BN/2 + 32 j + l31, clamped) as element offsets into the weight image, and the
+    // two register sets of B fragments: breg[set][k-group][j] = B[n][slice k0 + (2 g + lh) * 4 .. + 3]
+    int browB[TN];
+    f32x4 breg[2][4][TN];
+    if constexpr (BREG) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 32 + l31;
+            browB[j] = (n < a.Ng ? n : a.Ng - 1) * a.Ktot + lh * 4;
+        }
+    }
+    auto loadB = [&](auto set_tag, int tap_, int cs_) {
+        constexpr int SET = decltype(set_tag)::value;
+        const float* const wk = a.w + tap_ * a.Cp + cs_ * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) breg[SET][g][j] = *reinterpret_cast<const f32x4*>(wk + browB[j] + g * 8);
+    };
     auto issueB = [&](int stage, int tap_, int cs_) {
+        if constexpr (BREG) return;
         unsigned char* const Bs = smem + stage * G::STAGE + G::A_BYTES;
         const uint32_t kb = (uint32_t)(tap_ * a.Cp + cs_ * 32) * 4u;
 #pragma unroll
@@ -381,7 +407,7 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
     };
     // 1x1, stride 1, no padding: the source pixel IS the destination pixel, and the first weight slice depends on no row set-up
     const bool pointwise = a.taps == 1 && a.mul == 1 && a.off0 == 0 && a.off0w == 0 && a.H == a.P && a.W == a.Q;
-    const bool early_b = pointwise && !split;
+    const bool early_b = pointwise && !split && !BREG;
     if (early_b) issueB(0, 0, 0);
 
     int roffA[NA];        // byte offset of (filter tap (0,0), this lane's chunk) of the row in the activation tensor
@@ -451,7 +477,7 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
     }
 
     bool b_issued = early_b;   // the weight slice of the first issue is already on its way
-    auto issue = [&](int stage) {
+    auto issue = [&](int stage, auto set_tag) {      // set_tag: BREG's register set of the slice being issued (= its LDS stage)
         unsigned char* const As = smem + stage * G::STAGE;
         const int r = fdiv(tap, a.fS);
         const int sx = tap - r * a.S;
@@ -461,6 +487,7 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
             const bool ok = WIDE ? (((tmA[i] >> r) & (tmA[i] >> (16 + sx))) & 1u) != 0u : ((tmA[i] >> tap) & 1u) != 0u;
             load16_to_lds(rsA, ok ? (uint32_t)(roffA[i] + delta) : OOB, As + (wave + 4 * i) * 1024);
         }
+        if constexpr (BREG) loadB(set_tag, tap, cs);
         if (!b_issued) issueB(stage, tap, cs);
         b_issued = false;
         if (++cs == spt) {   // next live tap
@@ -486,7 +513,8 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
     const int swz = G::swz(l31) << 4;
     const int a_rd = (wm * (BM / 2) + l31) * G::ROWB;
     const int b_rd = G::A_BYTES + (wn * (BN / 2) + l31) * G::ROWB;
-    auto mfmas = [&](const unsigned char* base) {
+    auto mfmas = [&](const unsigned char* base, auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
         // (a plain vector type, not HIP's float4 struct: with the struct's loads the compiler put an `s_waitcnt vmcnt(0)` in
         //  front of the first fragment read of every slice — it could not tell the LDS-DMA writes of the NEXT slice, just
         //  issued into the other stage, from the stage being read — which serialised load and compute)
@@ -495,8 +523,13 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
             const int col = ((2 * g + lh) << 4) ^ swz;
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[b][i] = *reinterpret_cast<const f32x4*>(base + a_rd + i * 32 * G::ROWB + col);
+            if constexpr (BREG) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[b][j] = *reinterpret_cast<const f32x4*>(base + b_rd + j * 32 * G::ROWB + col);
+                for (int j = 0; j < TN; ++j) bf[b][j] = breg[SET][g][j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[b][j] = *reinterpret_cast<const f32x4*>(base + b_rd + j * 32 * G::ROWB + col);
+            }
         };
         frag(0, 0);
 #pragma unroll
@@ -513,10 +546,11 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
         }
         // pin the order: the fragment reads of k-group g + 1 BEFORE the MFMAs of group g (left alone, the scheduler issues each
         // read pair right before its use and the wave waits out the LDS latency four times per slice)
-        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+        constexpr int NDS = BREG ? TM : TM + TN;      // LDS fragment reads per k-group
+        __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (g + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            if (g + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
         }
     };
@@ -526,27 +560,48 @@ __global__ void __launch_bounds__(256, OCC) igemm_glds32_kernel(IgemmArgs a) {
     if constexpr (EPI == 1) {
         if (finisher) epi.rows(a, m0, tid, m_end, gbase, grp);
     }
-    if constexpr (ST == 2) {
-        if (nsl > 0) issue(0);
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    if constexpr (ST == 2 && BREG) {
+        // as below, unrolled by two so that the register set of the B fragments is static
+        auto step = [&](auto cur_tag, auto nxt_tag, int it) {
+            wait_dma();
+            __syncthreads();
+            if (it + 1 < nsl) issue(decltype(nxt_tag)::value, nxt_tag);
+            if constexpr (EPI == 1) {
+                if (it + 1 == nsl && finisher) epi.prefetch(a, n0, tid);
+            }
+            mfmas(smem + decltype(cur_tag)::value * G::STAGE, cur_tag);
+        };
+        if (nsl > 0) issue(0, S0{});
+        int it = 0;
+        for (; it + 1 < nsl; it += 2) {
+            step(S0{}, S1{}, it);
+            step(S1{}, S0{}, it + 1);
+        }
+        if (it < nsl) step(S0{}, S1{}, it);
+        __syncthreads();
+    } else if constexpr (ST == 2) {
+        if (nsl > 0) issue(0, S0{});
         for (int it = 0; it < nsl; ++it) {
             wait_dma();
             __syncthreads();   // slice `it` has landed for every wave, and every wave is done with the other stage
-            if (it + 1 < nsl) issue((it + 1) & 1);
+            if (it + 1 < nsl) issue((it + 1) & 1, S0{});
             if constexpr (EPI == 1) {
                 if (it + 1 == nsl && finisher) epi.prefetch(a, n0, tid);   // epilogue operands ride behind the last slice's MFMAs
             }
-            mfmas(smem + (it & 1) * G::STAGE);
+            mfmas(smem + (it & 1) * G::STAGE, S0{});
         }
         __syncthreads();   // every wave is past its last fragment read: the stages become the epilogue image
     } else {
         for (int it = 0; it < nsl; ++it) {
-            issue(0);
+            issue(0, S0{});
             wait_dma();
             __syncthreads();
             if constexpr (EPI == 1) {
                 if (it + 1 == nsl && finisher) epi.prefetch(a, n0, tid);
             }
-            mfmas(smem);
+            mfmas(smem, S0{});
             __syncthreads();
         }
     }
