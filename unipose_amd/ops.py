@@ -667,7 +667,8 @@ class GradLink:
         self.masked_ok = False
 
 
-def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws_tag: str = "main", out=None, accumulate=None):
+def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws_tag: str = "main", out=None, accumulate=None,
+                        db_out=None):
     """dw (and db) of one convolution.  `out`: an existing fp32 gradient buffer the result is ADDED to by the split-K reduce
     pass itself (up_conv2d_bwd_weight_acc, accumulate = 1): the sum over the uses of a shared weight without an add kernel;
     with accumulate=False `out` is simply the destination (a slice of a gradient-exchange bucket, see set_grad_destinations)."""
@@ -679,7 +680,7 @@ def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws
     need = _C.lib().up_conv2d_bwd_weight_workspace(C.byref(dd))
     ws = workspace(x.device, need, ws_tag)
     dw = out if out is not None else torch.empty(weight_shape, dtype=torch.float32, device=x.device)
-    db = torch.empty(weight_shape[0], dtype=torch.float32, device=x.device) if want_bias else None
+    db = (db_out if db_out is not None else torch.empty(weight_shape[0], dtype=torch.float32, device=x.device)) if want_bias else None
     if x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16:
         math = MATH_BF16S
     elif x.dtype != torch.float32 or dy.dtype != torch.float32:
@@ -839,30 +840,34 @@ def conv_bwd_weight(x, dy, weight, d, want_bias):
             _PASS["task"] = task
         except RuntimeError:
             return conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias)
+    # The results are allocated HERE, from the main stream's pool, and written by the side stream behind the wait below; main reads
+    # or frees them only behind the end-of-backward fence.  (Rounds 1-5 allocated them inside the side-stream context and marked
+    # them record_stream(main): the caching allocator then records one event on the MAIN stream per freed gradient — 229 marker
+    # packets = 0.66 ms of main-stream time in every zero_grad, profiles/r06_experiments.txt item 8.)
+    defer = _DEFER["on"] and not want_bias and not getattr(weight, "_post_accumulate_grad_hooks", None)
+    entry = _DEFER["acc"].get(id(weight)) if defer else None
+    dst = None
+    if entry is None:
+        if _GRAD_DEST["fn"] is not None and not defer and weight.grad is None and id(weight) not in _PASS["seen"]:
+            dst = _GRAD_DEST["fn"](weight)
+        if dst is None:
+            dst = torch.empty(weight.shape, dtype=torch.float32, device=dev)
+    db_buf = torch.empty(weight.shape[0], dtype=torch.float32, device=dev) if want_bias else None
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        defer = _DEFER["on"] and not want_bias and not getattr(weight, "_post_accumulate_grad_hooks", None)
-        entry = _DEFER["acc"].get(id(weight)) if defer else None
         if entry is not None:             # a later use of the weight: the reduce pass adds to the first use's buffer
             conv_bwd_weight_raw(x, dy, weight.shape, d, False, ws_tag="side", out=entry[1])
             for t in (x, dy):
                 t.record_stream(side)
             return None, None
-        dst = None
-        if _GRAD_DEST["fn"] is not None and not defer and weight.grad is None and id(weight) not in _PASS["seen"]:
-            dst = _GRAD_DEST["fn"](weight)
-        dw, db = conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias, ws_tag="side", out=dst, accumulate=False)
+        dw, db = conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias, ws_tag="side", out=dst, accumulate=False, db_out=db_buf)
         if defer:
             _DEFER["acc"][id(weight)] = (weight, dw)
             for t in (x, dy):
                 t.record_stream(side)
-            dw.record_stream(main)
             return None, None
     for t in (x, dy):
         t.record_stream(side)
-    for t in (dw, db):
-        if t is not None:
-            t.record_stream(main)
     key = id(weight)
     if key in _PASS["seen"] or weight.grad is not None:
         main.wait_stream(side)        # autograd is about to accumulate into an earlier, possibly in-flight dW
