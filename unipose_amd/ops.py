@@ -707,7 +707,13 @@ def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws
 # `wgrad_fence()` is called (the data-parallel reducer does before it reads a gradient).
 ASYNC_WGRAD = os.environ.get("UNIPOSE_SYNC_WGRAD", "") == ""   # development switch: weight gradients on the main stream
 _SIDE = {}
-_PASS = {"seen": set(), "task": None}      # task: id of the autograd graph task whose end-of-backward callback is queued
+_PASS = {"seen": set(), "task": None, "keep": []}      # task: id of the autograd graph task whose end-of-backward callback is queued
+# The side stream reads x and dy of a layer after autograd has dropped them: every such tensor is marked record_stream(side) (the
+# caching allocator records an event on the side stream when it is freed and polls it before re-use).  UNIPOSE_KEEP_WGRAD_INPUTS=1
+# instead keeps the tensors referenced until the end-of-backward fence has made the main stream wait for the side stream (freed
+# once, behind the fence, no events; +18 GB held at B = 32) — measured in round 6: fp32 -0.1 ms, UniPose-LSTM -0.1 ms, bf16
+# storage at 736^2 +0.35 ms (profiles/r06_experiments.txt item 9), so the events stay the default.
+KEEP_WGRAD_INPUTS = os.environ.get("UNIPOSE_KEEP_WGRAD_INPUTS", "0") != "0"
 _DEFER = {"on": False, "acc": {}, "bn": {}}          # see deferred_wgrad
 
 
@@ -809,7 +815,16 @@ def wgrad_fence(dev=None):
 def _end_of_backward():
     wgrad_fence()
     _PASS["seen"].clear()
+    _PASS["keep"].clear()          # (behind the fence: whatever re-uses these blocks on the main stream runs after the side stream's reads)
     _PASS["task"] = None
+
+
+def _hold_for_side(side, *tensors):
+    if KEEP_WGRAD_INPUTS:
+        _PASS["keep"].extend(tensors)
+    else:
+        for t in tensors:
+            t.record_stream(side)
 
 
 def _graph_task_id():
@@ -835,6 +850,7 @@ def conv_bwd_weight(x, dy, weight, d, want_bias):
         if _PASS["task"] is not None:             # an earlier backward died before its callback ran: fence for it now
             wgrad_fence(dev)
             _PASS["seen"].clear()
+            _PASS["keep"].clear()
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
             _PASS["task"] = task
@@ -857,17 +873,14 @@ def conv_bwd_weight(x, dy, weight, d, want_bias):
     with torch.cuda.stream(side):
         if entry is not None:             # a later use of the weight: the reduce pass adds to the first use's buffer
             conv_bwd_weight_raw(x, dy, weight.shape, d, False, ws_tag="side", out=entry[1])
-            for t in (x, dy):
-                t.record_stream(side)
+            _hold_for_side(side, x, dy)
             return None, None
         dw, db = conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias, ws_tag="side", out=dst, accumulate=False, db_out=db_buf)
         if defer:
             _DEFER["acc"][id(weight)] = (weight, dw)
-            for t in (x, dy):
-                t.record_stream(side)
+            _hold_for_side(side, x, dy)
             return None, None
-    for t in (x, dy):
-        t.record_stream(side)
+    _hold_for_side(side, x, dy)
     key = id(weight)
     if key in _PASS["seen"] or weight.grad is not None:
         main.wait_stream(side)        # autograd is about to accumulate into an earlier, possibly in-flight dW
