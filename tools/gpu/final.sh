@@ -2,7 +2,7 @@
 # stats of the bench command in both stream modes, PMC passes; with TESTS=1 also the full -m gpu suite (default + bf16x3 arithmetic);
 # LIGHT=1 stops after the kernel statistics.
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r05_z}
+TAG=${1:-r06_z}
 mkdir -p gpurun_out/$TAG
 # the measured binary is the tree's: the stamp next to the shipped library names the sha256 of the sources it was built from
 python -c "
@@ -21,7 +21,7 @@ for o in d.get("other_configs", []): print("other", o["value"], o["ms_per_step"]
 for w in r.get("wasp_dilated", []): print("wasp", w["dilation"], w["ms"], w["effective_mfma_frac"])
 PY
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --settle 0 --no-cpu-baseline --no-stock-baseline --no-profile --no-alt-math --no-other-configs"
+ARGS="--steps 4 --warmup 2 --settle 0 --no-cpu-baseline --no-stock-baseline --no-profile --no-alt-math --no-other-configs"
 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof.log 2>&1
 UNIPOSE_SYNC_WGRAD=1 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_sync -o bench -- python $GRAFT_REPO_ROOT/bench.py $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_sync.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_736 -o bench -- python $GRAFT_REPO_ROOT/bench.py --size 736 --batch 16 --math bf16s $ARGS > $GRAFT_REPO_ROOT/gpurun_out/$TAG/prof_736.log 2>&1
@@ -39,9 +39,12 @@ python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof_736x -name "*.db" | 
 # weights and the allocator have settled — the first step's ~260 fills / ~150 copies stay out
 python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof_sync -name "*.db" | head -1) --steady 1 > gpurun_out/$TAG/kernel_stats_exclusive_steady.txt 2>&1
 python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof_736x -name "*.db" | head -1) --steady 1 > gpurun_out/$TAG/kernel_stats_736_bf16s_exclusive_steady.txt 2>&1
+python tools/wall_accounting.py $(find gpurun_out/$TAG/prof -name "*.db" | head -1) > gpurun_out/$TAG/wall_accounting.txt 2>&1
+python tools/wall_accounting.py $(find gpurun_out/$TAG/prof_736 -name "*.db" | head -1) > gpurun_out/$TAG/wall_accounting_736_bf16s.txt 2>&1
+python tools/rocprof_summary.py $(find gpurun_out/$TAG/prof -name "*.db" | head -1) --steady 1 > gpurun_out/$TAG/kernel_stats_steady.txt 2>&1
 find gpurun_out/$TAG -name "*.db" -delete
+python tools/gpu/skew.py --steps 10 > gpurun_out/$TAG/skew_fp32.txt 2>&1
 # what the exact-fp32 MFMA sustains on this box, alone and next to the K loop's other instructions (round 5)
-./tools/gpu/mfma_peak > gpurun_out/$TAG/mfma_peak.txt 2>&1; ./tools/gpu/mix_probe > gpurun_out/$TAG/mix_probe.txt 2>&1; ./tools/gpu/clock_probe > gpurun_out/$TAG/clock_probe.txt 2>&1
 head -3 gpurun_out/$TAG/kernel_stats_exclusive_steady.txt
 head -8 gpurun_out/$TAG/kernel_stats.txt
 head -8 gpurun_out/$TAG/kernel_stats_exclusive.txt
@@ -52,9 +55,9 @@ UNIPOSE_SYNC_WGRAD=1 UP_PROFILE_CSV=$GRAFT_REPO_ROOT/gpurun_out/$TAG/launches.cs
 python tools/gpu/csv_loss.py gpurun_out/$TAG/launches.csv.1 157.3 20 > gpurun_out/$TAG/lost_time_by_shape.txt 2>&1 || python tools/gpu/csv_loss.py gpurun_out/$TAG/launches.csv 157.3 20 > gpurun_out/$TAG/lost_time_by_shape.txt 2>&1
 head -4 gpurun_out/$TAG/lost_time_by_shape.txt
 bash tools/gpu/pmc.sh $TAG
-# whole-step A/B of the round-4 switches (fp32 headline step, alternating, two rounds): fused BatchNorm-backward reduction, masked
-# skip-gradient addend, direct-to-LDS forward / data gradient, direct-to-LDS weight gradient
-VARIANTS="A=default;UNIPOSE_ASYNC_REPACK=0;UNIPOSE_BN_FUSE_REDUCE=0;UP_GLDS32_WGRAD=0;UP_GLDS32=0 UP_GLDS32_WGRAD=0" REPS=2 bash tools/gpu/run.sh $TAG abenv368 > gpurun_out/$TAG/knob_ab.txt 2>&1; cat gpurun_out/$TAG/knob_ab.txt
+# whole-step A/B of the switches that carry the round's design (fp32 headline step, alternating, two rounds): BatchNorm finalize folded
+# into the producers (0 = the stand-alone arrive kernels), fused BatchNorm-backward reduction, hybrid operand path, async re-pack
+VARIANTS="A=default;UP_BN_FOLD=0;UNIPOSE_BN_FUSE_REDUCE=0;UP_BREG=1;UNIPOSE_ASYNC_REPACK=0" REPS=2 bash tools/gpu/run.sh $TAG abenv368 > gpurun_out/$TAG/knob_ab.txt 2>&1; cat gpurun_out/$TAG/knob_ab.txt
 UNIPOSE_SYNC_WGRAD=1 UP_PROFILE_CSV=$GRAFT_REPO_ROOT/gpurun_out/$TAG/launches_736.csv timeout 300 python bench.py --size 736 --batch 16 --math bf16s --steps 4 --warmup 2 --no-cpu-baseline --no-stock-baseline --no-alt-math --no-other-configs > gpurun_out/$TAG/bench_csv_736.log 2>&1
 python tools/gpu/csv_loss.py $(ls gpurun_out/$TAG/launches_736.csv* | tail -1) 2500 24 > gpurun_out/$TAG/lost_time_by_shape_736.txt 2>&1; head -3 gpurun_out/$TAG/lost_time_by_shape_736.txt
 bash tools/gpu/pmc_sq.sh ${TAG}_736 --size 736 --batch 16 --math bf16s
