@@ -319,7 +319,7 @@ static inline float __uint_as_float(uint32_t u) {
 }
 // A: lane l holds A[i = l&31][k = 8*(l>>5) + e], B: lane l holds B[k = 8*(l>>5) + e][j = l&31], e = 0..7
 static inline f32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf16x8 a, bf16x8 b, f32x16 c, int, int, int) {
-    static thread_local uint16_t xa[4][64][8], xb[4][64][8];
+    static thread_local uint16_t xa[8][64][8], xb[8][64][8];   // up to eight waves per block
     ::emu::Wave& w = ::emu::wave();
     int l = ::emu::lane();
     int wid = ::emu::st().cur->lin >> 6;

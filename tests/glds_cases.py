@@ -59,9 +59,11 @@ def _merge(st):
 
 
 def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, affine=False, residual=False, relu=False,
-            add=False, seed=0):
+            add=False, seed=0, knob="glds", tune=None, expect_big=None):
     """forward (+ optional BatchNorm partials / folded epilogue / residual), data gradient (+ optional addend) and weight
-    gradient of one convolution in bf16 storage: glds = 1 against glds = 0 under the same tile rule."""
+    gradient of one convolution in bf16 storage: glds = 1 against glds = 0 under the same tile rule
+    (knob="glds_big": the 8-wave (32 TM) x 256 tiles of bf16s_big.h against igemm_glds_kernel; `tune`: knobs held for the
+    whole case; expect_big: launches that must have run on igemm_big_kernel with the knob on)."""
     cp, kp = ops.rup32(c), ops.rup32(k)
     x = _nhwc(torch.randn(n, c, h, w, generator=_g(seed)), dev, cp)
     wt = (torch.randn(k, c, r, r, generator=_g(seed + 1)) * (2.0 / (c * r * r)) ** 0.5).to(dev)
@@ -73,9 +75,10 @@ def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, 
         kw["bias"] = torch.randn(k, generator=_g(seed + 4)).to(dev)
     out = {}
     try:
-        _tune(tile_want_bf16=tile_want)
+        _tune(tile_want_bf16=tile_want, **(tune or {}))
         for mode in (1, 0):
-            _tune(glds=mode)
+            _tune(**{knob: mode})
+            big0 = _C.lib().up_conv_counter(b"big")
             d0 = ops.make_desc(x, wt, cfg)
             res = None
             if residual:
@@ -86,8 +89,11 @@ def conv_ab(dev, n, c, h, w, k, r, stride, pad, dil, *, tile_want, stats=False, 
             dx = ops.conv_bwd_data_raw(dy, wt, d, x.shape, x.device, add=addt) if stride == 1 else None
             dw, _ = ops.conv_bwd_weight_raw(x, dy, wt.shape, d, False)
             out[mode] = (y, st, dx, dw)
+            if expect_big is not None:
+                ran = _C.lib().up_conv_counter(b"big") - big0
+                assert ran == (expect_big if mode else 0), ("launches on igemm_big_kernel", mode, ran)
     finally:
-        _tune(glds=1, tile_want_bf16=500)
+        _tune(glds=1, glds_big=1, tile_want_bf16=500, cu_count=0, big_min_k=1024)
     (y1, s1, dx1, dw1), (y0, s0, dx0, dw0) = out[1], out[0]
     _same(dw1, dw0, "dw")
     _same(y1, y0, "y")
@@ -135,7 +141,7 @@ FULL = [
 ]
 
 
-def bnred_case(dev, n, c, h, w, k, r, pad, dil, *, tile_want, add=False, mask_add=False, relu=True, seed=0):
+def bnred_case(dev, n, c, h, w, k, r, pad, dil, *, tile_want, add=False, mask_add=False, relu=True, seed=0, tune=None, expect_big=None):
     """bf16 storage: the data gradient of a convolution whose INPUT is z = relu(bn(y) (+ res)) also reduces that layer's
     BatchNorm-backward sums (up_conv2d_bwd_data_ex) — against up_bn_bwd's own reduce pass on the same dz;
     mask_add: the addend is an unmasked gradient whose ReLU mask the epilogue applies — against the pre-masked addend."""
@@ -164,14 +170,17 @@ def bnred_case(dev, n, c, h, w, k, r, pad, dil, *, tile_want, add=False, mask_ad
     invstd = (0.5 + torch.rand(c, generator=_g(seed + 11))).to(dev)
     gamma = (0.5 + torch.rand(c, generator=_g(seed + 12))).to(dev)
     try:
-        _tune(tile_want_bf16=tile_want, glds=1)
+        _tune(tile_want_bf16=tile_want, glds=1, **(tune or {}))
+        big0 = _C.lib().up_conv_counter(b"big")
         slot = ops.BnSlot(ybn, bits, mean, invstd, c)
         dx = ops.conv_bwd_data_raw(dy, wt, d, x.shape, x.device, add=addt, bn_slot=slot, add_bits=abits)
         assert slot.partial is not None, "the launch did not take the fused reduction"
         pre = addt if abits is None else (addt.float() * apos.to(dev).float()).to(BF)
         dx0 = ops.conv_bwd_data_raw(dy, wt, d, x.shape, x.device, add=pre)
+        if expect_big is not None:
+            assert _C.lib().up_conv_counter(b"big") - big0 == expect_big, "launches on igemm_big_kernel"
     finally:
-        _tune(glds=1, tile_want_bf16=500)
+        _tune(glds=1, glds_big=1, tile_want_bf16=500, cu_count=0, big_min_k=1024)
     _same(dx, dx0, "dx (fused reduction / masked addend on / off)")
     outs = []
     for fused in (True, False):
@@ -212,3 +221,39 @@ BNRED_FULL = [
     dict(n=16, c=256, h=46, w=46, k=256, r=3, pad=1, dil=1, tile_want=500),                            # conv2's (tap-sorted) reduces bn1
     dict(n=16, c=1024, h=46, w=46, k=256, r=1, pad=0, dil=1, tile_want=500, add=True, mask_add=True),  # next block's conv1 reduces bn3
 ]
+
+
+# igemm_big_kernel (bf16s_big.h) against igemm_glds_kernel: knob glds_big; cu_count = 1 makes the tile rule pick the row count
+# that needs the fewest rows in total (M = 160 / 192 / 256 -> TM = 5 / 6 / 8), big_min_k lets short reductions through
+_BIG = dict(knob="glds_big", tile_want=1)
+BIG_SMALL = [
+    dict(n=2, c=64, h=9, w=9, k=256, r=1, stride=1, pad=0, dil=1, stats=True, tune=dict(big_min_k=64), expect_big=1, **_BIG),            # 162 rows: a full 160-row tile + 2 rows
+    dict(n=3, c=64, h=8, w=8, k=256, r=1, stride=1, pad=0, dil=1, stats=True, tune=dict(big_min_k=64, cu_count=1), expect_big=1, **_BIG),  # 192 rows: TM = 6
+    dict(n=4, c=128, h=8, w=8, k=256, r=1, stride=1, pad=0, dil=1, stats=True, add=True, tune=dict(big_min_k=64, cu_count=1), expect_big=1, **_BIG),  # 256 rows: TM = 8, two slices, addend (dgrad N = 128: old kernel)
+    dict(n=3, c=64, h=7, w=7, k=256, r=3, stride=1, pad=1, dil=1, stats=True, expect_big=1, **_BIG),                                     # 3x3, tap-sorted rows, ragged tile (147 rows)
+    dict(n=4, c=128, h=7, w=7, k=512, r=3, stride=1, pad=3, dil=3, stats=True, expect_big=1, **_BIG),                                    # dilated: dead taps, two column tiles
+    dict(n=2, c=64, h=9, w=9, k=256, r=1, stride=1, pad=0, dil=1, affine=True, relu=True, residual=True, tune=dict(big_min_k=64), expect_big=1, **_BIG),   # folded eval epilogue + residual
+    dict(n=2, c=64, h=9, w=9, k=256, r=3, stride=1, pad=2, dil=2, affine=True, relu=True, expect_big=1, **_BIG),                         # eval, no residual, tap-sorted
+    dict(n=2, c=64, h=17, w=17, k=256, r=3, stride=2, pad=1, dil=1, stats=True, expect_big=1, **_BIG),                                   # stride-2 forward
+    dict(n=2, c=256, h=9, w=9, k=256, r=1, stride=1, pad=0, dil=1, stats=True, add=True, expect_big=2, **_BIG),                          # data gradient on the big tiles too, with addend
+]
+BIG_BNRED = [
+    dict(n=2, c=256, h=9, w=9, k=64, r=1, pad=0, dil=1, tile_want=1, tune=dict(big_min_k=64), expect_big=2),                               # 1x1, ragged last tile
+    dict(n=2, c=256, h=9, w=9, k=64, r=1, pad=0, dil=1, tile_want=1, add=True, tune=dict(big_min_k=64), expect_big=2),                     # addend: fp32 image path
+    dict(n=2, c=256, h=9, w=9, k=64, r=1, pad=0, dil=1, tile_want=1, add=True, mask_add=True, tune=dict(big_min_k=64), expect_big=2),      # addend masked in the epilogue
+    dict(n=3, c=256, h=7, w=7, k=64, r=3, pad=1, dil=1, tile_want=1, expect_big=2),                                                        # 3x3, tap-sorted rows
+    dict(n=3, c=256, h=8, w=8, k=128, r=1, pad=0, dil=1, tile_want=1, relu=False, tune=dict(big_min_k=64, cu_count=1), expect_big=2),      # TM = 6, BatchNorm without ReLU
+]
+
+BIG_FULL = [
+    dict(n=16, c=256, h=46, w=46, k=256, r=3, stride=1, pad=1, dil=1, stats=True, add=True, expect_big=2, **_BIG),      # layer3 conv2: 212 tiles of 160 rows
+    dict(n=16, c=1024, h=46, w=46, k=256, r=1, stride=1, pad=0, dil=1, stats=True, expect_big=2, **_BIG),               # layer3 conv1; its data gradient: N = 1024, K = 256
+    dict(n=16, c=256, h=46, w=46, k=1024, r=1, stride=1, pad=0, dil=1, stats=True, expect_big=2, **_BIG),               # layer3 conv3: 708 tiles of 192 rows
+    dict(n=16, c=256, h=46, w=46, k=256, r=3, stride=1, pad=18, dil=18, stats=True, expect_big=2, **_BIG),              # WASP d = 18
+    dict(n=16, c=512, h=46, w=46, k=512, r=3, stride=1, pad=4, dil=4, stats=True, expect_big=2, **_BIG),                # layer4 d = 4
+    dict(n=5, c=256, h=46, w=46, k=256, r=3, stride=1, pad=1, dil=1, stats=True, expect_big=2, **_BIG),                 # fewer tiles than CUs, ragged last tile
+]
+BIG_BNRED_FULL = [dict(c, expect_big=2) for c in BNRED_FULL]
+# (the library's default sends reductions shorter than 1024 to igemm_glds_kernel: these cases exercise igemm_big_kernel at every length)
+for _c in BIG_SMALL + BIG_FULL + BIG_BNRED + BIG_BNRED_FULL:
+    _c["tune"] = dict(dict(big_min_k=64), **(_c.get("tune") or {}))

@@ -80,3 +80,15 @@ def test_glds_kernel_matches_register_staged_kernel(emu_backend, case):
 @pytest.mark.parametrize("case", gc.BNRED, ids=lambda c: "c%d_%dx%d_k%d_r%d_t%d_%s" % (c["c"], c["h"], c["w"], c["k"], c["r"], c["tile_want"], "m" if c.get("mask_add") else ("a" if c.get("add") else "n")))
 def test_bn_backward_reduction_fused_into_data_gradient_bf16(emu_backend, case):
     gc.bnred_case(emu_backend, **case)
+
+
+@pytest.mark.parametrize("case", gc.BIG_SMALL, ids=lambda c: "c%d_%dx%d_k%d_r%d_d%d_s%d" % (c["c"], c["h"], c["w"], c["k"], c["r"], c["dil"], c["stride"]))
+def test_big_tile_kernel_matches_glds_kernel(emu_backend, case):
+    """third-generation bf16-storage kernel (8 waves on (32 TM) x 256 tiles, bf16s_big.h) == igemm_glds_kernel, element for
+    element (outputs, data gradients); BatchNorm partials merged to fp32 round-off"""
+    gc.conv_ab(emu_backend, **case)
+
+
+@pytest.mark.parametrize("case", gc.BIG_BNRED, ids=lambda c: "c%d_%dx%d_k%d_r%d_%s" % (c["c"], c["h"], c["w"], c["k"], c["r"], "m" if c.get("mask_add") else ("a" if c.get("add") else "n")))
+def test_bn_backward_reduction_fused_into_big_tile_data_gradient(emu_backend, case):
+    gc.bnred_case(emu_backend, **case)

@@ -72,6 +72,20 @@ def test_bn_backward_reduction_fused_into_data_gradient_bf16(case):
     gc.bnred_case(DEV, **case)
 
 
+@pytest.mark.parametrize("case", gc.BIG_SMALL + gc.BIG_FULL,
+                         ids=lambda c: "n%d_c%d_%dx%d_k%d_r%d_d%d_s%d" % (c["n"], c["c"], c["h"], c["w"], c["k"], c["r"], c["dil"], c["stride"]))
+def test_big_tile_kernel_matches_glds_kernel(case):
+    """third-generation bf16-storage kernel (8 waves on (32 TM) x 256 tiles, bf16s_big.h) == igemm_glds_kernel, element for
+    element (outputs, data gradients; BatchNorm partials merged to fp32 round-off), small and at the geometries of configs[4]"""
+    gc.conv_ab(DEV, **case)
+
+
+@pytest.mark.parametrize("case", gc.BIG_BNRED + gc.BIG_BNRED_FULL,
+                         ids=lambda c: "n%d_c%d_%dx%d_k%d_r%d_%s" % (c["n"], c["c"], c["h"], c["w"], c["k"], c["r"], "m" if c.get("mask_add") else ("a" if c.get("add") else "n")))
+def test_bn_backward_reduction_fused_into_big_tile_data_gradient(case):
+    gc.bnred_case(DEV, **case)
+
+
 def _golden_eval(golden_dir, name, size, B):
     from unipose_amd import ops
     g = np.load(os.path.join(golden_dir, name))

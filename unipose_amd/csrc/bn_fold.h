@@ -95,8 +95,9 @@ __device__ __forceinline__ int ticket_take(int* p) { return __hip_atomic_fetch_a
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
 
-// Called by ALL 256 threads of a workgroup, uniformly, after it has issued the sc1 stores of partial row `tile` for the channels
-// [c0, c0 + ncols) (c0 a multiple of FOLD_COLS; ncols <= 128).  `lds`: >= FOLD_LDS_BYTES of workgroup memory nobody else uses any more.
+// Called by ALL threads of a workgroup (256, or 512: igemm_big_kernel — the waves beyond the fourth only keep the barriers), uniformly,
+// after it has issued the sc1 stores of partial row `tile` for the channels [c0, c0 + ncols) (c0 a multiple of FOLD_COLS).
+// `lds`: >= FOLD_LDS_BYTES of workgroup memory nobody else uses any more.
 constexpr int FOLD_LDS_BYTES = 4 * FOLD_COLS * 3 * 8 + 16;
 template <int NV>
 __device__ __forceinline__ void bn_fold_arrive(const BnFold& f, const float* partial, int tile, int c0, int ncols, unsigned char* lds,
@@ -125,7 +126,7 @@ __device__ __forceinline__ void bn_fold_arrive(const BnFold& f, const float* par
     const int t0 = g * FOLD_G, t1 = t0 + FOLD_G < f.tiles ? t0 + FOLD_G : f.tiles;
     for (int cb = 0; cb < ncols; cb += FOLD_COLS) {
         const int c = c0 + cb + cl;
-        const bool cok = cb + cl < ncols && c < f.C;
+        const bool cok = cb + cl < ncols && c < f.C && r < 4;
         double s[NV];
 #pragma unroll
         for (int k = 0; k < NV; ++k) s[k] = 0.0;
@@ -153,8 +154,10 @@ __device__ __forceinline__ void bn_fold_arrive(const BnFold& f, const float* par
                 }
             }
         }
+        if (r < 4) {
 #pragma unroll
-        for (int k = 0; k < NV; ++k) red[(r * FOLD_COLS + cl) * NV + k] = s[k];
+            for (int k = 0; k < NV; ++k) red[(r * FOLD_COLS + cl) * NV + k] = s[k];
+        }
         __syncthreads();
         if (r == 0 && cok) {
 #pragma unroll
@@ -179,7 +182,7 @@ __device__ __forceinline__ void bn_fold_arrive(const BnFold& f, const float* par
     //      finishes the groups in order ----
     for (int cb = 0; cb < ncols; cb += FOLD_COLS) {
         const int c = c0 + cb + cl;
-        const bool cok = cb + cl < ncols && c < f.C;
+        const bool cok = cb + cl < ncols && c < f.C && r < 4;
         // the finishing thread's per-channel operands ride with the level-1 rows (one round trip less on the launch's tail)
         float pg = 0.f, pb = 0.f, prm = 0.f, prv = 0.f;
         if constexpr (NV == 3) {
@@ -216,8 +219,10 @@ __device__ __forceinline__ void bn_fold_arrive(const BnFold& f, const float* par
                         }
                 }
             }
+            if (r < 4) {
 #pragma unroll
-            for (int k = 0; k < NV; ++k) red[(r * FOLD_COLS + cl) * NV + k] = s[k];
+                for (int k = 0; k < NV; ++k) red[(r * FOLD_COLS + cl) * NV + k] = s[k];
+            }
             __syncthreads();
             if (r == 0 && cok) {
                 double t[NV];

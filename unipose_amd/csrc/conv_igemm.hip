@@ -40,7 +40,7 @@ namespace up {
 // up_profile_begin() arms it; every igemm/wgrad launch is then bracketed by two hipEvents on the
 // launch stream; up_profile_end() synchronises and returns, per kernel variant, {launches, total ms,
 // total algorithmic flops}.  Off by default: no events, no overhead.
-constexpr int PROF_VARIANTS = 36;
+constexpr int PROF_VARIANTS = 39;
 static const char* const kVariantNames[PROF_VARIANTS] = {
     "igemm_kernel<128,128,aligned>", "igemm_kernel<128,128,generic>", "igemm_kernel<64,128,aligned>",
     "igemm_kernel<64,128,generic>",  "igemm_kernel<128,64,aligned>",  "igemm_kernel<128,64,generic>",
@@ -55,7 +55,9 @@ static const char* const kVariantNames[PROF_VARIANTS] = {
     "wgrad_glds_kernel<64,128> (bf16)",  "wgrad_glds_kernel<64,64> (bf16)",
     // exact fp32, direct-to-LDS generation (f32_glds.h)
     "igemm_glds32_kernel<128,128>", "igemm_glds32_kernel<64,128>", "igemm_glds32_kernel<128,64>", "igemm_glds32_kernel<64,64>",
-    "wgrad_glds32_kernel<128,128>", "wgrad_glds32_kernel<128,64>", "wgrad_glds32_kernel<64,128>", "wgrad_glds32_kernel<64,64>"};
+    "wgrad_glds32_kernel<128,128>", "wgrad_glds32_kernel<128,64>", "wgrad_glds32_kernel<64,128>", "wgrad_glds32_kernel<64,64>",
+    // bf16 storage, 8-wave workgroups on (32 TM) x 256 tiles (bf16s_big.h)
+    "igemm_big_kernel<256,256> (bf16)", "igemm_big_kernel<192,256> (bf16)", "igemm_big_kernel<160,256> (bf16)"};
 #ifndef UP_EMU
 struct ProfRec {
     hipEvent_t a, b;
@@ -1665,6 +1667,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradArgs a) {
 }
 
 #include "bf16s_glds.h"
+#include "bf16s_big.h"
 #include "f32_glds.h"
 
 // sum the split-K slabs and scatter into PyTorch OIHW
@@ -1993,9 +1996,16 @@ static int env_int(const char* name, int dflt, int min_ok) {
 static int g_tile_want = env_int("UP_TILE_WANT", 1500, 1);   // A/B in the network: 700 / 1000 / 1500 / 2200 / 4300 -> 70.1 / 69.9 / 69.6 / 69.9 / 69.8 ms
 static int g_tile_want_bf16 = env_int("UP_TILE_WANT_BF16", 500, 1);
 static int g_glds = env_int("UP_GLDS", 1, 0);   // bf16 storage: direct-to-LDS kernels of bf16s_glds.h (0 = the register-staged round-2 kernels)
+// bf16 storage, round 6: launches with N % 256 == 0, 64-aligned channels and a reduction of at least big_min_k run one 8-wave
+// workgroup per CU on 160/192/256 x 256 tiles (bf16s_big.h); 0 = igemm_glds_kernel everywhere
+static int g_big = env_int("UP_GLDS_BIG", 1, 0);
+static int g_big_min_k = env_int("UP_BIG_MIN_K", 1024, 1);   // (whole 736^2 step: 256 -> 39.5 ms, 512 -> 38.1, 1024 -> 36.1-36.3, 2048 -> 36.1-36.2 against 36.8-37.0 without; shorter reductions are all prologue + epilogue at one workgroup per CU)
+static int g_big_rows = env_int("UP_BIG_ROWS", 0, 0);         // 160 / 192 / 256: only this tile height (0: the rule of big_tile_rows)
+static int g_big_stages = env_int("UP_BIG_STAGES", 3, 2);   // LDS stages of the 160-row tiles (3: two slices in flight)
 // fp32 forward / data gradient with operands HBM -> LDS by LDS-DMA (f32_glds.h, round 4): glds32 = 0 keeps the register-staged
 // igemm_kernel; glds32_epi: 1 = LDS-transposed 16-byte-store epilogue, 0 = igemm_epilogue
 static long long g_count_igemm = 0, g_count_glds32 = 0, g_count_glds32_epi1 = 0, g_count_glds32_bnred = 0;   // up_conv_counter
+static long long g_count_big = 0;   // launches on igemm_big_kernel (bf16s_big.h)
 static long long g_count_wgrad32 = 0, g_count_wgrad32_st1 = 0, g_count_glds32_wide = 0, g_count_glds32_grouped = 0;
 static thread_local bool g_extras_dropped = false;   // (per host thread: autograd runs one thread per device) a launch was asked for a masked addend / fused reduction on a kernel without them
 static int g_glds32 = env_int("UP_GLDS32", 1, 0);
@@ -2033,6 +2043,22 @@ static TileChoice choose_tile(int64_t M, int Ng, int Ktot, int math = 0) {
         if (wgs >= want) return {c[0], c[1]};
     }
     return {64, 64};
+}
+
+// bf16 storage: the tile of a launch described by `a` (pointers may be null: the tile-count queries ask before there are tensors).
+// bn = 256 says igemm_big_kernel with bm rows per tile.
+static int fill_fwd_args(IgemmArgs& a, const up_conv_desc* d, const float* x, const float* w_fwd, float* y, const up_conv_epilogue* ep);
+static int fill_dgrad_args(IgemmArgs& a, const up_conv_desc* d, const float* dy, const float* w_dgrad, float* dx);
+static bool glds_eligible(const IgemmArgs& a, bool fast);
+static bool igemm_fast(const IgemmArgs& a) {
+    return a.taps <= 32 && a.divshift == 0 && (long long)a.H * a.W * a.ldx * ((long long)a.M / (a.P * a.Q) + 1) < (1ll << 31);
+}
+static TileChoice choose_tile_bf16s(const IgemmArgs& a) {
+    if (g_big && glds_eligible(a, igemm_fast(a))) {
+        const int bm = glds::big_tile_rows(a.M, a.Ng, a.Ktot, a.Cp, cu_count(), g_big_min_k, g_big_rows);
+        if (bm) return {bm, 256};
+    }
+    return choose_tile(a.M, a.Ng, a.Ktot, UP_MATH_BF16S);
 }
 
 // ---- tail split -------------------------------------------------------------------------------------
@@ -2550,6 +2576,10 @@ extern "C" int up_conv_stats_tiles(const up_conv_desc* d) { return up_conv_stats
 extern "C" int up_conv_stats_tiles_math(const up_conv_desc* d, int math) {
     if (!d || math < UP_MATH_F32 || math > UP_MATH_BF16S) return UP_ERR_INVALID;
     int64_t M = (int64_t)d->N * d->P * d->Q;
+    if (math == UP_MATH_BF16S && !check_desc(d)) {   // (the 8-wave tiles of bf16s_big.h depend on more than M, N, K)
+        IgemmArgs a;
+        if (fill_fwd_args(a, d, nullptr, nullptr, nullptr, nullptr) == UP_OK) return cdiv(M, choose_tile_bf16s(a).bm);
+    }
     return cdiv(M, choose_tile(M, d->K, d->R * d->S * d->Cp, math).bm);
 }
 
@@ -2566,6 +2596,10 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "tile_want_bf16") && value > 0) g_tile_want_bf16 = value;
     else if (!strcmp(key, "bn_rows")) set_bn_rows(value);
     else if (!strcmp(key, "glds")) g_glds = value ? 1 : 0;
+    else if (!strcmp(key, "glds_big")) g_big = value ? 1 : 0;
+    else if (!strcmp(key, "big_min_k") && value > 0) g_big_min_k = value;
+    else if (!strcmp(key, "big_stages") && value >= 2) g_big_stages = value;
+    else if (!strcmp(key, "big_rows") && (value == 0 || value == 160 || value == 192 || value == 256)) g_big_rows = value;
     else if (!strcmp(key, "cu_count") && value >= 0) g_cu_override = value;
     else if (!strcmp(key, "glds32")) g_glds32 = value ? 1 : 0;
     else if (!strcmp(key, "glds32_epi")) g_glds32_epi = value ? 1 : 0;
@@ -2590,6 +2624,7 @@ extern "C" long long up_conv_counter(const char* name) {
     if (!strcmp(name, "glds32_epi1")) return g_count_glds32_epi1;
     if (!strcmp(name, "glds32_bnred")) return g_count_glds32_bnred;
     if (!strcmp(name, "glds32_breg")) return g_count_glds32_breg;
+    if (!strcmp(name, "big")) return g_count_big;
     if (!strcmp(name, "wgrad_glds32")) return g_count_wgrad32;
     if (!strcmp(name, "wgrad_glds32_st1")) return g_count_wgrad32_st1;
     return -1;
@@ -2860,6 +2895,37 @@ static void launch_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
     else
         hipLaunchKernelGGL((igemm_bf16_kernel<BM, BN, 1, false, KT>), dim3(a.nwg), dim3(256), 0, st, a);
 }
+// bf16 storage on igemm_big_kernel (bf16s_big.h): 512 threads, (32 TM) x 256 tiles; the caller has checked glds_eligible
+template <int TM>
+static void launch_igemm_big(IgemmArgs& a, hipStream_t st) {
+    constexpr int BM = 32 * TM;
+    const int ntm = cdiv(a.M, BM);
+    a.ntn = cdiv(a.Ng, 256);
+    a.nwg = ntm * a.ntn;
+    a.fNtn = make_fastdiv(a.ntn);
+    a.no_tap_skip = g_tap_skip ? 0 : 1;
+    ProfScope prof(36 + (TM == 8 ? 0 : TM == 6 ? 1 : 2), 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st, a.M, a.Ng, a.Ktot,
+                   a.nwg, g_prof_on_host() ? live_tap_share(a) : 1.0);
+    apply_fold(a, ntm, st);
+    a.perm = nullptr;
+    a.x_bytes = (uint32_t)((long long)(a.M / (a.P * a.Q)) * a.H * a.W * a.ldx * 2);
+    if (g_tap_sort && a.taps > 1 && a.taps <= 16 && !a.residual && !a.no_tap_skip) a.perm = tap_sort_perm(a);
+    void (*kernel)(IgemmArgs);
+    constexpr int NS3 = TM <= 5 ? 3 : 2;   // three LDS stages where they fit (160-row tiles)
+    if (g_big_stages >= 3 && NS3 == 3) {
+        if (a.bn_partial)
+            kernel = a.perm ? glds::igemm_big_kernel<TM, true, true, NS3> : glds::igemm_big_kernel<TM, false, true, NS3>;
+        else
+            kernel = a.perm ? glds::igemm_big_kernel<TM, true, false, NS3> : glds::igemm_big_kernel<TM, false, false, NS3>;
+    } else if (a.bn_partial)
+        kernel = a.perm ? glds::igemm_big_kernel<TM, true, true, 2> : glds::igemm_big_kernel<TM, false, true, 2>;
+    else
+        kernel = a.perm ? glds::igemm_big_kernel<TM, true, false, 2> : glds::igemm_big_kernel<TM, false, false, 2>;
+    a.full_blocks = a.nwg;
+    a.parts = 1;
+    ++g_count_big;
+    hipLaunchKernelGGL(kernel, dim3(a.nwg), dim3(512), 0, st, a);
+}
 static int run_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
     UP_REQUIRE(math == UP_MATH_BF16X3 || math == UP_MATH_BF16 || math == UP_MATH_BF16S || math == UP_MATH_BF16S_F32OUT, UP_ERR_INVALID,
                "bf16 convolution: math mode %d", math);
@@ -2871,7 +2937,20 @@ static int run_igemm_bf16(IgemmArgs& a, int math, hipStream_t st) {
     UP_REQUIRE(a.Cp % 32 == 0, UP_ERR_UNSUPPORTED, "bf16 convolution: padded channel count %d is not a multiple of 32",
                a.Cp);
     TileChoice t = choose_tile(a.M, a.Ng, a.Ktot, math);
-    if (t.bm == 128 && t.bn == 128)
+    if (math == UP_MATH_BF16S) {
+        // the tile the host was told (pointer-free query) and the one this launch can run must agree wherever per-tile rows are handed over
+        IgemmArgs q = a;
+        q.x = nullptr; q.y = nullptr; q.w_hi = nullptr; q.residual = nullptr;
+        const TileChoice told = choose_tile_bf16s(q);
+        t = choose_tile_bf16s(a);
+        UP_REQUIRE((told.bm == t.bm && told.bn == t.bn) || !(a.stats || a.bn_partial), UP_ERR_UNSUPPORTED,
+                   "bf16-storage convolution: unaligned pointers on a launch whose per-tile rows were sized for %d x %d tiles", told.bm, told.bn);
+    }
+    if (t.bn == 256) {
+        if (t.bm == 256) launch_igemm_big<8>(a, st);
+        else if (t.bm == 192) launch_igemm_big<6>(a, st);
+        else launch_igemm_big<5>(a, st);
+    } else if (t.bm == 128 && t.bn == 128)
         launch_igemm_bf16<128, 128>(a, math, st);
     else if (t.bm == 64 && t.bn == 128)
         launch_igemm_bf16<64, 128>(a, math, st);
@@ -2974,6 +3053,10 @@ extern "C" int up_conv2d_bwd_data_tiles_math(const up_conv_desc* d, int math) {
     if ((long long)d->N * d->P * d->Q * d->ldy * eb >= (1ll << 31) || (long long)d->C * d->R * d->S * d->Kp * eb >= (1ll << 31) ||
         (long long)d->P * d->Q * d->ldy * ((long long)d->N + 1) >= (1ll << 31) || M * d->ldx >= (1ll << 31))
         return 0;
+    if (math == UP_MATH_BF16S) {
+        IgemmArgs a;
+        if (fill_dgrad_args(a, d, nullptr, nullptr, nullptr) == UP_OK) return cdiv(M, choose_tile_bf16s(a).bm);
+    }
     return cdiv(M, choose_tile(M, d->C, d->R * d->S * d->Kp, math).bm);
 }
 extern "C" int up_conv2d_bwd_data_tiles(const up_conv_desc* d) { return up_conv2d_bwd_data_tiles_math(d, UP_MATH_F32); }
