@@ -445,3 +445,56 @@ def test_debug_pack_mode_catches_a_weight_edited_behind_the_cache(emu_backend):
 ])
 def test_grouped_bn_finalize_folded(emu_backend, cfg):
     print(oc.bn_groups_fold_case(emu_backend, *cfg))
+
+
+def _shared_weight_graph(dev, uses, seed=3):
+    """`uses` convolutions (with bias) of a NON-LEAF weight built by torch.cat from two leaves, like the ConvLSTM cell's stacked gates"""
+    import torch
+    from unipose_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    wa = (torch.randn(8, 16, 3, 3, generator=g) * 0.1).to(dev).requires_grad_(True)
+    wb = (torch.randn(8, 16, 3, 3, generator=g) * 0.1).to(dev).requires_grad_(True)
+    ba = torch.randn(16, generator=g).to(dev).requires_grad_(True)
+    xs = [torch.randn(2, 5, 5, 16, generator=g).to(dev) for _ in range(uses)]
+    w, b = torch.cat([wa, wb], 0), ba * 1.0
+    ys = [ops.ConvBias.apply(x, w, b, ops.ConvCfg(1, 1, 1), False) for x in xs]
+    return (wa, wb, ba), w, ys
+
+
+def test_deferred_wgrad_hands_a_shared_non_leaf_weight_one_summed_gradient(emu_backend):
+    """ops.deferred_wgrad, non-leaf weight used by three convolutions: autograd receives ONE gradient for it (the last use hands over
+    the sum the library accumulated) and the leaves behind the cat get what the engine's own accumulation gives them."""
+    import torch
+    from unipose_amd import ops
+    leaves, w, ys = _shared_weight_graph(emu_backend, 3)
+    seen = []
+    w.register_hook(lambda g: seen.append(1))
+    sum((y * y).sum() for y in ys).backward()
+    ref = [p.grad.clone() for p in leaves]
+    assert len(seen) == 1                       # (hooks on a tensor fire once, on the engine's accumulated gradient)
+    leaves2, w2, ys2 = _shared_weight_graph(emu_backend, 3)
+    calls = []
+    orig = ops.conv_bwd_weight_raw
+
+    def counting(*a, **k):
+        calls.append(bool(k.get("accumulate", k.get("out") is not None)))
+        return orig(*a, **k)
+    ops.conv_bwd_weight_raw = counting
+    try:
+        with ops.deferred_wgrad():
+            sum((y * y).sum() for y in ys2).backward()
+    finally:
+        ops.conv_bwd_weight_raw = orig
+    assert calls == [False, True, True]         # first use writes the buffer, the later ones add to it inside the reduce pass
+    for a, b in zip(ref, [p.grad for p in leaves2]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+
+
+def test_deferred_wgrad_reports_a_shared_use_without_gradient(emu_backend):
+    """a forward use of a shared non-leaf weight whose gradient never arrives inside the context must not swallow the others' sum"""
+    import pytest
+    from unipose_amd import ops
+    leaves, w, ys = _shared_weight_graph(emu_backend, 3)
+    with pytest.raises(RuntimeError, match="never arrived"):
+        with ops.deferred_wgrad():
+            sum((y * y).sum() for y in ys[:2]).backward()          # the third use is left out of the loss

@@ -670,7 +670,8 @@ class GradLink:
 def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws_tag: str = "main", out=None, accumulate=None,
                         db_out=None):
     """dw (and db) of one convolution.  `out`: an existing fp32 gradient buffer the result is ADDED to by the split-K reduce
-    pass itself (up_conv2d_bwd_weight_acc, accumulate = 1): the sum over the uses of a shared weight without an add kernel;
+    pass itself (up_conv2d_bwd_weight_acc, accumulate = 1): the sum over the uses of a shared weight without an add kernel
+    (db_out, when given, is accumulated the same way by the bias gradient's finishing kernel);
     with accumulate=False `out` is simply the destination (a slice of a gradient-exchange bucket, see set_grad_destinations)."""
     if accumulate is None:
         accumulate = out is not None
@@ -690,8 +691,6 @@ def conv_bwd_weight_raw(x, dy, weight_shape, d: _C.ConvDesc, want_bias: bool, ws
         # the 15-channel ConvLSTM convolutions stay on the exact fp32 MFMA in every pass
         bf = CONV_MATH in (MATH_BF16, MATH_BF16S) and (WGRAD_BF16_ANY_WIDTH or (dd.Cp % 32 == 0 and dd.Kp % 32 == 0))
         math = MATH_BF16 if bf else MATH_F32
-    if accumulate and want_bias:
-        raise ValueError("accumulating weight gradient: the bias gradient is not accumulated here")
     _C.check(_C.lib().up_conv2d_bwd_weight_acc(C.byref(dd), x.data_ptr(), dy.data_ptr(), dw.data_ptr(), _ptr(db), ws.data_ptr(),
                                                ws.numel(), math, int(bool(accumulate)), _stream(x)), "conv2d_bwd_weight")
     return dw, db
@@ -714,7 +713,17 @@ _PASS = {"seen": set(), "task": None, "keep": []}      # task: id of the autogra
 # once, behind the fence, no events; +18 GB held at B = 32) — measured in round 6: fp32 -0.1 ms, UniPose-LSTM -0.1 ms, bf16
 # storage at 736^2 +0.35 ms (profiles/r06_experiments.txt item 9), so the events stay the default.
 KEEP_WGRAD_INPUTS = os.environ.get("UNIPOSE_KEEP_WGRAD_INPUTS", "0") != "0"
-_DEFER = {"on": False, "acc": {}, "bn": {}}          # see deferred_wgrad
+_DEFER = {"on": False, "acc": {}, "bn": {}, "shared": {}}          # see deferred_wgrad
+_SHARED_USES = {}     # id(non-leaf weight) -> forward uses by ConvBias that have not been back-propagated yet (entry dies with the tensor)
+
+
+def _count_shared_use(weight):
+    key = id(weight)
+    if key not in _SHARED_USES:
+        import weakref
+        _SHARED_USES[key] = 0
+        weakref.finalize(weight, _SHARED_USES.pop, key, None)
+    _SHARED_USES[key] += 1
 
 
 class deferred_wgrad:
@@ -728,21 +737,33 @@ class deferred_wgrad:
     to it on the side stream behind the kernel that produced them, and on exit (the end-of-backward callback has made the
     main stream wait for the side stream by then) every buffer is installed as / added to ``weight.grad``.
     Opt-in because it changes what autograd sees: ``torch.autograd.grad`` w.r.t. such a weight and gradient hooks on it get
-    no gradient inside the context (weights with post-accumulate hooks keep the normal path).  Convolutions with a bias
-    and non-leaf weights keep the normal path too."""
+    no gradient inside the context (weights with post-accumulate hooks keep the normal path).  A leaf bias travels with its
+    weight (round 6: the five head convolutions of the video model, 40 gradient adds and 20 main-waits-for-side per step).
+    NON-LEAF weights that several convolutions share (the ConvLSTM cell's stacked gate weights, one cat per clip): every
+    forward use is counted (ConvBias.forward); in the backward the uses accumulate into one buffer on the side stream and
+    the LAST one hands autograd the sum — one gradient through the cat / pad graph per clip instead of one per frame.  A use
+    whose gradient never arrives inside the context is reported on exit (RuntimeError), not dropped."""
 
     def __enter__(self):
         if _DEFER["on"]:
             raise RuntimeError("ops.deferred_wgrad() does not nest")
-        _DEFER["on"], _DEFER["acc"], _DEFER["bn"] = True, {}, {}
+        _DEFER["on"], _DEFER["acc"], _DEFER["bn"], _DEFER["shared"] = True, {}, {}, {}
         return self
 
     def __exit__(self, exc_type, exc, tb):
-        acc, bn = _DEFER["acc"], _DEFER["bn"]
-        _DEFER["acc"], _DEFER["bn"], _DEFER["on"] = {}, {}, False
+        acc, bn, shared = _DEFER["acc"], _DEFER["bn"], _DEFER["shared"]
+        _DEFER["acc"], _DEFER["bn"], _DEFER["shared"], _DEFER["on"] = {}, {}, {}, False
         if exc_type is None:
             wgrad_fence()                     # (no-op after a completed backward; covers a backward that never ran the callback)
-            pairs = [(w, buf) for w, buf in acc.values()]
+            pending = [e for e in shared.values() if e[2] > 0]
+            if pending:
+                raise RuntimeError(f"ops.deferred_wgrad: {len(pending)} shared non-leaf weight(s) still wait for "
+                                   f"{sum(e[2] for e in pending)} use(s) whose gradient never arrived; their sums were not handed to autograd")
+            pairs = []
+            for ent in acc.values():
+                pairs.append((ent[0], ent[1]))
+                if ent[2] is not None:
+                    pairs.append((ent[2], ent[3]))
             for gamma, beta, dgb in bn.values():       # BatchNorm affine parameters: sums kept by up_bn_bwd_acc_t
                 pairs += [(gamma, dgb[0]), (beta, dgb[1])]
             for p, buf in pairs:
@@ -837,7 +858,71 @@ def _graph_task_id():
         return 0
 
 
-def conv_bwd_weight(x, dy, weight, d, want_bias):
+def _shared_wgrad(x, dy, weight, d, want_bias):
+    """ops.deferred_wgrad, non-leaf weight used by several convolutions: accumulate on the side stream, hand over at the last use."""
+    dev = dy.device
+    key = id(weight)
+    uses = _SHARED_USES.get(key, 0)
+    if uses > 0:
+        _SHARED_USES[key] = uses - 1
+    ent = _DEFER["shared"].get(key)
+    first = ent is None
+    if first and uses <= 1:               # a single use (LSTM_0's gate weights): nothing to share
+        return conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias)
+    if first:
+        ent = [torch.empty(weight.shape, dtype=torch.float32, device=dev),
+               torch.empty(weight.shape[0], dtype=torch.float32, device=dev) if want_bias else None, max(uses, 1), weight]
+        _DEFER["shared"][key] = ent
+    ent[2] -= 1
+    if ASYNC_WGRAD and dy.is_cuda and _graph_task_id() != -1:
+        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+        _ensure_end_of_backward(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias, ws_tag="side", out=ent[0], accumulate=not first, db_out=ent[1])
+        _hold_for_side(side, x, dy)
+        if ent[2] > 0:
+            return None, None
+        main.wait_stream(side)            # the sum goes to torch operators (cat / pad backward) on the main stream
+    else:
+        conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias, out=ent[0], accumulate=not first, db_out=ent[1])
+        if ent[2] > 0:
+            return None, None
+    return ent[0], ent[1]
+
+
+def _ensure_end_of_backward(dev):
+    """Queue the end-of-backward fence for the running autograd graph task (once per task); False outside a backward pass."""
+    task = _graph_task_id()
+    if task == -1:
+        return False
+    if _PASS["task"] != task:
+        if _PASS["task"] is not None:             # an earlier backward died before its callback ran: fence for it now
+            wgrad_fence(dev)
+            _PASS["seen"].clear()
+            _PASS["keep"].clear()
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+            _PASS["task"] = task
+        except RuntimeError:
+            return False
+    return True
+
+
+# A/B switches of the round-6 extensions of deferred_wgrad (UniPose-LSTM step, profiles/r06_experiments.txt item 13): a bias travels
+# with its weight, shared non-leaf weights hand over one sum; DEFER_WAIT: main waits for the side stream behind the weight gradient
+# of a convolution WITH bias (2: every use, 1: the later uses, 0: never).  Those are the video head's 11x11 convolutions: with their
+# five frames' weight gradients free-running on the side stream the step took 102.4-103.0 ms against 99.4-99.9 with the waits the
+# engine's accumulation used to force — the waits stay, the 50 add kernels go.
+DEFER_BIAS = os.environ.get("UNIPOSE_DEFER_BIAS", "1") != "0"
+DEFER_SHARED = os.environ.get("UNIPOSE_DEFER_SHARED", "1") != "0"
+DEFER_WAIT = int(os.environ.get("UNIPOSE_DEFER_WAIT", "2"))
+
+
+def conv_bwd_weight(x, dy, weight, d, want_bias, bias=None):
+    """bias: the bias PARAMETER (for ops.deferred_wgrad, which installs its gradient on exit)."""
+    if _DEFER["on"] and DEFER_SHARED and not weight.is_leaf and weight.requires_grad:
+        return _shared_wgrad(x, dy, weight, d, want_bias)
     if not (ASYNC_WGRAD and dy.is_cuda and weight.is_leaf):
         # non-leaf weights (the stacked ConvLSTM gate weights) feed torch ops on the main stream right away
         return conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias)
@@ -860,7 +945,8 @@ def conv_bwd_weight(x, dy, weight, d, want_bias):
     # or frees them only behind the end-of-backward fence.  (Rounds 1-5 allocated them inside the side-stream context and marked
     # them record_stream(main): the caching allocator then records one event on the MAIN stream per freed gradient — 229 marker
     # packets = 0.66 ms of main-stream time in every zero_grad, profiles/r06_experiments.txt item 8.)
-    defer = _DEFER["on"] and not want_bias and not getattr(weight, "_post_accumulate_grad_hooks", None)
+    bias_ok = not want_bias or (DEFER_BIAS and bias is not None and bias.is_leaf and not getattr(bias, "_post_accumulate_grad_hooks", None))
+    defer = _DEFER["on"] and bias_ok and not getattr(weight, "_post_accumulate_grad_hooks", None)
     entry = _DEFER["acc"].get(id(weight)) if defer else None
     dst = None
     if entry is None:
@@ -872,13 +958,17 @@ def conv_bwd_weight(x, dy, weight, d, want_bias):
     side.wait_stream(main)
     with torch.cuda.stream(side):
         if entry is not None:             # a later use of the weight: the reduce pass adds to the first use's buffer
-            conv_bwd_weight_raw(x, dy, weight.shape, d, False, ws_tag="side", out=entry[1])
+            conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias, ws_tag="side", out=entry[1], db_out=entry[3])
             _hold_for_side(side, x, dy)
+            if want_bias and DEFER_WAIT:
+                main.wait_stream(side)
             return None, None
         dw, db = conv_bwd_weight_raw(x, dy, weight.shape, d, want_bias, ws_tag="side", out=dst, accumulate=False, db_out=db_buf)
         if defer:
-            _DEFER["acc"][id(weight)] = (weight, dw)
+            _DEFER["acc"][id(weight)] = (weight, dw, bias if want_bias else None, db)
             _hold_for_side(side, x, dy)
+            if want_bias and DEFER_WAIT > 1:
+                main.wait_stream(side)
             return None, None
     _hold_for_side(side, x, dy)
     key = id(weight)
@@ -908,6 +998,10 @@ class ConvBias(Function):
         if relu and _RELU_TRACE is not None:
             _RELU_TRACE.append(y.detach())
         ctx.d, ctx.relu, ctx.has_bias = d, relu, bias is not None
+        ctx.bias = bias                       # (the parameter object: deferred_wgrad installs its gradient)
+        if ctx.needs_input_grad[1] and not weight.is_leaf:
+            _count_shared_use(weight)         # see deferred_wgrad: the last use in the backward hands over the sum
+            ctx.shared_w = weight             # (keeps THIS Python object — the key of the count — alive as long as the graph)
         ctx.save_for_backward(x, weight, y if relu else None)
         return y
 
@@ -931,7 +1025,8 @@ class ConvBias(Function):
         dx = conv_bwd_data_raw(dy, weight, ctx.d, x.shape, x.device) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1]:
-            dw, db = conv_bwd_weight(x, dy, weight, ctx.d, ctx.has_bias and ctx.needs_input_grad[2])
+            # (a shared non-leaf weight: the Python object the forward counted, not a fresh wrapper of the saved tensor)
+            dw, db = conv_bwd_weight(x, dy, getattr(ctx, "shared_w", weight), ctx.d, ctx.has_bias and ctx.needs_input_grad[2], bias=ctx.bias)
         elif ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.reshape(-1, dy.shape[3]).float().sum(0)[:weight.shape[0]]      # fp32 sum for an fp32 bias, also in bf16 storage
         return dx, dw, db, None, None, None
