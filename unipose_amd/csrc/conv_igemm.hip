@@ -2000,6 +2000,7 @@ static int g_glds = env_int("UP_GLDS", 1, 0);   // bf16 storage: direct-to-LDS k
 // workgroup per CU on 160/192/256 x 256 tiles (bf16s_big.h); 0 = igemm_glds_kernel everywhere
 static int g_big = env_int("UP_GLDS_BIG", 1, 0);
 static int g_big_min_k = env_int("UP_BIG_MIN_K", 1024, 1);   // (whole 736^2 step: 256 -> 39.5 ms, 512 -> 38.1, 1024 -> 36.1-36.3, 2048 -> 36.1-36.2 against 36.8-37.0 without; shorter reductions are all prologue + epilogue at one workgroup per CU)
+static int g_big_dgrad = env_int("UP_BIG_DGRAD", 1, 0);      // 0: data gradients (tapstep < 0) stay on igemm_glds_kernel
 static int g_big_rows = env_int("UP_BIG_ROWS", 0, 0);         // 160 / 192 / 256: only this tile height (0: the rule of big_tile_rows)
 static int g_big_stages = env_int("UP_BIG_STAGES", 3, 2);   // LDS stages of the 160-row tiles (3: two slices in flight)
 // fp32 forward / data gradient with operands HBM -> LDS by LDS-DMA (f32_glds.h, round 4): glds32 = 0 keeps the register-staged
@@ -2054,7 +2055,7 @@ static bool igemm_fast(const IgemmArgs& a) {
     return a.taps <= 32 && a.divshift == 0 && (long long)a.H * a.W * a.ldx * ((long long)a.M / (a.P * a.Q) + 1) < (1ll << 31);
 }
 static TileChoice choose_tile_bf16s(const IgemmArgs& a) {
-    if (g_big && glds_eligible(a, igemm_fast(a))) {
+    if (g_big && (g_big_dgrad || a.tapstep >= 0) && glds_eligible(a, igemm_fast(a))) {
         const int bm = glds::big_tile_rows(a.M, a.Ng, a.Ktot, a.Cp, cu_count(), g_big_min_k, g_big_rows);
         if (bm) return {bm, 256};
     }
@@ -2599,6 +2600,7 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "glds_big")) g_big = value ? 1 : 0;
     else if (!strcmp(key, "big_min_k") && value > 0) g_big_min_k = value;
     else if (!strcmp(key, "big_stages") && value >= 2) g_big_stages = value;
+    else if (!strcmp(key, "big_dgrad")) g_big_dgrad = value ? 1 : 0;
     else if (!strcmp(key, "big_rows") && (value == 0 || value == 160 || value == 192 || value == 256)) g_big_rows = value;
     else if (!strcmp(key, "cu_count") && value >= 0) g_cu_override = value;
     else if (!strcmp(key, "glds32")) g_glds32 = value ? 1 : 0;
