@@ -126,7 +126,7 @@ int up_stream_release(void* stream);
 int up_stream_create_cu_mask(const uint32_t* mask, int words, void** stream);
 int up_stream_destroy(void* stream);
 int up_probe_placement(int blocks, int* out_device, void* stream);
-/* Development knobs (A/B runs inside one process; each also has an environment variable read at load time).  Twelve keys
+/* Development knobs (A/B runs inside one process; each also has an environment variable read at load time).  Twelve keys + five of round 6
  * (round 4 removed the ones whose question is settled: short_k, short_k_mult, db_min_k, wgrad_per_cu, tap_skip, lds_swz and
  * the bf16 forms that lost in round 3):
  * "tiny_k" (UP_TINY_K, round 5: fp32 reductions of at most this length always take 64x64 tiles; default 128),
@@ -135,14 +135,17 @@ int up_probe_placement(int blocks, int* out_device, void* stream);
  * along K up to this many workgroups per CU), "tap_sort" (UP_TAP_SORT: GEMM rows ordered by their set of live filter taps so that
  * the tile-level tap skipping becomes near exact), "wgrad_rect" (UP_WGRAD_RECT, see up_conv_wgrad_visits).
  * bf16 storage: "glds" (UP_GLDS: direct-to-LDS kernels of bf16s_glds.h, default 1; 0 = the register-staged kernels), "bn_rows"
- * (row-strided BatchNorm kernels).  fp32 (round 4): "glds32" (UP_GLDS32: forward / data gradient on f32_glds.h, default 1),
+ * (row-strided BatchNorm kernels).  Round 6, the 8-wave (32 TM) x 256 tiles of bf16s_big.h: "glds_big" (UP_GLDS_BIG, default 1: launches
+ * with N % 256 == 0, 64-aligned channels and a reduction of at least "big_min_k" (UP_BIG_MIN_K, 1024) run on igemm_big_kernel),
+ * "big_stages" (UP_BIG_STAGES: LDS stages of the 160-row tiles, 3 | 2), "big_rows" (UP_BIG_ROWS: 0 = rows per tile by the fill
+ * rule, else only 160 / 192 / 256), "big_dgrad" (UP_BIG_DGRAD: 0 keeps data gradients on igemm_glds_kernel).  fp32 (round 4): "glds32" (UP_GLDS32: forward / data gradient on f32_glds.h, default 1),
  * "glds32_epi" (LDS-transposed 16-byte-store epilogue, 1), "glds32_wgrad" (weight gradient on f32_glds.h, 1).  "cu_count" (tests: pretend the chip has this many CUs when planning
  * splits; 0 = the real count).
  * These knobs and the UP_* environment variables they mirror are PROCESS-GLOBAL host state (kernel selection of every later
  * launch on every stream), like the library's per-stream K-split scratch and per-geometry tables; see the note at the top.
  * Change them only between steps: workspace sizes and the BatchNorm partial-row count follow the tile choice. */
 int up_conv_tune(const char* key, int value);
-/* Diagnostics: fp32 forward / data-gradient launches since load, by kernel family — "igemm" (register-staged igemm_kernel),
+/* Diagnostics: fp32 forward / data-gradient launches since load, by kernel family ("big": bf16-storage launches on igemm_big_kernel) — "igemm" (register-staged igemm_kernel),
  * "glds32" (f32_glds.h), "glds32_epi1" (of those, with the LDS-transposed epilogue), "glds32_bnred" (with the fused
  * BatchNorm-backward reduction), "wgrad_glds32" / "wgrad_glds32_st1" (fp32 weight-gradient launches on the direct-to-LDS kernel /
  * of those, the one-stage form); -1 for an unknown name.  Tests use it to prove which kernel a case ran on. */

@@ -1414,6 +1414,27 @@ def conv_bias_act(x, conv, relu=False, out_f32=False):
 # --------------------------------------------------------------------------------------------
 # layout, pooling, resampling, concat, dropout, loss
 # --------------------------------------------------------------------------------------------
+class SplitBatch(Function):
+    """(n * b, ...) -> n tensors of b leading rows each (views).  Plain slicing gives every part a slice_backward node: zeros +
+    copy per part and n - 1 full-size gradient adds in the backward (the four WASP branches behind the batched conv2: 4 fills,
+    4 copies and 3 adds of 69 MB tensors per step; the five frames of the video model's batched trunk); here the n gradients are
+    concatenated once."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        b = x.shape[0] // n
+        ctx.b, ctx.tail = b, x.shape[1:]
+        return tuple(x.narrow(0, i * b, b) for i in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        like = next((g for g in grads if g is not None), None)
+        if like is None:
+            return None, None
+        parts = [g if g is not None else torch.zeros((ctx.b,) + tuple(ctx.tail), dtype=like.dtype, device=like.device) for g in grads]
+        return torch.cat(parts, 0), None
+
+
 class ToNHWC(Function):
     @staticmethod
     def forward(ctx, x):

@@ -34,26 +34,6 @@ class _AddCenter(torch.autograd.Function):
         return dz, None, None     # channels >= k are ignored upstream (the producer masks them)
 
 
-class _SplitFrames(torch.autograd.Function):
-    """The trunk's output for the whole clip batch (T * b, h, w, C), frame-major -> T tensors of b images.  Plain slicing gave
-    every frame a slice_backward node: zeros + copy per frame and T - 1 gradient adds in the backward (14 launches per step at
-    T = 5); here the T gradients are concatenated once."""
-
-    @staticmethod
-    def forward(ctx, x, T):
-        b = x.shape[0] // T
-        ctx.b, ctx.tail = b, x.shape[1:]
-        return tuple(x.narrow(0, i * b, b) for i in range(T))
-
-    @staticmethod
-    def backward(ctx, *grads):
-        like = next((g for g in grads if g is not None), None)
-        if like is None:
-            return None, None
-        parts = [g if g is not None else torch.zeros((ctx.b,) + tuple(ctx.tail), dtype=like.dtype, device=like.device) for g in grads]
-        return torch.cat(parts, 0), None
-
-
 class unipose(nn.Module):
     def __init__(self, backbone="resnet", output_stride=16, num_classes=21, sync_bn=True, freeze_bn=False, stride=8):
         super().__init__()
@@ -106,7 +86,7 @@ class unipose(nn.Module):
         if iter == 0:
             xa = input.transpose(0, 1).reshape(T * b, *input.shape[2:])      # frame-major: BatchNorm group g = frame g
             with ops.bn_groups(T if self.training else 1), ops.bn_counters(self):
-                self._frames = (input, key, _SplitFrames.apply(self._trunk(xa), T))
+                self._frames = (input, key, ops.SplitBatch.apply(self._trunk(xa), T))
         elif not hit:
             self._frames = None
             with ops.bn_counters(self):
