@@ -2,7 +2,7 @@
 # stats of the bench command in both stream modes, PMC passes; with TESTS=1 also the full -m gpu suite (default + bf16x3 arithmetic);
 # LIGHT=1 stops after the kernel statistics.
 cd $GRAFT_REPO_ROOT
-TAG=${1:-r06_z}
+TAG=${1:-r06_zz}
 mkdir -p gpurun_out/$TAG
 # the measured binary is the tree's: the stamp next to the shipped library names the sha256 of the sources it was built from
 python -c "
@@ -61,6 +61,8 @@ VARIANTS="A=default;UP_BN_FOLD=0;UNIPOSE_BN_FUSE_REDUCE=0;UP_BREG=1;UNIPOSE_ASYN
 UNIPOSE_SYNC_WGRAD=1 UP_PROFILE_CSV=$GRAFT_REPO_ROOT/gpurun_out/$TAG/launches_736.csv timeout 300 python bench.py --size 736 --batch 16 --math bf16s --steps 4 --warmup 2 --no-cpu-baseline --no-stock-baseline --no-alt-math --no-other-configs > gpurun_out/$TAG/bench_csv_736.log 2>&1
 python tools/gpu/csv_loss.py $(ls gpurun_out/$TAG/launches_736.csv* | tail -1) 2500 24 > gpurun_out/$TAG/lost_time_by_shape_736.txt 2>&1; head -3 gpurun_out/$TAG/lost_time_by_shape_736.txt
 bash tools/gpu/pmc_sq.sh ${TAG}_736 --size 736 --batch 16 --math bf16s
+# the same A/B on the 736^2 bf16-storage step: third-generation tiles (bf16s_big.h) off / on / with two LDS stages / forward only
+VARIANTS="UP_GLDS_BIG=0;A=default;UP_BIG_STAGES=2;UP_BIG_DGRAD=0" REPS=2 bash tools/gpu/run.sh $TAG abenv > gpurun_out/$TAG/knob_ab_736.txt 2>&1; cat gpurun_out/$TAG/knob_ab_736.txt
 if [ -n "$TESTS" ]; then
 timeout 1200 python -m pytest tests -m gpu -q --timeout 600 --durations=15 > gpurun_out/$TAG/pytest_gpu.log 2>&1; echo "pytest exit $?"
 tail -2 gpurun_out/$TAG/pytest_gpu.log
