@@ -138,7 +138,8 @@ int up_probe_placement(int blocks, int* out_device, void* stream);
  * (row-strided BatchNorm kernels).  Round 6, the 8-wave (32 TM) x 256 tiles of bf16s_big.h: "glds_big" (UP_GLDS_BIG, default 1: launches
  * with N % 256 == 0, 64-aligned channels and a reduction of at least "big_min_k" (UP_BIG_MIN_K, 1024) run on igemm_big_kernel),
  * "big_stages" (UP_BIG_STAGES: LDS stages of the 160-row tiles, 3 | 2), "big_rows" (UP_BIG_ROWS: 0 = rows per tile by the fill
- * rule, else only 160 / 192 / 256), "big_dgrad" (UP_BIG_DGRAD: 0 keeps data gradients on igemm_glds_kernel).  fp32 (round 4): "glds32" (UP_GLDS32: forward / data gradient on f32_glds.h, default 1),
+ * rule, else only 160 / 192 / 256), "big_dgrad" (UP_BIG_DGRAD: 0 keeps data gradients on igemm_glds_kernel); "stem7" (UP_STEM7, default 0:
+ * the 7x7 stride-2 first convolution on stem7_kernel of stem_f32.h — equal bits, faster alone, not faster inside the step).  fp32 (round 4): "glds32" (UP_GLDS32: forward / data gradient on f32_glds.h, default 1),
  * "glds32_epi" (LDS-transposed 16-byte-store epilogue, 1), "glds32_wgrad" (weight gradient on f32_glds.h, 1).  "cu_count" (tests: pretend the chip has this many CUs when planning
  * splits; 0 = the real count).
  * These knobs and the UP_* environment variables they mirror are PROCESS-GLOBAL host state (kernel selection of every later

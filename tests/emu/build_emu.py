@@ -12,7 +12,7 @@ SOURCES = ["conv_igemm.hip", "norm_act.hip", "spatial.hip", "plan.hip"]
 
 def build(force: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "up_common.h"), os.path.join(CSRC, "bf16s_glds.h"), os.path.join(CSRC, "bf16s_big.h"), os.path.join(CSRC, "f32_glds.h"), os.path.join(CSRC, "bn_fold.h"),
+    deps = srcs + [os.path.join(CSRC, "up_common.h"), os.path.join(CSRC, "bf16s_glds.h"), os.path.join(CSRC, "bf16s_big.h"), os.path.join(CSRC, "f32_glds.h"), os.path.join(CSRC, "stem_f32.h"), os.path.join(CSRC, "bn_fold.h"),
                    os.path.join(HERE, "hip_emu.h"),
                    os.path.join(HERE, "emu_switch.cpp"), os.path.join(ROOT, "include", "unipose_hip.h")]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):

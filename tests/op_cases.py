@@ -765,3 +765,33 @@ def bn_groups_fold_case(dev, groups, n, c, h, w, k1, k2, r2=1, seed=0):
     for k_ in out[1]:
         assert torch.equal(out[1][k_], out[0][k_]), (k_, float((out[1][k_].double() - out[0][k_].double()).abs().max()))
     return merged
+
+
+def stem_ab_case(dev, n, size, seed=0):
+    """The first convolution (7x7, stride 2, padding 3, 3 -> 64 channels, resnet.py:113) on stem7_kernel (stem_f32.h: input patch in
+    LDS, weights in registers) against igemm_kernel<128,64,generic>: same MFMA, same k order -> EQUAL outputs; the BatchNorm partials
+    (same tiles, same epilogue) too.  size >= 256 (an output row of at least 128 pixels) or the launch stays on the generic kernel."""
+    from unipose_amd import _C
+    L = _C.lib()
+    x = nhwc(torch.randn(n, 3, size, size, generator=g(seed)), dev)
+    w = (torch.randn(64, 3, 7, 7, generator=g(seed + 1)) * 0.05).to(dev)
+    cfg = ops.ConvCfg(2, 3, 1)
+    out = {}
+    try:
+        _C.check(L.up_conv_tune(b"tile_want", 1), "tile_want")      # (small batches: keep the 128 x 64 tiles the network's launch takes)
+        for mode in (1, 0):
+            _C.check(L.up_conv_tune(b"stem7", mode), "stem7")
+            c0 = L.up_conv_counter(b"stem7")
+            y, d, st = ops.conv_fwd_raw(x, w, cfg, stats=True)
+            assert L.up_conv_counter(b"stem7") - c0 == mode, "launches on stem7_kernel"
+            out[mode] = (y.cpu(), st.cpu())
+    finally:
+        L.up_conv_tune(b"stem7", 0)
+        L.up_conv_tune(b"tile_want", 1500)
+    (y1, s1), (y0, s0) = out[1], out[0]
+    assert torch.equal(y1, y0), ("stem output", float((y1 - y0).abs().max()))
+    assert torch.equal(s1, s0), ("stem BatchNorm partials", float((s1 - s0).abs().max()))
+    ref = F.conv2d(x.cpu()[..., :3].permute(0, 3, 1, 2), w.cpu(), stride=2, padding=3)
+    err = rel(nchw(y1, 64), ref)
+    assert err < 2e-5, err
+    return y1

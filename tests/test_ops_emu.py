@@ -498,3 +498,8 @@ def test_deferred_wgrad_reports_a_shared_use_without_gradient(emu_backend):
     with pytest.raises(RuntimeError, match="never arrived"):
         with ops.deferred_wgrad():
             sum((y * y).sum() for y in ys[:2]).backward()          # the third use is left out of the loss
+
+
+def test_stem_kernel_matches_generic_kernel_emu(emu_backend):
+    oc.stem_ab_case(emu_backend, 1, 256)            # one image, 128 x 128 output pixels: every tile is one run of a row
+    oc.stem_ab_case(emu_backend, 2, 264, seed=3)    # 132 x 132: tiles of two runs, across the image boundary, ragged last tile

@@ -281,3 +281,9 @@ def test_bn_fold_is_deterministic_under_load():
 ])
 def test_grouped_bn_finalize_folded(cfg):
     print(oc.bn_groups_fold_case(DEV, *cfg))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,size", [(1, 256), (2, 264), (4, 368), (3, 736)])
+def test_stem_kernel_matches_generic_kernel(n, size):
+    oc.stem_ab_case(DEV, n, size, seed=size)

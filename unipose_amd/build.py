@@ -8,7 +8,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["conv_igemm.hip", "norm_act.hip", "spatial.hip", "plan.hip"]
-HEADERS = ["up_common.h", "bf16s_glds.h", "bf16s_big.h", "f32_glds.h", "bn_fold.h"]
+HEADERS = ["up_common.h", "bf16s_glds.h", "bf16s_big.h", "f32_glds.h", "stem_f32.h", "bn_fold.h"]
 OUT = os.path.join(HERE, "libunipose_hip.so")
 STAMP = OUT + ".stamp"          # sha256 of the sources the library next to it was built from
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]

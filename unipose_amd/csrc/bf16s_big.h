@@ -1,21 +1,27 @@
 // bf16-STORAGE implicit GEMM, third generation: one 8-wave workgroup per CU on a (32 TM) x 256 tile (round 6).
 // Included by conv_igemm.hip inside namespace up, after bf16s_glds.h.
 //
-// Why: igemm_glds_kernel's 128 x 128 tile moves (128 + 128) * 64 B through the CU's L1 -> LDS path per 32-channel slice for 8 MFMAs per
-// wave, 64 B per MFMA-cycle of the CU — and the path delivers 16-19 B per cycle (its outstanding-miss queue against ~480 cycles of
-// L2 latency, profiles/r06_n_bf16_quant.txt: 746 TFLOP/s at any number of tiles per CU).  The reduction is bound by operand
-// FETCH, so the tile has to grow: (BM + 256) * 128 B per 64-channel slice for BM * 256 outputs is 2 BM * 256 / (BM + 256) FLOP
-// per byte = 98 / 110 / 128 at BM = 160 / 192 / 256 against 64.  What that takes:
+// Why: igemm_glds_kernel's 128 x 128 tile moves (128 + 128) * 64 B through the CU's global -> LDS path per 32-channel slice for 8 MFMAs
+// per wave, 64 B per MFMA-cycle of the CU — and gets 16-21 B per cycle (profiles/r06_n_bf16_quant.txt: 746 TFLOP/s at any number of
+// tiles per CU).  The path itself delivers 37-52 B per cycle to a bare streaming loop (tools/gpu/fetch_probe.hip): the kernel is
+// bound by how much it keeps in flight against the latency of operands that the previous kernel left in the Infinity Cache / HBM,
+// and by the bytes it asks for per FLOP.  So the tile grows — (BM + 256) * 128 B per 64-channel slice for BM * 256 outputs is
+// 2 BM * 256 / (BM + 256) FLOP per byte = 98 / 110 / 128 at BM = 160 / 192 / 256 against 64 — and the pipeline deepens:
 //  * 512 threads = 8 wavefronts, wave w owns the 32 output columns n0 + 32 w .. + 31 of ALL BM rows (TM accumulator tiles of
 //    32 x 32, <= 128 registers): one B fragment and TM A fragments per 16-channel step; a column's BatchNorm statistics and
 //    backward sums never leave the wave.
-//  * K slice = 64 channels: 128-byte LDS rows = whole cache lines (a 32-channel slice fetches every line twice, the second half an
-//    L1 miss once the stage is 32 KB), two stages of (BM + 256) * 128 B (128 KB at BM = 256), one workgroup per CU, the same
-//    one-barrier loop: [own DMA landed] -> barrier -> [issue slice t + 1] -> 4 TM MFMAs per wave on slice t.
+//  * K slice = 64 channels: 128-byte LDS rows = whole cache lines; stages of (BM + 256) * 128 B, ONE workgroup per CU.  BM = 160
+//    keeps THREE stages (156 KB): two slices in flight behind the one computed, per-wave counted `s_waitcnt vmcnt(n)` + a raw
+//    s_barrier (a __syncthreads() drains the LDS-DMA queue); BM = 192 / 256: two stages, one slice in flight.
+//  * the LDS-DMA pieces of the slice being fetched are issued BETWEEN the MFMAs of the slice being computed (<= 2 per 16-channel
+//    step and wave), and the TM + 1 fragment reads of step s + 1 before the MFMAs of step s (two fragment sets, sched_group_barrier
+//    pins).  Left alone the scheduler kept four fragment registers and emitted read, read, wait, MFMA, MFMA.
 //  * BM = 160 / 192 / 256 per launch (big_tile_rows): the 46 x 46 stage has M = 33 856 rows, 264.5 tiles of 128 — the row count
 //    per tile is chosen so that the launch fills whole rounds of the 256 CUs (212 tiles of 160 for N = 256, 708 of 192 for N = 1024).
 //  * epilogue without workgroup barriers: every wave transposes its 32 x 32 blocks through 4 KB of its own LDS (bf16 row pairs,
 //    or fp32 when an addend comes in before the single rounding) and stores 16 bytes = 8 channels per lane.
+// One workgroup per CU leaves one prologue + epilogue per tile exposed (10-15 us): the launch logic sends only reductions of at
+// least big_min_k = 1024 here (measured, profiles/r06_experiments.txt item 12).
 // Same bits as igemm_glds_kernel for y / dx (same MFMA, same k order, skipped taps contribute exact zeros); BatchNorm partials
 // have one row per BM-row tile (merged values agree to fp32 round-off).
 #pragma once

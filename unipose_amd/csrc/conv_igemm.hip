@@ -40,7 +40,7 @@ namespace up {
 // up_profile_begin() arms it; every igemm/wgrad launch is then bracketed by two hipEvents on the
 // launch stream; up_profile_end() synchronises and returns, per kernel variant, {launches, total ms,
 // total algorithmic flops}.  Off by default: no events, no overhead.
-constexpr int PROF_VARIANTS = 39;
+constexpr int PROF_VARIANTS = 40;
 static const char* const kVariantNames[PROF_VARIANTS] = {
     "igemm_kernel<128,128,aligned>", "igemm_kernel<128,128,generic>", "igemm_kernel<64,128,aligned>",
     "igemm_kernel<64,128,generic>",  "igemm_kernel<128,64,aligned>",  "igemm_kernel<128,64,generic>",
@@ -57,7 +57,9 @@ static const char* const kVariantNames[PROF_VARIANTS] = {
     "igemm_glds32_kernel<128,128>", "igemm_glds32_kernel<64,128>", "igemm_glds32_kernel<128,64>", "igemm_glds32_kernel<64,64>",
     "wgrad_glds32_kernel<128,128>", "wgrad_glds32_kernel<128,64>", "wgrad_glds32_kernel<64,128>", "wgrad_glds32_kernel<64,64>",
     // bf16 storage, 8-wave workgroups on (32 TM) x 256 tiles (bf16s_big.h)
-    "igemm_big_kernel<256,256> (bf16)", "igemm_big_kernel<192,256> (bf16)", "igemm_big_kernel<160,256> (bf16)"};
+    "igemm_big_kernel<256,256> (bf16)", "igemm_big_kernel<192,256> (bf16)", "igemm_big_kernel<160,256> (bf16)",
+    // the 7x7 stride-2 first convolution (stem_f32.h)
+    "stem7_kernel<128,64>"};
 #ifndef UP_EMU
 struct ProfRec {
     hipEvent_t a, b;
@@ -1669,6 +1671,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(WgradArgs a) {
 #include "bf16s_glds.h"
 #include "bf16s_big.h"
 #include "f32_glds.h"
+#include "stem_f32.h"
 
 // sum the split-K slabs and scatter into PyTorch OIHW
 // (Measured and removed in round 2: the merge folded into the weight-gradient kernels — every split publishes its slab with
@@ -2557,8 +2560,28 @@ static void launch_igemm(IgemmArgs& a, bool aligned, hipStream_t st) {
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, st, a);
 }
 
+static int g_stem7 = env_int("UP_STEM7", 0, 0);   // 1: the first convolution on stem7_kernel (stem_f32.h: faster alone, not inside the step — off)
+static long long g_count_stem7 = 0;
+static void launch_stem7(IgemmArgs& a, hipStream_t st) {
+    const int ntm = cdiv(a.M, 128);
+    a.ntn = 1;
+    a.nwg = ntm;
+    a.fNtn = make_fastdiv(1);
+    a.x_bytes = (uint32_t)((long long)(a.M / (a.P * a.Q)) * a.H * a.W * 16);
+    ProfScope prof(39, 2.0 * (double)a.M * (double)a.Ng * (double)a.Ktot_real, st, a.M, a.Ng, a.Ktot, a.nwg);
+    apply_fold(a, ntm, st);
+    a.full_blocks = a.nwg;
+    a.parts = 1;
+    ++g_count_stem7;
+    const int grid = std::min(ntm, 2 * cu_count());   // two workgroups per CU, each walks its share of the tiles
+    hipLaunchKernelGGL(glds::stem7_kernel, dim3(grid), dim3(256), 0, st, a);
+}
 static void run_igemm(IgemmArgs& a, TileChoice t, hipStream_t st) {
     bool aligned = (a.Cp % BK) == 0;
+    if (g_stem7 && t.bm == 128 && t.bn == 64 && !a.residual && glds::stem7_eligible(a)) {
+        launch_stem7(a, st);
+        return;
+    }
     if (t.bm == 128 && t.bn == 128)
         launch_igemm<128, 128>(a, aligned, st);
     else if (t.bm == 64 && t.bn == 128)
@@ -2597,6 +2620,7 @@ extern "C" int up_conv_tune(const char* key, int value) {
     else if (!strcmp(key, "tile_want_bf16") && value > 0) g_tile_want_bf16 = value;
     else if (!strcmp(key, "bn_rows")) set_bn_rows(value);
     else if (!strcmp(key, "glds")) g_glds = value ? 1 : 0;
+    else if (!strcmp(key, "stem7")) g_stem7 = value ? 1 : 0;
     else if (!strcmp(key, "glds_big")) g_big = value ? 1 : 0;
     else if (!strcmp(key, "big_min_k") && value > 0) g_big_min_k = value;
     else if (!strcmp(key, "big_stages") && value >= 2) g_big_stages = value;
@@ -2627,6 +2651,7 @@ extern "C" long long up_conv_counter(const char* name) {
     if (!strcmp(name, "glds32_bnred")) return g_count_glds32_bnred;
     if (!strcmp(name, "glds32_breg")) return g_count_glds32_breg;
     if (!strcmp(name, "big")) return g_count_big;
+    if (!strcmp(name, "stem7")) return g_count_stem7;
     if (!strcmp(name, "wgrad_glds32")) return g_count_wgrad32;
     if (!strcmp(name, "wgrad_glds32_st1")) return g_count_wgrad32_st1;
     return -1;
