@@ -226,6 +226,7 @@ def make_workload(dev, lstm, K, B, S, T, seed, emu=False, init=None, graph=False
         # the trunk runs once on all T frames of the clip batch (every convolution on B*T images), each frame with its own
         # BatchNorm batch statistics: the results of the reference's T calls (tests: lstm_case(batch_frames=True), G5)
         model.batch_frames = os.environ.get("UNIPOSE_BATCH_FRAMES", "1") != "0"
+        model.batch_head = os.environ.get("UNIPOSE_BATCH_HEAD", "1") != "0"      # (A/B: the head once on all T * B hidden states)
         x = torch.randn(B, T, 3, S, S, generator=g).to(dev)
         cm = torch.rand(B, T, 1, S, S, generator=g).to(dev)
         t = torch.rand(B, T, K + 1, S // 8, S // 8, generator=g).to(dev)

@@ -211,9 +211,15 @@ def lstm_case(dev, K=13, B=1, size=32, T=3, wseed=4, tol=1e-3, train=False, defe
                 # the batched trunk recorded ONE entry per ReLU for all T frames (frame-major rows), then the head's five
                 # per frame; the oracle consumes them frame by frame: trunk entries of frame j, then its head entries
                 nh = 5
-                trunk, head = trace[:len(trace) - T * nh], trace[len(trace) - T * nh:]
-                assert all(z.shape[0] == T * B for z in trunk) and all(z.shape[0] == B for z in head)
-                trace = [e for j in range(T) for e in [z[j * B:(j + 1) * B] for z in trunk] + head[j * nh:(j + 1) * nh]]
+                if trace[-1].shape[0] == T * B:
+                    # whole-clip unroll (unipose_lstm._unroll_clip): the head ran ONCE on the T * B hidden states, frame-major too
+                    trunk, head = trace[:len(trace) - nh], trace[len(trace) - nh:]
+                    assert all(z.shape[0] == T * B for z in trunk + head)
+                    trace = [e for j in range(T) for e in [z[j * B:(j + 1) * B] for z in trunk + head]]
+                else:
+                    trunk, head = trace[:len(trace) - T * nh], trace[len(trace) - T * nh:]
+                    assert all(z.shape[0] == T * B for z in trunk) and all(z.shape[0] == B for z in head)
+                    trace = [e for j in range(T) for e in [z[j * B:(j + 1) * B] for z in trunk] + head[j * nh:(j + 1) * nh]]
             with O.relu_masks_from(trace):
                 o32, l32 = run_oracle(sd32, torch.float32)
             sd64 = _sd64(sd, True)
@@ -725,3 +731,40 @@ def lstm_bf16s_case(dev, K=13, B=2, size=32, T=2, wseed=4, train=False, batch_fr
         for n in ("conv5.weight", "conv5.bias", "conv4.weight"):        # the head's last layers: no ReLU-flip amplification yet
             assert cos(g16[n], g32[n]) > 0.98, (n, cos(g16[n], g32[n]))
     return l16, l32
+
+
+def lstm_unroll_fallback_case(dev, K=13, B=1, size=32, T=3, wseed=4):
+    """unipose_lstm with batch_frames: the whole clip is unrolled at iter == 0 and later calls are served from it ONLY while the caller
+    passes back the very tensors it was given.  A caller that hands in a different hidden state (here: a clone scaled by 0.5) must
+    get what the per-frame path computes from THAT state, and the served path must equal the per-frame path bit for bit in eval."""
+    m = skeleton("lstm", K)
+    m.load_state_dict(O.synth_state_dict(K, wseed, lstm=True))
+    m = m.to(dev).eval()
+    hs = size // 8
+    x = O.synth_input((B, T, 3, size, size), 15).to(dev)
+    cm = O.synth_input((B, T, 1, size, size), 16, "rand").to(dev)
+
+    def run(batch_frames, batch_head, tamper):
+        m.batch_frames, m.batch_head = batch_frames, batch_head
+        heat = torch.zeros(K + 1, hs, hs, device=dev)
+        cell = torch.zeros(K + 2, hs, hs, device=dev)
+        hide = torch.zeros(K + 2, hs, hs, device=dev)
+        outs = []
+        with torch.no_grad():
+            for j in range(T):
+                if tamper and j == 2:
+                    hide = hide.clone() * 0.5
+                heat, cell, hide = m(x, cm, j, heat, hide, cell)
+                outs.append((heat.clone(), cell.clone(), hide.clone()))
+        return outs
+
+    ref, served = run(True, False, False), run(True, True, False)
+    for a, b in zip(ref, served):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    ref_t, got_t = run(True, False, True), run(True, True, True)
+    for a, b in zip(ref_t, got_t):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    assert not torch.equal(ref[2][0], ref_t[2][0])           # the tampered state did change the last frame
+    assert m._clip is None and m._frames is None             # nothing outlives the clip

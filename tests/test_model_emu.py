@@ -98,3 +98,7 @@ def test_lstm_any_num_classes(emu_backend):
     mc.lstm_case(emu_backend, K=15, size=32, T=2, B=1)
     mc.lstm_case(emu_backend, K=15, size=32, T=3, B=2, train=True, deferred=True, batch_frames=True)
     mc.lstm_case(emu_backend, K=19, size=32, T=2, B=1, batch_frames=True)
+
+
+def test_lstm_whole_clip_unroll_serves_only_its_own_states_emu(emu_backend):
+    mc.lstm_unroll_fallback_case(emu_backend)

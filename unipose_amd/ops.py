@@ -909,14 +909,15 @@ def _ensure_end_of_backward(dev):
     return True
 
 
-# A/B switches of the round-6 extensions of deferred_wgrad (UniPose-LSTM step, profiles/r06_experiments.txt item 13): a bias travels
-# with its weight, shared non-leaf weights hand over one sum; DEFER_WAIT: main waits for the side stream behind the weight gradient
-# of a convolution WITH bias (2: every use, 1: the later uses, 0: never).  Those are the video head's 11x11 convolutions: with their
-# five frames' weight gradients free-running on the side stream the step took 102.4-103.0 ms against 99.4-99.9 with the waits the
-# engine's accumulation used to force — the waits stay, the 50 add kernels go.
+# A/B switches of the round-6 extensions of deferred_wgrad (UniPose-LSTM step, profiles/r06_experiments.txt items 13 / 17): a bias
+# travels with its weight, shared non-leaf weights hand over one sum; DEFER_WAIT: main waits for the side stream behind the weight
+# gradient of a convolution WITH bias (2: every use, 1: the later uses of a weight, 0: never).  Per-frame head (five uses of the
+# video head's 11x11 convolutions): free-running weight gradients 102.4-103.0 ms, with the waits the engine's accumulation used to
+# force 99.4-99.9.  With the head batched over the clip (unipose_lstm._unroll_clip: every head weight is used once) 2 / 1 / 0 measure
+# 95.4-95.6 / 94.7-95.2 / 94.6-95.1 ms: 1 keeps both.
 DEFER_BIAS = os.environ.get("UNIPOSE_DEFER_BIAS", "1") != "0"
 DEFER_SHARED = os.environ.get("UNIPOSE_DEFER_SHARED", "1") != "0"
-DEFER_WAIT = int(os.environ.get("UNIPOSE_DEFER_WAIT", "2"))
+DEFER_WAIT = int(os.environ.get("UNIPOSE_DEFER_WAIT", "1"))
 
 
 def conv_bwd_weight(x, dy, weight, d, want_bias, bias=None):

@@ -59,6 +59,8 @@ class unipose(nn.Module):
         # 268-tile launches become 1300-tile launches).  Off by default: a caller that only ever asks for iter == 0 would pay
         # for T frames and see T running-statistics updates.  unipose_amd.trainer.VideoTrainer and bench.py switch it on.
         self.batch_frames = False
+        self.batch_head = True       # with batch_frames: the recurrence of the whole clip at iter == 0, the head once on T * B states (_unroll_clip)
+        self._clip = None
         self._frames = None
         self._stacked = None        # the ConvLSTM cell's stacked gate weights of the running clip unroll, see modules.LSTM.forward
         if freeze_bn:
@@ -99,6 +101,7 @@ class unipose(nn.Module):
     def train(self, mode: bool = True):
         self._frames = None          # a clip that was not served to its last frame must not outlive a mode switch
         self._stacked = None
+        self._clip = None
         return super().train(mode)
 
     def _state(self, t, like, b):
@@ -107,16 +110,64 @@ class unipose(nn.Module):
             t = t.unsqueeze(0).expand(b, -1, -1, -1)
         return ops.ToNHWC.apply(t.to(like.device))
 
-    def forward(self, input, centermap, iter, previous, previousHide, previousCell):
-        b = input.shape[0]
-        # bf16 storage (ops.set_conv_math("bf16s")): the trunk runs on bf16 tensors like the image model's and hands over fp32
-        # heat-maps (the decoder's last convolution writes fp32); the ConvLSTM cell and the head — 15 / 16-channel state, outside
-        # the 32-channel granularity of the bf16 kernels — stay fp32 tensors, their 128-channel convolutions on bf16 MFMA operands
+    def _head(self, hide):
+        h = hide
+        for conv in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5):
+            h = ops.conv_bias_act(h, conv, relu=True)
+        return h
+
+    def _frame_input(self, input, centermap, iter):
         x = self._trunk_frame(input, iter)                         # (B,h,w,16) fp32, 14 real channels
         cpad = ops.rup4(self.num_classes + 1)
         if x.shape[3] != cpad:          # (a bf16-storage convolution pads its output to 32 channels: back to the fp32 layout, whose
             x = x[..., :cpad]           #  one spare pad channel takes the centre map and whose width the stacked gate weights assume)
-        z = _AddCenter.apply(x, centermap[:, iter], self.num_classes + 1)
+        return _AddCenter.apply(x, centermap[:, iter], self.num_classes + 1)
+
+    def _unroll_clip(self, input, centermap):
+        """batch_frames, iter == 0: the WHOLE clip at once.  The recurrence needs nothing the later calls bring (their states are the
+        ones this module returned), so cell / hide of all T frames are computed here — state kept in NHWC between the frames, one
+        stacked gate weight — and the five head convolutions (model/uniposeLSTM.py:85-89: two 11x11 128 -> 128 among them, a fifth
+        of the step's FLOP) run ONCE on the T * B hidden states instead of T times on B: 2 650-tile launches instead of 530-tile
+        ones, one weight gradient per head weight instead of T accumulated ones.  Later calls are served from the result as long
+        as they pass back the tensors they were given (identity); anything else takes the per-frame path."""
+        T = input.shape[1]
+        c = self.num_classes + 2
+        cells, hides = [], []
+        stacked = None
+        for t in range(T):
+            z = self._frame_input(input, centermap, t)
+            if t == 0:
+                cell, hide = self.lstm_0(z)
+            else:
+                if stacked is None:
+                    stacked = self.lstm.stacked()
+                cell, hide = self.lstm(z, hides[-1], cells[-1], stacked=stacked)
+            cells.append(cell)
+            hides.append(hide)
+        heats = ops.SplitBatch.apply(self._head(torch.cat(hides, 0)), T)
+        out = [(ops.ToNCHW.apply(heats[t], self.num_classes + 1), ops.ToNCHW.apply(cells[t], c), ops.ToNCHW.apply(hides[t], c))
+               for t in range(T)]
+        key = (input._version, centermap._version, self.training, torch.is_grad_enabled(), ops.OPTIMIZER_STEPS)
+        self._clip = (input, centermap, key, out)
+        return out[0]
+
+    def forward(self, input, centermap, iter, previous, previousHide, previousCell):
+        b = input.shape[0]
+        T = input.shape[1]
+        if self.batch_frames and self.batch_head and T > 1:
+            if iter == 0:
+                return self._unroll_clip(input, centermap)
+            cl, self._clip = self._clip, (None if iter == T - 1 else self._clip)
+            if cl is not None and cl[0] is input and cl[1] is centermap and \
+                    cl[2] == (input._version, centermap._version, self.training, torch.is_grad_enabled(), ops.OPTIMIZER_STEPS) and \
+                    previousHide is cl[3][iter - 1][2] and previousCell is cl[3][iter - 1][1]:
+                return cl[3][iter]
+            self._clip = None          # the caller left the unroll this module prepared: per-frame path from here on
+        # bf16 storage (ops.set_conv_math("bf16s")): the trunk runs on bf16 tensors like the image model's and hands over fp32
+        # heat-maps (the decoder's last convolution writes fp32); the ConvLSTM cell and the head — 15 / 16-channel state, outside
+        # the 32-channel granularity of the bf16 kernels — stay fp32 tensors, their 128-channel convolutions on bf16 MFMA operands
+        z = self._frame_input(input, centermap, iter)
+        x = z
         if iter == 0:
             self._stacked = None
             cell, hide = self.lstm_0(z)
@@ -130,9 +181,7 @@ class unipose(nn.Module):
             cell, hide = self.lstm(z, self._state(previousHide, x, b), self._state(previousCell, x, b), stacked=self._stacked[1])
             if iter == input.shape[1] - 1:
                 self._stacked = None                                # the clip is served
-        h = hide
-        for conv in (self.conv1, self.conv2, self.conv3, self.conv4, self.conv5):
-            h = ops.conv_bias_act(h, conv, relu=True)
+        h = self._head(hide)
         c = self.num_classes + 2
         return ops.ToNCHW.apply(h, self.num_classes + 1), ops.ToNCHW.apply(cell, c), ops.ToNCHW.apply(hide, c)
 
